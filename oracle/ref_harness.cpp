@@ -1,0 +1,214 @@
+/* TEST INFRASTRUCTURE — never linked into or called by the product path.
+ *
+ * Builds the UNMODIFIED reference translation unit (by #include from where it
+ * lies, -DCUP3D_REFERENCE_MAIN="\"/root/reference/main.cpp\"") into
+ * oracle/_ref/ref_tool, a small command interpreter that drives the
+ * reference's own objects so that
+ *   (1) the C restatement in oracle/cup3d_oracle.c can be pinned against the
+ *       reference itself, and
+ *   (2) golden vectors under tests/golden/ can be generated
+ *       (tests/golden/make_golden.py), and
+ *   (3) bench.py can time the reference's CPU operators ("cpu_baseline",
+ *       kind "reference") on the GPU box's host cores.
+ *
+ * Usage:  ref_tool <script> -- <reference command line>
+ * Script lines (whitespace separated):
+ *   tables <file>          int64[nb][6] = level,Z,ix,iy,iz,blockID_2 then
+ *                          double[nb][4] = h,origin[3]   (m_vInfo order)
+ *   sfc <file>             forward/Encode/neighbour tables for every level
+ *   loadg <field> <file>   fill a field from a global x-fastest array
+ *                          [NZ][NY][NX][ncomp] (uniform single-level grids)
+ *   dump <field> <file>    block-order dump [nb][8][8][8][ncomp] (the
+ *                          reference's own memory layout per block)
+ *   set step|dt|time|nu|uinfx|uinfy|uinfz|mean <value>
+ *   op advdiff <dt> | lhs | precond | solve | project <dt> | maxu |
+ *      steps <n> | forcing <dt>
+ *   rep <n>                repeat every following `op` n times when timing
+ * Every `op` prints one line `REF <op> seconds=<t> iters=<k> value=<v>`.
+ */
+#include <chrono>
+static long cup3d_stub_iallreduce7 = 0; /* one 7-double Iallreduce per BiCGSTAB iteration (main.cpp:14546) */
+#define CUP3D_STUB_COUNT_IALLREDUCE(n)                                         \
+  do {                                                                         \
+    if ((n) == 7) cup3d_stub_iallreduce7++;                                    \
+  } while (0)
+#define main cup3d_reference_main
+#include CUP3D_REFERENCE_MAIN
+#undef main
+
+namespace {
+struct Field {
+  int ncomp;
+  std::vector<Info> *infos;
+};
+Field field_of(SimulationData &s, const std::string &name) {
+  if (name == "vel") return {3, &s.velInfo()};
+  if (name == "tmpV") return {3, &s.tmpVInfo()};
+  if (name == "pres") return {1, &s.presInfo()};
+  if (name == "lhs") return {1, &s.lhsInfo()};
+  if (name == "chi") return {1, &s.chiInfo()};
+  fprintf(stderr, "ref_tool: unknown field %s\n", name.c_str());
+  exit(2);
+}
+double now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+void write_file(const std::string &path, const void *p, size_t bytes) {
+  FILE *f = fopen(path.c_str(), "wb");
+  if (!f || fwrite(p, 1, bytes, f) != bytes) { perror(path.c_str()); exit(2); }
+  fclose(f);
+}
+std::vector<char> read_file(const std::string &path) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) { perror(path.c_str()); exit(2); }
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  std::vector<char> b(n);
+  if (fread(b.data(), 1, n, f) != (size_t)n) { perror(path.c_str()); exit(2); }
+  fclose(f);
+  return b;
+}
+} // namespace
+
+int main(int argc, char **argv) {
+  int split = -1;
+  for (int i = 1; i < argc; i++)
+    if (std::string(argv[i]) == "--") { split = i; break; }
+  if (argc < 3 || split != 2) {
+    fprintf(stderr, "usage: ref_tool <script> -- <reference args>\n");
+    return 2;
+  }
+  int provided;
+  MPI_Init_thread(&argc, &argv, MPI_THREAD_FUNNELED, &provided);
+  MPI_Comm_rank(MPI_COMM_WORLD, &::sim.rank);
+  MPI_Comm_size(MPI_COMM_WORLD, &::sim.size);
+  int rargc = argc - split;
+  char **rargv = argv + split; /* rargv[0] = "--" plays the role of argv[0] */
+  Simulation *S = new Simulation(rargc, rargv, MPI_COMM_WORLD);
+  S->init();
+  SimulationData &sd = S->sim;
+  AdvectionDiffusion advdiff(sd);
+  ComputeLHS lhsop(sd);
+  std::shared_ptr<PressureProjection> proj;
+  for (auto &op : sd.pipeline)
+    if (auto p = std::dynamic_pointer_cast<PressureProjection>(op)) proj = p;
+  std::ifstream script(argv[1]);
+  std::string cmd;
+  int rep = 1;
+  while (script >> cmd) {
+    if (cmd == "tables") {
+      std::string path; script >> path;
+      auto &I = sd.velInfo();
+      std::vector<long long> t(I.size() * 6);
+      std::vector<double> g(I.size() * 4);
+      for (size_t i = 0; i < I.size(); i++) {
+        t[6 * i + 0] = I[i].level; t[6 * i + 1] = I[i].Z;
+        t[6 * i + 2] = I[i].index[0]; t[6 * i + 3] = I[i].index[1]; t[6 * i + 4] = I[i].index[2];
+        t[6 * i + 5] = I[i].blockID_2;
+        g[4 * i] = I[i].h; g[4 * i + 1] = I[i].origin[0]; g[4 * i + 2] = I[i].origin[1]; g[4 * i + 3] = I[i].origin[2];
+      }
+      std::vector<char> out(t.size() * 8 + g.size() * 8);
+      memcpy(out.data(), t.data(), t.size() * 8);
+      memcpy(out.data() + t.size() * 8, g.data(), g.size() * 8);
+      write_file(path, out.data(), out.size());
+    } else if (cmd == "sfc") {
+      /* per level l < levelMax, per (k,j,i) x-fastest: forward, Encode, Zparent,
+         27 Znei, 8 Zchild  (int64 each) — Info::setup main.cpp:384-420 */
+      std::string path; script >> path;
+      std::vector<long long> out;
+      for (int l = 0; l < sd.levelMax; l++) {
+        const int nx = sd.bpdx << l, ny = sd.bpdy << l, nz = sd.bpdz << l;
+        for (int k = 0; k < nz; k++)
+          for (int j = 0; j < ny; j++)
+            for (int i = 0; i < nx; i++) {
+              const long long Z = Info::forward(l, i, j, k);
+              Info &inf = sd.vel->getInfoAll(l, Z);
+              int ii, jj, kk;
+              Info::inverse(Z, l, ii, jj, kk);
+              if (ii != i || jj != j || kk != k) { fprintf(stderr, "sfc inverse mismatch\n"); exit(3); }
+              out.push_back(Z);
+              out.push_back(inf.blockID_2);
+              out.push_back(inf.Zparent);
+              for (int a = 0; a < 27; a++) out.push_back((&inf.Znei[0][0][0])[a]);
+              for (int a = 0; a < 8; a++) out.push_back((&inf.Zchild[0][0][0])[a]);
+            }
+      }
+      write_file(path, out.data(), out.size() * 8);
+    } else if (cmd == "loadg") {
+      std::string fname, path; script >> fname >> path;
+      Field F = field_of(sd, fname);
+      auto buf = read_file(path);
+      const double *g = (const double *)buf.data();
+      const int lvl = (*F.infos)[0].level;
+      const long NXc = (long)(sd.bpdx << lvl) * 8, NYc = (long)(sd.bpdy << lvl) * 8, NZc = (long)(sd.bpdz << lvl) * 8;
+      if (buf.size() != (size_t)(NXc * NYc * NZc * F.ncomp * 8)) { fprintf(stderr, "loadg %s: size mismatch\n", fname.c_str()); exit(2); }
+      for (auto &inf : *F.infos) {
+        if (inf.level != lvl) { fprintf(stderr, "loadg needs a uniform grid\n"); exit(2); }
+        double *b = (double *)inf.block;
+        for (int z = 0; z < 8; z++)
+          for (int y = 0; y < 8; y++)
+            for (int x = 0; x < 8; x++)
+              for (int c = 0; c < F.ncomp; c++) {
+                const long gx = inf.index[0] * 8 + x, gy = inf.index[1] * 8 + y, gz = inf.index[2] * 8 + z;
+                b[((z * 8 + y) * 8 + x) * F.ncomp + c] = g[((gz * NYc + gy) * NXc + gx) * F.ncomp + c];
+              }
+      }
+    } else if (cmd == "dump") {
+      std::string fname, path; script >> fname >> path;
+      Field F = field_of(sd, fname);
+      const size_t per = 512 * F.ncomp;
+      std::vector<double> out(F.infos->size() * per);
+      for (size_t i = 0; i < F.infos->size(); i++)
+        memcpy(&out[i * per], (*F.infos)[i].block, per * 8);
+      write_file(path, out.data(), out.size() * 8);
+    } else if (cmd == "set") {
+      std::string k; double v; script >> k >> v;
+      if (k == "step") sd.step = (int)v;
+      else if (k == "dt") sd.dt = v;
+      else if (k == "time") sd.time = v;
+      else if (k == "nu") sd.nu = v;
+      else if (k == "uinfx") sd.uinf[0] = v;
+      else if (k == "uinfy") sd.uinf[1] = v;
+      else if (k == "uinfz") sd.uinf[2] = v;
+      else if (k == "mean") sd.bMeanConstraint = (int)v;
+      else { fprintf(stderr, "ref_tool: unknown set key %s\n", k.c_str()); exit(2); }
+    } else if (cmd == "rep") {
+      script >> rep;
+    } else if (cmd == "op") {
+      std::string op; script >> op;
+      double arg = 0;
+      if (op == "advdiff" || op == "project" || op == "steps" || op == "forcing") script >> arg;
+      for (int r = 0; r < rep; r++) {
+        cup3d_stub_iallreduce7 = 0;
+        double value = 0;
+        const double t0 = now();
+        if (op == "advdiff") { sd.dt = arg; advdiff(arg); }
+        else if (op == "lhs") lhsop(0);
+        else if (op == "precond") {
+#pragma omp parallel
+          { poisson_kernels::getZImplParallel(sd.presInfo()); }
+        }
+        else if (op == "solve") sd.pressureSolver->solve();
+        else if (op == "project") { sd.dt = arg; (*proj)(arg); }
+        else if (op == "maxu") value = findMaxU(sd);
+        else if (op == "forcing") { ExternalForcing f(sd); f(arg); }
+        else if (op == "steps") {
+          for (int n = 0; n < (int)arg; n++) {
+            const Real dt = S->calcMaxTimestep();
+            S->advance(dt);
+            value = dt;
+          }
+        } else { fprintf(stderr, "ref_tool: unknown op %s\n", op.c_str()); exit(2); }
+        const double t1 = now();
+        printf("REF %s seconds=%.6f iters=%ld value=%.17g\n", op.c_str(), t1 - t0, cup3d_stub_iallreduce7, value);
+        fflush(stdout);
+      }
+    } else {
+      fprintf(stderr, "ref_tool: unknown command %s\n", cmd.c_str());
+      return 2;
+    }
+  }
+  fflush(0);
+  _exit(0); /* skip the reference's destructors: nothing left to verify */
+}
