@@ -1,0 +1,77 @@
+/* TEST INFRASTRUCTURE — CPU restatement ("oracle") of the reference hot path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product (cup3d_amd/, include/) never does.
+ *
+ * Plain C restatement of slitvinov/CUP3D's per-block stencil + Poisson path
+ * for single-level (uniform) block grids, one rank.  Every function cites the
+ * reference lines (main.cpp:NNNN) it follows and keeps the reference's
+ * floating-point association so that, built without FMA contraction, it is
+ * bit-identical to the reference run with OMP_NUM_THREADS=1.  Pinned against
+ * oracle/_ref/ref_tool (the unmodified reference TU) by tests/test_oracle_vs_ref.py
+ * and against the committed vectors in tests/golden/.
+ *
+ * Field layout = the reference's own block memory: scalar [nb][8][8][8],
+ * vector [nb][8][8][8][3] (AoS), block order = m_vInfo order (sorted by
+ * blockID_2, main.cpp:943-964).
+ */
+#ifndef CUP3D_ORACLE_H
+#define CUP3D_ORACLE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_BC_FREESPACE = 0, ORC_BC_PERIODIC = 1, ORC_BC_WALL = 2 }; /* enum BCflag, main.cpp:6081 */
+
+typedef struct orc_sfc orc_sfc;
+typedef struct orc_grid orc_grid;
+
+/* --- indexing (integer, bit-exact contract) ------------------ */
+orc_sfc *orc_sfc_create(int bx, int by, int bz, int level_max);             /* main.cpp:196-236 */
+void orc_sfc_destroy(orc_sfc *);
+long long orc_sfc_forward(const orc_sfc *, int l, int i, int j, int k);       /* main.cpp:237-255 */
+void orc_sfc_inverse(const orc_sfc *, long long Z, int l, int ijk[3]);        /* main.cpp:256-276 */
+long long orc_sfc_encode(const orc_sfc *, int level, const int index[3]);     /* main.cpp:287-318 */
+/* Info::setup tables (main.cpp:384-420): nei[27] (x slowest as Znei[i][j][k]), child[8], parent */
+void orc_info_tables(const orc_sfc *, const int bpd[3], int level, const int index[3],
+                     long long nei[27], long long child[8], long long *parent);
+
+/* --- uniform grid (GridMPI ctor main.cpp:2959-2986 + FillPos 943-964) -------- */
+orc_grid *orc_grid_create(int bx, int by, int bz, int level_max, int level,
+                          double maxextent, const int bc[3]);
+void orc_grid_destroy(orc_grid *);
+long orc_grid_nblocks(const orc_grid *);
+double orc_grid_h(const orc_grid *);
+/* tables in block order: out6 = level,Z,ix,iy,iz,blockID_2 ; geom4 = h,origin[3] */
+void orc_grid_tables(const orc_grid *, long long *out6, double *geom4);
+/* contiguous Z-range ownership of rank r of n (main.cpp:2970-2986): first Z and count */
+void orc_partition(long long total_blocks, int rank, int size, long long *z_start, long long *count);
+
+/* --- operators ------------------------------------------------------------ */
+void orc_ic_taylor_green(const orc_grid *, double *vel, const double ext[3], double umax); /* 12516-12539 */
+double orc_max_u(const orc_grid *, const double *vel, const double uinf[3]);           /* 8603-8623 */
+/* Simulation::calcMaxTimestep, main.cpp:15254-15305; returns dt, updates coefU when step>2 */
+double orc_calc_dt(double hmin, double umax, double nu, double cfl, int step, int rampup,
+                   double dt_old, double coefU[3]);
+void orc_external_forcing(const orc_grid *, double *vel, double umax_forced, double nu, double H, double dt); /* 10581-10596 */
+/* AdvectionDiffusion::operator(), main.cpp:9640-9728 (RK3, KernelAdvectDiffuse 9461-9549) */
+void orc_advect_diffuse(const orc_grid *, double *vel, double *tmpV, double dt, double nu, const double uinf[3]);
+/* one application of KernelAdvectDiffuse: tmpV += rhs(vel) (main.cpp:9484-9549) */
+void orc_advdiff_stage_rhs(const orc_grid *, const double *vel, double *tmpV, double dt, double nu, const double uinf[3]);
+/* ComputeLHS::operator(), main.cpp:9273-9327 */
+void orc_lhs(const orc_grid *, const double *pres, double *lhs, int mean_constraint);
+/* poisson_kernels::getZImplParallel, main.cpp:14704-14745 (in place on pres) */
+void orc_precond(const orc_grid *, double *pres);
+/* PoissonSolverAMR::solve, main.cpp:14363-14616: rhs in lhs (clobbered), x0/result in pres */
+typedef struct { double tol, tol_rel; int mean_constraint; int iters; int restarts; double norm0, norm; } orc_solve_info;
+void orc_solve(const orc_grid *, double *lhs, double *pres, orc_solve_info *);
+void orc_pressure_rhs(const orc_grid *, const double *vel, const double *udef, const double *chi, double *lhs, double dt); /* 14849-14875 */
+void orc_div_pressure(const orc_grid *, const double *pres, double *tmpV);   /* 14769-14778 */
+void orc_grad_p(const orc_grid *, const double *pres, double *tmpV, double dt); /* 14990-14999 */
+/* PressureProjection::operator(), main.cpp:15061-15160 (no obstacles: chi=0, udef=0) */
+void orc_project(const orc_grid *, double *vel, double *pres, double *tmpV, double *lhs, const double *chi,
+                 double dt, int step, orc_solve_info *);
+#ifdef __cplusplus
+}
+#endif
+#endif

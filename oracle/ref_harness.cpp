@@ -18,11 +18,12 @@
  *   sfc <file>             forward/Encode/neighbour tables for every level
  *   loadg <field> <file>   fill a field from a global x-fastest array
  *                          [NZ][NY][NX][ncomp] (uniform single-level grids)
+ *   zero <field>           clear a field (chi is uninitialised memory without obstacles)
  *   dump <field> <file>    block-order dump [nb][8][8][8][ncomp] (the
  *                          reference's own memory layout per block)
  *   set step|dt|time|nu|uinfx|uinfy|uinfz|mean <value>
  *   op advdiff <dt> | lhs | precond | solve | project <dt> | maxu |
- *      steps <n> | forcing <dt>
+ *      steps <n> | forcing <dt> | rhs | divp | gradp   (the last three use `set dt`)
  *   rep <n>                repeat every following `op` n times when timing
  * Every `op` prints one line `REF <op> seconds=<t> iters=<k> value=<v>`.
  */
@@ -154,6 +155,12 @@ int main(int argc, char **argv) {
                 b[((z * 8 + y) * 8 + x) * F.ncomp + c] = g[((gz * NYc + gy) * NXc + gx) * F.ncomp + c];
               }
       }
+    } else if (cmd == "zero") {
+      /* the reference never initialises chi when there are no obstacles (posix_memalign'd
+         blocks, main.cpp:877-884): scripts zero it so that runs are deterministic */
+      std::string fname; script >> fname;
+      Field F = field_of(sd, fname);
+      for (auto &inf : *F.infos) memset(inf.block, 0, 512 * F.ncomp * 8);
     } else if (cmd == "dump") {
       std::string fname, path; script >> fname >> path;
       Field F = field_of(sd, fname);
@@ -191,6 +198,12 @@ int main(int argc, char **argv) {
         }
         else if (op == "solve") sd.pressureSolver->solve();
         else if (op == "project") { sd.dt = arg; (*proj)(arg); }
+        else if (op == "rhs") { /* the call at main.cpp:15083-15085 */
+          KernelPressureRHS K(sd, sd.dt);
+          compute<KernelPressureRHS, VectorGrid, VectorLab, VectorGrid, VectorLab, ScalarGrid>(K, *sd.vel, *sd.tmpV, true, sd.lhs);
+        }
+        else if (op == "divp") compute<ScalarLab>(KernelDivPressure(sd), sd.pres, sd.tmpV);   /* main.cpp:15088 */
+        else if (op == "gradp") compute<ScalarLab>(KernelGradP(sd, sd.dt), sd.pres, sd.tmpV); /* main.cpp:15146 */
         else if (op == "maxu") value = findMaxU(sd);
         else if (op == "forcing") { ExternalForcing f(sd); f(arg); }
         else if (op == "steps") {

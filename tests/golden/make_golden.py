@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/*.npz from the compiled, unmodified
+reference (oracle/_ref/ref_tool, built by `make -C oracle ref` from /root/reference).
+
+Run in the build container only (the GPU box has no /root/reference and uses the
+committed .npz files).  The reference runs with OMP_NUM_THREADS=1 so that its
+OpenMP reductions are sequential and the bits are reproducible.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_lib as O  # noqa: E402
+
+EXT = 2 * np.pi
+
+FIELD_CASES = [
+    # name, bpd, levelMax, levelStart, bc, seed
+    ("f16_periodic", (2, 2, 2), 1, 0, ("periodic", "periodic", "periodic"), 11),
+    ("f16_wall", (1, 1, 1), 2, 1, ("wall", "wall", "wall"), 12),
+    ("f16_mixed", (2, 2, 2), 1, 0, ("freespace", "wall", "periodic"), 13),
+    ("f24x16x8_mixed", (3, 2, 1), 1, 0, ("periodic", "freespace", "wall"), 14),
+]
+SFC_CASES = [((1, 1, 1), 4), ((2, 2, 2), 3), ((2, 1, 1), 3), ((3, 2, 1), 2), ((4, 4, 4), 1)]
+
+
+def field_case(name, bpd, lmax, lstart, bc, seed):
+    rng = np.random.default_rng(seed)
+    NX, NY, NZ = [(b << lstart) * 8 for b in bpd]
+    velg = rng.uniform(-1, 1, (NZ, NY, NX, 3))
+    presg = rng.uniform(-1, 1, (NZ, NY, NX))
+    rhsg = rng.uniform(-1, 1, (NZ, NY, NX))
+    chig = (rng.uniform(0, 1, (NZ, NY, NX)) > 0.7) * rng.uniform(0, 1, (NZ, NY, NX))
+    udefg = rng.uniform(-1, 1, (NZ, NY, NX, 3))
+    wd = O.tempfile.mkdtemp(prefix="golden_")
+    for n, a in (("vel", velg), ("pres", presg), ("rhs", rhsg), ("chi", chig), ("udef", udefg)):
+        a.tofile(os.path.join(wd, n + "_in.bin"))
+    dt, nu, uinf, step = 0.01, 0.02, (0.1, -0.2, 0.3), 5
+    script = [
+        "tables tables.bin", "zero chi",
+        "loadg vel vel_in.bin", f"set nu {nu}", f"set uinfx {uinf[0]}", f"set uinfy {uinf[1]}", f"set uinfz {uinf[2]}",
+        "op maxu",
+        f"op advdiff {dt}", "dump vel ad_vel.bin", "dump tmpV ad_tmpV.bin",
+        "loadg pres pres_in.bin", "op lhs", "dump lhs lhs.bin",
+        "set mean 2", "loadg pres pres_in.bin", "op lhs", "dump lhs lhs_mean2.bin",
+        "set mean 0", "loadg pres pres_in.bin", "op lhs", "dump lhs lhs_mean0.bin", "set mean 1",
+        "loadg pres pres_in.bin", "op precond", "dump pres precond.bin",
+        "loadg lhs rhs_in.bin", "loadg pres pres_in.bin", "op solve", "dump pres solve.bin",
+        # pressure RHS with a non-trivial chi / udef (tmpV holds udef, main.cpp:15081-15085)
+        f"set dt {dt}", "loadg vel vel_in.bin", "loadg tmpV udef_in.bin", "loadg chi chi_in.bin", "op rhs", "dump lhs rhs.bin",
+        "zero chi", "loadg pres pres_in.bin", "op divp", "dump tmpV divp.bin", "op gradp", "dump tmpV gradp.bin",
+        "loadg vel vel_in.bin", "loadg pres pres_in.bin", f"set step {step}", f"op project {dt}",
+        "dump vel pr_vel.bin", "dump pres pr_pres.bin",
+        "loadg vel vel_in.bin", "loadg pres pres_in.bin", "set step 1", f"op project {dt}",
+        "dump vel pr1_vel.bin", "dump pres pr1_pres.bin",
+    ]
+    recs, wd = O.run_ref(script, O.ref_args(bpd, lmax, lstart, EXT, bc), threads=1, workdir=wd)
+    t, geom = O.read_tables(os.path.join(wd, "tables.bin"))
+    nb = t.shape[0]
+    rb = lambda f, nc: O.read_blocks(os.path.join(wd, f), nb, nc)  # noqa: E731
+    iters = {r["op"] + str(i): int(r["iters"]) for i, r in enumerate(recs)}
+    solve_iters = [int(r["iters"]) for r in recs if r["op"] == "solve"]
+    proj_iters = [int(r["iters"]) for r in recs if r["op"] == "project"]
+    out = dict(
+        bpd=np.array(bpd), level_max=lmax, level=lstart, bc=np.array([O.BC[b] for b in bc]), extent=EXT,
+        dt=dt, nu=nu, uinf=np.array(uinf), step=step,
+        tables=t, geom=geom, vel_in=velg, pres_in=presg, rhs_in=rhsg, chi_in=chig, udef_in=udefg,
+        maxu=[r for r in recs if r["op"] == "maxu"][0]["value"],
+        ad_vel=rb("ad_vel.bin", 3), ad_tmpV=rb("ad_tmpV.bin", 3),
+        lhs=rb("lhs.bin", 1), lhs_mean2=rb("lhs_mean2.bin", 1), lhs_mean0=rb("lhs_mean0.bin", 1),
+        precond=rb("precond.bin", 1), solve=rb("solve.bin", 1), solve_iters=solve_iters[0],
+        rhs=rb("rhs.bin", 1), divp=rb("divp.bin", 3)[..., 0].copy(), gradp=rb("gradp.bin", 3),
+        pr_vel=rb("pr_vel.bin", 3), pr_pres=rb("pr_pres.bin", 1), pr_iters=proj_iters[0],
+        pr1_vel=rb("pr1_vel.bin", 3), pr1_pres=rb("pr1_pres.bin", 1), pr1_iters=proj_iters[1],
+    )
+    del iters
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "blocks", nb, "solve iters", solve_iters, "project iters", proj_iters)
+
+
+def traj_case():
+    """Full reference time stepping (calcMaxTimestep + advance) from the Taylor-Green IC."""
+    bpd, lmax, lstart, bc = (2, 2, 2), 1, 0, ("periodic", "periodic", "periodic")
+    nsteps = 6
+    script = ["tables tables.bin", "zero chi", "dump vel v0.bin"]
+    for n in range(nsteps):
+        script += ["op steps 1", f"dump vel v{n + 1}.bin", f"dump pres p{n + 1}.bin"]
+    recs, wd = O.run_ref(script, O.ref_args(bpd, lmax, lstart, EXT, bc, nu=0.01, cfl=0.3, extra=["-rampup", "4"]), threads=1)
+    t, geom = O.read_tables(os.path.join(wd, "tables.bin"))
+    nb = t.shape[0]
+    out = dict(bpd=np.array(bpd), level_max=lmax, level=lstart, bc=np.array([O.BC[b] for b in bc]), extent=EXT,
+               nu=0.01, cfl=0.3, rampup=4, umax_forced=1.0, tables=t,
+               dts=np.array([r["value"] for r in recs]), iters=np.array([int(r["iters"]) for r in recs]),
+               vel=np.stack([O.read_blocks(os.path.join(wd, f"v{n}.bin"), nb, 3) for n in range(nsteps + 1)]),
+               pres=np.stack([O.read_blocks(os.path.join(wd, f"p{n + 1}.bin"), nb, 1) for n in range(nsteps)]))
+    np.savez_compressed(os.path.join(HERE, "traj16_tgv.npz"), **out)
+    print("traj16_tgv dts", out["dts"], "iters", out["iters"])
+
+
+def sfc_cases():
+    out = {}
+    for bpd, lmax in SFC_CASES:
+        recs, wd = O.run_ref(["sfc sfc.bin"], O.ref_args(bpd, lmax, lmax - 1, EXT, ("periodic",) * 3), threads=1)
+        a = np.fromfile(os.path.join(wd, "sfc.bin"), dtype=np.int64).reshape(-1, 38)
+        out["sfc_%d_%d_%d_L%d" % (bpd + (lmax,))] = a
+    np.savez_compressed(os.path.join(HERE, "sfc_tables.npz"), **out)
+    print("sfc tables:", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    if not O.have_ref_tool():
+        sys.exit("oracle/_ref/ref_tool missing: run `make -C oracle ref` where /root/reference exists")
+    sfc_cases()
+    for c in FIELD_CASES:
+        field_case(*c)
+    traj_case()

@@ -1,0 +1,225 @@
+"""ctypes binding of the CPU oracle (oracle/libcup3d_oracle.so) and a driver for the
+compiled reference (oracle/_ref/ref_tool).  TEST INFRASTRUCTURE: imported only by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+
+Field layout everywhere in this module = the reference's block memory:
+scalar [nb,8,8,8] (z,y,x), vector [nb,8,8,8,3]; block order = reference m_vInfo order.
+"""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libcup3d_oracle.so")
+REF_TOOL = os.path.join(ORACLE_DIR, "_ref", "ref_tool")
+
+BC = {"freespace": 0, "periodic": 1, "wall": 2}
+BC_NAMES = {v: k for k, v in BC.items()}
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_lp = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+class SolveInfo(C.Structure):
+    _fields_ = [("tol", C.c_double), ("tol_rel", C.c_double), ("mean_constraint", C.c_int),
+                ("iters", C.c_int), ("restarts", C.c_int), ("norm0", C.c_double), ("norm", C.c_double)]
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libcup3d_oracle.so"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(ORACLE_SO):
+        build_oracle()
+    L = C.CDLL(ORACLE_SO)
+    vp = C.c_void_p
+    L.orc_sfc_create.restype = vp
+    L.orc_sfc_create.argtypes = [C.c_int] * 4
+    L.orc_sfc_destroy.argtypes = [vp]
+    L.orc_sfc_forward.restype = C.c_longlong
+    L.orc_sfc_forward.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_sfc_inverse.argtypes = [vp, C.c_longlong, C.c_int, _ip]
+    L.orc_sfc_encode.restype = C.c_longlong
+    L.orc_sfc_encode.argtypes = [vp, C.c_int, _ip]
+    L.orc_info_tables.argtypes = [vp, _ip, C.c_int, _ip, _lp, _lp, _lp]
+    L.orc_grid_create.restype = vp
+    L.orc_grid_create.argtypes = [C.c_int] * 5 + [C.c_double, _ip]
+    L.orc_grid_destroy.argtypes = [vp]
+    L.orc_grid_nblocks.restype = C.c_long
+    L.orc_grid_nblocks.argtypes = [vp]
+    L.orc_grid_h.restype = C.c_double
+    L.orc_grid_h.argtypes = [vp]
+    L.orc_grid_tables.argtypes = [vp, _lp, _dp]
+    L.orc_partition.argtypes = [C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    L.orc_ic_taylor_green.argtypes = [vp, _dp, _dp, C.c_double]
+    L.orc_max_u.restype = C.c_double
+    L.orc_max_u.argtypes = [vp, _dp, _dp]
+    L.orc_calc_dt.restype = C.c_double
+    L.orc_calc_dt.argtypes = [C.c_double] * 4 + [C.c_int, C.c_int, C.c_double, _dp]
+    L.orc_external_forcing.argtypes = [vp, _dp] + [C.c_double] * 4
+    L.orc_advect_diffuse.argtypes = [vp, _dp, _dp, C.c_double, C.c_double, _dp]
+    L.orc_advdiff_stage_rhs.argtypes = [vp, _dp, _dp, C.c_double, C.c_double, _dp]
+    L.orc_lhs.argtypes = [vp, _dp, _dp, C.c_int]
+    L.orc_precond.argtypes = [vp, _dp]
+    L.orc_solve.argtypes = [vp, _dp, _dp, C.POINTER(SolveInfo)]
+    L.orc_pressure_rhs.argtypes = [vp, _dp, _dp, _dp, _dp, C.c_double]
+    L.orc_div_pressure.argtypes = [vp, _dp, _dp]
+    L.orc_grad_p.argtypes = [vp, _dp, _dp, C.c_double]
+    L.orc_project.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.POINTER(SolveInfo)]
+    _lib = L
+    return L
+
+
+class OracleGrid:
+    """Uniform single-level block grid in the reference's block order."""
+
+    def __init__(self, bpd, level_max, level, maxextent, bc):
+        self.bpd = tuple(int(b) for b in bpd)
+        self.level_max, self.level, self.maxextent = int(level_max), int(level), float(maxextent)
+        self.bc = tuple(BC[b] if isinstance(b, str) else int(b) for b in bc)
+        self._bc = np.array(self.bc, dtype=np.int32)
+        self.g = lib().orc_grid_create(*self.bpd, self.level_max, self.level, self.maxextent, self._bc)
+        self.nb = lib().orc_grid_nblocks(self.g)
+        self.h = lib().orc_grid_h(self.g)
+        t = np.zeros((self.nb, 6), dtype=np.int64)
+        geom = np.zeros((self.nb, 4), dtype=np.float64)
+        lib().orc_grid_tables(self.g, t, geom)
+        self.tables, self.geom = t, geom
+        self.index = t[:, 2:5].copy()
+        self.ncell = tuple((b << self.level) * 8 for b in self.bpd)  # (NX, NY, NZ)
+
+    def __del__(self):
+        try:
+            lib().orc_grid_destroy(self.g)
+        except Exception:
+            pass
+
+    # ---- layout helpers: global [NZ,NY,NX(,3)] <-> block order ----
+    def to_blocks(self, glob):
+        glob = np.asarray(glob, dtype=np.float64)
+        nc = glob.shape[3:]
+        out = np.empty((self.nb, 8, 8, 8) + nc)
+        for s, (i, j, k) in enumerate(self.index):
+            out[s] = glob[8 * k:8 * k + 8, 8 * j:8 * j + 8, 8 * i:8 * i + 8]
+        return np.ascontiguousarray(out)
+
+    def to_global(self, blocks):
+        nc = blocks.shape[4:]
+        NX, NY, NZ = self.ncell
+        out = np.empty((NZ, NY, NX) + nc)
+        for s, (i, j, k) in enumerate(self.index):
+            out[8 * k:8 * k + 8, 8 * j:8 * j + 8, 8 * i:8 * i + 8] = blocks[s]
+        return out
+
+    # ---- operators (all in place on contiguous float64 arrays) ----
+    def taylor_green(self, ext, umax):
+        v = np.zeros((self.nb, 8, 8, 8, 3))
+        lib().orc_ic_taylor_green(self.g, v, np.asarray(ext, dtype=np.float64), umax)
+        return v
+
+    def max_u(self, vel, uinf=(0, 0, 0)):
+        return lib().orc_max_u(self.g, vel, np.asarray(uinf, dtype=np.float64))
+
+    def advect_diffuse(self, vel, tmpV, dt, nu, uinf=(0, 0, 0)):
+        lib().orc_advect_diffuse(self.g, vel, tmpV, dt, nu, np.asarray(uinf, dtype=np.float64))
+
+    def advdiff_stage_rhs(self, vel, tmpV, dt, nu, uinf=(0, 0, 0)):
+        lib().orc_advdiff_stage_rhs(self.g, vel, tmpV, dt, nu, np.asarray(uinf, dtype=np.float64))
+
+    def lhs(self, pres, mean_constraint=1):
+        out = np.zeros_like(pres)
+        lib().orc_lhs(self.g, pres, out, mean_constraint)
+        return out
+
+    def precond(self, pres):
+        lib().orc_precond(self.g, pres)
+
+    def solve(self, lhs, pres, tol=1e-6, tol_rel=1e-4, mean_constraint=1):
+        info = SolveInfo(tol, tol_rel, mean_constraint, 0, 0, 0.0, 0.0)
+        lib().orc_solve(self.g, lhs, pres, C.byref(info))
+        return info
+
+    def pressure_rhs(self, vel, udef, chi, dt):
+        out = np.zeros(vel.shape[:4])
+        lib().orc_pressure_rhs(self.g, vel, udef, chi, out, dt)
+        return out
+
+    def div_pressure(self, pres):
+        out = np.zeros(pres.shape + (3,))
+        lib().orc_div_pressure(self.g, pres, out)
+        return out
+
+    def grad_p(self, pres, dt):
+        out = np.zeros(pres.shape + (3,))
+        lib().orc_grad_p(self.g, pres, out, dt)
+        return out
+
+    def project(self, vel, pres, dt, step, tol=1e-6, tol_rel=1e-4, mean_constraint=1, chi=None):
+        tmpV = np.zeros_like(vel)
+        lhs = np.zeros_like(pres)
+        chi = np.zeros_like(pres) if chi is None else chi
+        info = SolveInfo(tol, tol_rel, mean_constraint, 0, 0, 0.0, 0.0)
+        lib().orc_project(self.g, vel, pres, tmpV, lhs, chi, dt, step, C.byref(info))
+        return info, tmpV, lhs
+
+
+# ------------------------------ compiled reference ------------------------------
+def have_ref_tool():
+    return os.path.exists(REF_TOOL) and os.access(REF_TOOL, os.X_OK)
+
+
+def ref_args(bpd, level_max, level_start, extent, bc, nu=0.01, cfl=0.3, ic="taylorGreen", umax_forced=1.0,
+             extra=()):
+    a = ["-bpdx", bpd[0], "-bpdy", bpd[1], "-bpdz", bpd[2], "-levelMax", level_max, "-levelStart", level_start,
+         "-extentx", repr(float(extent)), "-CFL", cfl, "-nu", nu, "-initCond", ic, "-uMax_forced", umax_forced,
+         "-BC_x", BC_NAMES[BC[bc[0]]] if isinstance(bc[0], str) else BC_NAMES[bc[0]],
+         "-BC_y", BC_NAMES[BC[bc[1]]] if isinstance(bc[1], str) else BC_NAMES[bc[1]],
+         "-BC_z", BC_NAMES[BC[bc[2]]] if isinstance(bc[2], str) else BC_NAMES[bc[2]],
+         "-Rtol", "1e9", "-Ctol", "0", "-factory", ""]
+    return [str(x) for x in a] + [str(x) for x in extra]
+
+
+def run_ref(script_lines, args, threads=1, workdir=None, timeout=3600):
+    """Run oracle/_ref/ref_tool; returns (stdout REF records, workdir)."""
+    wd = workdir or tempfile.mkdtemp(prefix="cup3d_ref_")
+    with open(os.path.join(wd, "script.txt"), "w") as f:
+        f.write("\n".join(script_lines) + "\n")
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+    out = subprocess.run([REF_TOOL, "script.txt", "--"] + list(args), cwd=wd, env=env, check=True,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout).stdout.decode()
+    recs = []
+    for line in out.splitlines():
+        if line.startswith("REF "):
+            p = line.split()
+            d = {"op": p[1]}
+            for kv in p[2:]:
+                k, v = kv.split("=")
+                d[k] = float(v)
+            recs.append(d)
+    return recs, wd
+
+
+def read_blocks(path, nb, ncomp):
+    a = np.fromfile(path, dtype=np.float64)
+    shape = (nb, 8, 8, 8, 3) if ncomp == 3 else (nb, 8, 8, 8)
+    return a.reshape(shape)
+
+
+def read_tables(path):
+    raw = np.fromfile(path, dtype=np.uint8)
+    nb = raw.size // (6 * 8 + 4 * 8)
+    t = raw[:nb * 48].view(np.int64).reshape(nb, 6)
+    g = raw[nb * 48:].view(np.float64).reshape(nb, 4)
+    return t, g

@@ -1,0 +1,52 @@
+"""Pins the oracle restatement against the compiled, unmodified reference
+(oracle/_ref/ref_tool) on fresh seeded inputs.  Skipped where the reference binary
+is absent (it is built from /root/reference by `make -C oracle ref`)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.skipif(not O.have_ref_tool(), reason="oracle/_ref/ref_tool not built")
+
+CASES = [
+    ((4, 4, 4), 1, 0, ("periodic", "periodic", "periodic"), 21),
+    ((1, 1, 1), 3, 2, ("wall", "wall", "wall"), 22),
+    ((2, 1, 1), 2, 1, ("periodic", "wall", "freespace"), 23),
+    ((1, 2, 3), 2, 1, ("freespace", "freespace", "freespace"), 24),
+]
+
+
+@pytest.mark.parametrize("bpd,lmax,lstart,bc,seed", CASES)
+def test_all_ops_bit_exact(bpd, lmax, lstart, bc, seed):
+    rng = np.random.default_rng(seed)
+    ext = 2 * np.pi
+    g = O.OracleGrid(bpd, lmax, lstart, ext, bc)
+    NX, NY, NZ = g.ncell
+    velg, presg = rng.uniform(-1, 1, (NZ, NY, NX, 3)), rng.uniform(-1, 1, (NZ, NY, NX))
+    wd = O.tempfile.mkdtemp(prefix="pin_")
+    velg.tofile(os.path.join(wd, "vel_in.bin"))
+    presg.tofile(os.path.join(wd, "pres_in.bin"))
+    dt, nu, uinf = 0.02, 0.005, (0.3, 0.0, -0.1)
+    script = ["tables tables.bin", "zero chi", "loadg vel vel_in.bin", f"set nu {nu}",
+              f"set uinfx {uinf[0]}", f"set uinfy {uinf[1]}", f"set uinfz {uinf[2]}",
+              f"op advdiff {dt}", "dump vel ad.bin",
+              "loadg pres pres_in.bin", "op precond", "dump pres z.bin",
+              "loadg vel vel_in.bin", "loadg pres pres_in.bin", "set step 7", f"op project {dt}",
+              "dump vel prv.bin", "dump pres prp.bin"]
+    recs, wd = O.run_ref(script, O.ref_args(bpd, lmax, lstart, ext, bc), threads=1, workdir=wd)
+    t, geom = O.read_tables(os.path.join(wd, "tables.bin"))
+    assert np.array_equal(t, g.tables) and np.array_equal(geom, g.geom)
+    vel, pres = g.to_blocks(velg), g.to_blocks(presg)
+    v, tv = vel.copy(), np.zeros_like(vel)
+    g.advect_diffuse(v, tv, dt, nu, uinf)
+    assert np.array_equal(v, O.read_blocks(os.path.join(wd, "ad.bin"), g.nb, 3))
+    p = pres.copy()
+    g.precond(p)
+    assert np.array_equal(p, O.read_blocks(os.path.join(wd, "z.bin"), g.nb, 1))
+    v, p = vel.copy(), pres.copy()
+    info, _, _ = g.project(v, p, dt, 7)
+    assert info.iters == int([r for r in recs if r["op"] == "project"][0]["iters"])
+    assert np.array_equal(v, O.read_blocks(os.path.join(wd, "prv.bin"), g.nb, 3))
+    assert np.array_equal(p, O.read_blocks(os.path.join(wd, "prp.bin"), g.nb, 1))
