@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py — whole-step throughput of the hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one reference time step of the hot path on a synthetic uniform grid:
+calcMaxTimestep (findMaxU) + AdvectionDiffusion (fused RK3) + ExternalForcing +
+PressureProjection (pressure RHS, pipelined BiCGSTAB with block-CG preconditioner,
+mean removal, gradient update) — main.cpp:15254-15326 with the obstacle-free pipeline of
+15229-15246.  Workload (BASELINE.json configs[2] as far as the reference can express it,
+SURVEY §0 F3): Taylor-Green initial condition on an all-`wall` box, 2*pi extent, nu=0.01,
+CFL 0.3, -rampup 0, default Poisson tolerances, steps numbered from 21 (2nd-order pressure
+path, no adaptMesh step).  Fields are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0): metric Mcell-updates/s = cells * steps / seconds over all
+ranks (strong scaling: the grid is fixed, blocks are sharded by Hilbert ranges), plus
+`roofline` (dominant kernel by device time, algorithmic bytes / measured kernel time vs
+8 TB/s) and `cpu_baseline` (the compiled reference on this host's cores, bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# algorithmic HBM bytes per cell per launch, SURVEY.md §8(d)
+ALGO_BYTES = {
+    "advdiff_stage": 96.0,     # vel 24 in + tmpV 24 in + vel' 24 out + tmpV 24 out
+    "bicgstab_loop1": 144.0,   # 11 reads + 7 writes
+    "bicgstab_loop2": 128.0,   # 12 reads + 4 writes
+    "poisson_lhs": 16.0,       # p in, Ap out
+    "poisson_block_cg": 16.0,  # r in, z out (FP64-VALU bound, shown against HBM for reference)
+}
+
+
+def taylor_green_blocks(grid, ext, umax):
+    """KernelIC_taylorGreen (main.cpp:12516-12539) for this rank's blocks, block order."""
+    h = grid.h
+    idx = grid.index.astype(np.float64)
+    cell = np.arange(8) + 0.5
+    px = idx[:, 0:1] * 8 * h + h * cell[None, :]
+    py = idx[:, 1:2] * 8 * h + h * cell[None, :]
+    pz = idx[:, 2:3] * 8 * h + h * cell[None, :]
+    a, b, c = 2 * np.pi / ext[0], 2 * np.pi / ext[1], 2 * np.pi / ext[2]
+    A, B = umax, -umax * ext[1] / ext[0]
+    vel = np.zeros((grid.nblocks, 8, 8, 8, 3))
+    sz = np.sin(c * pz)[:, :, None, None]
+    vel[..., 0] = (A * np.cos(a * px))[:, None, None, :] * np.sin(b * py)[:, None, :, None] * sz
+    vel[..., 1] = (B * np.sin(a * px))[:, None, None, :] * np.cos(b * py)[:, None, :, None] * sz
+    return vel
+
+
+def cpu_baseline(size_cpu, steps, threads):
+    """Time the compiled reference (oracle/_ref/ref_tool = unmodified main.cpp) on the host."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    level = int(np.log2(size_cpu // 8))
+    if O.have_ref_tool():
+        args = O.ref_args((1, 1, 1), level + 1, level, 2 * np.pi, ("wall",) * 3, nu=0.01, cfl=0.3, extra=["-rampup", "0"])
+        try:
+            recs, _ = O.run_ref(["zero chi", "set step 21", "rep 1", f"op steps {steps}"], args, threads=threads, timeout=1200)
+            sec = [r for r in recs if r["op"] == "steps"][0]["seconds"]
+            its = [r for r in recs if r["op"] == "steps"][0]["iters"]
+            return {"value": size_cpu ** 3 * steps / sec / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "reference",
+                    "sample": f"reference main.cpp operators, {size_cpu}^3 all-wall TGV, {steps} steps from step 21, "
+                              f"{sec:.2f} s, {its / steps:.1f} BiCGSTAB its/step"}
+        except Exception as e:  # fall through to the port
+            sys.stderr.write(f"bench: ref_tool failed ({e}); timing the oracle port instead\n")
+    g = O.OracleGrid((1, 1, 1), level + 1, level, 2 * np.pi, ("wall",) * 3)
+    vel = g.taylor_green([2 * np.pi] * 3, 1.0)
+    pres = np.zeros((g.nb, 8, 8, 8))
+    coef = np.array([1.5, -2.0, 0.5])
+    dt, t0, its = 0.0, time.time(), 0
+    for n in range(steps):
+        dt = O.lib().orc_calc_dt(g.h, g.max_u(vel), 0.01, 0.3, 21 + n, 0, dt, coef)
+        g.advect_diffuse(vel, np.zeros_like(vel), dt, 0.01)
+        O.lib().orc_external_forcing(g.g, vel, 1.0, 0.01, 2 * np.pi, dt)
+        info, _, _ = g.project(vel, pres, dt, 21 + n)
+        its += info.iters
+    sec = time.time() - t0
+    return {"value": size_cpu ** 3 * steps / sec / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "port",
+            "sample": f"oracle C port (block loops OpenMP, reductions serial), {size_cpu}^3 all-wall TGV, {steps} steps, "
+                      f"{sec:.2f} s, {its / steps:.1f} BiCGSTAB its/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=512, help="cells per side (power of two >= 16)")
+    ap.add_argument("--cpu-size", type=int, default=128)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--stencil-only", action="store_true", help="BASELINE configs[1]: periodic, advect-diffuse only")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        a.gpus = world
+
+    import torch
+    import cup3d_amd as cu
+    from cup3d_amd.capi import ProfileEntry, check, lib
+
+    torch.cuda.set_device(local_rank)
+    cu.device_init(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # bootstrap the library's own RCCL communicator with rank 0's unique id
+        idbuf = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            raw = (C.c_ubyte * 128)()
+            check(lib().cup3d_comm_unique_id(raw))
+            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+        idbuf = idbuf.cuda()
+        dist.broadcast(idbuf, 0)
+        raw = (C.c_ubyte * 128)(*idbuf.cpu().tolist())
+        check(lib().cup3d_comm_init(rank, world, raw))
+
+    level = int(round(np.log2(a.size // 8)))
+    assert 8 << level == a.size, "--size must be 8 * 2^k"
+    ext = 2 * np.pi
+    bc = "periodic" if a.stencil_only else "wall"
+    sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=level + 1, levelStart=level, extent=ext, nu=0.01, CFL=0.3,
+                            BC_x=bc, BC_y=bc, BC_z=bc, uMax_forced=1.0, rampup=0, rank=rank, nranks=world)
+    sim.upload("vel", taylor_green_blocks(sim.grid, [ext] * 3, 1.0))
+    sim.step = 21
+    S = cu.Simulation(sim)
+    adv = cu.AdvectionDiffusion(sim)
+    iters = []
+
+    def one_step():
+        dt = S.calcMaxTimestep()
+        if a.stencil_only:
+            adv(dt)
+            sim.step += 1
+        else:
+            S.advance(dt)
+            iters.append(sim.last_poisson.iterations)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_step()
+    iters.clear()
+    lib().cup3d_profile_enable(1)
+    lib().cup3d_profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    fence()
+    sec = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([sec], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sec = float(t.item())
+    ents = (ProfileEntry * 64)()
+    n = C.c_int(0)
+    lib().cup3d_profile_read(ents, 64, C.byref(n))
+    lib().cup3d_profile_enable(0)
+    prof = {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n.value)}
+
+    if rank == 0:
+        report(a, sim, prof, sec, iters, world)
+    if dist is not None:
+        lib().cup3d_comm_finalize()
+        dist.destroy_process_group()
+
+
+def report(a, sim, prof, sec, iters, world):
+    cells = float(a.size) ** 3
+    cells_local = sim.nblocks * 512.0
+    value = cells * a.steps / sec / 1e6
+    kernels = []
+    total_ms = sum(ms for _, ms in prof.values()) or 1.0
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    traffic = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
+    for name, (launches, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+        if launches == 0:
+            continue
+        avg_ms = ms / launches
+        e = {"kernel": name, "launches": launches, "avg_ms": round(avg_ms, 5), "share": round(ms / total_ms, 4)}
+        if name in ALGO_BYTES:
+            ach = ALGO_BYTES[name] * cells_local / (avg_ms * 1e-3) / 1e9
+            e.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(f"{name}@{a.size}")})
+        kernels.append(e)
+    with_roof = [k for k in kernels if "achieved" in k]
+    dominant = with_roof[0] if with_roof else None
+    out = {
+        "metric": "Mcell-updates/s (advect+diffuse+Poisson), 512^3 uniform, 1/2/4/8 GPUs" if not a.stencil_only
+        else "Mcell-updates/s (advect+diffuse only), uniform periodic",
+        "value": round(value, 2), "unit": "Mcell-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(sec / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": (f"taylor-green {a.size}^3 uniform, all-wall box (reference has no lid BC), nu=0.01, CFL=0.3, rampup=0, "
+                                f"poissonTol 1e-6/1e-4, bMeanConstraint 1, steps from 21") if not a.stencil_only
+                   else f"taylor-green {a.size}^3 uniform periodic, advect-diffuse RK3 only",
+                   "cells": int(cells), "blocks": int(cells // 512), "block": "8^3", "partition": f"hilbert-range x{world}",
+                   "bicgstab_iters_per_step": round(float(np.mean(iters)), 2) if iters else None},
+        "roofline": ({k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]})
+        if dominant else None,
+        "kernels": kernels,
+    }
+    if not a.no_cpu and world == 1:
+        out["cpu_baseline"] = cpu_baseline(a.cpu_size, a.cpu_steps, os.cpu_count() or 1)
+    print(json.dumps(out))
+    sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,249 @@
+// Fused advection-diffusion Runge-Kutta stage.
+//
+// Replaces, per RK stage, compute<VectorLab>(KernelAdvectDiffuse, vel, tmpV)
+// (main.cpp:9708 -> 5584-5644 -> BlockLab::load 3623-3743 -> kernel 9484-9549) AND the
+// pointwise update loop that follows it (9709-9725) with ONE launch:
+//   tmpV' = tmpV + facA*(u.grad)u + facD*lap(u) ;  vel' = vel + tmpV'*alpha/h^3 ;  tmpV = tmpV'*beta
+// One 256-thread workgroup per 8^3 block (2 cells per thread).  The ghosted tile is
+// assembled in LDS straight from the six face neighbours' slots (or the RCCL halo
+// slabs, or the boundary condition) -- only the star-shaped part the stencil reads:
+// centre 8^3 + six 3-deep face slabs = 1664 cells x 3 components (the reference copies
+// the full 14^3 cube).  Arithmetic keeps the reference's association and is compiled
+// with -ffp-contract=off, so the result is bit-identical to the CPU reference.
+//
+// Algorithmic HBM traffic: 96 B/cell/stage (vel 24 in, tmpV 24 in, vel' 24 out,
+// tmpV 24 out); stage 1 skips the tmpV read (tmpV is 0 there).  FP64, no MFMA: pure
+// stencil, bandwidth-bound once the ~300 FP64 VALU ops per cell are overlapped.
+#include "sim.hpp"
+#include "tile.hpp"
+
+namespace cup3d {
+
+constexpr int kXYPitch = 14;                    // x and y extended by the 3-deep ghosts
+constexpr int kXYSize = 8 * 14 * 14;            // centre + x/y ghosts: [z 8][y 14][x 14]
+constexpr int kZGSize = 6 * 64;                 // z ghost planes: [-1,-2,-3, 8,9,10][y][x]
+constexpr int kCompStride = kXYSize + kZGSize;  // 1952 doubles per component
+
+struct AdvArgs {
+  const double *vel;   // [nb][3][512] in
+  double *vel_out;     // [nb][3][512] out (double buffer: neighbours still read `vel`)
+  double *tmp;         // [nb][3][512] in/out
+  const double *halo;  // remote face slabs [(e*3+c)*3+gl][64]
+  double dt, nu, u0, u1, u2;
+  double alpha, beta;  // Williamson RK3 coefficients, main.cpp:9700-9701
+};
+
+// KernelAdvectDiffuse::derivative (main.cpp:9474-9483).  The U<=0 branch is the exact
+// negation of the U>0 polynomial on mirrored inputs (round-to-nearest is symmetric
+// under negation at every step), so one polynomial and one division serve both.
+__device__ __forceinline__ double upwind5(bool pos, double m3, double m2, double m1, double c, double p1, double p2, double p3) {
+  const double a = pos ? m3 : p3, b = pos ? m2 : p2, d = pos ? m1 : p1, e = pos ? p1 : m1, f = pos ? p2 : m2;
+  const double q = (-2 * a + 15 * b - 60 * d + 20 * c + 30 * e - 3 * f) / 60.;
+  return pos ? q : -q;
+}
+
+// Decode element e (0..191) of the 3-deep slab behind face f into: the cell of the
+// same-level neighbour that holds it, the own face cell used by boundary conditions,
+// its LDS position and its position inside a packed halo slab (3 layers x 64).
+__device__ __forceinline__ void face_element(int f, int e, int &nb_cell, int &own_cell, int &lds, int &halo) {
+  const int d = f >> 1, side = f & 1;
+  if (d == 2) {
+    const int gl = e >> 6, a = e & 63;
+    nb_cell = (side ? gl : 7 - gl) * 64 + a;
+    own_cell = (side ? 7 : 0) * 64 + a;
+    lds = kXYSize + (side * 3 + gl) * 64 + a;
+    halo = gl * 64 + a;
+  } else if (d == 1) {
+    const int z = e / 24, r = e - 24 * z, gr = r >> 3, x = r & 7;
+    const int ys = side ? gr : 5 + gr, yg = side ? 8 + gr : gr - 3, gl = side ? gr : 2 - gr;
+    nb_cell = z * 64 + ys * 8 + x;
+    own_cell = z * 64 + (side ? 7 : 0) * 8 + x;
+    lds = (z * kXYPitch + (yg + 3)) * kXYPitch + (x + 3);
+    halo = gl * 64 + z * 8 + x;
+  } else {
+    const int row = e / 3, xx = e - 3 * row, z = row >> 3, y = row & 7;
+    const int xs = side ? xx : 5 + xx, xg = side ? 8 + xx : xx - 3, gl = side ? xx : 2 - xx;
+    nb_cell = row * 8 + xs;
+    own_cell = row * 8 + (side ? 7 : 0);
+    lds = (z * kXYPitch + (y + 3)) * kXYPitch + (xg + 3);
+    halo = gl * 64 + z * 8 + y;
+  }
+}
+
+template <bool FIRST_STAGE>
+__global__ void __launch_bounds__(256) k_advdiff(GridDev g, AdvArgs a) {
+  __shared__ double tile[3 * kCompStride];  // 46,848 B -> 3 workgroups per CU
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const double *__restrict__ own = a.vel + (size_t)slot * 1536;
+
+  // ---- stage the tile: centre (each thread's own two cells stay in registers too)
+  const int x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;  // cells (x,y,z0) and (x,y,z0+4)
+  double uc[2][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    uc[0][c] = own[c * 512 + t];
+    uc[1][c] = own[c * 512 + 256 + t];
+  }
+  double told[2][3];
+  if (!FIRST_STAGE) {
+    const double *__restrict__ tp = a.tmp + (size_t)slot * 1536;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      told[0][c] = tp[c * 512 + t];
+      told[1][c] = tp[c * 512 + 256 + t];
+    }
+  }
+  const int xy = (y + 3) * kXYPitch + (x + 3);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    tile[c * kCompStride + z0 * 196 + xy] = uc[0][c];
+    tile[c * kCompStride + (z0 + 4) * 196 + xy] = uc[1][c];
+  }
+  // ---- ghosts: 18 (face, component) units of 192 values, dealt round-robin to the 4 waves
+  for (int u = wave; u < 18; u += 4) {
+    const int f = u / 3, c = u - 3 * f;
+    const int n = g.nbr[slot * 6 + f];  // wave-uniform
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      int nb_cell, own_cell, lds, hal;
+      face_element(f, j * 64 + lane, nb_cell, own_cell, lds, hal);
+      double v;
+      if (n >= kNbrHalo) {
+        v = a.halo[((size_t)(n - kNbrHalo) * 3 + c) * 192 + hal];
+      } else if (n >= 0) {
+        v = a.vel[(size_t)n * 1536 + c * 512 + nb_cell];
+      } else {
+        // domain face: BlockLabBC, main.cpp:6513-6551.  wall (n == -3): every component
+        // negated (6384-6394); freespace (n == -1): copy, normal component negated (6137-6153)
+        v = own[c * 512 + own_cell];
+        if (n == -3 || c == (f >> 1)) v = -v;
+      }
+      tile[c * kCompStride + lds] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- compute
+  const double h = g.h, h3 = h * h * h;
+  const double facA = -a.dt / h * h3 * 1.0;                 // main.cpp:9487 (coef = 1)
+  const double facD = (a.nu / h) * (a.dt / h) * h3 * 1.0;   // main.cpp:9488
+  double *__restrict__ vout = a.vel_out + (size_t)slot * 1536;
+  double *__restrict__ tout = a.tmp + (size_t)slot * 1536;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int z = z0 + 4 * k;
+    int zo[7];
+#pragma unroll
+    for (int dz = -3; dz <= 3; ++dz) {
+      const int zz = z + dz;
+      zo[dz + 3] = (zz >= 0 && zz < 8) ? zz * 196 + xy : kXYSize + (zz < 0 ? -1 - zz : zz - 5) * 64 + y * 8 + x;
+    }
+    const int b = z * 196 + xy;
+    const double ua0 = uc[k][0] + a.u0, ua1 = uc[k][1] + a.u1, ua2 = uc[k][2] + a.u2;  // uAbs, 9492-9494
+    const bool p0 = ua0 > 0, p1 = ua1 > 0, p2 = ua2 > 0;
+    double res[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double *L = tile + c * kCompStride;
+      const double cc = uc[k][c];
+      const double xm1 = L[b - 1], xp1 = L[b + 1], ym1 = L[b - kXYPitch], yp1 = L[b + kXYPitch], zm1 = L[zo[2]], zp1 = L[zo[4]];
+      const double dx = upwind5(p0, L[b - 3], L[b - 2], xm1, cc, xp1, L[b + 2], L[b + 3]);
+      const double dy = upwind5(p1, L[b - 3 * kXYPitch], L[b - 2 * kXYPitch], ym1, cc, yp1, L[b + 2 * kXYPitch], L[b + 3 * kXYPitch]);
+      const double dz = upwind5(p2, L[zo[0]], L[zo[1]], zm1, cc, zp1, L[zo[5]], L[zo[6]]);
+      const double sx = xp1 + xm1, sy = yp1 + ym1, sz = zp1 + zm1;
+      double lap, adv;  // the three components use three association orders, main.cpp:9531-9545
+      if (c == 0) {
+        lap = (sx + (sy + sz)) - 6 * cc;
+        adv = ua0 * dx + (ua1 * dy + ua2 * dz);
+      } else if (c == 1) {
+        lap = (sy + (sz + sx)) - 6 * cc;
+        adv = ua1 * dy + (ua2 * dz + ua0 * dx);
+      } else {
+        lap = (sz + (sx + sy)) - 6 * cc;
+        adv = ua2 * dz + (ua0 * dx + ua1 * dy);
+      }
+      res[c] = facA * adv + facD * lap;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double tn = (FIRST_STAGE ? 0.0 : told[k][c]) + res[c];  // o += ..., main.cpp:9546-9548
+      vout[c * 512 + k * 256 + t] = uc[k][c] + tn * a.alpha;         // V += tmpV*ih3, 9718-9720
+      tout[c * 512 + k * 256 + t] = tn * a.beta;                     // tmpV *= beta, 9721-9723
+    }
+  }
+}
+
+// face slabs of `field` behind the faces listed in send_faces -> packed send buffer
+// [(s*nc + c)*w + gl][64]  (the device-side `pack`, main.cpp:1128-1157)
+__global__ void __launch_bounds__(64) k_pack_faces(const double *__restrict__ field, const int32_t *__restrict__ send_faces, int nc, int w,
+                                                   double *__restrict__ out) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int sf = send_faces[s], slot = sf / 6, f = sf - 6 * slot, d = f >> 1, side = f & 1;
+  // the receiver sees this slab through ITS face f^1: ghost layer gl is my layer `gl` counted from face f
+  const int a1 = lane & 7, a2 = lane >> 3;
+  for (int c = 0; c < nc; ++c)
+    for (int gl = 0; gl < w; ++gl) {
+      const int q = side ? 7 - gl : gl;
+      int cell;
+      if (d == 2) cell = q * 64 + a2 * 8 + a1;        // (a1,a2) = (x,y)
+      else if (d == 1) cell = a2 * 64 + q * 8 + a1;   // (x,z)
+      else cell = a2 * 64 + a1 * 8 + q;               // (y,z)
+      out[(((size_t)s * nc + c) * w + gl) * 64 + lane] = field[((size_t)slot * nc + c) * 512 + cell];
+    }
+}
+
+int launch_pack(Sim *src, const double *field, int nc, int w) {
+  const unsigned nsend = (unsigned)src->grid->send_faces.size();
+  if (!nsend) return CUP3D_OK;
+  hipLaunchKernelGGL(k_pack_faces, dim3(nsend), dim3(64), 0, stream(), field, src->d_send_faces, nc, w, src->halo_send);
+  CUP3D_HIP(hipGetLastError());
+  return CUP3D_OK;
+}
+
+static int advdiff_stage(Sim *s, int rk, double dt, double nu, const double uinf[3]) {
+  const double alpha[3] = {1.0 / 3.0, 15.0 / 16.0, 8.0 / 15.0};   // main.cpp:9700
+  const double beta[3] = {-5.0 / 9.0, -153.0 / 128.0, 0.0};       // main.cpp:9701
+  const double h = s->grid->h;
+  {
+    int rc = halo_exchange(s, s->vel, 3, 3);  // grid->sync(stencil{-3..4}), main.cpp:5589-5590
+    if (rc) return rc;
+    AdvArgs a;
+    a.vel = s->vel;
+    a.vel_out = s->vel2;
+    a.tmp = s->tmpV;
+    a.halo = s->halo_recv;
+    a.dt = dt; a.nu = nu; a.u0 = uinf[0]; a.u1 = uinf[1]; a.u2 = uinf[2];
+    a.alpha = alpha[rk] / (h * h * h);  // ih3, main.cpp:9711-9712
+    a.beta = beta[rk];
+    GridDev g = s->gdev();
+    {
+      ProfileScope ps("advdiff_stage");
+      if (rk == 0) hipLaunchKernelGGL(k_advdiff<true>, dim3(launch_groups(g)), dim3(256), 0, stream(), g, a);
+      else hipLaunchKernelGGL(k_advdiff<false>, dim3(launch_groups(g)), dim3(256), 0, stream(), g, a);
+    }
+    CUP3D_HIP(hipGetLastError());
+    std::swap(s->vel, s->vel2);
+  }
+  return CUP3D_OK;
+}
+
+}  // namespace cup3d
+
+using namespace cup3d;
+
+extern "C" int cup3d_advect_diffuse(cup3d_sim_t *hs, double dt, double nu, const double uinf[3]) {
+  if (!hs || !uinf) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(hs);
+  for (int rk = 0; rk < 3; ++rk) {
+    int rc = advdiff_stage(s, rk, dt, nu, uinf);
+    if (rc) return rc;
+  }
+  return CUP3D_OK;
+}
+// TEST SUPPORT: a single RK stage (tmpV must be 0 before stage 0), for the virtual-rank tests
+extern "C" int cup3d_debug_advdiff_stage(cup3d_sim_t *hs, int rk, double dt, double nu, const double uinf[3]) {
+  if (!hs || !uinf || rk < 0 || rk > 2) return CUP3D_EINVAL;
+  return advdiff_stage(reinterpret_cast<Sim *>(hs), rk, dt, nu, uinf);
+}

@@ -1,0 +1,121 @@
+// Host-only part of the C ABI (include/cup3d_hip.h): indexing, topology, time step.
+// No HIP calls here: these entry points work on a machine without a GPU.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <exception>
+#include <stdexcept>
+
+#include "../../include/cup3d_hip.h"
+#include "grid.hpp"
+
+namespace cup3d {
+void set_error(const char *fmt, ...);
+}
+using namespace cup3d;
+
+extern "C" {
+
+int cup3d_sfc_create(int bx, int by, int bz, int level_max, cup3d_sfc_t **out) {
+  if (!out || bx < 1 || by < 1 || bz < 1 || level_max < 1) { set_error("cup3d_sfc_create: bad arguments"); return CUP3D_EINVAL; }
+  try {
+    *out = reinterpret_cast<cup3d_sfc_t *>(new HilbertCurve(bx, by, bz, level_max));
+  } catch (const std::exception &e) {
+    set_error("cup3d_sfc_create: %s", e.what());
+    return CUP3D_ENOMEM;
+  }
+  return CUP3D_OK;
+}
+void cup3d_sfc_destroy(cup3d_sfc_t *s) { delete reinterpret_cast<HilbertCurve *>(s); }
+long long cup3d_sfc_forward(const cup3d_sfc_t *s, int level, int i, int j, int k) {
+  return reinterpret_cast<const HilbertCurve *>(s)->forward(level, i, j, k);
+}
+void cup3d_sfc_inverse(const cup3d_sfc_t *s, long long Z, int level, int ijk[3]) {
+  reinterpret_cast<const HilbertCurve *>(s)->inverse(Z, level, ijk);
+}
+long long cup3d_sfc_encode(const cup3d_sfc_t *s, int level, const int index[3]) {
+  return reinterpret_cast<const HilbertCurve *>(s)->encode(level, index);
+}
+void cup3d_sfc_info(const cup3d_sfc_t *s, int level, const int index[3], long long nei[27], long long child[8], long long *parent) {
+  int64_t n[27], c[8], p;
+  reinterpret_cast<const HilbertCurve *>(s)->info(level, index, n, c, &p);
+  for (int i = 0; i < 27; ++i) nei[i] = n[i];
+  for (int i = 0; i < 8; ++i) child[i] = c[i];
+  *parent = p;
+}
+
+int cup3d_grid_create_uniform(const int bpd[3], int level_max, int level, double maxextent, const int bc[3], int rank, int nranks,
+                              cup3d_grid_t **out) {
+  if (!bpd || !bc || !out) { set_error("cup3d_grid_create_uniform: null argument"); return CUP3D_EINVAL; }
+  try {
+    *out = reinterpret_cast<cup3d_grid_t *>(new Grid(bpd, level_max, level, maxextent, bc, rank, nranks));
+  } catch (const std::invalid_argument &e) {
+    set_error("cup3d_grid_create_uniform: %s", e.what());
+    return CUP3D_EINVAL;
+  } catch (const std::exception &e) {
+    set_error("cup3d_grid_create_uniform: %s", e.what());
+    return CUP3D_ENOMEM;
+  }
+  return CUP3D_OK;
+}
+void cup3d_grid_destroy(cup3d_grid_t *g) { delete reinterpret_cast<Grid *>(g); }
+long cup3d_grid_nblocks(const cup3d_grid_t *g) { return (long)reinterpret_cast<const Grid *>(g)->nblocks(); }
+long cup3d_grid_nblocks_global(const cup3d_grid_t *g) { return (long)reinterpret_cast<const Grid *>(g)->total_blocks; }
+long cup3d_grid_nhalo_faces(const cup3d_grid_t *g) { return (long)reinterpret_cast<const Grid *>(g)->n_recv_faces; }
+long cup3d_grid_nsend_faces(const cup3d_grid_t *g) { return (long)reinterpret_cast<const Grid *>(g)->send_faces.size(); }
+long cup3d_grid_ninner(const cup3d_grid_t *g) { return (long)reinterpret_cast<const Grid *>(g)->inner.size(); }
+
+int cup3d_grid_tables(const cup3d_grid_t *gh, long long *t, double *geom) {
+  if (!gh || !t || !geom) return CUP3D_EINVAL;
+  const Grid *g = reinterpret_cast<const Grid *>(gh);
+  for (int64_t s = 0; s < g->nblocks(); ++s) {
+    t[6 * s + 0] = g->level;
+    t[6 * s + 1] = g->Z[s];
+    for (int d = 0; d < 3; ++d) t[6 * s + 2 + d] = g->index[3 * s + d];
+    t[6 * s + 5] = g->id2[s];
+    geom[4 * s] = g->h;
+    for (int d = 0; d < 3; ++d) geom[4 * s + 1 + d] = g->index[3 * s + d] * kBS * g->h;  // origin, main.cpp:1066-1068
+  }
+  return CUP3D_OK;
+}
+int cup3d_grid_neighbours(const cup3d_grid_t *gh, int32_t *nbr) {
+  if (!gh || !nbr) return CUP3D_EINVAL;
+  const Grid *g = reinterpret_cast<const Grid *>(gh);
+  memcpy(nbr, g->nbr.data(), g->nbr.size() * sizeof(int32_t));
+  return CUP3D_OK;
+}
+int cup3d_grid_halo_plan(const cup3d_grid_t *gh, long *send_count, long *recv_count, int32_t *send_faces) {
+  if (!gh || !send_count || !recv_count) return CUP3D_EINVAL;
+  const Grid *g = reinterpret_cast<const Grid *>(gh);
+  for (int p = 0; p < g->nranks; ++p) {
+    send_count[p] = (long)g->send_count[p];
+    recv_count[p] = (long)g->recv_count[p];
+  }
+  if (send_faces) memcpy(send_faces, g->send_faces.data(), g->send_faces.size() * sizeof(int32_t));
+  return CUP3D_OK;
+}
+
+double cup3d_calc_max_timestep(double hmin, double umax, double nu, double cfl, int step, int rampup, double dt_old, double coefU[3]) {
+  // Simulation::calcMaxTimestep, main.cpp:15268-15303 (explicit diffusion, CFL > 0)
+  const double dt_diffusion = (1.0 / 6.0) * hmin * hmin / (nu + (1.0 / 6.0) * hmin * umax);
+  const double dt_advection = hmin / (umax + 1e-8);
+  double dt;
+  if (step < rampup) {
+    const double x = step / (double)rampup;
+    const double ramp_cfl = std::exp(std::log(1e-3) * (1 - x) + std::log(cfl) * x);
+    dt = std::min(dt_diffusion, ramp_cfl * dt_advection);
+  } else {
+    dt = std::min(dt_diffusion, cfl * dt_advection);
+  }
+  if (step > 2 && coefU) {  // step_2nd_start = 2
+    const double a = dt_old, b = dt;
+    const double c1 = -(a + b) / (a * b);
+    const double c2 = b / (a + b) / a;
+    coefU[0] = -b * (c1 + c2);
+    coefU[1] = b * c1;
+    coefU[2] = b * c2;
+  }
+  return dt;
+}
+
+}  // extern "C"

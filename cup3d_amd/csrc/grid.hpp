@@ -1,0 +1,49 @@
+// Block topology of one rank: ownership, ordering, face neighbours, halo plan (host).
+//
+// Mirrors what the hot path needs from the reference's Grid/GridMPI/Synchronizer:
+//   * ownership = contiguous Hilbert (Z) ranges, GridMPI ctor, main.cpp:2959-2986
+//   * local order = sorted by blockID_2 (FillPos, main.cpp:943-964)
+//   * neighbours = Info::Znei with periodic wrap (384-420) + owner lookup (Tree().rank())
+//   * halo plan = SynchronizerMPI_AMR::_Setup (1979-2286) reduced to face slabs, which is
+//     all the star-shaped hot-path stencils read; inner/halo block split (2196-2199).
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+#include "hilbert.hpp"
+
+namespace cup3d {
+
+constexpr int kBS = 8;             // _BS_ (Makefile:11)
+constexpr int kCells = 512;        // cells per block
+constexpr int32_t kNbrHalo = 0x40000000;
+
+struct Grid {
+  Grid(const int bpd[3], int level_max, int level, double maxextent, const int bc[3], int rank, int nranks);
+
+  std::unique_ptr<HilbertCurve> sfc;
+  int bpd[3], level_max, level, bc[3];
+  int nbd[3];          // blocks per dimension at `level`
+  double maxextent, h;
+  int rank, nranks;
+  int64_t total_blocks, z_begin, z_count;  // this rank owns Z in [z_begin, z_begin+z_count)
+
+  // local blocks in m_vInfo order
+  std::vector<int64_t> Z, id2;
+  std::vector<int32_t> index;  // [nb][3]
+  std::vector<int32_t> nbr;    // [nb][6]: x-,x+,y-,y+,z-,z+
+  std::vector<int32_t> inner, boundary;  // slots without / with a remote neighbour
+
+  // halo plan, peer-major; a "face slab" is the w-deep layer of a block behind one face
+  std::vector<int64_t> send_count, recv_count;  // [nranks]
+  std::vector<int32_t> send_faces;              // slot*6 + face of each slab sent, in send order
+  int64_t n_recv_faces = 0;
+  int32_t corner_slot = -1;  // local slot of the block with index (0,0,0), or -1 (mean constraint, main.cpp:9287-9289)
+
+  int64_t nblocks() const { return (int64_t)Z.size(); }
+  int owner_of(int64_t z) const;
+  static void partition(int64_t total, int rank, int nranks, int64_t *begin, int64_t *count);
+};
+
+}  // namespace cup3d

@@ -1,0 +1,423 @@
+// Pressure Poisson solve and projection on the device.
+//
+//   cup3d_preconditioner   <- poisson_kernels::getZImplParallel      main.cpp:14704-14745
+//   cup3d_poisson_solve    <- PoissonSolverAMR::solve                main.cpp:14363-14616
+//   cup3d_pressure_project <- PressureProjection::operator()         main.cpp:15061-15160
+//
+// The solver is the reference's pipelined, preconditioned BiCGSTAB, restated step for
+// step (same recurrences, same 50-iteration true-residual refresh, same breakdown
+// restart, same x_opt bookkeeping, same stopping rule) with the vectors resident in
+// HBM as flat [block][512] slabs -- which IS the block layout, so the reference's six
+// scatter/gather copies per iteration (9372-9392, 9342-9363) do not exist here.  The
+// scalar recurrences run on the host from 2 + 7 device-reduced dot products per
+// iteration, read back while the preconditioner + LHS of the same iteration execute
+// (the overlap the reference obtains from MPI_Iallreduce, 14486-14490 / 14546-14550).
+// Elementwise updates keep the reference's association (no FMA contraction); only the
+// summation ORDER of the dot products and of the block-CG inner products differs
+// from the CPU, so pressure agrees to solver tolerance, not bitwise.
+#include <cmath>
+
+#include "sim.hpp"
+#include "tile.hpp"
+
+namespace cup3d {
+
+enum { PHAT, RHAT, SHAT, WHAT, ZHAT, QHAT, S_, W_, Z_, T_, V_, Q_, R_, Y_, X_, R0, B_, XOPT, NVEC };
+
+// ------------------------------------------------------------------ block-local CG
+// One wavefront per 8^3 block: lane = (x,y) column, the 8 z-values of r, p, x, Ap in
+// registers; z-neighbours come from registers, x/y-neighbours from a 10x10-pitched LDS
+// copy of p whose border stays 0 (the zero Dirichlet halo of the reference's
+// PaddedBlock).  Two wave reductions per CG iteration (p.Ap and r.r).
+__global__ void __launch_bounds__(64) k_precond(GridDev g, const double *__restrict__ in, double *__restrict__ out) {
+  __shared__ double P[8 * 100];
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  const int l = threadIdx.x;
+  const int base = ((l >> 3) + 1) * 10 + (l & 7) + 1;
+  for (int i = l; i < 800; i += 64) P[i] = 0.0;
+  const double invh = 1 / g.h;  // main.cpp:14723
+  double r[8], p[8], x[8], Ax[8];
+  double rr = 0;
+#pragma unroll
+  for (int z = 0; z < 8; ++z) {
+    r[z] = invh * in[(size_t)slot * 512 + z * 64 + l];
+    rr += r[z] * r[z];
+    p[z] = r[z];
+    x[z] = 0;
+  }
+  rr = wave_sum(rr);
+  const double kRel = 1e-7 * 1e-7, kAbs = 1e-16 * 1e-16;  // kSqrNorm{Rel,Abs}Criterion, 14619-14624
+  const double sqrNorm0 = (double)1 / (512 * 512) * rr;    // 14734
+  if (sqrNorm0 >= 1e-32) {                                  // else: block stays 0 (14735-14736)
+    __syncthreads();
+    for (int k = 0; k < 100; ++k) {                         // 14739
+#pragma unroll
+      for (int z = 0; z < 8; ++z) P[z * 100 + base] = p[z];
+      __syncthreads();
+      double a2 = 0;
+#pragma unroll
+      for (int z = 0; z < 8; ++z) {                         // kernelPoissonGetZInner, 14662-14682
+        double t = P[z * 100 + base - 1] + P[z * 100 + base + 1] - 6 * p[z];
+        t += P[z * 100 + base - 10];
+        t += P[z * 100 + base + 10];
+        t += z > 0 ? p[z - 1] : 0.0;
+        t += z < 7 ? p[z + 1] : 0.0;
+        Ax[z] = t;
+        a2 += p[z] * t;
+      }
+      __syncthreads();
+      a2 = wave_sum(a2);
+      const double a = rr / (a2 + 1e-55);                   // 14684
+      double ss = 0;
+#pragma unroll
+      for (int z = 0; z < 8; ++z) {
+        x[z] += a * p[z];                                   // 14688
+        r[z] -= a * Ax[z];                                  // subAndSumSqr, 14636-14638
+        ss += r[z] * r[z];
+      }
+      ss = wave_sum(ss);
+      const double beta = ss / (rr + 1e-55);                // 14690
+      const double sqrNorm = (double)1 / (512 * 512) * ss;  // 14691
+      if (sqrNorm < kRel * sqrNorm0 || sqrNorm < kAbs) break;  // 14692-14694 (returns -1)
+#pragma unroll
+      for (int z = 0; z < 8; ++z) p[z] = r[z] + beta * p[z];   // 14698-14699
+      rr = ss;
+      if (rr <= 0) break;                                   // 14741
+    }
+  }
+#pragma unroll
+  for (int z = 0; z < 8; ++z) out[(size_t)slot * 512 + z * 64 + l] = x[z];
+}
+
+int launch_precond(Sim *s, const double *in, double *out) {
+  GridDev g = s->gdev();
+  ProfileScope ps("poisson_block_cg");
+  hipLaunchKernelGGL(k_precond, dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out);
+  CUP3D_HIP(hipGetLastError());
+  return CUP3D_OK;
+}
+
+// ------------------------------------------------------------------ fused BiCGSTAB vector kernels
+struct Vecs { double *v[NVEC]; };
+
+template <int K>
+__device__ __forceinline__ void emit_partials(double (&acc)[K], double *__restrict__ partials) {
+  __shared__ double red[4];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const double s = group_sum<4>(acc[i], red);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 8 + i] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_reduce_partials(const double *__restrict__ partials, int ngroups, int k, double *__restrict__ out) {
+  __shared__ double red[4];
+  for (int i = 0; i < k; ++i) {
+    double s = 0;
+    for (int j = threadIdx.x; j < ngroups; j += 256) s += partials[(size_t)j * 8 + i];
+    s = group_sum<4>(s, red);
+    if (threadIdx.x == 0) out[i] = s;
+  }
+}
+
+#define GRID_STRIDE(j, n) for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < (n); j += (long)gridDim.x * 256)
+
+// b = r = rhs, x = pres   (main.cpp:14408-14415)
+__global__ void __launch_bounds__(256) k_solver_init(Vecs V, const double *__restrict__ rhs, const double *__restrict__ pres, long n) {
+  GRID_STRIDE(j, n) { const double b = rhs[j]; V.v[B_][j] = b; V.v[R_][j] = b; V.v[X_][j] = pres[j]; }
+}
+// r0 = r - r0 ; r = r0   (14419-14422)
+__global__ void __launch_bounds__(256) k_resid0(Vecs V, long n) {
+  GRID_STRIDE(j, n) { const double d = V.v[R_][j] - V.v[R0][j]; V.v[R0][j] = d; V.v[R_][j] = d; }
+}
+// r0.r0, r0.w  (14436-14440 and 14578-14581)
+__global__ void __launch_bounds__(256) k_dots_r0(Vecs V, long n, double *__restrict__ partials) {
+  double acc[2] = {0, 0};
+  GRID_STRIDE(j, n) { const double a = V.v[R0][j]; acc[0] += a * a; acc[1] += a * V.v[W_][j]; }
+  emit_partials<2>(acc, partials);
+}
+// first fused loop, k % 50 != 0   (14454-14464)
+__global__ void __launch_bounds__(256) k_loop1(Vecs V, long n, double alpha, double beta, double omega, double *__restrict__ partials) {
+  double acc[2] = {0, 0};
+  GRID_STRIDE(j, n) {
+    const double rhat = V.v[RHAT][j], w = V.v[W_][j];
+    const double phat = rhat + beta * (V.v[PHAT][j] - omega * V.v[SHAT][j]);
+    const double s = w + beta * (V.v[S_][j] - omega * V.v[Z_][j]);
+    const double shat = V.v[WHAT][j] + beta * (V.v[SHAT][j] - omega * V.v[ZHAT][j]);
+    const double z = V.v[T_][j] + beta * (V.v[Z_][j] - omega * V.v[V_][j]);
+    const double q = V.v[R_][j] - alpha * s;
+    const double qhat = rhat - alpha * shat;
+    const double y = w - alpha * z;
+    V.v[PHAT][j] = phat; V.v[S_][j] = s; V.v[SHAT][j] = shat; V.v[Z_][j] = z; V.v[Q_][j] = q; V.v[QHAT][j] = qhat; V.v[Y_][j] = y;
+    acc[0] += q * y;
+    acc[1] += y * y;
+  }
+  emit_partials<2>(acc, partials);
+}
+// k % 50 == 0 variants   (14467-14480)
+__global__ void __launch_bounds__(256) k_loop1_phat(Vecs V, long n, double beta, double omega) {
+  GRID_STRIDE(j, n) V.v[PHAT][j] = V.v[RHAT][j] + beta * (V.v[PHAT][j] - omega * V.v[SHAT][j]);
+}
+__global__ void __launch_bounds__(256) k_loop1_tail(Vecs V, long n, double alpha, double *__restrict__ partials) {
+  double acc[2] = {0, 0};
+  GRID_STRIDE(j, n) {
+    const double q = V.v[R_][j] - alpha * V.v[S_][j];
+    const double qhat = V.v[RHAT][j] - alpha * V.v[SHAT][j];
+    const double y = V.v[W_][j] - alpha * V.v[Z_][j];
+    V.v[Q_][j] = q; V.v[QHAT][j] = qhat; V.v[Y_][j] = y;
+    acc[0] += q * y;
+    acc[1] += y * y;
+  }
+  emit_partials<2>(acc, partials);
+}
+// second fused loop, k % 50 != 0   (14503-14515)
+__global__ void __launch_bounds__(256) k_loop2(Vecs V, long n, double alpha, double omega, double *__restrict__ partials) {
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  GRID_STRIDE(j, n) {
+    const double qhat = V.v[QHAT][j], y = V.v[Y_][j], r0 = V.v[R0][j];
+    const double x = V.v[X_][j] + alpha * V.v[PHAT][j] + omega * qhat;
+    const double r = V.v[Q_][j] - omega * y;
+    const double rhat = qhat - omega * (V.v[WHAT][j] - alpha * V.v[ZHAT][j]);
+    const double w = y - omega * (V.v[T_][j] - alpha * V.v[V_][j]);
+    V.v[X_][j] = x; V.v[R_][j] = r; V.v[RHAT][j] = rhat; V.v[W_][j] = w;
+    acc[0] += r0 * r;
+    acc[1] += r0 * w;
+    acc[2] += r0 * V.v[S_][j];
+    acc[3] += r0 * V.v[Z_][j];
+    acc[4] += r * r;   // norm_1
+    acc[5] += r0 * r0; // norm_2
+    acc[6] += r * r;   // norm
+  }
+  emit_partials<7>(acc, partials);
+}
+// k % 50 == 0 variants   (14518-14537)
+__global__ void __launch_bounds__(256) k_loop2_x(Vecs V, long n, double alpha, double omega) {
+  GRID_STRIDE(j, n) V.v[X_][j] = V.v[X_][j] + alpha * V.v[PHAT][j] + omega * V.v[QHAT][j];
+}
+__global__ void __launch_bounds__(256) k_true_resid(Vecs V, long n) {
+  GRID_STRIDE(j, n) V.v[R_][j] = V.v[B_][j] - V.v[R_][j];
+}
+__global__ void __launch_bounds__(256) k_dots7(Vecs V, long n, double *__restrict__ partials) {
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  GRID_STRIDE(j, n) {
+    const double r0 = V.v[R0][j], r = V.v[R_][j];
+    acc[0] += r0 * r;
+    acc[1] += r0 * V.v[W_][j];
+    acc[2] += r0 * V.v[S_][j];
+    acc[3] += r0 * V.v[Z_][j];
+    acc[4] += r * r;
+    acc[5] += r0 * r0;
+    acc[6] += r * r;
+  }
+  emit_partials<7>(acc, partials);
+}
+__global__ void __launch_bounds__(256) k_copy(const double *__restrict__ src, double *__restrict__ dst, long n) {
+  GRID_STRIDE(j, n) dst[j] = src[j];
+}
+__global__ void k_set_one(double *p, size_t i, double v) { p[i] = v; }
+// lhs -= tmpV.u[0] ; pres = 0   (main.cpp:15090-15099)
+__global__ void __launch_bounds__(256) k_sub_divp(double *__restrict__ lhs, const double *__restrict__ tmpV, double *__restrict__ pres, long n) {
+  GRID_STRIDE(j, n) { lhs[j] -= tmpV[(j >> 9) * 1536 + (j & 511)]; pres[j] = 0; }
+}
+// sum(p*vv), sum(vv)   (15111-15121)
+__global__ void __launch_bounds__(256) k_mean_dots(const double *__restrict__ p, long n, double vv, double *__restrict__ partials) {
+  double acc[2] = {0, 0};
+  GRID_STRIDE(j, n) { acc[0] += p[j] * vv; acc[1] += vv; }
+  emit_partials<2>(acc, partials);
+}
+// p -= avg ; (p += pOld)   (15127-15145)
+__global__ void __launch_bounds__(256) k_shift_mean(double *__restrict__ p, const double *__restrict__ pold, long n, double avg) {
+  GRID_STRIDE(j, n) { double v = p[j] - avg; if (pold) v += pold[j]; p[j] = v; }
+}
+
+static unsigned vec_groups(long n) {
+  long g = (n + 255) / 256;
+  return (unsigned)(g > 2048 ? 2048 : g);
+}
+
+struct Reducer {
+  Sim *s;
+  unsigned groups;
+  // finalise `k` dot products from the per-group partials, all-reduce, start the read-back
+  int begin(int k) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, stream(), s->d_partials, (int)groups, k, s->d_red);
+    int rc = allreduce(s, s->d_red, k, false, stream());
+    if (rc) return rc;
+    CUP3D_HIP(hipMemcpyAsync(s->h_red, s->d_red, k * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    CUP3D_HIP(hipEventRecord(s->ev_a, stream()));
+    return CUP3D_OK;
+  }
+  int wait() {
+    CUP3D_HIP(hipEventSynchronize(s->ev_a));
+    return CUP3D_OK;
+  }
+};
+
+static int ensure_vectors(Sim *s) {
+  if (s->sv[0]) return CUP3D_OK;
+  for (int i = 0; i < NVEC; ++i) {
+    int rc = sim_alloc(&s->sv[i], (size_t)s->nb * 512, s);
+    if (rc) return rc;
+  }
+  return CUP3D_OK;
+}
+
+#define LAUNCH_VEC(kern, ...) hipLaunchKernelGGL(kern, dim3(G), dim3(256), 0, stream(), __VA_ARGS__)
+#define TRY(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *res) {
+  TRY(ensure_vectors(s));
+  Vecs V;
+  for (int i = 0; i < NVEC; ++i) V.v[i] = s->sv[i];
+  const long N = s->nb * 512L;
+  const unsigned G = vec_groups(N);
+  const int mc = P.mean_constraint;
+  const double eps = 1e-100;
+  Reducer red{s, G};
+  auto LHS = [&](int in, int out) { return launch_lhs(s, V.v[in], V.v[out], mc); };       // _lhs, 9365-9393
+  auto PRE = [&](int in, int out) { return launch_precond(s, V.v[in], V.v[out]); };       // _preconditioner, 9334-9364
+
+  if ((mc == 1 || mc > 2) && s->grid->corner_slot >= 0)  // rhs(0,0,0) = 0, 14404-14407
+    hipLaunchKernelGGL(k_set_one, dim3(1), dim3(1), 0, stream(), s->lhs, (size_t)s->grid->corner_slot * 512, 0.0);
+  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_solver_init, V, s->lhs, s->pres, N); }
+  TRY(LHS(X_, R0));
+  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_resid0, V, N); }
+  TRY(PRE(R0, RHAT)); TRY(LHS(RHAT, W_)); TRY(PRE(W_, WHAT)); TRY(LHS(WHAT, T_));
+  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots_r0, V, N, s->d_partials); }
+  TRY(red.begin(2)); TRY(red.wait());
+  double alpha = s->h_red[0] / (s->h_red[1] + eps);  // 14443
+  double r0r_prev = s->h_red[0];
+  double norm = std::sqrt(s->h_red[0]);
+  const double init_norm = norm;
+  double beta = 0.0, omega = 0.0, min_norm = 1e50;
+  bool use_xopt = false;
+  int restarts = 0, k;
+  for (k = 0; k < P.max_iter; ++k) {
+    if (k % 50 != 0) {
+      ProfileScope ps("bicgstab_loop1");
+      LAUNCH_VEC(k_loop1, V, N, alpha, beta, omega, s->d_partials);
+    } else {
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_loop1_phat, V, N, beta, omega); }
+      TRY(LHS(PHAT, S_)); TRY(PRE(S_, SHAT)); TRY(LHS(SHAT, Z_));
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_loop1_tail, V, N, alpha, s->d_partials); }
+    }
+    TRY(red.begin(2));                       // MPI_Iallreduce(2), 14486
+    TRY(PRE(Z_, ZHAT)); TRY(LHS(ZHAT, V_));  // overlapped with the reduction read-back, 14488-14489
+    TRY(red.wait());
+    omega = s->h_red[0] / (s->h_red[1] + eps);  // 14493
+    if (k % 50 != 0) {
+      ProfileScope ps("bicgstab_loop2");
+      LAUNCH_VEC(k_loop2, V, N, alpha, omega, s->d_partials);
+    } else {
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_loop2_x, V, N, alpha, omega); }
+      TRY(LHS(X_, R_));
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_true_resid, V, N); }
+      TRY(PRE(R_, RHAT)); TRY(LHS(RHAT, W_));
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots7, V, N, s->d_partials); }
+    }
+    TRY(red.begin(7));                       // MPI_Iallreduce(7), 14546
+    TRY(PRE(W_, WHAT)); TRY(LHS(WHAT, T_));  // 14548-14549
+    TRY(red.wait());
+    const double r0r = s->h_red[0], r0w = s->h_red[1], r0s = s->h_red[2], r0z = s->h_red[3];
+    const double norm_1 = s->h_red[4], norm_2 = s->h_red[5];
+    norm = std::sqrt(s->h_red[6]);
+    beta = alpha / (omega + eps) * r0r / (r0r_prev + eps);              // 14558
+    alpha = r0r / (r0w + beta * r0s - beta * omega * r0z);              // 14559
+    double alphat = 1.0 / (omega + eps) + r0w / (r0r + eps) - beta * omega * r0z / (r0r + eps);
+    alphat = 1.0 / (alphat + eps);
+    if (std::fabs(alphat) < 10 * std::fabs(alpha)) alpha = alphat;      // 14563-14564
+    r0r_prev = r0r;
+    const bool serious_breakdown = r0r * r0r < 1e-16 * norm_1 * norm_2;  // 14566
+    if (serious_breakdown && restarts < P.max_restarts) {               // 14567-14593
+      restarts++;
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_copy, V.v[R_], V.v[R0], N); }
+      TRY(PRE(R0, RHAT)); TRY(LHS(RHAT, W_));
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots_r0, V, N, s->d_partials); }
+      TRY(red.begin(2));
+      TRY(PRE(W_, WHAT)); TRY(LHS(WHAT, T_));
+      TRY(red.wait());
+      alpha = s->h_red[0] / (s->h_red[1] + eps);
+      r0r_prev = s->h_red[0];
+      beta = 0.0;
+      omega = 0.0;
+    }
+    if (norm < min_norm) {                                              // 14594-14600
+      use_xopt = true;
+      min_norm = norm;
+      ProfileScope ps("bicgstab_vector");
+      LAUNCH_VEC(k_copy, V.v[X_], V.v[XOPT], N);
+    }
+    if (norm < P.tol || norm / (init_norm + eps) < P.tol_rel) break;   // 14601
+  }
+  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_copy, use_xopt ? V.v[XOPT] : V.v[X_], s->pres, N); }  // 14605-14615
+  CUP3D_HIP(hipGetLastError());
+  if (res) {
+    res->iterations = k < P.max_iter ? k + 1 : P.max_iter;
+    res->restarts = restarts;
+    res->norm0 = init_norm;
+    res->norm = norm;
+    res->used_xopt = use_xopt;
+  }
+  return CUP3D_OK;
+}
+
+}  // namespace cup3d
+
+using namespace cup3d;
+
+extern "C" {
+
+int cup3d_grad_p_update(cup3d_sim_t *h, double dt);  // stencil.hip
+
+void cup3d_poisson_default_params(cup3d_poisson_params *p) {
+  if (!p) return;
+  p->tol = 1e-6; p->tol_rel = 1e-4; p->mean_constraint = 1; p->max_iter = 1000; p->max_restarts = 100;
+}
+
+int cup3d_preconditioner(cup3d_sim_t *h) {
+  if (!h) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  return launch_precond(s, s->pres, s->pres);  // in place: each wavefront reads its block before writing it
+}
+
+int cup3d_poisson_solve(cup3d_sim_t *h, const cup3d_poisson_params *p, cup3d_poisson_result *r) {
+  if (!h) return CUP3D_EINVAL;
+  cup3d_poisson_params d;
+  cup3d_poisson_default_params(&d);
+  return solve(reinterpret_cast<Sim *>(h), p ? *p : d, r);
+}
+
+int cup3d_pressure_project(cup3d_sim_t *h, double dt, int step, const cup3d_poisson_params *pp, cup3d_poisson_result *r) {
+  if (!h) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  cup3d_poisson_params P;
+  cup3d_poisson_default_params(&P);
+  if (pp) P = *pp;
+  const long N = s->nb * 512L;
+  const unsigned G = vec_groups(N);
+  const bool second_order = step > 2;  // sim.step > sim.step_2nd_start (= 2), main.cpp:15087, 15355
+  if (second_order) { ProfileScope ps("project_pointwise"); LAUNCH_VEC(k_copy, s->pres, s->pold, N); }  // pOld, 15075
+  // tmpV = 0 (15076-15078) matters only as the udef lab of KernelPressureRHS; without
+  // obstacles the RHS kernel does not read it (adding -0*fac*0 is the identity).
+  TRY(cup3d_pressure_rhs(h, dt));
+  if (second_order) {
+    TRY(cup3d_div_pressure(h));
+    ProfileScope ps("project_pointwise");
+    LAUNCH_VEC(k_sub_divp, s->lhs, s->tmpV, s->pres, N);
+  } else {
+    TRY(cup3d_sim_fill(h, CUP3D_FIELD_PRES, 0.0));  // 15102-15106
+  }
+  TRY(solve(s, P, r));
+  const double hh = s->grid->h, vv = hh * hh * hh;
+  { ProfileScope ps("project_pointwise"); LAUNCH_VEC(k_mean_dots, s->pres, N, vv, s->d_partials); }
+  Reducer red{s, G};
+  TRY(red.begin(2)); TRY(red.wait());                        // MPI_Allreduce(2), 15123
+  const double avg = s->h_red[0] / s->h_red[1];              // 15126
+  { ProfileScope ps("project_pointwise"); LAUNCH_VEC(k_shift_mean, s->pres, second_order ? s->pold : (const double *)nullptr, N, avg); }
+  TRY(cup3d_grad_p_update(h, dt));                           // KernelGradP + vel += tmpV/h^3, 15146-15159
+  CUP3D_HIP(hipGetLastError());
+  return CUP3D_OK;
+}
+
+}  // extern "C"

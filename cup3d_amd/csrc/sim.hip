@@ -1,0 +1,426 @@
+// Device block store, host<->device transfers, pointwise operators.  See sim.hpp.
+#include <cstdarg>
+#include <cstring>
+#include <map>
+
+#include "sim.hpp"
+#include "tile.hpp"
+
+namespace cup3d {
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+  set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+  return CUP3D_EDEVICE;
+}
+
+// ------------------------------------------------------------------ stream / profile
+static hipStream_t g_stream = nullptr;
+hipStream_t stream() { return g_stream; }
+
+struct ProfileRec { int idx; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<std::string> g_prof_names;
+static std::vector<long> g_prof_launches;
+static std::vector<double> g_prof_ms;
+static std::vector<ProfileRec> g_prof_open;
+
+static void profile_drain() {
+  for (auto &r : g_prof_open) {
+    float ms = 0;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      g_prof_ms[r.idx] += ms;
+      g_prof_launches[r.idx] += 1;
+    }
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  g_prof_open.clear();
+}
+ProfileScope::ProfileScope(const char *name) : idx(-1), start(nullptr) {
+  if (!g_prof_on) return;
+  for (size_t i = 0; i < g_prof_names.size(); ++i)
+    if (g_prof_names[i] == name) idx = (int)i;
+  if (idx < 0) {
+    idx = (int)g_prof_names.size();
+    g_prof_names.push_back(name);
+    g_prof_launches.push_back(0);
+    g_prof_ms.push_back(0);
+  }
+  if (hipEventCreate(&start) != hipSuccess) { idx = -1; return; }
+  hipEventRecord(start, g_stream);
+}
+ProfileScope::~ProfileScope() {
+  if (idx < 0) return;
+  hipEvent_t stop;
+  if (hipEventCreate(&stop) != hipSuccess) return;
+  hipEventRecord(stop, g_stream);
+  g_prof_open.push_back({idx, start, stop});
+  if (g_prof_open.size() > 4096) profile_drain();
+}
+
+// ------------------------------------------------------------------ Sim
+GridDev Sim::gdev(bool boundary_only, bool inner_only) const {
+  GridDev g;
+  g.nbr = d_nbr;
+  g.h = grid->h;
+  if (boundary_only) {
+    g.list = d_boundary;
+    g.nblocks = (int)grid->boundary.size();
+  } else if (inner_only) {
+    g.list = d_inner;
+    g.nblocks = (int)grid->inner.size();
+  } else {
+    g.list = nullptr;
+    g.nblocks = (int)nb;
+  }
+  g.chunk = (g.nblocks + 7) / 8;
+  return g;
+}
+double *Sim::field(int id, int *ncomp) const {
+  switch (id) {
+    case CUP3D_FIELD_CHI: *ncomp = 1; return chi;
+    case CUP3D_FIELD_PRES: *ncomp = 1; return pres;
+    case CUP3D_FIELD_LHS: *ncomp = 1; return lhs;
+    case CUP3D_FIELD_VEL: *ncomp = 3; return vel;
+    case CUP3D_FIELD_TMPV: *ncomp = 3; return tmpV;
+  }
+  *ncomp = 0;
+  return nullptr;
+}
+int sim_alloc(double **p, size_t n, Sim *s) {
+  CUP3D_HIP(hipMalloc((void **)p, n * sizeof(double)));
+  CUP3D_HIP(hipMemsetAsync(*p, 0, n * sizeof(double), g_stream));
+  s->bytes += n * sizeof(double);
+  return CUP3D_OK;
+}
+
+// ------------------------------------------------------------------ layout conversion
+// reference block memory [blk][cell][c]  <->  device slab [blk][c][cell]
+__global__ void __launch_bounds__(256) k_aos_to_soa(const double *__restrict__ aos, double *__restrict__ soa, long ncell_total, int nc) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ncell_total * nc) return;
+  const long blk = i / (512L * nc);
+  const int r = (int)(i - blk * 512L * nc);
+  const int c = r / 512, cell = r - c * 512;
+  soa[i] = aos[(blk * 512 + cell) * nc + c];
+}
+__global__ void __launch_bounds__(256) k_soa_to_aos(const double *__restrict__ soa, double *__restrict__ aos, long ncell_total, int nc) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ncell_total * nc) return;
+  const long blk = i / (512L * nc);
+  const int r = (int)(i - blk * 512L * nc);
+  const int cell = r / nc, c = r - cell * nc;
+  aos[i] = soa[(blk * nc + c) * 512 + cell];
+}
+__global__ void __launch_bounds__(256) k_fill(double *__restrict__ p, long n, double v) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
+}
+// findMaxU, main.cpp:8603-8623
+__global__ void __launch_bounds__(256) k_max_u(const double *__restrict__ vel, long nblk, double u0, double u1, double u2, double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double m = 0;
+  const long n = nblk * 1536;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)((i / 512) % 3);
+    const double uinf = c == 0 ? u0 : (c == 1 ? u1 : u2);
+    m = fmax(m, fabs(vel[i] + uinf));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+__global__ void __launch_bounds__(256) k_max_final(const double *__restrict__ partial, int n, double *__restrict__ out) {
+  __shared__ double sh[4];
+  double m = 0;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, partial[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+// ExternalForcing::operator(), main.cpp:10581-10596 : component 0 += gradPdt
+__global__ void __launch_bounds__(256) k_forcing(double *__restrict__ vel, long nblk, double g) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nblk * 512; i += (long)gridDim.x * 256) {
+    const long blk = i >> 9;
+    vel[blk * 1536 + (i & 511)] += g;
+  }
+}
+
+static unsigned stride_groups(long n) {
+  long g = (n + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace cup3d
+
+using namespace cup3d;
+
+extern "C" {
+
+const char *cup3d_last_error(void) { return g_err; }
+const char *cup3d_version(void) { return "cup3d-hip 0.1 (gfx950)"; }
+
+int cup3d_device_count(int *n) {
+  if (!n) return CUP3D_EINVAL;
+  hipError_t e = hipGetDeviceCount(n);
+  if (e != hipSuccess) { *n = 0; return hip_fail(e, "hipGetDeviceCount", __FILE__, __LINE__); }
+  return CUP3D_OK;
+}
+int cup3d_device_init(int device) {
+  int n = 0;
+  if (cup3d_device_count(&n) != CUP3D_OK || n == 0) {
+    set_error("no HIP device visible: the cup3d hot path runs on MI355X (gfx950) only and has no CPU fallback");
+    return CUP3D_EDEVICE;
+  }
+  if (device < 0 || device >= n) { set_error("device %d out of range (%d visible)", device, n); return CUP3D_EINVAL; }
+  CUP3D_HIP(hipSetDevice(device));
+  hipDeviceProp_t p;
+  CUP3D_HIP(hipGetDeviceProperties(&p, device));
+  if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device, p.gcnArchName);
+    return CUP3D_EDEVICE;
+  }
+  return CUP3D_OK;
+}
+int cup3d_set_stream(void *s) { g_stream = (hipStream_t)s; return CUP3D_OK; }
+int cup3d_device_synchronize(void) {
+  CUP3D_HIP(hipStreamSynchronize(g_stream));
+  CUP3D_HIP(hipDeviceSynchronize());
+  return CUP3D_OK;
+}
+
+int cup3d_profile_enable(int on) { g_prof_on = on != 0; return CUP3D_OK; }
+int cup3d_profile_reset(void) {
+  profile_drain();
+  std::fill(g_prof_ms.begin(), g_prof_ms.end(), 0.0);
+  std::fill(g_prof_launches.begin(), g_prof_launches.end(), 0L);
+  return CUP3D_OK;
+}
+int cup3d_profile_read(cup3d_profile_entry *e, int max, int *n) {
+  profile_drain();
+  const int m = (int)g_prof_names.size();
+  if (n) *n = m;
+  for (int i = 0; i < m && i < max; ++i) {
+    snprintf(e[i].name, sizeof e[i].name, "%s", g_prof_names[i].c_str());
+    e[i].launches = g_prof_launches[i];
+    e[i].total_ms = g_prof_ms[i];
+  }
+  return CUP3D_OK;
+}
+
+int cup3d_sim_create(const cup3d_grid_t *gh, cup3d_sim_t **out) {
+  if (!gh || !out) return CUP3D_EINVAL;
+  const Grid *g = reinterpret_cast<const Grid *>(gh);
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("cup3d_sim_create: no HIP device (call cup3d_device_init first)"); return CUP3D_EDEVICE; }
+  if (g->nranks > 1 && !comm() && !virtual_ranks()) { set_error("grid spans %d ranks but cup3d_comm_init was not called", g->nranks); return CUP3D_ESTATE; }
+  Sim *s = new Sim();
+  s->grid = g;
+  s->nb = g->nblocks();
+  const size_t nb = (size_t)s->nb;
+  int rc;
+#define A(ptr, n) if ((rc = sim_alloc(&(ptr), (n), s)) != CUP3D_OK) { cup3d_sim_destroy((cup3d_sim_t *)s); return rc; }
+  A(s->vel, nb * 1536) A(s->vel2, nb * 1536) A(s->tmpV, nb * 1536)
+  A(s->pres, nb * 512) A(s->lhs, nb * 512) A(s->chi, nb * 512) A(s->pold, nb * 512)
+  s->max_groups = 4096;
+  A(s->d_partials, (size_t)s->max_groups * 8 + nb) A(s->d_red, 16)
+#undef A
+  CUP3D_HIP(hipHostMalloc((void **)&s->h_red, 16 * sizeof(double), hipHostMallocDefault));
+  CUP3D_HIP(hipMalloc((void **)&s->d_nbr, nb * 6 * sizeof(int32_t)));
+  CUP3D_HIP(hipMemcpy(s->d_nbr, g->nbr.data(), nb * 6 * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (g->nranks > 1) {
+    auto up = [&](int32_t **d, const std::vector<int32_t> &v) -> int {
+      if (v.empty()) { *d = nullptr; return CUP3D_OK; }
+      CUP3D_HIP(hipMalloc((void **)d, v.size() * sizeof(int32_t)));
+      CUP3D_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      return CUP3D_OK;
+    };
+    if ((rc = up(&s->d_inner, g->inner)) || (rc = up(&s->d_boundary, g->boundary)) || (rc = up(&s->d_send_faces, g->send_faces))) {
+      cup3d_sim_destroy((cup3d_sim_t *)s);
+      return rc;
+    }
+    const size_t slab = 3 * 3 * 64;  // widest exchange: 3 components x 3 layers
+    if (g->n_recv_faces) { if ((rc = sim_alloc(&s->halo_recv, (size_t)g->n_recv_faces * slab, s))) return rc; }
+    if (!g->send_faces.empty()) { if ((rc = sim_alloc(&s->halo_send, g->send_faces.size() * slab, s))) return rc; }
+    CUP3D_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+  }
+  CUP3D_HIP(hipEventCreateWithFlags(&s->ev_a, hipEventDisableTiming));
+  CUP3D_HIP(hipEventCreateWithFlags(&s->ev_b, hipEventDisableTiming));
+  CUP3D_HIP(hipStreamSynchronize(g_stream));
+  *out = reinterpret_cast<cup3d_sim_t *>(s);
+  return CUP3D_OK;
+}
+
+void cup3d_sim_destroy(cup3d_sim_t *h) {
+  if (!h) return;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  hipStreamSynchronize(g_stream);
+  double *ptrs[] = {s->vel, s->vel2, s->tmpV, s->pres, s->lhs, s->chi, s->pold, s->d_partials, s->d_red, s->d_stage, s->halo_recv, s->halo_send};
+  for (double *p : ptrs) if (p) hipFree(p);
+  for (double *p : s->sv) if (p) hipFree(p);
+  if (s->h_red) hipHostFree(s->h_red);
+  if (s->h_stage) hipHostFree(s->h_stage);
+  int32_t *ip[] = {s->d_nbr, s->d_inner, s->d_boundary, s->d_send_faces};
+  for (int32_t *p : ip) if (p) hipFree(p);
+  if (s->comm_stream) hipStreamDestroy(s->comm_stream);
+  if (s->ev_a) hipEventDestroy(s->ev_a);
+  if (s->ev_b) hipEventDestroy(s->ev_b);
+  delete s;
+}
+size_t cup3d_sim_device_bytes(const cup3d_sim_t *h) { return h ? reinterpret_cast<const Sim *>(h)->bytes : 0; }
+
+int cup3d_sim_device_ptr(cup3d_sim_t *h, int field, void **ptr) {
+  if (!h || !ptr) return CUP3D_EINVAL;
+  int nc;
+  double *p = reinterpret_cast<Sim *>(h)->field(field, &nc);
+  if (!p) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+  *ptr = p;
+  return CUP3D_OK;
+}
+
+static int mark_written(Sim *s, int field) {
+  if (field == CUP3D_FIELD_CHI) s->chi_nonzero = true;   // obstacles present: KernelPressureRHS must read chi/udef
+  return CUP3D_OK;
+}
+
+int cup3d_sim_upload(cup3d_sim_t *h, int field, const double *blocks) {
+  if (!h || !blocks) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  int nc;
+  double *dst = s->field(field, &nc);
+  if (!dst) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+  const long n = s->nb * 512L * nc;
+  if (nc == 1) {
+    CUP3D_HIP(hipMemcpyAsync(dst, blocks, n * sizeof(double), hipMemcpyHostToDevice, g_stream));
+  } else {
+    double *tmp;
+    CUP3D_HIP(hipMalloc((void **)&tmp, n * sizeof(double)));
+    CUP3D_HIP(hipMemcpyAsync(tmp, blocks, n * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    hipLaunchKernelGGL(k_aos_to_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, tmp, dst, s->nb * 512L, nc);
+    CUP3D_HIP(hipGetLastError());
+    CUP3D_HIP(hipStreamSynchronize(g_stream));
+    CUP3D_HIP(hipFree(tmp));
+  }
+  CUP3D_HIP(hipStreamSynchronize(g_stream));
+  return mark_written(s, field);
+}
+
+int cup3d_sim_download(cup3d_sim_t *h, int field, double *blocks) {
+  if (!h || !blocks) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  int nc;
+  double *src = s->field(field, &nc);
+  if (!src) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+  const long n = s->nb * 512L * nc;
+  if (nc == 1) {
+    CUP3D_HIP(hipMemcpyAsync(blocks, src, n * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  } else {
+    double *tmp;
+    CUP3D_HIP(hipMalloc((void **)&tmp, n * sizeof(double)));
+    hipLaunchKernelGGL(k_soa_to_aos, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, src, tmp, s->nb * 512L, nc);
+    CUP3D_HIP(hipGetLastError());
+    CUP3D_HIP(hipMemcpyAsync(blocks, tmp, n * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    CUP3D_HIP(hipStreamSynchronize(g_stream));
+    CUP3D_HIP(hipFree(tmp));
+  }
+  CUP3D_HIP(hipStreamSynchronize(g_stream));
+  return CUP3D_OK;
+}
+
+// One pointer per block (Info::block of the reference's per-block allocations,
+// main.cpp:877-884): gather through a pinned staging buffer in chunks.
+static int ensure_stage(Sim *s) {
+  if (s->h_stage) return CUP3D_OK;
+  s->stage_blocks = 4096;
+  CUP3D_HIP(hipHostMalloc((void **)&s->h_stage, s->stage_blocks * 1536 * sizeof(double), hipHostMallocDefault));
+  CUP3D_HIP(hipMalloc((void **)&s->d_stage, s->stage_blocks * 1536 * sizeof(double)));
+  return CUP3D_OK;
+}
+int cup3d_sim_upload_blocks(cup3d_sim_t *h, int field, const void *const *ptrs) {
+  if (!h || !ptrs) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  int nc, rc;
+  double *dst = s->field(field, &nc);
+  if (!dst) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+  if ((rc = ensure_stage(s))) return rc;
+  const size_t per = 512 * (size_t)nc;
+  for (size_t b0 = 0; b0 < (size_t)s->nb; b0 += s->stage_blocks) {
+    const size_t n = std::min(s->stage_blocks, (size_t)s->nb - b0);
+    for (size_t i = 0; i < n; ++i) memcpy(s->h_stage + i * per, ptrs[b0 + i], per * sizeof(double));
+    CUP3D_HIP(hipMemcpyAsync(s->d_stage, s->h_stage, n * per * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    hipLaunchKernelGGL(k_aos_to_soa, dim3((unsigned)((n * per + 255) / 256)), dim3(256), 0, g_stream, s->d_stage, dst + b0 * per, (long)n * 512, nc);
+    CUP3D_HIP(hipGetLastError());
+    CUP3D_HIP(hipStreamSynchronize(g_stream));
+  }
+  return mark_written(s, field);
+}
+int cup3d_sim_download_blocks(cup3d_sim_t *h, int field, void *const *ptrs) {
+  if (!h || !ptrs) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  int nc, rc;
+  double *src = s->field(field, &nc);
+  if (!src) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+  if ((rc = ensure_stage(s))) return rc;
+  const size_t per = 512 * (size_t)nc;
+  for (size_t b0 = 0; b0 < (size_t)s->nb; b0 += s->stage_blocks) {
+    const size_t n = std::min(s->stage_blocks, (size_t)s->nb - b0);
+    hipLaunchKernelGGL(k_soa_to_aos, dim3((unsigned)((n * per + 255) / 256)), dim3(256), 0, g_stream, src + b0 * per, s->d_stage, (long)n * 512, nc);
+    CUP3D_HIP(hipGetLastError());
+    CUP3D_HIP(hipMemcpyAsync(s->h_stage, s->d_stage, n * per * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    CUP3D_HIP(hipStreamSynchronize(g_stream));
+    for (size_t i = 0; i < n; ++i) memcpy(ptrs[b0 + i], s->h_stage + i * per, per * sizeof(double));
+  }
+  return CUP3D_OK;
+}
+
+int cup3d_sim_fill(cup3d_sim_t *h, int field, double value) {
+  if (!h) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  int nc;
+  double *p = s->field(field, &nc);
+  if (!p) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+  const long n = s->nb * 512L * nc;
+  hipLaunchKernelGGL(k_fill, dim3(stride_groups(n)), dim3(256), 0, g_stream, p, n, value);
+  CUP3D_HIP(hipGetLastError());
+  if (field == CUP3D_FIELD_CHI) s->chi_nonzero = value != 0.0;
+  return CUP3D_OK;
+}
+
+int cup3d_max_u(cup3d_sim_t *h, const double uinf[3], double *umax) {
+  if (!h || !uinf || !umax) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  const unsigned groups = std::min<unsigned>(stride_groups(s->nb * 1536), (unsigned)s->max_groups);
+  {
+    ProfileScope ps("max_u");
+    hipLaunchKernelGGL(k_max_u, dim3(groups), dim3(256), 0, g_stream, s->vel, (long)s->nb, uinf[0], uinf[1], uinf[2], s->d_partials);
+    hipLaunchKernelGGL(k_max_final, dim3(1), dim3(256), 0, g_stream, s->d_partials, (int)groups, s->d_red);
+  }
+  CUP3D_HIP(hipGetLastError());
+  int rc = allreduce(s, s->d_red, 1, /*is_max=*/true, g_stream);  // MPI_Allreduce MAX, main.cpp:8620
+  if (rc) return rc;
+  CUP3D_HIP(hipMemcpyAsync(s->h_red, s->d_red, sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  CUP3D_HIP(hipStreamSynchronize(g_stream));
+  *umax = s->h_red[0];
+  return CUP3D_OK;
+}
+
+int cup3d_external_forcing(cup3d_sim_t *h, double umax_forced, double nu, double H, double dt) {
+  if (!h) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  const double gradPdt = 8 * umax_forced * nu / H / H * dt;  // main.cpp:10584
+  ProfileScope ps("external_forcing");
+  hipLaunchKernelGGL(k_forcing, dim3(stride_groups(s->nb * 512)), dim3(256), 0, g_stream, s->vel, (long)s->nb, gradPdt);
+  CUP3D_HIP(hipGetLastError());
+  return CUP3D_OK;
+}
+
+}  // extern "C"

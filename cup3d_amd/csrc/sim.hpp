@@ -1,0 +1,95 @@
+// Device mirror of SimulationData's five block grids (main.cpp:6603-6607) plus the
+// solver work vectors of PoissonSolverAMR (main.cpp:9394-9411), for one rank.
+//
+// HBM layout: every field is one slab  [block slot][component][z][y][x]  of FP64
+// (SoA per block: 4 KiB per component per block), slots in m_vInfo order.  Ghost
+// cells are never materialised in HBM: kernels stage the ghosted tile of a block in
+// LDS straight from the neighbour slots (this replaces BlockLab::load, 3623-3743).
+// Face slabs owned by other ranks live in `halo_*` buffers filled by RCCL.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/cup3d_hip.h"
+#include "grid.hpp"
+
+namespace cup3d {
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+#define CUP3D_HIP(call)                                                        \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) return ::cup3d::hip_fail(e_, #call, __FILE__, __LINE__); \
+  } while (0)
+
+hipStream_t stream();  // compute stream (cup3d_set_stream)
+
+// ---- per-kernel timing (cup3d_profile_*) ----
+struct ProfileScope {
+  explicit ProfileScope(const char *name);
+  ~ProfileScope();
+  int idx;
+  hipEvent_t start;
+};
+
+struct Comm;  // RCCL state (comm.cpp)
+Comm *comm();  // nullptr when single rank
+bool virtual_ranks();  // test mode (cup3d_debug_virtual_ranks)
+
+// Device-side description of the topology, passed by value to kernels.
+struct GridDev {
+  const int32_t *nbr;   // [nb][6]
+  const int32_t *list;  // optional block list (inner / boundary); nullptr = all blocks
+  int nblocks;          // number of blocks this launch covers
+  int chunk;            // ceil(nblocks / 8): blocks per XCD
+  double h;
+};
+
+struct Sim {
+  const Grid *grid = nullptr;
+  int64_t nb = 0;
+  // topology on device
+  int32_t *d_nbr = nullptr, *d_inner = nullptr, *d_boundary = nullptr, *d_send_faces = nullptr;
+  // fields
+  double *vel = nullptr, *vel2 = nullptr, *tmpV = nullptr;    // [nb][3][512]
+  double *pres = nullptr, *lhs = nullptr, *chi = nullptr;     // [nb][512]
+  double *pold = nullptr;
+  bool chi_nonzero = false, udef_nonzero = false;
+  // solver vectors (allocated on first solve), each [nb][512]
+  double *sv[18] = {nullptr};
+  // reductions
+  double *d_partials = nullptr;  // [max_groups][8]
+  double *d_red = nullptr;       // [16] final reduced scalars
+  double *h_red = nullptr;       // pinned host mirror
+  int max_groups = 0;
+  // staging for host transfers
+  double *d_stage = nullptr;
+  double *h_stage = nullptr;  // pinned
+  size_t stage_blocks = 0;
+  // halo buffers (multi-rank)
+  double *halo_recv = nullptr, *halo_send = nullptr;  // n faces x 3 comps x 3 layers x 64
+  size_t bytes = 0;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+
+  GridDev gdev(bool boundary_only = false, bool inner_only = false) const;
+  double *field(int id, int *ncomp) const;
+};
+
+int sim_alloc(double **p, size_t n_doubles, Sim *s);
+
+// halo exchange of the face slabs of `field` (ncomp components, w ghost layers); no-op on one rank
+int halo_exchange(Sim *s, const double *field, int ncomp, int w);
+// sum / max all-reduce of n doubles resident in device memory; no-op on one rank
+int allreduce(Sim *s, double *d_buf, int n, bool is_max, hipStream_t st);
+
+// kernels' launchers shared across translation units
+int launch_lhs(Sim *s, const double *p, double *out, int mean_constraint);
+int launch_precond(Sim *s, const double *in, double *out);
+
+}  // namespace cup3d

@@ -1,0 +1,272 @@
+// 7-point (stencil [-1,2)) kernels on the ghosted 10^3 tile: Poisson LHS, pressure RHS,
+// div(grad p) increment, pressure gradient.  One 256-thread workgroup per 8^3 block,
+// tile staged in LDS from the face neighbours / halo slabs / boundary conditions
+// (replaces ScalarLab / VectorLab loads, main.cpp:3623-3743, 5929-6004, 6107-6503).
+// All arithmetic keeps the reference's association (-ffp-contract=off).
+#include "sim.hpp"
+#include "tile.hpp"
+
+namespace cup3d {
+
+constexpr int kT = 1000;  // [10][10][10]
+__device__ __forceinline__ int tix(int x, int y, int z) { return (z + 1) * 100 + (y + 1) * 10 + (x + 1); }
+
+// 1-deep face slab element `lane` of face f: neighbour cell, own face cell, LDS slot
+__device__ __forceinline__ void face1(int f, int lane, int &nb_cell, int &own_cell, int &lds) {
+  const int d = f >> 1, side = f & 1, a1 = lane & 7, a2 = lane >> 3;
+  const int qn = side ? 0 : 7, qo = side ? 7 : 0, g = side ? 8 : -1;
+  if (d == 2) { nb_cell = qn * 64 + a2 * 8 + a1; own_cell = qo * 64 + a2 * 8 + a1; lds = tix(a1, a2, g); }
+  else if (d == 1) { nb_cell = a2 * 64 + qn * 8 + a1; own_cell = a2 * 64 + qo * 8 + a1; lds = tix(a1, g, a2); }
+  else { nb_cell = a2 * 64 + a1 * 8 + qn; own_cell = a2 * 64 + a1 * 8 + qo; lds = tix(g, a1, a2); }
+}
+
+// scalar tile with zero-gradient domain faces (BlockLabNeumann3D, main.cpp:6561-6581)
+__device__ __forceinline__ void load_scalar_tile(const GridDev &g, int slot, const double *__restrict__ f, const double *__restrict__ halo,
+                                                 double *tile, double c[2]) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const double *own = f + (size_t)slot * 512;
+  c[0] = own[t];
+  c[1] = own[256 + t];
+  const int x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
+  tile[tix(x, y, z0)] = c[0];
+  tile[tix(x, y, z0 + 4)] = c[1];
+  for (int face = wave; face < 6; face += 4) {
+    const int n = g.nbr[slot * 6 + face];
+    int nb_cell, own_cell, lds;
+    face1(face, lane, nb_cell, own_cell, lds);
+    double v;
+    if (n >= kNbrHalo) v = halo[(size_t)(n - kNbrHalo) * 64 + lane];
+    else if (n >= 0) v = f[(size_t)n * 512 + nb_cell];
+    else v = own[own_cell];
+    tile[lds] = v;
+  }
+}
+
+// component c of a vector field, ghosts only on the two faces normal to axis c (all the
+// divergence reads); domain faces: wall negates every component, freespace negates the
+// normal one -> the normal component is negated under both (main.cpp:6137-6153, 6384-6394)
+__device__ __forceinline__ void load_normal_tile(const GridDev &g, int slot, const double *__restrict__ f, const double *__restrict__ halo,
+                                                 int c, double *tile) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const double *own = f + (size_t)slot * 1536 + c * 512;
+  const int x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
+  tile[tix(x, y, z0)] = own[t];
+  tile[tix(x, y, z0 + 4)] = own[256 + t];
+  if (wave < 2) {
+    const int face = 2 * c + wave;
+    const int n = g.nbr[slot * 6 + face];
+    int nb_cell, own_cell, lds;
+    face1(face, lane, nb_cell, own_cell, lds);
+    double v;
+    if (n >= kNbrHalo) v = halo[((size_t)(n - kNbrHalo) * 3 + c) * 64 + lane];
+    else if (n >= 0) v = f[(size_t)n * 1536 + c * 512 + nb_cell];
+    else v = -own[own_cell];
+    tile[lds] = v;
+  }
+}
+
+// ---- KernelLHSPoisson (main.cpp:9205-9215) + the per-block partial of sum(p*h^3) that
+// ComputeLHS needs for the mean constraint (9283-9294)
+__global__ void __launch_bounds__(256) k_lhs(GridDev g, const double *__restrict__ p, const double *__restrict__ halo, double *__restrict__ out,
+                                             double *__restrict__ block_sums) {
+  __shared__ double tile[kT];
+  __shared__ double red[4];
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  double c[2];
+  load_scalar_tile(g, slot, p, halo, tile, c);
+  __syncthreads();
+  const int t = threadIdx.x, x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
+  const double h = g.h;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int z = z0 + 4 * k, b = tix(x, y, z);
+    out[(size_t)slot * 512 + k * 256 + t] =
+        h * (tile[b - 1] + tile[b + 1] + tile[b - 10] + tile[b + 10] + tile[b - 100] + tile[b + 100] - 6.0 * c[k]);
+  }
+  if (block_sums) {
+    const double h3 = h * h * h;
+    const double s = group_sum<4>(c[0] * h3 + c[1] * h3, red);
+    if (t == 0) block_sums[slot] = s;
+  }
+}
+
+// deterministic sum of n per-block values -> out[0] (single workgroup)
+__global__ void __launch_bounds__(256) k_sum_blocks(const double *__restrict__ v, int n, double *__restrict__ out) {
+  __shared__ double red[4];
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+  s = group_sum<4>(s, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+// mean-constraint fix-ups of ComputeLHS::operator(), main.cpp:9299-9326
+__global__ void k_lhs_corner(double *__restrict__ out, const double *__restrict__ in, const double *__restrict__ avg, int corner_slot, int mode) {
+  if (mode == 1) out[(size_t)corner_slot * 512] = avg[0];          // LHS(0,0,0) = avgP
+  else out[(size_t)corner_slot * 512] = in[(size_t)corner_slot * 512];  // bMeanConstraint > 2
+}
+__global__ void __launch_bounds__(256) k_lhs_add_mean(double *__restrict__ out, long n, const double *__restrict__ avg, double h3) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] += avg[0] * h3;  // 9314
+}
+
+// ---- KernelPressureRHS (main.cpp:14849-14875)
+__global__ void __launch_bounds__(256) k_pressure_rhs(GridDev g, const double *__restrict__ vel, const double *__restrict__ udef,
+                                                      const double *__restrict__ chi, const double *__restrict__ halo_v,
+                                                      const double *__restrict__ halo_u, double dt, double *__restrict__ out) {
+  __shared__ double tv[3 * kT];
+  __shared__ double tu[3 * kT];
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) load_normal_tile(g, slot, vel, halo_v, c, tv + c * kT);
+  if (chi)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) load_normal_tile(g, slot, udef, halo_u, c, tu + c * kT);
+  __syncthreads();
+  const int t = threadIdx.x, x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
+  const double h = g.h, fac = 0.5 * h * h / dt;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int b = tix(x, y, z0 + 4 * k);
+    double p = fac * (tv[b + 1] - tv[b - 1] + tv[kT + b + 10] - tv[kT + b - 10] + tv[2 * kT + b + 100] - tv[2 * kT + b - 100]);
+    if (chi) {
+      const double divUs = tu[b + 1] - tu[b - 1] + tu[kT + b + 10] - tu[kT + b - 10] + tu[2 * kT + b + 100] - tu[2 * kT + b - 100];
+      p += -chi[(size_t)slot * 512 + k * 256 + t] * fac * divUs;
+    }
+    out[(size_t)slot * 512 + k * 256 + t] = p;
+  }
+}
+
+// ---- KernelDivPressure (main.cpp:14769-14778): tmpV.u[0] = h*lap(p)
+__global__ void __launch_bounds__(256) k_div_pressure(GridDev g, const double *__restrict__ p, const double *__restrict__ halo, double *__restrict__ tmpV) {
+  __shared__ double tile[kT];
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  double c[2];
+  load_scalar_tile(g, slot, p, halo, tile, c);
+  __syncthreads();
+  const int t = threadIdx.x, x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
+  const double fac = g.h;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int b = tix(x, y, z0 + 4 * k);
+    tmpV[(size_t)slot * 1536 + k * 256 + t] =
+        fac * (tile[b + 1] + tile[b - 1] + tile[b + 10] + tile[b - 10] + tile[b + 100] + tile[b - 100] - 6.0 * c[k]);
+  }
+}
+
+// ---- KernelGradP (main.cpp:14990-14999), optionally fused with vel += tmpV/h^3 (15147-15159)
+__global__ void __launch_bounds__(256) k_grad_p(GridDev g, const double *__restrict__ p, const double *__restrict__ halo, double dt,
+                                                double *__restrict__ tmpV, double *__restrict__ vel) {
+  __shared__ double tile[kT];
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  double c[2];
+  load_scalar_tile(g, slot, p, halo, tile, c);
+  __syncthreads();
+  const int t = threadIdx.x, x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
+  const double h = g.h, fac = -0.5 * dt * h * h, ih3 = 1.0 / (h * h * h);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int b = tix(x, y, z0 + 4 * k);
+    const double gx = fac * (tile[b + 1] - tile[b - 1]);
+    const double gy = fac * (tile[b + 10] - tile[b - 10]);
+    const double gz = fac * (tile[b + 100] - tile[b - 100]);
+    const size_t o = (size_t)slot * 1536 + k * 256 + t;
+    tmpV[o] = gx; tmpV[o + 512] = gy; tmpV[o + 1024] = gz;
+    if (vel) {
+      vel[o] += ih3 * gx; vel[o + 512] += ih3 * gy; vel[o + 1024] += ih3 * gz;
+    }
+  }
+}
+
+int launch_lhs(Sim *s, const double *p, double *out, int mc) {
+  int rc = halo_exchange(s, p, 1, 1);
+  if (rc) return rc;
+  const bool need_sum = mc > 0 && mc <= 2;
+  GridDev g = s->gdev();
+  double *block_sums = s->d_partials + (size_t)s->max_groups * 8;
+  {
+    ProfileScope ps("poisson_lhs");
+    hipLaunchKernelGGL(k_lhs, dim3(launch_groups(g)), dim3(256), 0, stream(), g, p, s->halo_recv, out, need_sum ? block_sums : nullptr);
+  }
+  CUP3D_HIP(hipGetLastError());
+  if (mc == 0) return CUP3D_OK;
+  const int corner = s->grid->corner_slot;
+  if (need_sum) {
+    hipLaunchKernelGGL(k_sum_blocks, dim3(1), dim3(256), 0, stream(), block_sums, (int)s->nb, s->d_red + 8);
+    if ((rc = allreduce(s, s->d_red + 8, 1, false, stream()))) return rc;  // MPI_Iallreduce, main.cpp:9295
+    if (mc == 1) {
+      if (corner >= 0) hipLaunchKernelGGL(k_lhs_corner, dim3(1), dim3(1), 0, stream(), out, p, s->d_red + 8, corner, 1);
+    } else {
+      const double h = s->grid->h;
+      hipLaunchKernelGGL(k_lhs_add_mean, dim3(2048), dim3(256), 0, stream(), out, s->nb * 512L, s->d_red + 8, h * h * h);
+    }
+  } else if (corner >= 0) {
+    hipLaunchKernelGGL(k_lhs_corner, dim3(1), dim3(1), 0, stream(), out, p, s->d_red + 8, corner, 3);
+  }
+  CUP3D_HIP(hipGetLastError());
+  return CUP3D_OK;
+}
+
+}  // namespace cup3d
+
+using namespace cup3d;
+
+extern "C" {
+
+int cup3d_compute_lhs(cup3d_sim_t *h, int mean_constraint) {
+  if (!h) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  return launch_lhs(s, s->pres, s->lhs, mean_constraint);
+}
+
+int cup3d_pressure_rhs(cup3d_sim_t *h, double dt) {
+  if (!h) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  int rc;
+  const bool obst = s->chi_nonzero;
+  double *halo_u = nullptr;
+  if (obst && s->grid->nranks > 1) {
+    // udef slabs go to the second half of the receive buffer (each exchange uses <= 3*64 per face of 9*64)
+    if ((rc = halo_exchange(s, s->tmpV, 3, 1))) return rc;
+    halo_u = s->halo_recv + (size_t)s->grid->n_recv_faces * 3 * 64;
+    CUP3D_HIP(hipMemcpyAsync(halo_u, s->halo_recv, (size_t)s->grid->n_recv_faces * 3 * 64 * sizeof(double), hipMemcpyDeviceToDevice, stream()));
+  }
+  if ((rc = halo_exchange(s, s->vel, 3, 1))) return rc;
+  GridDev g = s->gdev();
+  ProfileScope ps("pressure_rhs");
+  hipLaunchKernelGGL(k_pressure_rhs, dim3(launch_groups(g)), dim3(256), 0, stream(), g, s->vel, s->tmpV, obst ? s->chi : nullptr, s->halo_recv, halo_u, dt, s->lhs);
+  CUP3D_HIP(hipGetLastError());
+  return CUP3D_OK;
+}
+
+int cup3d_div_pressure(cup3d_sim_t *h) {
+  if (!h) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  int rc = halo_exchange(s, s->pres, 1, 1);
+  if (rc) return rc;
+  GridDev g = s->gdev();
+  ProfileScope ps("div_pressure");
+  hipLaunchKernelGGL(k_div_pressure, dim3(launch_groups(g)), dim3(256), 0, stream(), g, s->pres, s->halo_recv, s->tmpV);
+  CUP3D_HIP(hipGetLastError());
+  return CUP3D_OK;
+}
+
+static int grad_p(Sim *s, double dt, bool update_vel) {
+  int rc = halo_exchange(s, s->pres, 1, 1);
+  if (rc) return rc;
+  GridDev g = s->gdev();
+  ProfileScope ps("grad_p");
+  hipLaunchKernelGGL(k_grad_p, dim3(launch_groups(g)), dim3(256), 0, stream(), g, s->pres, s->halo_recv, dt, s->tmpV, update_vel ? s->vel : nullptr);
+  CUP3D_HIP(hipGetLastError());
+  return CUP3D_OK;
+}
+int cup3d_grad_p(cup3d_sim_t *h, double dt) {
+  if (!h) return CUP3D_EINVAL;
+  return grad_p(reinterpret_cast<Sim *>(h), dt, false);
+}
+int cup3d_grad_p_update(cup3d_sim_t *h, double dt) {  // internal to cup3d_pressure_project
+  return grad_p(reinterpret_cast<Sim *>(h), dt, true);
+}
+
+}  // extern "C"

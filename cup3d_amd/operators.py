@@ -1,0 +1,268 @@
+"""Host-side mirror of the reference's Operator / PoissonSolverBase surface for the hot
+path, driving the C ABI (include/cup3d_hip.h).  Names, argument meaning and call order
+follow slitvinov/CUP3D main.cpp so that tests read like the reference:
+
+    sim = SimulationData(bpdx=.., levelMax=.., BC_x="periodic", nu=.., ...)   # 15330-15387
+    pipeline = [AdvectionDiffusion(sim), ExternalForcing(sim), PressureProjection(sim)]  # 15229-15246
+    dt = Simulation(sim).calcMaxTimestep(); for op in pipeline: op(dt)                   # 15254-15326
+
+All field data lives on the GPU; host arrays cross the boundary only through
+upload()/download() in the reference's block memory layout.  No CPU fallback exists.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import (BC, FIELD_CHI, FIELD_LHS, FIELD_NCOMP, FIELD_PRES, FIELD_TMPV, FIELD_VEL, Cup3dError,
+                   PoissonParams, PoissonResult, check, lib)
+
+FIELDS = {"chi": FIELD_CHI, "pres": FIELD_PRES, "vel": FIELD_VEL, "tmpV": FIELD_TMPV, "lhs": FIELD_LHS}
+
+
+class Grid:
+    """Block topology of one rank (host only): GridMPI ownership + m_vInfo order + face
+    neighbours + halo plan.  Works without a GPU."""
+
+    def __init__(self, bpd, levelMax, level, maxextent, bc, rank=0, nranks=1):
+        self.bpd = np.array(bpd, dtype=np.int32)
+        self.bc = np.array([BC[b] if isinstance(b, str) else int(b) for b in bc], dtype=np.int32)
+        self.levelMax, self.level, self.maxextent = int(levelMax), int(level), float(maxextent)
+        self.rank, self.nranks = int(rank), int(nranks)
+        h = C.c_void_p()
+        check(lib().cup3d_grid_create_uniform(self.bpd, self.levelMax, self.level, self.maxextent, self.bc,
+                                              self.rank, self.nranks, C.byref(h)))
+        self.handle = h
+        self.nblocks = lib().cup3d_grid_nblocks(h)
+        self.nblocks_global = lib().cup3d_grid_nblocks_global(h)
+        self.tables = np.zeros((self.nblocks, 6), dtype=np.int64)
+        self.geom = np.zeros((self.nblocks, 4), dtype=np.float64)
+        check(lib().cup3d_grid_tables(h, self.tables, self.geom))
+        self.index = self.tables[:, 2:5]
+        self.h = float(self.geom[0, 0])
+        self.ncell = tuple(int(b << self.level) * 8 for b in self.bpd)
+
+    def __del__(self):
+        try:
+            lib().cup3d_grid_destroy(self.handle)
+        except Exception:
+            pass
+
+    def neighbours(self):
+        nbr = np.zeros((self.nblocks, 6), dtype=np.int32)
+        check(lib().cup3d_grid_neighbours(self.handle, nbr))
+        return nbr
+
+    def halo_plan(self):
+        send = np.zeros(self.nranks, dtype=np.int64)
+        recv = np.zeros(self.nranks, dtype=np.int64)
+        faces = np.zeros(max(1, lib().cup3d_grid_nsend_faces(self.handle)), dtype=np.int32)
+        check(lib().cup3d_grid_halo_plan(self.handle, send, recv, faces.ctypes.data_as(C.c_void_p)))
+        return send, recv, faces[:lib().cup3d_grid_nsend_faces(self.handle)]
+
+    # global [NZ,NY,NX(,3)] array <-> this rank's blocks in the reference layout
+    def to_blocks(self, glob):
+        glob = np.asarray(glob, dtype=np.float64)
+        out = np.empty((self.nblocks, 8, 8, 8) + glob.shape[3:])
+        for s, (i, j, k) in enumerate(self.index):
+            out[s] = glob[8 * k:8 * k + 8, 8 * j:8 * j + 8, 8 * i:8 * i + 8]
+        return np.ascontiguousarray(out)
+
+    def scatter_to_global(self, blocks, glob):
+        for s, (i, j, k) in enumerate(self.index):
+            glob[8 * k:8 * k + 8, 8 * j:8 * j + 8, 8 * i:8 * i + 8] = blocks[s]
+
+
+class SimulationData:
+    """Device-resident counterpart of struct SimulationData (main.cpp:6600-6677): the five
+    block grids chi, pres, vel, tmpV, lhs plus the run parameters the hot path reads."""
+
+    def __init__(self, bpdx=1, bpdy=1, bpdz=1, levelMax=1, levelStart=None, extent=1.0, nu=0.0, CFL=0.1,
+                 BC_x="freespace", BC_y="freespace", BC_z="freespace", uinf=(0.0, 0.0, 0.0), uMax_forced=0.0,
+                 poissonTol=1e-6, poissonTolRel=1e-4, bMeanConstraint=1, poissonSolver="hip_iterative", rampup=100,
+                 rank=0, nranks=1, device=None):
+        if device is not None or not capi._device_ready:
+            capi.device_init(0 if device is None else device)
+        self.bpdx, self.bpdy, self.bpdz = bpdx, bpdy, bpdz
+        self.levelMax = levelMax
+        self.levelStart = levelMax - 1 if levelStart is None else levelStart
+        self.maxextent = float(extent)
+        self.grid = Grid((bpdx, bpdy, bpdz), levelMax, self.levelStart, self.maxextent, (BC_x, BC_y, BC_z), rank, nranks)
+        # extents / hmin as in _preprocessArguments, main.cpp:15394-15415
+        aux = 1 << (levelMax - 1)
+        nfe = [bpdx * aux * 8, bpdy * aux * 8, bpdz * aux * 8]
+        self.extents = [n / max(nfe) * self.maxextent for n in nfe]
+        self.hmin = self.extents[0] / nfe[0]
+        self.BCx_flag, self.BCy_flag, self.BCz_flag = BC_x, BC_y, BC_z
+        self.nu, self.CFL, self.uinf = float(nu), float(CFL), np.array(uinf, dtype=np.float64)
+        self.uMax_forced, self.rampup = float(uMax_forced), int(rampup)
+        self.PoissonErrorTol, self.PoissonErrorTolRel, self.bMeanConstraint = poissonTol, poissonTolRel, bMeanConstraint
+        self.poissonSolver = poissonSolver
+        self.dt, self.dt_old, self.time, self.step, self.step_2nd_start = 0.0, 0.0, 0.0, 0, 2
+        self.coefU = np.array([1.5, -2.0, 0.5])
+        self.uMax_measured = 0.0
+        h = C.c_void_p()
+        check(lib().cup3d_sim_create(self.grid.handle, C.byref(h)))
+        self.handle = h
+        self.pressureSolver = None
+        self.last_poisson = None
+
+    def __del__(self):
+        try:
+            lib().cup3d_sim_destroy(self.handle)
+        except Exception:
+            pass
+
+    @property
+    def nblocks(self):
+        return self.grid.nblocks
+
+    def upload(self, field, blocks):
+        fid = FIELDS[field]
+        nc = FIELD_NCOMP[fid]
+        a = np.ascontiguousarray(blocks, dtype=np.float64)
+        want = (self.nblocks, 8, 8, 8, 3) if nc == 3 else (self.nblocks, 8, 8, 8)
+        if a.shape != want:
+            raise ValueError(f"{field}: expected block array of shape {want}, got {a.shape}")
+        check(lib().cup3d_sim_upload(self.handle, fid, a))
+
+    def download(self, field):
+        fid = FIELDS[field]
+        nc = FIELD_NCOMP[fid]
+        out = np.empty((self.nblocks, 8, 8, 8, 3) if nc == 3 else (self.nblocks, 8, 8, 8))
+        check(lib().cup3d_sim_download(self.handle, fid, out))
+        return out
+
+    def fill(self, field, value):
+        check(lib().cup3d_sim_fill(self.handle, FIELDS[field], float(value)))
+
+    def poisson_params(self):
+        p = PoissonParams()
+        lib().cup3d_poisson_default_params(C.byref(p))
+        p.tol, p.tol_rel, p.mean_constraint = self.PoissonErrorTol, self.PoissonErrorTolRel, self.bMeanConstraint
+        return p
+
+    def device_bytes(self):
+        return lib().cup3d_sim_device_bytes(self.handle)
+
+
+class Operator:
+    """class Operator, main.cpp:6678-6684."""
+
+    def __init__(self, sim):
+        self.sim = sim
+
+    def __call__(self, dt):
+        raise NotImplementedError
+
+
+class AdvectionDiffusion(Operator):
+    """AdvectionDiffusion::operator()(dt), main.cpp:9640-9728 (uses sim.dt like KernelAdvectDiffuse, 9465)."""
+
+    def __call__(self, dt):
+        s = self.sim
+        s.dt = dt
+        check(lib().cup3d_advect_diffuse(s.handle, dt, s.nu, s.uinf))
+
+
+class ExternalForcing(Operator):
+    """ExternalForcing::operator()(dt), main.cpp:10581-10596."""
+
+    def __call__(self, dt):
+        s = self.sim
+        d = 1 if s.BCy_flag == "wall" else 2
+        check(lib().cup3d_external_forcing(s.handle, s.uMax_forced, s.nu, s.extents[d], dt))
+
+
+class ComputeLHS(Operator):
+    """ComputeLHS::operator()(dt), main.cpp:9273-9327: lhs <- A(pres)."""
+
+    def __call__(self, dt=0):
+        check(lib().cup3d_compute_lhs(self.sim.handle, self.sim.bMeanConstraint))
+
+
+class PoissonSolverBase:
+    """class PoissonSolverBase, main.cpp:8921-8928."""
+
+    def solve(self):
+        raise NotImplementedError
+
+
+class PoissonSolverHIP(PoissonSolverBase):
+    """PoissonSolverAMR (main.cpp:9329-9435, solve 14363-14616) on the device: RHS in sim.lhs,
+    initial guess and result in sim.pres."""
+
+    def __init__(self, sim):
+        self.sim = sim
+
+    def solve(self):
+        p, r = self.sim.poisson_params(), PoissonResult()
+        check(lib().cup3d_poisson_solve(self.sim.handle, C.byref(p), C.byref(r)))
+        self.sim.last_poisson = r
+        return r
+
+    def preconditioner(self):
+        """_preconditioner on sim.pres in place (getZImplParallel, main.cpp:14704-14745)."""
+        check(lib().cup3d_preconditioner(self.sim.handle))
+
+
+def makePoissonSolver(sim):
+    """makePoissonSolver, main.cpp:14747-14758.  "iterative" is the reference's CPU solver and
+    is not provided here; "cuda_iterative" is the slot the reference reserves for a GPU solver
+    (14750) and is accepted as an alias of "hip_iterative"."""
+    if sim.poissonSolver in ("hip_iterative", "cuda_iterative"):
+        return PoissonSolverHIP(sim)
+    if sim.poissonSolver == "iterative":
+        raise RuntimeError('Poisson solver: "iterative" is the CPU reference; this library has no CPU path')
+    raise ValueError(f'Poisson solver: "{sim.poissonSolver}" unrecognized!')
+
+
+class PressureProjection(Operator):
+    """PressureProjection::operator()(dt), main.cpp:15061-15160."""
+
+    def __init__(self, sim):
+        super().__init__(sim)
+        self.pressureSolver = makePoissonSolver(sim)  # 15058-15059
+        sim.pressureSolver = self.pressureSolver
+
+    def __call__(self, dt):
+        s = self.sim
+        s.dt = dt
+        p, r = s.poisson_params(), PoissonResult()
+        check(lib().cup3d_pressure_project(s.handle, dt, s.step, C.byref(p), C.byref(r)))
+        s.last_poisson = r
+        return r
+
+
+def findMaxU(sim):
+    """findMaxU, main.cpp:8603-8623."""
+    out = C.c_double(0.0)
+    check(lib().cup3d_max_u(sim.handle, sim.uinf, C.byref(out)))
+    return out.value
+
+
+class Simulation:
+    """The time loop of struct Simulation restricted to the hot path (no obstacles, frozen mesh):
+    calcMaxTimestep 15254-15305, advance 15306-15326, pipeline order of setupOperators 15229-15246."""
+
+    def __init__(self, sim):
+        self.sim = sim
+        self.pipeline = [AdvectionDiffusion(sim)]
+        if sim.uMax_forced > 0:
+            self.pipeline.append(ExternalForcing(sim))
+        self.pipeline.append(PressureProjection(sim))
+
+    def calcMaxTimestep(self):
+        s = self.sim
+        s.dt_old = s.dt
+        s.uMax_measured = findMaxU(s)
+        s.dt = lib().cup3d_calc_max_timestep(s.hmin, s.uMax_measured, s.nu, s.CFL, s.step, s.rampup, s.dt_old, s.coefU)
+        if s.dt <= 0:
+            raise Cup3dError(f"dt <= 0. CFL={s.CFL}, hMin={s.hmin}, sim.uMax_measured={s.uMax_measured}")
+        return s.dt
+
+    def advance(self, dt):
+        for op in self.pipeline:
+            op(dt)
+        self.sim.step += 1
+        self.sim.time += dt

@@ -1,0 +1,170 @@
+/* cup3d_hip.h — C ABI of the MI355X-native (HIP, gfx950) implementation of CUP3D's
+ * per-block stencil + pressure-Poisson hot path.
+ *
+ * Every entry point names the reference interface it replaces (slitvinov/CUP3D,
+ * main.cpp:LINE).  Plain pointers and sizes only; all functions return 0 on success
+ * and a negative CUP3D_E* code on failure (the reference has no return codes: it
+ * abort()s / MPI_Abort()s, main.cpp:1098, 15265 — the C++ shim in
+ * cup3d_amd/host/cup3d_hip_operators.h turns a non-zero status into the same).
+ * cup3d_last_error() returns a human readable message for the calling thread.
+ *
+ * Host block memory at this boundary is the reference's own:
+ *   ScalarBlock = double[8][8][8]      (z,y,x; 4096 B,  main.cpp:5882-5919, 6586)
+ *   VectorBlock = double[8][8][8][3]   (AoS u,v,w; 12288 B, main.cpp:6590)
+ * in m_vInfo order (sorted by blockID_2, main.cpp:943-964).  On the device every
+ * field is a slab [block][component][z][y][x] (SoA per block).
+ */
+#ifndef CUP3D_HIP_H
+#define CUP3D_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUP3D_OK 0
+#define CUP3D_EINVAL (-1)   /* bad argument */
+#define CUP3D_EDEVICE (-2)  /* HIP error / no usable GPU */
+#define CUP3D_ENOMEM (-3)
+#define CUP3D_ECOMM (-4)    /* RCCL error */
+#define CUP3D_ESTATE (-5)   /* call out of order */
+
+const char *cup3d_last_error(void);
+const char *cup3d_version(void);
+
+/* enum BCflag { freespace, periodic, wall }  (main.cpp:6081) */
+enum { CUP3D_BC_FREESPACE = 0, CUP3D_BC_PERIODIC = 1, CUP3D_BC_WALL = 2 };
+/* fields of SimulationData (main.cpp:6603-6607) */
+enum { CUP3D_FIELD_CHI = 0, CUP3D_FIELD_PRES = 1, CUP3D_FIELD_VEL = 2, CUP3D_FIELD_TMPV = 3, CUP3D_FIELD_LHS = 4 };
+
+/* ---------------------------------------------------------------------------
+ * Indexing (host, integer, bit-exact contract).
+ * Replaces class SpaceFillingCurve (main.cpp:95-319) and Info::setup (384-420).
+ * ------------------------------------------------------------------------- */
+typedef struct cup3d_sfc cup3d_sfc_t;
+int cup3d_sfc_create(int bpdx, int bpdy, int bpdz, int level_max, cup3d_sfc_t **out);   /* ctor 196-236 */
+void cup3d_sfc_destroy(cup3d_sfc_t *);
+long long cup3d_sfc_forward(const cup3d_sfc_t *, int level, int i, int j, int k);       /* 237-255 */
+void cup3d_sfc_inverse(const cup3d_sfc_t *, long long Z, int level, int ijk[3]);        /* 256-276 */
+long long cup3d_sfc_encode(const cup3d_sfc_t *, int level, const int index[3]);         /* 287-318 (blockID_2) */
+/* Info::setup neighbour / child / parent ids: nei[27] as Znei[i+1][j+1][k+1] */
+void cup3d_sfc_info(const cup3d_sfc_t *, int level, const int index[3], long long nei[27], long long child[8],
+                    long long *parent);
+
+/* ---------------------------------------------------------------------------
+ * Block topology of one rank (host).  Replaces the parts of Grid / GridMPI the hot
+ * path needs: block ownership by contiguous Hilbert ranges (GridMPI ctor,
+ * main.cpp:2959-2986), m_vInfo ordering (FillPos 943-964), neighbour lookup
+ * (Info::Znei + Tree().rank(), 384-420, 840-855) and the inner/halo block split of
+ * SynchronizerMPI_AMR::_Setup (1979-2286) reduced to what face-only stencils need.
+ * ------------------------------------------------------------------------- */
+typedef struct cup3d_grid cup3d_grid_t;
+/* uniform grid at `level` (< level_max) of a bpd[0] x bpd[1] x bpd[2] level-0 block box;
+ * maxextent = SimulationData::maxextent (15401); bc[d] per axis; this rank owns the
+ * Z range of GridMPI's constructor. */
+int cup3d_grid_create_uniform(const int bpd[3], int level_max, int level, double maxextent, const int bc[3],
+                              int rank, int nranks, cup3d_grid_t **out);
+void cup3d_grid_destroy(cup3d_grid_t *);
+long cup3d_grid_nblocks(const cup3d_grid_t *);        /* local blocks = m_vInfo.size() */
+long cup3d_grid_nblocks_global(const cup3d_grid_t *);
+long cup3d_grid_nhalo_faces(const cup3d_grid_t *);    /* remote face slabs this rank receives */
+long cup3d_grid_ninner(const cup3d_grid_t *);         /* blocks with no remote neighbour (Synchronizer inner_blocks) */
+/* per local block, m_vInfo order: tab6 = level, Z, index[3], blockID_2 ; geom4 = h, origin[3] (Info 331-346) */
+int cup3d_grid_tables(const cup3d_grid_t *, long long *tab6, double *geom4);
+/* face neighbour table nbr[nblocks][6] (faces x-,x+,y-,y+,z-,z+): >=0 local slot,
+ * CUP3D_NBR_HALO + e = remote slab e, CUP3D_NBR_BC - bc = domain face with that BC */
+#define CUP3D_NBR_HALO 0x40000000
+#define CUP3D_NBR_BC (-1)
+int cup3d_grid_neighbours(const cup3d_grid_t *, int32_t *nbr);
+/* halo-exchange plan (what SynchronizerMPI_AMR::_Setup computes, 1979-2286): for peer
+ * p in [0,nranks): number of face slabs sent to / received from p; send_faces[s] =
+ * local_slot*6+face of the s-th slab sent (peer-major, then (Z,face) of the sender's
+ * block); received slabs are numbered in the same peer-major order. */
+int cup3d_grid_halo_plan(const cup3d_grid_t *, long *send_count, long *recv_count, int32_t *send_faces);
+long cup3d_grid_nsend_faces(const cup3d_grid_t *);
+
+/* Simulation::calcMaxTimestep (main.cpp:15254-15305), explicit diffusion, CFL > 0;
+ * updates coefU when step > step_2nd_start. */
+double cup3d_calc_max_timestep(double hmin, double umax, double nu, double cfl, int step, int rampup, double dt_old,
+                               double coefU[3]);
+
+/* ---------------------------------------------------------------------------
+ * Device side.
+ * ------------------------------------------------------------------------- */
+int cup3d_device_count(int *n);
+int cup3d_device_init(int device);            /* hipSetDevice; fails loudly unless the device is gfx950 */
+int cup3d_set_stream(void *hip_stream);       /* compute stream for all launches (NULL = default stream) */
+int cup3d_device_synchronize(void);
+
+/* RCCL communicator owned by the library (replaces sim.comm's role on the hot path:
+ * halo Isend/Irecv 2370/2402 and the Allreduce/Iallreduce sites 8620, 9295, 14442,
+ * 14486, 14546, 14584, 15123).  id is the 128-byte ncclUniqueId from rank 0. */
+int cup3d_comm_unique_id(void *id128);
+int cup3d_comm_init(int rank, int nranks, const void *id128);
+int cup3d_comm_finalize(void);
+
+typedef struct cup3d_sim cup3d_sim_t; /* device mirror of SimulationData's five grids + solver vectors */
+int cup3d_sim_create(const cup3d_grid_t *, cup3d_sim_t **out);
+void cup3d_sim_destroy(cup3d_sim_t *);
+size_t cup3d_sim_device_bytes(const cup3d_sim_t *);
+/* host <-> device; host side is the reference's block memory: either one pointer per
+ * block (Info::block, main.cpp:343, 877-884) or one contiguous array [nb][8][8][8][nc] */
+int cup3d_sim_upload_blocks(cup3d_sim_t *, int field, const void *const *block_ptrs);
+int cup3d_sim_download_blocks(cup3d_sim_t *, int field, void *const *block_ptrs);
+int cup3d_sim_upload(cup3d_sim_t *, int field, const double *blocks);
+int cup3d_sim_download(cup3d_sim_t *, int field, double *blocks);
+int cup3d_sim_fill(cup3d_sim_t *, int field, double value);
+/* raw device pointer of a field slab [nb][nc][512] (for zero-copy hosts) */
+int cup3d_sim_device_ptr(cup3d_sim_t *, int field, void **ptr);
+
+/* AdvectionDiffusion::operator()(dt) (main.cpp:9640-9728): low-storage RK3 of
+ * KernelAdvectDiffuse (9461-9549) on vel, scratch tmpV; fused into 3 launches. */
+int cup3d_advect_diffuse(cup3d_sim_t *, double dt, double nu, const double uinf[3]);
+/* findMaxU (main.cpp:8603-8623) incl. the MAX all-reduce */
+int cup3d_max_u(cup3d_sim_t *, const double uinf[3], double *umax);
+/* ExternalForcing::operator() (main.cpp:10581-10596): vel.u[0] += 8*uMax*nu/H/H*dt */
+int cup3d_external_forcing(cup3d_sim_t *, double umax_forced, double nu, double H, double dt);
+
+typedef struct {
+  double tol;          /* sim.PoissonErrorTol     (-poissonTol, 1e-6)    */
+  double tol_rel;      /* sim.PoissonErrorTolRel  (-poissonTolRel, 1e-4) */
+  int mean_constraint; /* sim.bMeanConstraint     (-bMeanConstraint, 1)  */
+  int max_iter;        /* 1000 (main.cpp:14449) */
+  int max_restarts;    /* 100  (main.cpp:14374) */
+} cup3d_poisson_params;
+typedef struct {
+  int iterations; /* BiCGSTAB iterations performed (= 7-double reductions, main.cpp:14546) */
+  int restarts;
+  double norm0, norm; /* ||r0||, last ||r|| */
+  int used_xopt;
+} cup3d_poisson_result;
+void cup3d_poisson_default_params(cup3d_poisson_params *);
+
+/* ComputeLHS::operator() (main.cpp:9273-9327): lhs = h*(sum6 - 6p) of pres + mean constraint */
+int cup3d_compute_lhs(cup3d_sim_t *, int mean_constraint);
+/* poisson_kernels::getZImplParallel (main.cpp:14704-14745): block-local CG on pres, in place */
+int cup3d_preconditioner(cup3d_sim_t *);
+/* PoissonSolverBase::solve() (main.cpp:8921-8928; PoissonSolverAMR::solve 14363-14616):
+ * RHS in lhs, initial guess and result in pres; lhs is clobbered. */
+int cup3d_poisson_solve(cup3d_sim_t *, const cup3d_poisson_params *, cup3d_poisson_result *);
+/* KernelPressureRHS via compute<> (main.cpp:15083-15085): lhs from vel, tmpV(=udef), chi */
+int cup3d_pressure_rhs(cup3d_sim_t *, double dt);
+/* KernelDivPressure (main.cpp:15088): tmpV.u[0] = h * lap(pres) */
+int cup3d_div_pressure(cup3d_sim_t *);
+/* KernelGradP (main.cpp:15146): tmpV = -0.5*dt*h^2 * central grad(pres) */
+int cup3d_grad_p(cup3d_sim_t *, double dt);
+/* PressureProjection::operator()(dt) (main.cpp:15061-15160), obstacle-free or with
+ * chi/udef already resident (tmpV is zeroed exactly as at 15076-15078). */
+int cup3d_pressure_project(cup3d_sim_t *, double dt, int step, const cup3d_poisson_params *, cup3d_poisson_result *);
+
+/* per-kernel device time accounting (hipEvents on the compute stream) */
+int cup3d_profile_enable(int on);
+int cup3d_profile_reset(void);
+/* fills up to max entries; returns the number of distinct kernels in *n */
+typedef struct { char name[48]; long launches; double total_ms; } cup3d_profile_entry;
+int cup3d_profile_read(cup3d_profile_entry *entries, int max, int *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,357 @@
+"""Parity of the HIP hot path (through the C ABI) against the CPU oracle and the golden
+vectors of the compiled reference.  Runs on an MI355X only (-m gpu).
+
+Stated tolerances
+  * advect-diffuse RK3, LHS / divP / gradP / pressure-RHS stencils, pointwise passes:
+    BIT-EXACT (same IEEE operations in the same order; -ffp-contract=off).
+  * anything behind a reduction whose summation order differs from the CPU's sequential
+    sum (block-CG inner products, BiCGSTAB dot products, mean pressure):
+      preconditioner   max|dz|            <= 2e-5 * max|z|    (block CG stops at 1e-7 relative residual)
+      Poisson solve    same iteration count (+-1), max|dp| <= 1e-6 * max|p| when counts agree
+      projection       max|du|            <= 1e-8 * max|u|,  trajectory of 6 steps <= 1e-7
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import cup3d_amd as cu
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+FIELD_CASES = ["f16_periodic", "f16_wall", "f16_mixed", "f24x16x8_mixed"]
+BCN = {0: "freespace", 1: "periodic", 2: "wall"}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    cu.device_init(0)
+
+
+def make_sim(z, **kw):
+    bpd = [int(b) for b in z["bpd"]]
+    bc = [BCN[int(b)] for b in z["bc"]]
+    return cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=int(z["level_max"]), levelStart=int(z["level"]),
+                             extent=float(z["extent"]), BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], **kw)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def test_upload_download_roundtrip():
+    sim = cu.SimulationData(bpdx=2, bpdy=1, bpdz=3, levelMax=1, BC_x="periodic", BC_y="periodic", BC_z="periodic")
+    rng = np.random.default_rng(1)
+    v = rng.normal(size=(sim.nblocks, 8, 8, 8, 3))
+    p = rng.normal(size=(sim.nblocks, 8, 8, 8))
+    sim.upload("vel", v)
+    sim.upload("pres", p)
+    assert np.array_equal(sim.download("vel"), v) and np.array_equal(sim.download("pres"), p)
+    # one pointer per block, like the reference's per-block allocations (main.cpp:877-884)
+    blocks = [np.ascontiguousarray(rng.normal(size=(8, 8, 8, 3))) for _ in range(sim.nblocks)]
+    ptrs = (C.c_void_p * sim.nblocks)(*[b.ctypes.data for b in blocks])
+    cu.capi.check(cu.lib().cup3d_sim_upload_blocks(sim.handle, cu.capi.FIELD_TMPV, ptrs))
+    assert np.array_equal(sim.download("tmpV"), np.stack(blocks))
+    outs = [np.zeros((8, 8, 8, 3)) for _ in range(sim.nblocks)]
+    optrs = (C.c_void_p * sim.nblocks)(*[b.ctypes.data for b in outs])
+    cu.capi.check(cu.lib().cup3d_sim_download_blocks(sim.handle, cu.capi.FIELD_TMPV, optrs))
+    assert np.array_equal(np.stack(outs), np.stack(blocks))
+
+
+@pytest.mark.parametrize("name", FIELD_CASES)
+def test_golden_stencil_operators_bit_exact(golden_dir, name):
+    z = load(golden_dir, name)
+    sim = make_sim(z, nu=float(z["nu"]), uinf=z["uinf"])
+    g = sim.grid
+    assert np.array_equal(g.tables, z["tables"])
+    vel, pres = g.to_blocks(z["vel_in"]), g.to_blocks(z["pres_in"])
+    dt = float(z["dt"])
+    sim.upload("vel", vel)
+    assert cu.findMaxU(sim) == float(z["maxu"])
+    cu.AdvectionDiffusion(sim)(dt)
+    assert np.array_equal(sim.download("vel"), z["ad_vel"])
+    assert np.array_equal(sim.download("tmpV"), z["ad_tmpV"])
+    # ComputeLHS: the stencil is bit-exact; the mean-constraint cell holds a global sum
+    sim.upload("pres", pres)
+    sim.bMeanConstraint = 0
+    cu.ComputeLHS(sim)()
+    assert np.array_equal(sim.download("lhs"), z["lhs_mean0"])
+    sim.bMeanConstraint = 1
+    cu.ComputeLHS(sim)()
+    got, ref = sim.download("lhs"), z["lhs"]
+    corner = int(np.where((g.index == 0).all(axis=1))[0][0])
+    assert abs(got[corner, 0, 0, 0] - ref[corner, 0, 0, 0]) <= 1e-12 * np.abs(pres).sum() * g.h ** 3
+    got[corner, 0, 0, 0] = ref[corner, 0, 0, 0]
+    assert np.array_equal(got, ref)
+    sim.bMeanConstraint = 2
+    cu.ComputeLHS(sim)()
+    assert np.allclose(sim.download("lhs"), z["lhs_mean2"], rtol=0, atol=1e-12 * np.abs(z["lhs_mean2"]).max())
+    sim.bMeanConstraint = 1
+    # KernelDivPressure / KernelGradP
+    cu.capi.check(cu.lib().cup3d_div_pressure(sim.handle))
+    assert np.array_equal(sim.download("tmpV")[..., 0], z["divp"])
+    cu.capi.check(cu.lib().cup3d_grad_p(sim.handle, dt))
+    assert np.array_equal(sim.download("tmpV"), z["gradp"])
+    # KernelPressureRHS with obstacles' chi / udef resident
+    sim.upload("vel", vel)
+    sim.upload("tmpV", g.to_blocks(z["udef_in"]))
+    sim.upload("chi", g.to_blocks(z["chi_in"]))
+    cu.capi.check(cu.lib().cup3d_pressure_rhs(sim.handle, dt))
+    assert np.array_equal(sim.download("lhs"), z["rhs"])
+
+
+@pytest.mark.parametrize("name", FIELD_CASES)
+def test_golden_preconditioner(golden_dir, name):
+    z = load(golden_dir, name)
+    sim = make_sim(z)
+    sim.upload("pres", sim.grid.to_blocks(z["pres_in"]))
+    cu.makePoissonSolver(sim).preconditioner()
+    got, ref = sim.download("pres"), z["precond"]
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("name", FIELD_CASES)
+def test_golden_poisson_solve(golden_dir, name):
+    z = load(golden_dir, name)
+    sim = make_sim(z)
+    g = sim.grid
+    sim.upload("lhs", g.to_blocks(z["rhs_in"]))
+    sim.upload("pres", g.to_blocks(z["pres_in"]))
+    r = cu.makePoissonSolver(sim).solve()
+    got, ref = sim.download("pres"), z["solve"]
+    assert abs(r.iterations - int(z["solve_iters"])) <= 1
+    if r.iterations == int(z["solve_iters"]):
+        assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max()
+    # independent of the oracle: the returned iterate satisfies the reference's stopping rule
+    o = O.OracleGrid(z["bpd"], int(z["level_max"]), int(z["level"]), float(z["extent"]), [int(b) for b in z["bc"]])
+    b = g.to_blocks(z["rhs_in"]).copy()
+    b[np.where((g.index == 0).all(axis=1))[0][0], 0, 0, 0] = 0.0
+    res = np.linalg.norm((b - o.lhs(got, 1)).ravel())
+    x0 = g.to_blocks(z["pres_in"])
+    res0 = np.linalg.norm((b - o.lhs(x0, 1)).ravel())
+    assert res < 1e-6 or res / res0 < 1e-4 * 1.01
+
+
+@pytest.mark.parametrize("name", FIELD_CASES)
+@pytest.mark.parametrize("tag,step", [("pr", None), ("pr1", 1)])
+def test_golden_projection(golden_dir, name, tag, step):
+    z = load(golden_dir, name)
+    sim = make_sim(z)
+    g = sim.grid
+    sim.upload("vel", g.to_blocks(z["vel_in"]))
+    sim.upload("pres", g.to_blocks(z["pres_in"]))
+    sim.step = int(z["step"]) if step is None else step
+    r = cu.PressureProjection(sim)(float(z["dt"]))
+    assert abs(r.iterations - int(z[tag + "_iters"])) <= 1
+    v, p = sim.download("vel"), sim.download("pres")
+    if r.iterations == int(z[tag + "_iters"]):
+        assert np.abs(v - z[tag + "_vel"]).max() <= 1e-8 * np.abs(z[tag + "_vel"]).max()
+        assert np.abs(p - z[tag + "_pres"]).max() <= 1e-6 * np.abs(z[tag + "_pres"]).max()
+
+
+def test_trajectory_against_reference(golden_dir):
+    """6 full time steps of the reference (calcMaxTimestep, AdvectionDiffusion, ExternalForcing,
+    PressureProjection) from the Taylor-Green initial condition."""
+    z = load(golden_dir, "traj16_tgv")
+    sim = make_sim(z, nu=float(z["nu"]), CFL=float(z["cfl"]), rampup=int(z["rampup"]), uMax_forced=float(z["umax_forced"]))
+    sim.upload("vel", z["vel"][0])
+    S = cu.Simulation(sim)
+    for n in range(len(z["dts"])):
+        dt = S.calcMaxTimestep()
+        assert abs(dt - z["dts"][n]) <= 1e-9 * z["dts"][n]
+        S.advance(dt)
+        assert abs(sim.last_poisson.iterations - int(z["iters"][n])) <= 1
+        assert np.abs(sim.download("vel") - z["vel"][n + 1]).max() <= 1e-7
+        assert np.abs(sim.download("pres") - z["pres"][n]).max() <= 1e-6 * max(1e-3, np.abs(z["pres"][n]).max())
+
+
+@pytest.mark.parametrize("bpd,lmax,level,bc", [
+    ((4, 4, 4), 1, 0, ("periodic", "periodic", "periodic")),
+    ((1, 1, 1), 3, 2, ("wall", "wall", "wall")),
+    ((1, 2, 3), 2, 1, ("freespace", "periodic", "wall")),
+    ((8, 8, 8), 1, 0, ("periodic", "wall", "periodic")),
+])
+def test_oracle_random_fields(bpd, lmax, level, bc):
+    """Fresh seeded inputs against the oracle (pinned to the reference by tests/test_oracle_*.py)."""
+    ext = 2 * np.pi
+    rng = np.random.default_rng(hash((bpd, lmax, level)) % 2 ** 31)
+    o = O.OracleGrid(bpd, lmax, level, ext, bc)
+    sim = cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=level, extent=ext, nu=0.003,
+                            BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], uinf=(0.2, 0.0, -0.4))
+    assert np.array_equal(sim.grid.tables, o.tables)
+    vel = rng.uniform(-1, 1, (o.nb, 8, 8, 8, 3))
+    vel[rng.uniform(size=vel.shape) < 0.05] = 0.0     # exact zeros exercise the U > 0 / U <= 0 switch and signed zeros
+    sim.upload("vel", vel)
+    dt = 0.013
+    for _ in range(2):
+        cu.AdvectionDiffusion(sim)(dt)
+    ref, tmp = vel.copy(), np.zeros_like(vel)
+    for _ in range(2):
+        o.advect_diffuse(ref, tmp, dt, 0.003, (0.2, 0.0, -0.4))
+    got = sim.download("vel")
+    assert np.array_equal(got, ref)
+    assert np.array_equal(np.signbit(got), np.signbit(ref))
+    # projection of the advected field
+    sim.step = 3
+    r = cu.PressureProjection(sim)(dt)
+    pref = np.zeros((o.nb, 8, 8, 8))
+    info, _, _ = o.project(ref, pref, dt, 3)
+    assert abs(r.iterations - info.iters) <= 1
+    if r.iterations == info.iters:
+        assert np.abs(sim.download("vel") - ref).max() <= 1e-8 * np.abs(ref).max()
+
+
+def test_projection_removes_divergence():
+    """Property test: after PressureProjection the discrete divergence (the same central
+    difference KernelPressureRHS uses) drops by the solver tolerance."""
+    ext, n = 2 * np.pi, 4
+    o = O.OracleGrid((n, n, n), 1, 0, ext, ("periodic",) * 3)
+    sim = cu.SimulationData(bpdx=n, bpdy=n, bpdz=n, levelMax=1, extent=ext, BC_x="periodic", BC_y="periodic", BC_z="periodic")
+    rng = np.random.default_rng(5)
+    # smooth divergent field
+    N = 8 * n
+    x = (np.arange(N) + 0.5) * ext / N
+    Z, Y, X = np.meshgrid(x, x, x, indexing="ij")
+    velg = np.stack([np.sin(X) * np.cos(Y), np.cos(2 * Y) * np.sin(Z), np.sin(Z) * np.cos(X) + np.sin(X)], axis=-1)
+    vel = sim.grid.to_blocks(velg)
+    dt = 0.05
+    zero3, zero1 = np.zeros_like(vel), np.zeros(vel.shape[:4])
+    div0 = np.abs(o.pressure_rhs(vel, zero3, zero1, dt)).max()
+    sim.upload("vel", vel)
+    sim.step = 0
+    cu.PressureProjection(sim)(dt)
+    div1 = np.abs(o.pressure_rhs(sim.download("vel"), zero3, zero1, dt)).max()
+    assert div1 < 2e-3 * div0
+    del rng
+
+
+def _virtual_rank_sims(bpd, lmax, level, ext, bc, nranks, **kw):
+    cu.lib().cup3d_debug_virtual_ranks(1)
+    return [cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=level, extent=ext,
+                              BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], rank=r, nranks=nranks, **kw) for r in range(nranks)]
+
+
+def _pull(sims, field, nc, w):
+    arr = (C.c_void_p * len(sims))(*[s.handle for s in sims])
+    for s in sims:
+        cu.capi.check(cu.lib().cup3d_debug_halo_pull(s.handle, arr, len(sims), cu.operators.FIELDS[field], nc, w))
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+@pytest.mark.parametrize("bc", [("periodic", "periodic", "periodic"), ("wall", "periodic", "freespace")])
+def test_sharded_blocks_equal_single_rank(nranks, bc):
+    """Blocks sharded over `nranks` virtual ranks on this one GPU (same partition, plan, pack
+    kernel and halo-slab reads as the RCCL path; only the transport is replaced by device
+    copies) reproduce the single-rank oracle bit for bit."""
+    bpd, lmax, level, ext = (2, 2, 2), 2, 1, 2 * np.pi
+    o = O.OracleGrid(bpd, lmax, level, ext, bc)
+    rng = np.random.default_rng(9)
+    NX, NY, NZ = o.ncell
+    velg, presg = rng.uniform(-1, 1, (NZ, NY, NX, 3)), rng.uniform(-1, 1, (NZ, NY, NX))
+    dt, nu, uinf = 0.02, 0.01, np.array([0.1, 0.2, -0.3])
+    try:
+        sims = _virtual_rank_sims(bpd, lmax, level, ext, bc, nranks, nu=nu, uinf=uinf)
+        for s in sims:
+            s.upload("vel", s.grid.to_blocks(velg))
+            s.upload("pres", s.grid.to_blocks(presg))
+            s.fill("tmpV", 0.0)
+        # one full RK3 advect-diffuse, exchanging the 3-deep velocity slabs before every stage
+        for rk in range(3):
+            _pull(sims, "vel", 3, 3)
+            for s in sims:
+                cu.capi.check(cu.lib().cup3d_debug_advdiff_stage(s.handle, rk, dt, nu, uinf))
+        ref, tmp = o.to_blocks(velg), np.zeros((o.nb, 8, 8, 8, 3))
+        o.advect_diffuse(ref, tmp, dt, nu, uinf)
+        refg = o.to_global(ref)
+        got = np.zeros_like(refg)
+        for s in sims:
+            s.grid.scatter_to_global(s.download("vel"), got)
+        assert np.array_equal(got, refg)
+        # scalar 1-deep exchange: LHS (no mean constraint), gradP; vector 1-deep: pressure RHS
+        _pull(sims, "pres", 1, 1)
+        lhs_ref, grad_ref = o.to_global(o.lhs(o.to_blocks(presg), 0)), o.to_global(o.grad_p(o.to_blocks(presg), dt))
+        got_l, got_g = np.zeros_like(lhs_ref), np.zeros_like(grad_ref)
+        for s in sims:
+            s.bMeanConstraint = 0
+            cu.ComputeLHS(s)()
+            s.grid.scatter_to_global(s.download("lhs"), got_l)
+            cu.capi.check(cu.lib().cup3d_grad_p(s.handle, dt))
+            s.grid.scatter_to_global(s.download("tmpV"), got_g)
+        assert np.array_equal(got_l, lhs_ref) and np.array_equal(got_g, grad_ref)
+        for s in sims:
+            s.upload("vel", s.grid.to_blocks(velg))
+        _pull(sims, "vel", 3, 1)
+        rhs_ref = o.to_global(o.pressure_rhs(o.to_blocks(velg), np.zeros((o.nb, 8, 8, 8, 3)), np.zeros((o.nb, 8, 8, 8)), dt))
+        got_r = np.zeros_like(rhs_ref)
+        for s in sims:
+            cu.capi.check(cu.lib().cup3d_pressure_rhs(s.handle, dt))
+            s.grid.scatter_to_global(s.download("lhs"), got_r)
+        assert np.array_equal(got_r, rhs_ref)
+    finally:
+        cu.lib().cup3d_debug_virtual_ranks(0)
+
+
+# ------------------------------------------------------------------ BASELINE sizes
+def test_full_size_256_advect_diffuse_properties():
+    """BASELINE configs[1] size (256^3, periodic, 32768 blocks): size-independent properties.
+    (a) equivariance under a periodic shift by one block, bit-exact, which exercises every
+    neighbour link of the Hilbert-ordered slab; (b) a uniform flow is a fixed point."""
+    ext = 2 * np.pi
+    sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=6, levelStart=5, extent=ext, nu=0.01,
+                            BC_x="periodic", BC_y="periodic", BC_z="periodic")
+    g = sim.grid
+    assert g.nblocks == 32768
+    N = 256
+    x = (np.arange(N) + 0.5) * ext / N
+    Z, Y, X = np.meshgrid(x, x, x, indexing="ij", sparse=True)
+    velg = np.empty((N, N, N, 3))
+    velg[..., 0] = np.cos(X) * np.sin(Y) * np.sin(Z) + 0.1 * np.sin(3 * Z + X)
+    velg[..., 1] = -np.sin(X) * np.cos(Y) * np.sin(Z) + 0.05 * np.cos(2 * X)
+    velg[..., 2] = 0.2 * np.sin(X + Y) * np.cos(2 * Z)
+    dt = 0.3 * g.h
+
+    def run(field):
+        sim.upload("vel", g.to_blocks(field))
+        cu.AdvectionDiffusion(sim)(dt)
+        out = np.empty_like(field)
+        g.scatter_to_global(sim.download("vel"), out)
+        return out
+
+    a = run(velg)
+    shifted = np.roll(velg, (8, 16, -8), axis=(0, 1, 2))
+    b = run(shifted)
+    assert np.array_equal(np.roll(a, (8, 16, -8), axis=(0, 1, 2)), b)
+    const = np.empty_like(velg)
+    const[...] = (0.3, -0.7, 1.1)
+    assert np.array_equal(run(const), const)
+    # and a 2-block-thick slab of it against the oracle's arithmetic: compare with the same
+    # field computed on a 128^3 sub-problem is not meaningful for a non-periodic cut, so
+    # check the discrete kinetic energy decays (viscous, periodic, smooth field)
+    assert (a ** 2).sum() < (velg ** 2).sum()
+
+
+def test_medium_128_oracle_advect_diffuse_and_solver():
+    """128^3 (4096 blocks) against the oracle: advect-diffuse bit-exact, one Poisson solve with a
+    manufactured right-hand side within tolerance."""
+    ext = 2 * np.pi
+    bc = ("periodic", "wall", "periodic")
+    o = O.OracleGrid((1, 1, 1), 5, 4, ext, bc)
+    sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=5, levelStart=4, extent=ext, nu=0.01, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2])
+    vel = o.taylor_green([ext] * 3, 1.0)
+    vel[..., 2] = 0.3 * vel[..., 0] * vel[..., 1]
+    sim.upload("vel", vel)
+    dt = 0.3 * o.h
+    cu.AdvectionDiffusion(sim)(dt)
+    ref, tmp = vel.copy(), np.zeros_like(vel)
+    o.advect_diffuse(ref, tmp, dt, 0.01)
+    assert np.array_equal(sim.download("vel"), ref)
+    sim.step = 4
+    r = cu.PressureProjection(sim)(dt)
+    pref = np.zeros((o.nb, 8, 8, 8))
+    info, _, _ = o.project(ref, pref, dt, 4)
+    assert abs(r.iterations - info.iters) <= 1
+    if r.iterations == info.iters:
+        assert np.abs(sim.download("vel") - ref).max() <= 1e-8 * np.abs(ref).max()
+        assert np.abs(sim.download("pres") - pref).max() <= 1e-6 * np.abs(pref).max()

@@ -1,0 +1,157 @@
+"""Host-side integer contract of the product library: Hilbert indexing,
+block order, neighbour tables, partition and halo plan — bit-exact against the golden
+tables produced by the compiled reference and against the oracle.  No GPU needed."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import cup3d_amd as cu
+import oracle_lib as O
+
+L = cu.lib()
+
+
+def test_every_header_symbol_is_exported():
+    import re
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "cup3d_hip.h")).read()
+    names = set(re.findall(r"\b(cup3d_[a-z0-9_]+)\s*\(", hdr))
+    assert names, "header parse failed"
+    from cup3d_amd.capi import SIGNATURES
+    assert names == set(SIGNATURES), (names ^ set(SIGNATURES))
+    for n in names:
+        assert getattr(L, n) is not None
+
+
+def test_sfc_tables_match_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "sfc_tables.npz"))
+    for key in z.files:
+        bx, by, bz, lmax = [int(t.lstrip("L")) for t in key.split("_")[1:]]
+        ref = z[key]
+        h = C.c_void_p()
+        assert L.cup3d_sfc_create(bx, by, bz, lmax, C.byref(h)) == 0
+        row = 0
+        for l in range(lmax):
+            for k in range(bz << l):
+                for j in range(by << l):
+                    for i in range(bx << l):
+                        idx = np.array([i, j, k], dtype=np.int32)
+                        Z = L.cup3d_sfc_forward(h, l, i, j, k)
+                        inv = np.zeros(3, dtype=np.int32)
+                        L.cup3d_sfc_inverse(h, Z, l, inv)
+                        nei, child, par = np.zeros(27, dtype=np.int64), np.zeros(8, dtype=np.int64), np.zeros(1, dtype=np.int64)
+                        L.cup3d_sfc_info(h, l, idx, nei, child, par)
+                        got = np.concatenate([[Z, L.cup3d_sfc_encode(h, l, idx), par[0]], nei, child])
+                        assert np.array_equal(inv, idx)
+                        assert np.array_equal(got, ref[row]), (key, l, i, j, k)
+                        row += 1
+        L.cup3d_sfc_destroy(h)
+
+
+@pytest.mark.parametrize("name", ["f16_periodic", "f16_wall", "f16_mixed", "f24x16x8_mixed", "traj16_tgv"])
+def test_block_order_matches_reference(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    g = cu.Grid(z["bpd"], int(z["level_max"]), int(z["level"]), float(z["extent"]), z["bc"])
+    assert np.array_equal(g.tables, z["tables"])
+    if "geom" in z.files:
+        assert np.array_equal(g.geom, z["geom"])
+
+
+@pytest.mark.parametrize("bpd,lmax,level", [((4, 4, 4), 1, 0), ((1, 1, 1), 4, 3), ((3, 2, 1), 2, 1), ((8, 8, 8), 1, 0)])
+def test_block_order_matches_oracle(bpd, lmax, level):
+    bc = ("periodic", "wall", "freespace")
+    g = cu.Grid(bpd, lmax, level, 2 * np.pi, bc)
+    o = O.OracleGrid(bpd, lmax, level, 2 * np.pi, bc)
+    assert np.array_equal(g.tables, o.tables) and np.array_equal(g.geom, o.geom)
+
+
+def expected_neighbour_index(idx, f, nbd, bc):
+    d, side = f >> 1, f & 1
+    c = list(idx)
+    at_face = c[d] == (nbd[d] - 1 if side else 0)
+    if at_face and bc[d] != 1:
+        return None
+    c[d] = (c[d] + (1 if side else -1)) % nbd[d]
+    return tuple(c)
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 3, 8])
+@pytest.mark.parametrize("bc", [(1, 1, 1), (2, 0, 1)])
+def test_neighbours_partition_and_plan(nranks, bc):
+    bpd, lmax, level = (2, 2, 1), 2, 1
+    grids = [cu.Grid(bpd, lmax, level, 1.0, bc, r, nranks) for r in range(nranks)]
+    nbd = [b << level for b in bpd]
+    total = nbd[0] * nbd[1] * nbd[2]
+    # ownership = contiguous Z ranges of the GridMPI constructor (main.cpp:2970-2980)
+    z0 = 0
+    owner = {}
+    for r, g in enumerate(grids):
+        a, n = C.c_longlong(), C.c_longlong()
+        O.lib().orc_partition(total, r, nranks, C.byref(a), C.byref(n))
+        assert sorted(g.tables[:, 1]) == list(range(a.value, a.value + n.value))
+        assert a.value == z0
+        z0 += n.value
+        for s, row in enumerate(g.tables):
+            owner[tuple(row[2:5])] = (r, s)
+        assert np.all(np.diff(g.tables[:, 5]) > 0)  # sorted by blockID_2
+    assert z0 == total
+    plans = [g.halo_plan() for g in grids]
+    for r, g in enumerate(grids):
+        nbr = g.neighbours()
+        send, recv, faces = plans[r]
+        # what each peer sends me must be what I expect to receive, in the same order
+        recv_entries = []
+        for p in range(nranks):
+            ps, _, pf = plans[p]
+            off = int(ps[:r].sum())
+            assert ps[r] == recv[p]
+            for e in range(int(ps[r])):
+                sf = int(pf[off + e])
+                recv_entries.append((p, sf // 6, sf % 6))
+        for s in range(g.nblocks):
+            for f in range(6):
+                exp = expected_neighbour_index(g.index[s], f, nbd, bc)
+                n = int(nbr[s, f])
+                if exp is None:
+                    assert n == -1 - bc[f >> 1]
+                    continue
+                pr, ps_ = owner[exp]
+                if pr == r:
+                    assert n == ps_
+                else:
+                    assert n >= cu.capi.NBR_HALO
+                    p, slot, face = recv_entries[n - cu.capi.NBR_HALO]
+                    # the slab comes from the neighbour block, through its opposite face
+                    assert (p, slot, face) == (pr, ps_, f ^ 1)
+        inner = L.cup3d_grid_ninner(g.handle)
+        has_remote = (nbr >= cu.capi.NBR_HALO).any(axis=1).sum()
+        assert inner == g.nblocks - has_remote
+
+
+def test_calc_max_timestep_matches_oracle():
+    coef_a, coef_b = np.array([1.5, -2.0, 0.5]), np.array([1.5, -2.0, 0.5])
+    dt_a = dt_b = 0.0
+    for step in range(8):
+        dt_a = L.cup3d_calc_max_timestep(0.05, 0.9 + 0.01 * step, 0.01, 0.3, step, 4, dt_a, coef_a)
+        dt_b = O.lib().orc_calc_dt(0.05, 0.9 + 0.01 * step, 0.01, 0.3, step, 4, dt_b, coef_b)
+        assert dt_a == dt_b and np.array_equal(coef_a, coef_b)
+
+
+def test_bad_arguments_are_reported():
+    h = C.c_void_p()
+    bad = np.array([0, 1, 1], dtype=np.int32)
+    bc = np.array([1, 1, 1], dtype=np.int32)
+    assert L.cup3d_grid_create_uniform(bad, 1, 0, 1.0, bc, 0, 1, C.byref(h)) == -1
+    assert b"bpd" in L.cup3d_last_error()
+    ok = np.array([1, 1, 1], dtype=np.int32)
+    assert L.cup3d_grid_create_uniform(ok, 1, 0, 1.0, bc, 0, 2, C.byref(h)) == -1   # fewer blocks than ranks
+
+
+def test_compute_fails_loudly_without_gpu():
+    if cu.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(cu.Cup3dError):
+        cu.device_init(0)
+    with pytest.raises(cu.Cup3dError):
+        cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=1)
