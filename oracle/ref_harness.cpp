@@ -24,6 +24,7 @@
  *   set step|dt|time|nu|uinfx|uinfy|uinfz|mean <value>
  *   op advdiff <dt> | lhs | precond | solve | project <dt> | maxu |
  *      steps <n> | forcing <dt> | rhs | divp | gradp   (the last three use `set dt`)
+ *   hip on                 (ref_tool_hip only) route advdiff/project/steps through the HIP drop-in
  *   rep <n>                repeat every following `op` n times when timing
  * Every `op` prints one line `REF <op> seconds=<t> iters=<k> value=<v>`.
  */
@@ -36,6 +37,10 @@ static long cup3d_stub_iallreduce7 = 0; /* one 7-double Iallreduce per BiCGSTAB 
 #define main cup3d_reference_main
 #include CUP3D_REFERENCE_MAIN
 #undef main
+#ifdef CUP3D_WITH_HIP
+/* the drop-in under test: HIP-backed operators behind the reference's own plugin surface */
+#include "../cup3d_amd/host/cup3d_hip_operators.h"
+#endif
 
 namespace {
 struct Field {
@@ -94,6 +99,7 @@ int main(int argc, char **argv) {
   std::shared_ptr<PressureProjection> proj;
   for (auto &op : sd.pipeline)
     if (auto p = std::dynamic_pointer_cast<PressureProjection>(op)) proj = p;
+  std::shared_ptr<Operator> hip_adv, hip_proj;
   std::ifstream script(argv[1]);
   std::string cmd;
   int rep = 1;
@@ -180,6 +186,17 @@ int main(int argc, char **argv) {
       else if (k == "uinfz") sd.uinf[2] = v;
       else if (k == "mean") sd.bMeanConstraint = (int)v;
       else { fprintf(stderr, "ref_tool: unknown set key %s\n", k.c_str()); exit(2); }
+    } else if (cmd == "hip") {
+      /* `hip on`: swap AdvectionDiffusion / PressureProjection in sim.pipeline for the HIP-backed
+         operators (cup3d_hip::install); every later op/steps command runs through them */
+      std::string v; script >> v;
+#ifdef CUP3D_WITH_HIP
+      static cup3d_hip::Installed inst;
+      inst = cup3d_hip::install(sd);
+      hip_adv = inst.advdiff; hip_proj = inst.projection;
+#else
+      fprintf(stderr, "ref_tool: built without CUP3D_WITH_HIP\n"); exit(2);
+#endif
     } else if (cmd == "rep") {
       script >> rep;
     } else if (cmd == "op") {
@@ -190,14 +207,14 @@ int main(int argc, char **argv) {
         cup3d_stub_iallreduce7 = 0;
         double value = 0;
         const double t0 = now();
-        if (op == "advdiff") { sd.dt = arg; advdiff(arg); }
+        if (op == "advdiff") { sd.dt = arg; if (hip_adv) (*hip_adv)(arg); else advdiff(arg); }
         else if (op == "lhs") lhsop(0);
         else if (op == "precond") {
 #pragma omp parallel
           { poisson_kernels::getZImplParallel(sd.presInfo()); }
         }
         else if (op == "solve") sd.pressureSolver->solve();
-        else if (op == "project") { sd.dt = arg; (*proj)(arg); }
+        else if (op == "project") { sd.dt = arg; if (hip_proj) (*hip_proj)(arg); else (*proj)(arg); }
         else if (op == "rhs") { /* the call at main.cpp:15083-15085 */
           KernelPressureRHS K(sd, sd.dt);
           compute<KernelPressureRHS, VectorGrid, VectorLab, VectorGrid, VectorLab, ScalarGrid>(K, *sd.vel, *sd.tmpV, true, sd.lhs);

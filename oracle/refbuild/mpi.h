@@ -78,6 +78,7 @@ static inline int MPI_Iallreduce(const void *s, void *r, int n, MPI_Datatype t, 
 static inline int MPI_Reduce(const void *s, void *r, int n, MPI_Datatype t, MPI_Op, int, MPI_Comm) { return cup3d_stub_copy(s, r, n, t); }
 static inline int MPI_Allgather(const void *s, int n, MPI_Datatype t, void *r, int, MPI_Datatype, MPI_Comm) { return cup3d_stub_copy(s, r, n, t); }
 static inline int MPI_Iallgather(const void *s, int n, MPI_Datatype t, void *r, int, MPI_Datatype, MPI_Comm, MPI_Request *q) { *q = 0; return cup3d_stub_copy(s, r, n, t); }
+static inline int MPI_Bcast(void *, int, MPI_Datatype, int, MPI_Comm) { return 0; } /* used by the HIP drop-in shim only */
 static inline int MPI_Exscan(const void *, void *, int, MPI_Datatype, MPI_Op, MPI_Comm) { return 0; /* rank 0: recvbuf undefined by the standard */ }
 
 /* traffic to MPI_PROC_NULL is a no-op by the standard (LoadBalancer, main.cpp:4822-4835) */

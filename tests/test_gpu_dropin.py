@@ -1,0 +1,66 @@
+"""End-to-end drop-in: the UNMODIFIED reference translation unit with its AdvectionDiffusion /
+PressureProjection pipeline entries swapped for the HIP-backed operators of
+cup3d_amd/host/cup3d_hip_operators.h (oracle/_ref/ref_tool_hip), against the
+same reference binary running its own CPU operators (oracle/_ref/ref_tool).  Same command line,
+same script, same initial condition; only the two hot-path operators differ."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+REF_HIP = os.path.join(O.ORACLE_DIR, "_ref", "ref_tool_hip")
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not (O.have_ref_tool() and os.path.exists(REF_HIP)), reason="oracle/_ref binaries not built")]
+
+
+def run(tool, script, args, wd):
+    with open(os.path.join(wd, "script.txt"), "w") as f:
+        f.write("\n".join(script) + "\n")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run([tool, "script.txt", "--"] + list(args), cwd=wd, env=env, check=True, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600).stdout.decode()
+    return [dict([("op", l.split()[1])] + [(kv.split("=")[0], float(kv.split("=")[1])) for kv in l.split()[2:]])
+            for l in out.splitlines() if l.startswith("REF ")]
+
+
+@pytest.mark.parametrize("bc", [("periodic", "periodic", "periodic"), ("wall", "wall", "wall"), ("freespace", "periodic", "wall")])
+def test_reference_time_loop_with_hip_operators(tmp_path, bc):
+    bpd, lmax, lstart, nsteps = (1, 1, 1), 3, 2, 5
+    args = O.ref_args(bpd, lmax, lstart, 2 * np.pi, bc, nu=0.01, cfl=0.3, extra=["-rampup", "3"])
+    tail = ["zero chi"] + sum([["op steps 1", f"dump vel v{n}.bin", f"dump pres p{n}.bin"] for n in range(nsteps)], [])
+    cpu_dir, hip_dir = tmp_path / "cpu", tmp_path / "hip"
+    cpu_dir.mkdir()
+    hip_dir.mkdir()
+    rc = run(O.REF_TOOL, tail, args, str(cpu_dir))
+    rh = run(REF_HIP, ["hip on"] + tail, args, str(hip_dir))
+    nb = 64
+    for n in range(nsteps):
+        assert abs(rc[n]["value"] - rh[n]["value"]) <= 1e-9 * rc[n]["value"]          # dt from findMaxU
+        vc, vh = (O.read_blocks(os.path.join(str(d), f"v{n}.bin"), nb, 3) for d in (cpu_dir, hip_dir))
+        pc, ph = (O.read_blocks(os.path.join(str(d), f"p{n}.bin"), nb, 1) for d in (cpu_dir, hip_dir))
+        assert np.abs(vc - vh).max() <= 1e-7 * max(1.0, np.abs(vc).max())
+        assert np.abs(pc - ph).max() <= 1e-6 * max(1e-3, np.abs(pc).max())
+
+
+def test_single_operators_through_the_shim(tmp_path):
+    """AdvectionDiffusionHIP bit-exact, PressureProjectionHIP within solver tolerance, on seeded input."""
+    bpd, lmax, lstart, bc = (2, 2, 2), 1, 0, ("periodic", "wall", "freespace")
+    rng = np.random.default_rng(3)
+    velg = rng.uniform(-1, 1, (16, 16, 16, 3))
+    args = O.ref_args(bpd, lmax, lstart, 2 * np.pi, bc)
+    script = ["zero chi", "loadg vel vel_in.bin", "set nu 0.02", "set uinfx 0.1", "op advdiff 0.01", "dump vel ad.bin", "dump tmpV adt.bin",
+              "set step 4", "op project 0.01", "dump vel pr.bin", "dump pres prp.bin"]
+    res = {}
+    for tag, tool, pre in (("cpu", O.REF_TOOL, []), ("hip", REF_HIP, ["hip on"])):
+        d = tmp_path / tag
+        d.mkdir()
+        velg.tofile(str(d / "vel_in.bin"))
+        run(tool, pre + script, args, str(d))
+        res[tag] = {k: O.read_blocks(str(d / f), 8, nc) for k, f, nc in (("ad", "ad.bin", 3), ("adt", "adt.bin", 3), ("pr", "pr.bin", 3), ("prp", "prp.bin", 1))}
+    assert np.array_equal(res["cpu"]["ad"], res["hip"]["ad"])
+    assert np.array_equal(res["cpu"]["adt"], res["hip"]["adt"])
+    assert np.abs(res["cpu"]["pr"] - res["hip"]["pr"]).max() <= 1e-8 * np.abs(res["cpu"]["pr"]).max()
+    assert np.abs(res["cpu"]["prp"] - res["hip"]["prp"]).max() <= 1e-6 * np.abs(res["cpu"]["prp"]).max()
