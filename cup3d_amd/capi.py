@@ -97,6 +97,7 @@ DEBUG_SIGNATURES = {
     "cup3d_debug_virtual_ranks": (C.c_int, [C.c_int]),
     "cup3d_debug_halo_pull": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int]),
     "cup3d_debug_advdiff_stage": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, _dp]),
+    "cup3d_debug_set_option": (C.c_int, [C.c_char_p, C.c_int]),
 }
 
 _lib = None

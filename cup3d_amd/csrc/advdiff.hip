@@ -36,9 +36,29 @@ struct AdvArgs {
 // KernelAdvectDiffuse::derivative (main.cpp:9474-9483).  The U<=0 branch is the exact
 // negation of the U>0 polynomial on mirrored inputs (round-to-nearest is symmetric
 // under negation at every step), so one polynomial and one division serve both.
+// n / 60 correctly rounded, in 3 FP64 operations instead of the ~11 of the IEEE division
+// expansion.  q0 = RN(n*C) with C = RN(1/60) is within 2 ulp of n/60; r = n - 60*q0 is then
+// exactly representable and the FMA delivers it exactly; q0 + r/60 equals n/60, and using
+// C for 1/60 perturbs it by < 2^-53 ulp, while n/60 (n a 53-bit float) is never closer than
+// ulp/30 to a rounding boundary and never on one.  Hence RN(q0 + r*C) = RN(n/60).  Signed
+// zero is restored with copysign; numerators whose residual could be subnormal, and
+// non-finite ones, take the IEEE division.  (Checked against n/60. on 2e9 random and 1.5e7
+// near-midpoint numerators on the host, and by the bit-exact GPU parity tests.)
+template <bool EXACT_TRICK>
+__device__ __forceinline__ double div60(double n) {
+  if constexpr (!EXACT_TRICK) return n / 60.;
+  const double C = 1.0 / 60.0;
+  const double q0 = n * C;
+  const double r = __builtin_fma(-60.0, q0, n);
+  double q = __builtin_copysign(__builtin_fma(r, C, q0), n);
+  const double an = __builtin_fabs(n);
+  if (__builtin_expect(!(an > 1e-280 && an < 1e300) && n != 0.0, 0)) q = n / 60.;
+  return q;
+}
+template <bool EXACT_TRICK>
 __device__ __forceinline__ double upwind5(bool pos, double m3, double m2, double m1, double c, double p1, double p2, double p3) {
   const double a = pos ? m3 : p3, b = pos ? m2 : p2, d = pos ? m1 : p1, e = pos ? p1 : m1, f = pos ? p2 : m2;
-  const double q = (-2 * a + 15 * b - 60 * d + 20 * c + 30 * e - 3 * f) / 60.;
+  const double q = div60<EXACT_TRICK>(-2 * a + 15 * b - 60 * d + 20 * c + 30 * e - 3 * f);
   return pos ? q : -q;
 }
 
@@ -70,39 +90,40 @@ __device__ __forceinline__ void face_element(int f, int e, int &nb_cell, int &ow
   }
 }
 
-template <bool FIRST_STAGE>
-__global__ void __launch_bounds__(256) k_advdiff(GridDev g, AdvArgs a) {
+// CPT = cells per thread (2 -> 256 threads, 1 -> 512 threads).  VAR: 0 production,
+// 1 IEEE division instead of div60 (A/B), 2/3 timing ablations with WRONG results
+// (2: no stencil arithmetic, 3: no ghost staging) -- cup3d_debug_set_option only.
+template <bool FIRST_STAGE, int CPT, int VAR>
+__global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
+  constexpr int NT = 512 / CPT, NW = NT / 64;
   __shared__ double tile[3 * kCompStride];  // 46,848 B -> 3 workgroups per CU
   const int slot = block_slot(g);
   if (slot < 0) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const double *__restrict__ own = a.vel + (size_t)slot * 1536;
 
-  // ---- stage the tile: centre (each thread's own two cells stay in registers too)
-  const int x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;  // cells (x,y,z0) and (x,y,z0+4)
-  double uc[2][3];
+  // ---- stage the tile: centre (each thread's own cells stay in registers too)
+  const int x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;  // cells (x,y,z0 + k*NW)
+  double uc[CPT][3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    uc[0][c] = own[c * 512 + t];
-    uc[1][c] = own[c * 512 + 256 + t];
-  }
-  double told[2][3];
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) uc[k][c] = own[c * 512 + k * NT + t];
+  double told[CPT][3];
   if (!FIRST_STAGE) {
     const double *__restrict__ tp = a.tmp + (size_t)slot * 1536;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      told[0][c] = tp[c * 512 + t];
-      told[1][c] = tp[c * 512 + 256 + t];
-    }
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int k = 0; k < CPT; ++k) told[k][c] = tp[c * 512 + k * NT + t];
   }
   const int xy = (y + 3) * kXYPitch + (x + 3);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    tile[c * kCompStride + z0 * 196 + xy] = uc[0][c];
-    tile[c * kCompStride + (z0 + 4) * 196 + xy] = uc[1][c];
-  }
-  // ---- ghosts: 18 (face, component) units of 192 values, dealt round-robin to the 4 waves
-  for (int u = wave; u < 18; u += 4) {
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) tile[c * kCompStride + (z0 + k * NW) * 196 + xy] = uc[k][c];
+  // ---- ghosts: 18 (face, component) units of 192 values, dealt round-robin to the waves
+  for (int u = wave; u < (VAR == 3 ? 0 : 18); u += NW) {
     const int f = u / 3, c = u - 3 * f;
     const int n = g.nbr[slot * 6 + f];  // wave-uniform
 #pragma unroll
@@ -132,8 +153,16 @@ __global__ void __launch_bounds__(256) k_advdiff(GridDev g, AdvArgs a) {
   double *__restrict__ vout = a.vel_out + (size_t)slot * 1536;
   double *__restrict__ tout = a.tmp + (size_t)slot * 1536;
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int z = z0 + 4 * k;
+  for (int k = 0; k < CPT; ++k) {
+    const int z = z0 + NW * k;
+    if (VAR == 2) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        vout[c * 512 + k * NT + t] = uc[k][c] + tile[c * kCompStride + ((t * 7 + c) % kCompStride)];
+        tout[c * 512 + k * NT + t] = FIRST_STAGE ? 0.0 : told[k][c];
+      }
+      continue;
+    }
     int zo[7];
 #pragma unroll
     for (int dz = -3; dz <= 3; ++dz) {
@@ -149,9 +178,9 @@ __global__ void __launch_bounds__(256) k_advdiff(GridDev g, AdvArgs a) {
       const double *L = tile + c * kCompStride;
       const double cc = uc[k][c];
       const double xm1 = L[b - 1], xp1 = L[b + 1], ym1 = L[b - kXYPitch], yp1 = L[b + kXYPitch], zm1 = L[zo[2]], zp1 = L[zo[4]];
-      const double dx = upwind5(p0, L[b - 3], L[b - 2], xm1, cc, xp1, L[b + 2], L[b + 3]);
-      const double dy = upwind5(p1, L[b - 3 * kXYPitch], L[b - 2 * kXYPitch], ym1, cc, yp1, L[b + 2 * kXYPitch], L[b + 3 * kXYPitch]);
-      const double dz = upwind5(p2, L[zo[0]], L[zo[1]], zm1, cc, zp1, L[zo[5]], L[zo[6]]);
+      const double dx = upwind5<VAR != 1>(p0, L[b - 3], L[b - 2], xm1, cc, xp1, L[b + 2], L[b + 3]);
+      const double dy = upwind5<VAR != 1>(p1, L[b - 3 * kXYPitch], L[b - 2 * kXYPitch], ym1, cc, yp1, L[b + 2 * kXYPitch], L[b + 3 * kXYPitch]);
+      const double dz = upwind5<VAR != 1>(p2, L[zo[0]], L[zo[1]], zm1, cc, zp1, L[zo[5]], L[zo[6]]);
       const double sx = xp1 + xm1, sy = yp1 + ym1, sz = zp1 + zm1;
       double lap, adv;  // the three components use three association orders, main.cpp:9531-9545
       if (c == 0) {
@@ -169,8 +198,8 @@ __global__ void __launch_bounds__(256) k_advdiff(GridDev g, AdvArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double tn = (FIRST_STAGE ? 0.0 : told[k][c]) + res[c];  // o += ..., main.cpp:9546-9548
-      vout[c * 512 + k * 256 + t] = uc[k][c] + tn * a.alpha;         // V += tmpV*ih3, 9718-9720
-      tout[c * 512 + k * 256 + t] = tn * a.beta;                     // tmpV *= beta, 9721-9723
+      vout[c * 512 + k * NT + t] = uc[k][c] + tn * a.alpha;          // V += tmpV*ih3, 9718-9720
+      tout[c * 512 + k * NT + t] = tn * a.beta;                      // tmpV *= beta, 9721-9723
     }
   }
 }
@@ -220,8 +249,20 @@ static int advdiff_stage(Sim *s, int rk, double dt, double nu, const double uinf
     GridDev g = s->gdev();
     {
       ProfileScope ps("advdiff_stage");
-      if (rk == 0) hipLaunchKernelGGL(k_advdiff<true>, dim3(launch_groups(g)), dim3(256), 0, stream(), g, a);
-      else hipLaunchKernelGGL(k_advdiff<false>, dim3(launch_groups(g)), dim3(256), 0, stream(), g, a);
+      const dim3 G(launch_groups(g));
+#define ADV(FIRST, CPT, VAR) hipLaunchKernelGGL((k_advdiff<FIRST, CPT, VAR>), G, dim3(512 / CPT), 0, stream(), g, a)
+#define ADV2(CPT, VAR) do { if (rk == 0) ADV(true, CPT, VAR); else ADV(false, CPT, VAR); } while (0)
+      switch (debug_option("advdiff_variant")) {  // 0 = production
+        case 0: ADV2(2, 0); break;
+        case 1: ADV2(2, 1); break;
+        case 2: ADV2(2, 2); break;
+        case 3: ADV2(2, 3); break;
+        case 10: ADV2(1, 0); break;
+        case 11: ADV2(1, 1); break;
+        default: set_error("unknown advdiff_variant"); return CUP3D_EINVAL;
+      }
+#undef ADV2
+#undef ADV
     }
     CUP3D_HIP(hipGetLastError());
     std::swap(s->vel, s->vel2);

@@ -29,7 +29,17 @@ enum { PHAT, RHAT, SHAT, WHAT, ZHAT, QHAT, S_, W_, Z_, T_, V_, Q_, R_, Y_, X_, R
 // registers; z-neighbours come from registers, x/y-neighbours from a 10x10-pitched LDS
 // copy of p whose border stays 0 (the zero Dirichlet halo of the reference's
 // PaddedBlock).  Two wave reductions per CG iteration (p.Ap and r.r).
-__global__ void __launch_bounds__(64) k_precond(GridDev g, const double *__restrict__ in, double *__restrict__ out) {
+// FMA = contract a*b+c where the reference has a separate multiply and add.  The block CG
+// already differs from the CPU in the summation order of its two inner products, so its
+// result is compared to the reference to a tolerance either way; FMA removes 6 of the 17
+// FP64 operations per cell per iteration of this VALU-bound kernel.
+template <bool FMA>
+__device__ __forceinline__ double mad(double a, double b, double c) {
+  if constexpr (FMA) return __builtin_fma(a, b, c);
+  else return a * b + c;
+}
+template <bool FMA>
+__global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, double *out, double *__restrict__ block_sums) {
   __shared__ double P[8 * 100];
   const int slot = block_slot(g);
   if (slot < 0) return;
@@ -42,7 +52,7 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *__restr
 #pragma unroll
   for (int z = 0; z < 8; ++z) {
     r[z] = invh * in[(size_t)slot * 512 + z * 64 + l];
-    rr += r[z] * r[z];
+    rr = mad<FMA>(r[z], r[z], rr);
     p[z] = r[z];
     x[z] = 0;
   }
@@ -58,13 +68,13 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *__restr
       double a2 = 0;
 #pragma unroll
       for (int z = 0; z < 8; ++z) {                         // kernelPoissonGetZInner, 14662-14682
-        double t = P[z * 100 + base - 1] + P[z * 100 + base + 1] - 6 * p[z];
+        double t = mad<FMA>(-6.0, p[z], P[z * 100 + base - 1] + P[z * 100 + base + 1]);
         t += P[z * 100 + base - 10];
         t += P[z * 100 + base + 10];
         t += z > 0 ? p[z - 1] : 0.0;
         t += z < 7 ? p[z + 1] : 0.0;
         Ax[z] = t;
-        a2 += p[z] * t;
+        a2 = mad<FMA>(p[z], t, a2);
       }
       __syncthreads();
       a2 = wave_sum(a2);
@@ -72,29 +82,41 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *__restr
       double ss = 0;
 #pragma unroll
       for (int z = 0; z < 8; ++z) {
-        x[z] += a * p[z];                                   // 14688
-        r[z] -= a * Ax[z];                                  // subAndSumSqr, 14636-14638
-        ss += r[z] * r[z];
+        x[z] = mad<FMA>(a, p[z], x[z]);                     // 14688
+        r[z] = mad<FMA>(-a, Ax[z], r[z]);                   // subAndSumSqr, 14636-14638
+        ss = mad<FMA>(r[z], r[z], ss);
       }
       ss = wave_sum(ss);
       const double beta = ss / (rr + 1e-55);                // 14690
       const double sqrNorm = (double)1 / (512 * 512) * ss;  // 14691
       if (sqrNorm < kRel * sqrNorm0 || sqrNorm < kAbs) break;  // 14692-14694 (returns -1)
 #pragma unroll
-      for (int z = 0; z < 8; ++z) p[z] = r[z] + beta * p[z];   // 14698-14699
+      for (int z = 0; z < 8; ++z) p[z] = mad<FMA>(beta, p[z], r[z]);   // 14698-14699
       rr = ss;
       if (rr <= 0) break;                                   // 14741
     }
   }
+  double sx = 0;
 #pragma unroll
-  for (int z = 0; z < 8; ++z) out[(size_t)slot * 512 + z * 64 + l] = x[z];
+  for (int z = 0; z < 8; ++z) {
+    out[(size_t)slot * 512 + z * 64 + l] = x[z];
+    sx += x[z];
+  }
+  if (block_sums) {  // sum(z*h^3) of this block for the mean constraint of the LHS that follows (9283-9294)
+    const double h3 = g.h * g.h * g.h;
+    sx = wave_sum(sx * h3);
+    if (l == 0) block_sums[slot] = sx;
+  }
 }
 
-int launch_precond(Sim *s, const double *in, double *out) {
+int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
   GridDev g = s->gdev();
+  double *sums = want_sums ? s->d_partials + (size_t)s->max_groups * 8 : nullptr;
   ProfileScope ps("poisson_block_cg");
-  hipLaunchKernelGGL(k_precond, dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out);
+  if (debug_option("precond_no_fma")) hipLaunchKernelGGL(k_precond<false>, dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, sums);
+  else hipLaunchKernelGGL(k_precond<true>, dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, sums);
   CUP3D_HIP(hipGetLastError());
+  s->sums_of = want_sums ? out : nullptr;  // block sums of `out` are fresh: the next LHS of `out` reuses them
   return CUP3D_OK;
 }
 
@@ -122,6 +144,14 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const double *__restric
 }
 
 #define GRID_STRIDE(j, n) for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < (n); j += (long)gridDim.x * 256)
+// 16 B per lane (double2): n is a multiple of 512
+#define GRID_STRIDE2(j, n) for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < (n) / 2; j += (long)gridDim.x * 256)
+#define LD2(v) (reinterpret_cast<const double2 *>(v)[j])
+#define ST2(v, val) (reinterpret_cast<double2 *>(v)[j] = (val))
+__device__ __forceinline__ double2 operator+(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 operator-(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 operator*(double s, double2 a) { return make_double2(s * a.x, s * a.y); }
+__device__ __forceinline__ double dot2(double2 a, double2 b, double acc) { acc += a.x * b.x; acc += a.y * b.y; return acc; }
 
 // b = r = rhs, x = pres   (main.cpp:14408-14415)
 __global__ void __launch_bounds__(256) k_solver_init(Vecs V, const double *__restrict__ rhs, const double *__restrict__ pres, long n) {
@@ -140,18 +170,18 @@ __global__ void __launch_bounds__(256) k_dots_r0(Vecs V, long n, double *__restr
 // first fused loop, k % 50 != 0   (14454-14464)
 __global__ void __launch_bounds__(256) k_loop1(Vecs V, long n, double alpha, double beta, double omega, double *__restrict__ partials) {
   double acc[2] = {0, 0};
-  GRID_STRIDE(j, n) {
-    const double rhat = V.v[RHAT][j], w = V.v[W_][j];
-    const double phat = rhat + beta * (V.v[PHAT][j] - omega * V.v[SHAT][j]);
-    const double s = w + beta * (V.v[S_][j] - omega * V.v[Z_][j]);
-    const double shat = V.v[WHAT][j] + beta * (V.v[SHAT][j] - omega * V.v[ZHAT][j]);
-    const double z = V.v[T_][j] + beta * (V.v[Z_][j] - omega * V.v[V_][j]);
-    const double q = V.v[R_][j] - alpha * s;
-    const double qhat = rhat - alpha * shat;
-    const double y = w - alpha * z;
-    V.v[PHAT][j] = phat; V.v[S_][j] = s; V.v[SHAT][j] = shat; V.v[Z_][j] = z; V.v[Q_][j] = q; V.v[QHAT][j] = qhat; V.v[Y_][j] = y;
-    acc[0] += q * y;
-    acc[1] += y * y;
+  GRID_STRIDE2(j, n) {
+    const double2 rhat = LD2(V.v[RHAT]), w = LD2(V.v[W_]), shat0 = LD2(V.v[SHAT]), z0 = LD2(V.v[Z_]);
+    const double2 phat = rhat + beta * (LD2(V.v[PHAT]) - omega * shat0);
+    const double2 s = w + beta * (LD2(V.v[S_]) - omega * z0);
+    const double2 shat = LD2(V.v[WHAT]) + beta * (shat0 - omega * LD2(V.v[ZHAT]));
+    const double2 z = LD2(V.v[T_]) + beta * (z0 - omega * LD2(V.v[V_]));
+    const double2 q = LD2(V.v[R_]) - alpha * s;
+    const double2 qhat = rhat - alpha * shat;
+    const double2 y = w - alpha * z;
+    ST2(V.v[PHAT], phat); ST2(V.v[S_], s); ST2(V.v[SHAT], shat); ST2(V.v[Z_], z); ST2(V.v[Q_], q); ST2(V.v[QHAT], qhat); ST2(V.v[Y_], y);
+    acc[0] = dot2(q, y, acc[0]);
+    acc[1] = dot2(y, y, acc[1]);
   }
   emit_partials<2>(acc, partials);
 }
@@ -174,20 +204,20 @@ __global__ void __launch_bounds__(256) k_loop1_tail(Vecs V, long n, double alpha
 // second fused loop, k % 50 != 0   (14503-14515)
 __global__ void __launch_bounds__(256) k_loop2(Vecs V, long n, double alpha, double omega, double *__restrict__ partials) {
   double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-  GRID_STRIDE(j, n) {
-    const double qhat = V.v[QHAT][j], y = V.v[Y_][j], r0 = V.v[R0][j];
-    const double x = V.v[X_][j] + alpha * V.v[PHAT][j] + omega * qhat;
-    const double r = V.v[Q_][j] - omega * y;
-    const double rhat = qhat - omega * (V.v[WHAT][j] - alpha * V.v[ZHAT][j]);
-    const double w = y - omega * (V.v[T_][j] - alpha * V.v[V_][j]);
-    V.v[X_][j] = x; V.v[R_][j] = r; V.v[RHAT][j] = rhat; V.v[W_][j] = w;
-    acc[0] += r0 * r;
-    acc[1] += r0 * w;
-    acc[2] += r0 * V.v[S_][j];
-    acc[3] += r0 * V.v[Z_][j];
-    acc[4] += r * r;   // norm_1
-    acc[5] += r0 * r0; // norm_2
-    acc[6] += r * r;   // norm
+  GRID_STRIDE2(j, n) {
+    const double2 qhat = LD2(V.v[QHAT]), y = LD2(V.v[Y_]), r0 = LD2(V.v[R0]);
+    const double2 x = LD2(V.v[X_]) + alpha * LD2(V.v[PHAT]) + omega * qhat;
+    const double2 r = LD2(V.v[Q_]) - omega * y;
+    const double2 rhat = qhat - omega * (LD2(V.v[WHAT]) - alpha * LD2(V.v[ZHAT]));
+    const double2 w = y - omega * (LD2(V.v[T_]) - alpha * LD2(V.v[V_]));
+    ST2(V.v[X_], x); ST2(V.v[R_], r); ST2(V.v[RHAT], rhat); ST2(V.v[W_], w);
+    acc[0] = dot2(r0, r, acc[0]);
+    acc[1] = dot2(r0, w, acc[1]);
+    acc[2] = dot2(r0, LD2(V.v[S_]), acc[2]);
+    acc[3] = dot2(r0, LD2(V.v[Z_]), acc[3]);
+    acc[4] = dot2(r, r, acc[4]);    // norm_1
+    acc[5] = dot2(r0, r0, acc[5]);  // norm_2
+    acc[6] = dot2(r, r, acc[6]);    // norm
   }
   emit_partials<7>(acc, partials);
 }
@@ -276,7 +306,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   const double eps = 1e-100;
   Reducer red{s, G};
   auto LHS = [&](int in, int out) { return launch_lhs(s, V.v[in], V.v[out], mc); };       // _lhs, 9365-9393
-  auto PRE = [&](int in, int out) { return launch_precond(s, V.v[in], V.v[out]); };       // _preconditioner, 9334-9364
+  auto PRE = [&](int in, int out) { return launch_precond(s, V.v[in], V.v[out], mc > 0 && mc <= 2); };       // _preconditioner, 9334-9364
 
   if ((mc == 1 || mc > 2) && s->grid->corner_slot >= 0)  // rhs(0,0,0) = 0, 14404-14407
     hipLaunchKernelGGL(k_set_one, dim3(1), dim3(1), 0, stream(), s->lhs, (size_t)s->grid->corner_slot * 512, 0.0);
@@ -378,7 +408,7 @@ void cup3d_poisson_default_params(cup3d_poisson_params *p) {
 int cup3d_preconditioner(cup3d_sim_t *h) {
   if (!h) return CUP3D_EINVAL;
   Sim *s = reinterpret_cast<Sim *>(h);
-  return launch_precond(s, s->pres, s->pres);  // in place: each wavefront reads its block before writing it
+  return launch_precond(s, s->pres, s->pres, false);  // in place: each wavefront reads its block before writing it
 }
 
 int cup3d_poisson_solve(cup3d_sim_t *h, const cup3d_poisson_params *p, cup3d_poisson_result *r) {

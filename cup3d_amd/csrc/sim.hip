@@ -66,6 +66,12 @@ ProfileScope::~ProfileScope() {
   if (g_prof_open.size() > 4096) profile_drain();
 }
 
+static std::map<std::string, int> g_debug_opts;
+int debug_option(const char *name) {
+  auto it = g_debug_opts.find(name);
+  return it == g_debug_opts.end() ? 0 : it->second;
+}
+
 // ------------------------------------------------------------------ Sim
 GridDev Sim::gdev(bool boundary_only, bool inner_only) const {
   GridDev g;
@@ -195,6 +201,13 @@ int cup3d_set_stream(void *s) { g_stream = (hipStream_t)s; return CUP3D_OK; }
 int cup3d_device_synchronize(void) {
   CUP3D_HIP(hipStreamSynchronize(g_stream));
   CUP3D_HIP(hipDeviceSynchronize());
+  return CUP3D_OK;
+}
+
+// TEST / TUNING SUPPORT: select kernel variants (A/B timing, ablations); 0 = production
+int cup3d_debug_set_option(const char *name, int value) {
+  if (!name) return CUP3D_EINVAL;
+  g_debug_opts[name] = value;
   return CUP3D_OK;
 }
 

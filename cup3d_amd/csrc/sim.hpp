@@ -28,6 +28,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
   } while (0)
 
 hipStream_t stream();  // compute stream (cup3d_set_stream)
+int debug_option(const char *name);  // cup3d_debug_set_option; 0 when unset (production behaviour)
 
 // ---- per-kernel timing (cup3d_profile_*) ----
 struct ProfileScope {
@@ -65,6 +66,7 @@ struct Sim {
   // reductions
   double *d_partials = nullptr;  // [max_groups][8]
   double *d_red = nullptr;       // [16] final reduced scalars
+  const double *sums_of = nullptr;  // vector whose per-block sums (mean constraint) are current in d_partials' tail
   double *h_red = nullptr;       // pinned host mirror
   int max_groups = 0;
   // staging for host transfers
@@ -90,6 +92,6 @@ int allreduce(Sim *s, double *d_buf, int n, bool is_max, hipStream_t st);
 
 // kernels' launchers shared across translation units
 int launch_lhs(Sim *s, const double *p, double *out, int mean_constraint);
-int launch_precond(Sim *s, const double *in, double *out);
+int launch_precond(Sim *s, const double *in, double *out, bool want_sums);
 
 }  // namespace cup3d

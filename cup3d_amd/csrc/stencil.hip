@@ -91,12 +91,17 @@ __global__ void __launch_bounds__(256) k_lhs(GridDev g, const double *__restrict
   }
 }
 
-// deterministic sum of n per-block values -> out[0] (single workgroup)
-__global__ void __launch_bounds__(256) k_sum_blocks(const double *__restrict__ v, int n, double *__restrict__ out) {
+// deterministic two-stage sum of n per-block values: 64 workgroups -> 64 partials -> out[0]
+__global__ void __launch_bounds__(256) k_sum_blocks(const double *__restrict__ v, int n, double *__restrict__ part) {
   __shared__ double red[4];
   double s = 0;
-  for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) s += v[i];
   s = group_sum<4>(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(64) k_sum_final(const double *__restrict__ part, int n, double *__restrict__ out) {
+  double s = threadIdx.x < n ? part[threadIdx.x] : 0.0;
+  s = wave_sum(s);
   if (threadIdx.x == 0) out[0] = s;
 }
 // mean-constraint fix-ups of ComputeLHS::operator(), main.cpp:9299-9326
@@ -185,15 +190,19 @@ int launch_lhs(Sim *s, const double *p, double *out, int mc) {
   const bool need_sum = mc > 0 && mc <= 2;
   GridDev g = s->gdev();
   double *block_sums = s->d_partials + (size_t)s->max_groups * 8;
+  const bool have_sums = need_sum && s->sums_of == p;  // the block CG that produced p already summed it
+  s->sums_of = nullptr;
   {
     ProfileScope ps("poisson_lhs");
-    hipLaunchKernelGGL(k_lhs, dim3(launch_groups(g)), dim3(256), 0, stream(), g, p, s->halo_recv, out, need_sum ? block_sums : nullptr);
+    hipLaunchKernelGGL(k_lhs, dim3(launch_groups(g)), dim3(256), 0, stream(), g, p, s->halo_recv, out, (need_sum && !have_sums) ? block_sums : nullptr);
   }
   CUP3D_HIP(hipGetLastError());
   if (mc == 0) return CUP3D_OK;
   const int corner = s->grid->corner_slot;
   if (need_sum) {
-    hipLaunchKernelGGL(k_sum_blocks, dim3(1), dim3(256), 0, stream(), block_sums, (int)s->nb, s->d_red + 8);
+    ProfileScope ps("poisson_mean_sum");
+    hipLaunchKernelGGL(k_sum_blocks, dim3(64), dim3(256), 0, stream(), block_sums, (int)s->nb, s->d_partials);
+    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64), 0, stream(), s->d_partials, 64, s->d_red + 8);
     if ((rc = allreduce(s, s->d_red + 8, 1, false, stream()))) return rc;  // MPI_Iallreduce, main.cpp:9295
     if (mc == 1) {
       if (corner >= 0) hipLaunchKernelGGL(k_lhs_corner, dim3(1), dim3(1), 0, stream(), out, p, s->d_red + 8, corner, 1);

@@ -488,10 +488,12 @@ static double precond_inner(double p[BS + 2][BS + 2][BS + 2], double Ax[BS][BS][
   return sqrSum;
 }
 
+long orc_precond_total_iters = 0; /* diagnostic: block-CG iterations summed over blocks by the last orc_precond call */
 void orc_precond(const orc_grid *g, double *pres) { /* getZImplParallel, main.cpp:14704-14745 */
+  long total = 0;
   static const double kRel = 1e-7 * 1e-7, kAbs = 1e-16 * 1e-16;
   (void)kRel; (void)kAbs;
-#pragma omp parallel for
+#pragma omp parallel for reduction(+ : total)
   for (long b = 0; b < g->nblocks; b++) {
     double p[BS + 2][BS + 2][BS + 2], Ax[BS][BS][BS], r[BS][BS][BS];
     memset(p, 0, sizeof p);
@@ -512,9 +514,11 @@ void orc_precond(const orc_grid *g, double *pres) { /* getZImplParallel, main.cp
     if (sqrNorm0 < 1e-32) continue;
     for (int k = 0; k < 100; k++) {
       rr = precond_inner(p, Ax, r, blk, sqrNorm0, rr);
+      total++;
       if (rr <= 0) break;
     }
   }
+  orc_precond_total_iters = total;
 }
 
 static void solver_lhs(const orc_grid *g, const double *in, double *out, int mc) { orc_lhs(g, in, out, mc); } /* _lhs 9365-9393 */

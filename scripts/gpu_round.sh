@@ -1,24 +1,46 @@
 #!/bin/bash
-# One gpurun call: smoke, GPU parity tests, bench lines, rocprof kernel trace.
-# Usage: gpurun --timeout 1500 -- 'bash scripts/gpu_round.sh [tag]'
-TAG=${1:-r01}
+# One gpurun call.  Usage: gpurun --timeout 1500 -- 'bash scripts/gpu_round.sh <tag> [stages...]'
+# stages: smoke tests probe bench pmc trace   (default: all)
+TAG=${1:-r01}; shift
+STAGES=${@:-smoke tests probe bench trace pmc}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
 ROOT=$PWD
-echo "== rocminfo" ; rocminfo 2>/dev/null | grep -m2 -E "gfx|Marketing" ; nproc ; free -g | head -2
-echo "== smoke"
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1 ; echo "smoke rc=$?" ; tail -3 $OUT/smoke.log
-echo "== pytest -m gpu"
-timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1 ; echo "pytest rc=$?" ; tail -15 $OUT/pytest_gpu.log
-echo "== bench 256 stencil-only"
-timeout 300 python bench.py --size 256 --steps 10 --warmup 2 --no-cpu --stencil-only > $OUT/bench_256_stencil.json 2> $OUT/bench_256_stencil.err ; tail -c 1500 $OUT/bench_256_stencil.json
-echo "== bench 512 stencil-only"
-timeout 300 python bench.py --size 512 --steps 5 --warmup 1 --no-cpu --stencil-only > $OUT/bench_512_stencil.json 2> $OUT/bench_512_stencil.err ; tail -c 1500 $OUT/bench_512_stencil.json
-echo "== bench default (512 full + cpu baseline)"
-timeout 900 python bench.py > $OUT/bench_512.json 2> $OUT/bench_512.err ; echo "bench rc=$?" ; tail -c 3000 $OUT/bench_512.json ; tail -5 $OUT/bench_512.err
-echo "== rocprof kernel trace (256 full, 2 steps)"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof -o trace -- python $ROOT/bench.py --size 256 --steps 2 --warmup 1 --no-cpu > $ROOT/$OUT/rocprof.log 2>&1 )
-find $OUT/prof -name "*stats*" | head ; for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -25 $f; done
+has() { [[ " $STAGES " == *" $1 "* ]]; }
+echo "== host: $(nproc) cpus" ; rocminfo 2>/dev/null | grep -m1 -E "gfx9" 
+if has smoke; then echo "== smoke"
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1 ; echo "smoke rc=$?" ; tail -3 $OUT/smoke.log; fi
+if has tests; then echo "== pytest -m gpu"
+  timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1 ; echo "pytest rc=$?" ; tail -25 $OUT/pytest_gpu.log | cut -c1-300; fi
+if has probe; then echo "== kernel probes"
+  timeout 300 python scripts/kernel_probe.py adv --size 512 > $OUT/probe_adv_512.jsonl 2>&1 ; cat $OUT/probe_adv_512.jsonl
+  timeout 300 python scripts/kernel_probe.py adv --size 256 --variants 0,10 > $OUT/probe_adv_256.jsonl 2>&1 ; cat $OUT/probe_adv_256.jsonl
+  timeout 300 python scripts/kernel_probe.py pre --size 256 > $OUT/probe_pre_256.jsonl 2>&1 ; cat $OUT/probe_pre_256.jsonl; fi
+if has bench; then echo "== bench 512 stencil-only"
+  timeout 300 python bench.py --size 512 --steps 5 --warmup 1 --no-cpu --stencil-only > $OUT/bench_512_stencil.json 2> $OUT/bench_512_stencil.err ; tail -c 1200 $OUT/bench_512_stencil.json
+  echo "== bench default (512 full + cpu baseline)"
+  timeout 1200 python bench.py > $OUT/bench_512.json 2> $OUT/bench_512.err ; echo "bench rc=$?" ; tail -c 4000 $OUT/bench_512.json ; tail -3 $OUT/bench_512.err; fi
+if has trace; then echo "== rocprofv3 kernel trace (256^3 full step x2)"
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace -o t -- python $ROOT/bench.py --size 256 --steps 2 --warmup 1 --no-cpu > $ROOT/$OUT/trace.log 2>&1 )
+  for f in $(find $OUT/trace -name "*kernel_stats.csv" | head -1); do cp $f $OUT/kernel_stats_256_full.csv; head -12 $f | cut -c1-200; done
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace512 -o t -- python $ROOT/scripts/kernel_probe.py one --size 512 --kernel adv > $ROOT/$OUT/trace512.log 2>&1 )
+  for f in $(find $OUT/trace512 -name "*kernel_stats.csv" | head -1); do cp $f $OUT/kernel_stats_512_adv.csv; head -6 $f | cut -c1-200; done
+  rm -rf $OUT/trace/*/*.db $OUT/trace512/*/*.db 2>/dev/null; fi
+if has pmc; then echo "== rocprofv3 PMC passes (advdiff 512^3): FETCH_SIZE, WRITE_SIZE in separate runs"
+  for C in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_$C -o p -- python $ROOT/scripts/kernel_probe.py one --size 512 --kernel adv > $ROOT/$OUT/pmc_$C.log 2>&1 )
+    for f in $(find $OUT/pmc_$C -name "*counter_collection.csv" | head -1); do python - "$f" $C <<'PY'
+import csv, sys, collections
+f, c = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if r.get("Counter_Name") == c:
+        acc[r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
+for k, v in acc.items():
+    print(c, k, "launches", len(v), "mean", sum(v) / len(v))
+PY
+    done
+  done; fi
 echo "== done"

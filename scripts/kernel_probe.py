@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Kernel A/B and ablation timing on one GPU, without torch (fast start).
+
+    python scripts/kernel_probe.py adv  --size 512 [--variants 0,1,2,3,10]   advect-diffuse variants
+    python scripts/kernel_probe.py pre  --size 256                          block-CG variants on solver-like input
+    python scripts/kernel_probe.py one  --size 512 --kernel adv|lhs|pre|loop  a few launches of one kernel (rocprof --pmc target)
+Times come from the library's own hipEvent profile (cup3d_profile_*)."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import cup3d_amd as cu  # noqa: E402
+from bench import taylor_green_blocks  # noqa: E402
+from cup3d_amd.capi import ProfileEntry, check, lib  # noqa: E402
+
+
+def profile():
+    ents = (ProfileEntry * 64)()
+    n = C.c_int(0)
+    lib().cup3d_profile_read(ents, 64, C.byref(n))
+    return {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n.value)}
+
+
+def make(size, bc="periodic"):
+    level = int(round(np.log2(size // 8)))
+    sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=level + 1, levelStart=level, extent=2 * np.pi, nu=0.01, CFL=0.3,
+                            BC_x=bc, BC_y=bc, BC_z=bc, uMax_forced=1.0, rampup=0)
+    sim.upload("vel", taylor_green_blocks(sim.grid, [2 * np.pi] * 3, 1.0))
+    return sim
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["adv", "pre", "one"])
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--variants", default="0,1,2,3,10,11")
+    ap.add_argument("--kernel", default="adv")
+    ap.add_argument("--reps", type=int, default=4)
+    a = ap.parse_args()
+    cu.device_init(0)
+    lib().cup3d_profile_enable(1)
+    cells = float(a.size) ** 3
+    if a.what == "adv":
+        sim = make(a.size)
+        adv = cu.AdvectionDiffusion(sim)
+        dt = 0.3 * sim.grid.h
+        for v in [int(x) for x in a.variants.split(",")]:
+            check(lib().cup3d_debug_set_option(b"advdiff_variant", v))
+            adv(dt)
+            lib().cup3d_device_synchronize()
+            lib().cup3d_profile_reset()
+            for _ in range(a.reps):
+                adv(dt)
+            n, ms = profile()["advdiff_stage"]
+            avg = ms / n
+            print(json.dumps({"probe": "advdiff", "size": a.size, "variant": v, "avg_ms": round(avg, 4),
+                              "GBps_algorithmic": round(96 * cells / avg / 1e6, 1), "frac_8TBs": round(96 * cells / avg / 1e6 / 8000, 4)}))
+        check(lib().cup3d_debug_set_option(b"advdiff_variant", 0))
+    elif a.what == "pre":
+        sim = make(a.size, "wall")
+        # solver-like inputs: the pressure RHS of the initial field, then A M^-1 of it, then noise
+        check(lib().cup3d_pressure_rhs(sim.handle, 0.3 * sim.grid.h))
+        rhs = sim.download("lhs")
+        rng = np.random.default_rng(0)
+        inputs = {"rhs": rhs, "noise": rng.uniform(-1, 1, rhs.shape)}
+        for name, x in inputs.items():
+            for nofma in (0, 1):
+                check(lib().cup3d_debug_set_option(b"precond_no_fma", nofma))
+                sim.upload("pres", x)
+                check(lib().cup3d_preconditioner(sim.handle))
+                lib().cup3d_device_synchronize()
+                lib().cup3d_profile_reset()
+                for _ in range(a.reps):
+                    sim.upload("pres", x)
+                    check(lib().cup3d_preconditioner(sim.handle))
+                n, ms = profile()["poisson_block_cg"]
+                print(json.dumps({"probe": "block_cg", "size": a.size, "input": name, "no_fma": nofma, "avg_ms": round(ms / n, 4)}))
+        check(lib().cup3d_debug_set_option(b"precond_no_fma", 0))
+    else:
+        bc = "periodic" if a.kernel == "adv" else "wall"
+        sim = make(a.size, bc)
+        dt = 0.3 * sim.grid.h
+        if a.kernel == "adv":
+            for _ in range(a.reps):
+                cu.AdvectionDiffusion(sim)(dt)
+        else:
+            sim.step = 21
+            cu.PressureProjection(sim)(dt)
+        lib().cup3d_device_synchronize()
+        print(json.dumps({k: {"launches": v[0], "avg_ms": round(v[1] / max(1, v[0]), 4)} for k, v in profile().items()}))
+
+
+if __name__ == "__main__":
+    main()
