@@ -39,6 +39,7 @@ ALGO_BYTES = {
     "bicgstab_loop2": 128.0,   # 12 reads + 4 writes
     "poisson_lhs": 16.0,       # p in, Ap out
     "poisson_block_cg": 16.0,  # r in, z out (FP64-VALU bound, shown against HBM for reference)
+    "poisson_block_fdm": 16.0,  # r in, z out (direct block solve)
 }
 
 
@@ -102,6 +103,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--stencil-only", action="store_true", help="BASELINE configs[1]: periodic, advect-diffuse only")
+    ap.add_argument("--block-solver", type=int, default=0, help="0: block CG as in the reference, 1: direct block solve")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -139,7 +141,7 @@ def main():
     ext = 2 * np.pi
     bc = "periodic" if a.stencil_only else "wall"
     sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=level + 1, levelStart=level, extent=ext, nu=0.01, CFL=0.3,
-                            BC_x=bc, BC_y=bc, BC_z=bc, uMax_forced=1.0, rampup=0, rank=rank, nranks=world)
+                            BC_x=bc, BC_y=bc, BC_z=bc, uMax_forced=1.0, rampup=0, rank=rank, nranks=world, blockSolver=a.block_solver)
     sim.upload("vel", taylor_green_blocks(sim.grid, [ext] * 3, 1.0))
     sim.step = 21
     S = cu.Simulation(sim)
@@ -218,7 +220,8 @@ def report(a, sim, prof, sec, iters, world):
                                 f"poissonTol 1e-6/1e-4, bMeanConstraint 1, steps from 21") if not a.stencil_only
                    else f"taylor-green {a.size}^3 uniform periodic, advect-diffuse RK3 only",
                    "cells": int(cells), "blocks": int(cells // 512), "block": "8^3", "partition": f"hilbert-range x{world}",
-                   "bicgstab_iters_per_step": round(float(np.mean(iters)), 2) if iters else None},
+                   "bicgstab_iters_per_step": round(float(np.mean(iters)), 2) if iters else None,
+                   "block_preconditioner": ("block CG (reference algorithm)", "direct block solve (fast diagonalisation)")[a.block_solver]},
         "roofline": ({k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]})
         if dominant else None,
         "kernels": kernels,

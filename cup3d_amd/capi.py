@@ -23,7 +23,7 @@ class Cup3dError(RuntimeError):
 
 class PoissonParams(C.Structure):
     _fields_ = [("tol", C.c_double), ("tol_rel", C.c_double), ("mean_constraint", C.c_int),
-                ("max_iter", C.c_int), ("max_restarts", C.c_int)]
+                ("max_iter", C.c_int), ("max_restarts", C.c_int), ("block_solver", C.c_int)]
 
 
 class PoissonResult(C.Structure):
@@ -82,7 +82,7 @@ SIGNATURES = {
     "cup3d_external_forcing": (C.c_int, [_vp] + [C.c_double] * 4),
     "cup3d_poisson_default_params": (None, [C.POINTER(PoissonParams)]),
     "cup3d_compute_lhs": (C.c_int, [_vp, C.c_int]),
-    "cup3d_preconditioner": (C.c_int, [_vp]),
+    "cup3d_preconditioner": (C.c_int, [_vp, C.c_int]),
     "cup3d_poisson_solve": (C.c_int, [_vp, C.POINTER(PoissonParams), C.POINTER(PoissonResult)]),
     "cup3d_pressure_rhs": (C.c_int, [_vp, C.c_double]),
     "cup3d_div_pressure": (C.c_int, [_vp]),

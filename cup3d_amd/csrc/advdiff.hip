@@ -117,33 +117,46 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
 #pragma unroll
       for (int k = 0; k < CPT; ++k) told[k][c] = tp[c * 512 + k * NT + t];
   }
+  // ---- ghosts: 18 (face, component) units of 192 values, dealt round-robin to the waves.
+  // Every global load of the tile (centre, tmpV, ghosts: ~27 per thread) is issued before the
+  // first LDS write, so one memory latency is exposed per block instead of one per unit.
+  constexpr int UPW = (18 + NW - 1) / NW;  // units per wave
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  double gv[UPW][3];
+  int gl[UPW][3];
+  bool gflip[UPW];
+#pragma unroll
+  for (int i = 0; i < UPW; ++i) {
+    const int u = wave_s + i * NW;  // wave-uniform
+    if (VAR != 3 && u < 18) {
+      const int f = u / 3, c = u - 3 * f;
+      const int n = g.nbr[slot * 6 + f];
+      // domain face: BlockLabBC, main.cpp:6513-6551.  wall (n == -3): every component negated
+      // (6384-6394); freespace (n == -1): copy, normal component negated (6137-6153)
+      const bool flip = n < 0 && (n == -3 || c == (f >> 1));
+      const double *__restrict__ base = n >= kNbrHalo ? a.halo + ((size_t)(n - kNbrHalo) * 3 + c) * 192
+                                        : (n >= 0 ? a.vel + (size_t)n * 1536 + c * 512 : own + c * 512);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        int nb_cell, own_cell, lds, hal;
+        face_element(f, j * 64 + lane, nb_cell, own_cell, lds, hal);
+        gv[i][j] = base[n >= kNbrHalo ? hal : (n >= 0 ? nb_cell : own_cell)];  // consumed only after all loads are out
+        gl[i][j] = c * kCompStride + lds;
+      }
+      gflip[i] = flip;
+    }
+  }
   const int xy = (y + 3) * kXYPitch + (x + 3);
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
     for (int k = 0; k < CPT; ++k) tile[c * kCompStride + (z0 + k * NW) * 196 + xy] = uc[k][c];
-  // ---- ghosts: 18 (face, component) units of 192 values, dealt round-robin to the waves
-  for (int u = wave; u < (VAR == 3 ? 0 : 18); u += NW) {
-    const int f = u / 3, c = u - 3 * f;
-    const int n = g.nbr[slot * 6 + f];  // wave-uniform
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      int nb_cell, own_cell, lds, hal;
-      face_element(f, j * 64 + lane, nb_cell, own_cell, lds, hal);
-      double v;
-      if (n >= kNbrHalo) {
-        v = a.halo[((size_t)(n - kNbrHalo) * 3 + c) * 192 + hal];
-      } else if (n >= 0) {
-        v = a.vel[(size_t)n * 1536 + c * 512 + nb_cell];
-      } else {
-        // domain face: BlockLabBC, main.cpp:6513-6551.  wall (n == -3): every component
-        // negated (6384-6394); freespace (n == -1): copy, normal component negated (6137-6153)
-        v = own[c * 512 + own_cell];
-        if (n == -3 || c == (f >> 1)) v = -v;
-      }
-      tile[c * kCompStride + lds] = v;
+  for (int i = 0; i < UPW; ++i)
+    if (VAR != 3 && wave_s + i * NW < 18) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) tile[gl[i][j]] = gflip[i] ? -gv[i][j] : gv[i][j];
     }
-  }
   __syncthreads();
 
   // ---- compute
@@ -223,10 +236,10 @@ __global__ void __launch_bounds__(64) k_pack_faces(const double *__restrict__ fi
     }
 }
 
-int launch_pack(Sim *src, const double *field, int nc, int w) {
+int launch_pack(Sim *src, const double *field, int nc, int w, hipStream_t st) {
   const unsigned nsend = (unsigned)src->grid->send_faces.size();
   if (!nsend) return CUP3D_OK;
-  hipLaunchKernelGGL(k_pack_faces, dim3(nsend), dim3(64), 0, stream(), field, src->d_send_faces, nc, w, src->halo_send);
+  hipLaunchKernelGGL(k_pack_faces, dim3(nsend), dim3(64), 0, st, field, src->d_send_faces, nc, w, src->halo_send);
   CUP3D_HIP(hipGetLastError());
   return CUP3D_OK;
 }
@@ -236,7 +249,9 @@ static int advdiff_stage(Sim *s, int rk, double dt, double nu, const double uinf
   const double beta[3] = {-5.0 / 9.0, -153.0 / 128.0, 0.0};       // main.cpp:9701
   const double h = s->grid->h;
   {
-    int rc = halo_exchange(s, s->vel, 3, 3);  // grid->sync(stencil{-3..4}), main.cpp:5589-5590
+    // grid->sync(stencil{-3..4}) (main.cpp:5589-5590) overlapped with the inner blocks (5598-5602)
+    const bool split = s->grid->nranks > 1;
+    int rc = halo_begin(s, s->vel, 3, 3);
     if (rc) return rc;
     AdvArgs a;
     a.vel = s->vel;
@@ -246,8 +261,10 @@ static int advdiff_stage(Sim *s, int rk, double dt, double nu, const double uinf
     a.dt = dt; a.nu = nu; a.u0 = uinf[0]; a.u1 = uinf[1]; a.u2 = uinf[2];
     a.alpha = alpha[rk] / (h * h * h);  // ih3, main.cpp:9711-9712
     a.beta = beta[rk];
-    GridDev g = s->gdev();
-    {
+    for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
+      GridDev g = split ? s->gdev(pass == 1, pass == 0) : s->gdev();
+      if (pass == 1 && (rc = halo_finish(s))) return rc;
+      if (g.nblocks == 0) continue;
       ProfileScope ps("advdiff_stage");
       const dim3 G(launch_groups(g));
 #define ADV(FIRST, CPT, VAR) hipLaunchKernelGGL((k_advdiff<FIRST, CPT, VAR>), G, dim3(512 / CPT), 0, stream(), g, a)

@@ -17,7 +17,7 @@
 
 namespace cup3d {
 
-int launch_pack(Sim *src, const double *field, int nc, int w);  // advdiff.hip
+int launch_pack(Sim *src, const double *field, int nc, int w, hipStream_t st);  // advdiff.hip
 static bool g_virtual_ranks = false;  // test mode: halos are pre-filled by cup3d_debug_halo_pull
 bool virtual_ranks() { return g_virtual_ranks; }
 
@@ -71,7 +71,7 @@ int halo_exchange(Sim *s, const double *field, int nc, int w) {
   const size_t per_face = (size_t)nc * w * 64;
   ProfileScope ps("halo_exchange");
   {
-    int rc = launch_pack(s, field, nc, w);
+    int rc = launch_pack(s, field, nc, w, stream());
     if (rc) return rc;
   }
   CUP3D_NCCL(c->GroupStart());
@@ -84,6 +84,42 @@ int halo_exchange(Sim *s, const double *field, int nc, int w) {
     ro += nr;
   }
   CUP3D_NCCL(c->GroupEnd());
+  return CUP3D_OK;
+}
+
+// Overlapped form (the reference's inner/halo split, compute<>() main.cpp:5598-5618): the
+// exchange runs on the communication stream while the caller launches the blocks that have
+// no remote neighbour on the compute stream; halo_finish() then makes the compute stream wait
+// for the slabs before the boundary blocks are launched.
+int halo_begin(Sim *s, const double *field, int nc, int w) {
+  const Grid *g = s->grid;
+  if (g->nranks == 1 || g_virtual_ranks) return CUP3D_OK;
+  Comm *c = comm();
+  if (!c) { set_error("multi-rank grid without cup3d_comm_init"); return CUP3D_ESTATE; }
+  const size_t per_face = (size_t)nc * w * 64;
+  // the field (and the previous consumers of the slab buffers) live on the compute stream
+  CUP3D_HIP(hipEventRecord(s->ev_h1, stream()));
+  CUP3D_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_h1, 0));
+  {
+    int rc = launch_pack(s, field, nc, w, s->comm_stream);
+    if (rc) return rc;
+  }
+  CUP3D_NCCL(c->GroupStart());
+  size_t so = 0, ro = 0;
+  for (int p = 0; p < g->nranks; ++p) {
+    const size_t ns = (size_t)g->send_count[p] * per_face, nr = (size_t)g->recv_count[p] * per_face;
+    if (ns) CUP3D_NCCL(c->Send(s->halo_send + so, ns, ncclDouble, p, c->comm, s->comm_stream));
+    if (nr) CUP3D_NCCL(c->Recv(s->halo_recv + ro, nr, ncclDouble, p, c->comm, s->comm_stream));
+    so += ns;
+    ro += nr;
+  }
+  CUP3D_NCCL(c->GroupEnd());
+  CUP3D_HIP(hipEventRecord(s->ev_h2, s->comm_stream));
+  return CUP3D_OK;
+}
+int halo_finish(Sim *s) {
+  if (s->grid->nranks == 1 || g_virtual_ranks) return CUP3D_OK;
+  CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
   return CUP3D_OK;
 }
 
@@ -158,7 +194,7 @@ int cup3d_debug_halo_pull(cup3d_sim_t *dst_h, cup3d_sim_t *const *peers, int npe
     int ncs;
     const double *f = src->field(field, &ncs);
     if (!f || ncs != nc) { set_error("bad field for halo pull"); return CUP3D_EINVAL; }
-    int rc = launch_pack(src, f, nc, w);
+    int rc = launch_pack(src, f, nc, w, stream());
     if (rc) return rc;
     size_t so = 0;
     for (int q = 0; q < g->rank; ++q) so += (size_t)gp->send_count[q] * per_face;

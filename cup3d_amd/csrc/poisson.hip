@@ -29,10 +29,8 @@ enum { PHAT, RHAT, SHAT, WHAT, ZHAT, QHAT, S_, W_, Z_, T_, V_, Q_, R_, Y_, X_, R
 // registers; z-neighbours come from registers, x/y-neighbours from a 10x10-pitched LDS
 // copy of p whose border stays 0 (the zero Dirichlet halo of the reference's
 // PaddedBlock).  Two wave reductions per CG iteration (p.Ap and r.r).
-// FMA = contract a*b+c where the reference has a separate multiply and add.  The block CG
-// already differs from the CPU in the summation order of its two inner products, so its
-// result is compared to the reference to a tolerance either way; FMA removes 6 of the 17
-// FP64 operations per cell per iteration of this VALU-bound kernel.
+// FMA = contract a*b+c where the reference has a separate multiply and add (tuning variant
+// only: the production launch keeps the reference's association).
 template <bool FMA>
 __device__ __forceinline__ double mad(double a, double b, double c) {
   if constexpr (FMA) return __builtin_fma(a, b, c);
@@ -109,12 +107,129 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
   }
 }
 
+// ------------------------------------------------------------------ direct block solve
+// The block preconditioner M^-1 is "solve sum6(z) - 6z = r/h on one 8^3 block with zero
+// ghosts".  The reference evaluates it by CG to a 1e-7 relative residual (14704-14745);
+// the same operator can be evaluated EXACTLY (to rounding) by fast diagonalisation:
+// the 1-D operator tridiag(1,-2,1) with Dirichlet ends has the sine eigenvectors
+// Q[k][j] = sqrt(2/9) sin(pi (j+1)(k+1)/9) (Q = Q^T = Q^-1) and eigenvalues
+// lam_k = 2 cos(pi (k+1)/9) - 2, so  z = (Q x Q x Q) [ (Q x Q x Q) r / (lam_i+lam_j+lam_k) ].
+// Six 8-point transforms per lane (40 FP64 ops each thanks to Q[k][7-j] = (-1)^k Q[k][j]),
+// four LDS transposes, no reductions, no iteration, no divergence: ~260 FP64 operations per
+// lane against ~124 per CG ITERATION.  Its result differs from the reference's CG result by
+// the CG's own truncation error (<= cond * 1e-7), i.e. it is the same preconditioner
+// evaluated more accurately; selected with cup3d_poisson_params.block_solver = 1.
+__constant__ double cQ[8][4];
+static double *g_invD = nullptr;  // [ky][kz][kx] = 1 / (lam_kx + lam_ky + lam_kz)
+
+__device__ __forceinline__ void sine_transform8(const double (&v)[8], double (&o)[8]) {
+  const double e0 = v[0] + v[7], e1 = v[1] + v[6], e2 = v[2] + v[5], e3 = v[3] + v[4];
+  const double d0 = v[0] - v[7], d1 = v[1] - v[6], d2 = v[2] - v[5], d3 = v[3] - v[4];
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+    o[k] = __builtin_fma(cQ[k][3], e3, __builtin_fma(cQ[k][2], e2, __builtin_fma(cQ[k][1], e1, cQ[k][0] * e0)));
+    o[k + 1] = __builtin_fma(cQ[k + 1][3], d3, __builtin_fma(cQ[k + 1][2], d2, __builtin_fma(cQ[k + 1][1], d1, cQ[k + 1][0] * d0)));
+  }
+}
+
+__global__ void __launch_bounds__(64) k_precond_fdm(GridDev g, const double *in, double *out, const double *__restrict__ invD,
+                                                    double *__restrict__ block_sums) {
+  __shared__ double T[64 * 9];  // transposes; pitch 9 doubles keeps every ds_read/write_b64 conflict-free
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  const int l = threadIdx.x, lo = l & 7, hi = l >> 3;
+  const double invh = 1 / g.h;
+  double v[8], w[8], scale[8];
+  double rr = 0;
+#pragma unroll
+  for (int z = 0; z < 8; ++z) {
+    scale[z] = invD[z * 64 + l];
+    v[z] = invh * in[(size_t)slot * 512 + z * 64 + l];
+    rr = __builtin_fma(v[z], v[z], rr);
+  }
+  rr = wave_sum(rr);
+  const bool tiny = (double)1 / (512 * 512) * rr < 1e-32;  // the reference leaves such a block at 0 (14735-14736)
+  // forward: z (registers), x, y
+  sine_transform8(v, w);  // lane (x=lo, y=hi), register kz
+#pragma unroll
+  for (int k = 0; k < 8; ++k) T[(k * 8 + hi) * 9 + lo] = w[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = T[l * 9 + k];  // lane (y=lo, kz=hi), register x
+  __syncthreads();
+  sine_transform8(v, w);  // register kx
+#pragma unroll
+  for (int k = 0; k < 8; ++k) T[(hi * 8 + k) * 9 + lo] = w[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = T[l * 9 + k];  // lane (kx=lo, kz=hi), register y
+  __syncthreads();
+  sine_transform8(v, w);  // register ky
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] *= scale[k];
+  // inverse: y, x, z
+  sine_transform8(w, v);  // register y, lane (kx, kz)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) T[(hi * 8 + k) * 9 + lo] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = T[l * 9 + k];  // lane (y=lo, kz=hi), register kx
+  __syncthreads();
+  sine_transform8(w, v);  // register x
+#pragma unroll
+  for (int k = 0; k < 8; ++k) T[l * 9 + k] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = T[(k * 8 + hi) * 9 + lo];  // lane (x=lo, y=hi), register kz
+  sine_transform8(w, v);  // register z
+  double sx = 0;
+#pragma unroll
+  for (int z = 0; z < 8; ++z) {
+    const double r = tiny ? 0.0 : v[z];
+    out[(size_t)slot * 512 + z * 64 + l] = r;
+    sx += r;
+  }
+  if (block_sums) {
+    const double h3 = g.h * g.h * g.h;
+    sx = wave_sum(sx * h3);
+    if (l == 0) block_sums[slot] = sx;
+  }
+}
+
+static int fdm_setup() {
+  if (g_invD) return CUP3D_OK;
+  double Q[8][4], lam[8], invD[512];
+  const double pi = 3.14159265358979323846;
+  for (int k = 0; k < 8; ++k) {
+    lam[k] = 2.0 * std::cos(pi * (k + 1) / 9.0) - 2.0;
+    for (int j = 0; j < 4; ++j) Q[k][j] = std::sqrt(2.0 / 9.0) * std::sin(pi * (j + 1) * (k + 1) / 9.0);
+  }
+  for (int ky = 0; ky < 8; ++ky)
+    for (int kz = 0; kz < 8; ++kz)
+      for (int kx = 0; kx < 8; ++kx) invD[ky * 64 + kz * 8 + kx] = 1.0 / (lam[kx] + lam[ky] + lam[kz]);
+  CUP3D_HIP(hipMemcpyToSymbol(HIP_SYMBOL(cQ), Q, sizeof Q));
+  CUP3D_HIP(hipMalloc((void **)&g_invD, sizeof invD));
+  CUP3D_HIP(hipMemcpy(g_invD, invD, sizeof invD, hipMemcpyHostToDevice));
+  return CUP3D_OK;
+}
+
 int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
   GridDev g = s->gdev();
   double *sums = want_sums ? s->d_partials + (size_t)s->max_groups * 8 : nullptr;
+  if (s->block_solver == 1) {
+    int rc = fdm_setup();
+    if (rc) return rc;
+    ProfileScope ps("poisson_block_fdm");
+    hipLaunchKernelGGL(k_precond_fdm, dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, g_invD, sums);
+    CUP3D_HIP(hipGetLastError());
+    s->sums_of = want_sums ? out : nullptr;
+    return CUP3D_OK;
+  }
   ProfileScope ps("poisson_block_cg");
-  if (debug_option("precond_no_fma")) hipLaunchKernelGGL(k_precond<false>, dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, sums);
-  else hipLaunchKernelGGL(k_precond<true>, dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, sums);
+  // default: the reference's association (no FMA contraction); measured on MI355X the kernel is bound by the
+  // latency of its two dependent wave reductions per iteration, not by FP64 issue (FMA: 0.827 vs 0.845 ms at 256^3)
+  if (debug_option("precond_fma")) hipLaunchKernelGGL(k_precond<true>, dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, sums);
+  else hipLaunchKernelGGL(k_precond<false>, dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, sums);
   CUP3D_HIP(hipGetLastError());
   s->sums_of = want_sums ? out : nullptr;  // block sums of `out` are fresh: the next LHS of `out` reuses them
   return CUP3D_OK;
@@ -298,6 +413,7 @@ static int ensure_vectors(Sim *s) {
 
 static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *res) {
   TRY(ensure_vectors(s));
+  s->block_solver = P.block_solver;
   Vecs V;
   for (int i = 0; i < NVEC; ++i) V.v[i] = s->sv[i];
   const long N = s->nb * 512L;
@@ -402,12 +518,13 @@ int cup3d_grad_p_update(cup3d_sim_t *h, double dt);  // stencil.hip
 
 void cup3d_poisson_default_params(cup3d_poisson_params *p) {
   if (!p) return;
-  p->tol = 1e-6; p->tol_rel = 1e-4; p->mean_constraint = 1; p->max_iter = 1000; p->max_restarts = 100;
+  p->tol = 1e-6; p->tol_rel = 1e-4; p->mean_constraint = 1; p->max_iter = 1000; p->max_restarts = 100; p->block_solver = 0;
 }
 
-int cup3d_preconditioner(cup3d_sim_t *h) {
+int cup3d_preconditioner(cup3d_sim_t *h, int block_solver) {
   if (!h) return CUP3D_EINVAL;
   Sim *s = reinterpret_cast<Sim *>(h);
+  s->block_solver = block_solver;
   return launch_precond(s, s->pres, s->pres, false);  // in place: each wavefront reads its block before writing it
 }
 

@@ -268,6 +268,8 @@ int cup3d_sim_create(const cup3d_grid_t *gh, cup3d_sim_t **out) {
   }
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_a, hipEventDisableTiming));
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_b, hipEventDisableTiming));
+  CUP3D_HIP(hipEventCreateWithFlags(&s->ev_h1, hipEventDisableTiming));
+  CUP3D_HIP(hipEventCreateWithFlags(&s->ev_h2, hipEventDisableTiming));
   CUP3D_HIP(hipStreamSynchronize(g_stream));
   *out = reinterpret_cast<cup3d_sim_t *>(s);
   return CUP3D_OK;
@@ -287,6 +289,8 @@ void cup3d_sim_destroy(cup3d_sim_t *h) {
   if (s->comm_stream) hipStreamDestroy(s->comm_stream);
   if (s->ev_a) hipEventDestroy(s->ev_a);
   if (s->ev_b) hipEventDestroy(s->ev_b);
+  if (s->ev_h1) hipEventDestroy(s->ev_h1);
+  if (s->ev_h2) hipEventDestroy(s->ev_h2);
   delete s;
 }
 size_t cup3d_sim_device_bytes(const cup3d_sim_t *h) { return h ? reinterpret_cast<const Sim *>(h)->bytes : 0; }

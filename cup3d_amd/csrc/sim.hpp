@@ -61,6 +61,7 @@ struct Sim {
   double *pres = nullptr, *lhs = nullptr, *chi = nullptr;     // [nb][512]
   double *pold = nullptr;
   bool chi_nonzero = false, udef_nonzero = false;
+  int block_solver = 0;  // cup3d_poisson_params.block_solver of the running solve
   // solver vectors (allocated on first solve), each [nb][512]
   double *sv[18] = {nullptr};
   // reductions
@@ -77,7 +78,7 @@ struct Sim {
   double *halo_recv = nullptr, *halo_send = nullptr;  // n faces x 3 comps x 3 layers x 64
   size_t bytes = 0;
   hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_h1 = nullptr, ev_h2 = nullptr;
 
   GridDev gdev(bool boundary_only = false, bool inner_only = false) const;
   double *field(int id, int *ncomp) const;
@@ -87,6 +88,9 @@ int sim_alloc(double **p, size_t n_doubles, Sim *s);
 
 // halo exchange of the face slabs of `field` (ncomp components, w ghost layers); no-op on one rank
 int halo_exchange(Sim *s, const double *field, int ncomp, int w);
+// overlapped form: begin on the communication stream, finish = compute stream waits for the slabs
+int halo_begin(Sim *s, const double *field, int ncomp, int w);
+int halo_finish(Sim *s);
 // sum / max all-reduce of n doubles resident in device memory; no-op on one rank
 int allreduce(Sim *s, double *d_buf, int n, bool is_max, hipStream_t st);
 

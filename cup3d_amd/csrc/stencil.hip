@@ -185,14 +185,17 @@ __global__ void __launch_bounds__(256) k_grad_p(GridDev g, const double *__restr
 }
 
 int launch_lhs(Sim *s, const double *p, double *out, int mc) {
-  int rc = halo_exchange(s, p, 1, 1);
+  int rc = halo_begin(s, p, 1, 1);  // overlapped with the inner blocks, as compute<>() does (main.cpp:5598-5618)
   if (rc) return rc;
   const bool need_sum = mc > 0 && mc <= 2;
-  GridDev g = s->gdev();
+  const bool split = s->grid->nranks > 1;
   double *block_sums = s->d_partials + (size_t)s->max_groups * 8;
-  const bool have_sums = need_sum && s->sums_of == p;  // the block CG that produced p already summed it
+  const bool have_sums = need_sum && s->sums_of == p;  // the block solve that produced p already summed it
   s->sums_of = nullptr;
-  {
+  for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
+    GridDev g = split ? s->gdev(pass == 1, pass == 0) : s->gdev();
+    if (pass == 1 && (rc = halo_finish(s))) return rc;
+    if (g.nblocks == 0) continue;
     ProfileScope ps("poisson_lhs");
     hipLaunchKernelGGL(k_lhs, dim3(launch_groups(g)), dim3(256), 0, stream(), g, p, s->halo_recv, out, (need_sum && !have_sums) ? block_sums : nullptr);
   }

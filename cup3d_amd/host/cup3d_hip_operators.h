@@ -16,6 +16,7 @@
 // the block list changes.  Errors follow the reference's convention: print and MPI_Abort.
 #pragma once
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/cup3d_hip.h"
@@ -141,6 +142,7 @@ inline cup3d_poisson_params poisson_params(const SimulationData &sim) {
   p.tol = sim.PoissonErrorTol;
   p.tol_rel = sim.PoissonErrorTolRel;
   p.mean_constraint = sim.bMeanConstraint;
+  if (const char *e = getenv("CUP3D_HIP_BLOCK_SOLVER")) p.block_solver = atoi(e);  // 0 block CG (default), 1 direct
   return p;
 }
 

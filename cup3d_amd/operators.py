@@ -80,6 +80,7 @@ class SimulationData:
     def __init__(self, bpdx=1, bpdy=1, bpdz=1, levelMax=1, levelStart=None, extent=1.0, nu=0.0, CFL=0.1,
                  BC_x="freespace", BC_y="freespace", BC_z="freespace", uinf=(0.0, 0.0, 0.0), uMax_forced=0.0,
                  poissonTol=1e-6, poissonTolRel=1e-4, bMeanConstraint=1, poissonSolver="hip_iterative", rampup=100,
+                 blockSolver=0,
                  rank=0, nranks=1, device=None):
         if device is not None or not capi._device_ready:
             capi.device_init(0 if device is None else device)
@@ -98,6 +99,7 @@ class SimulationData:
         self.uMax_forced, self.rampup = float(uMax_forced), int(rampup)
         self.PoissonErrorTol, self.PoissonErrorTolRel, self.bMeanConstraint = poissonTol, poissonTolRel, bMeanConstraint
         self.poissonSolver = poissonSolver
+        self.blockSolver = int(blockSolver)  # 0: block CG as in the reference, 1: direct block solve (fast diagonalisation)
         self.dt, self.dt_old, self.time, self.step, self.step_2nd_start = 0.0, 0.0, 0.0, 0, 2
         self.coefU = np.array([1.5, -2.0, 0.5])
         self.uMax_measured = 0.0
@@ -140,6 +142,7 @@ class SimulationData:
         p = PoissonParams()
         lib().cup3d_poisson_default_params(C.byref(p))
         p.tol, p.tol_rel, p.mean_constraint = self.PoissonErrorTol, self.PoissonErrorTolRel, self.bMeanConstraint
+        p.block_solver = self.blockSolver
         return p
 
     def device_bytes(self):
@@ -203,7 +206,7 @@ class PoissonSolverHIP(PoissonSolverBase):
 
     def preconditioner(self):
         """_preconditioner on sim.pres in place (getZImplParallel, main.cpp:14704-14745)."""
-        check(lib().cup3d_preconditioner(self.sim.handle))
+        check(lib().cup3d_preconditioner(self.sim.handle, self.sim.blockSolver))
 
 
 def makePoissonSolver(sim):

@@ -131,6 +131,9 @@ typedef struct {
   int mean_constraint; /* sim.bMeanConstraint     (-bMeanConstraint, 1)  */
   int max_iter;        /* 1000 (main.cpp:14449) */
   int max_restarts;    /* 100  (main.cpp:14374) */
+  int block_solver;    /* how the block preconditioner M^-1 (getZImplParallel, 14704-14745) is evaluated:
+                          0 = the reference's block-local CG, restated iteration for iteration;
+                          1 = direct block solve by fast diagonalisation (same operator, exact to rounding) */
 } cup3d_poisson_params;
 typedef struct {
   int iterations; /* BiCGSTAB iterations performed (= 7-double reductions, main.cpp:14546) */
@@ -142,8 +145,9 @@ void cup3d_poisson_default_params(cup3d_poisson_params *);
 
 /* ComputeLHS::operator() (main.cpp:9273-9327): lhs = h*(sum6 - 6p) of pres + mean constraint */
 int cup3d_compute_lhs(cup3d_sim_t *, int mean_constraint);
-/* poisson_kernels::getZImplParallel (main.cpp:14704-14745): block-local CG on pres, in place */
-int cup3d_preconditioner(cup3d_sim_t *);
+/* poisson_kernels::getZImplParallel (main.cpp:14704-14745): block preconditioner on pres, in place;
+ * block_solver as in cup3d_poisson_params */
+int cup3d_preconditioner(cup3d_sim_t *, int block_solver);
 /* PoissonSolverBase::solve() (main.cpp:8921-8928; PoissonSolverAMR::solve 14363-14616):
  * RHS in lhs, initial guess and result in pres; lhs is clobbered. */
 int cup3d_poisson_solve(cup3d_sim_t *, const cup3d_poisson_params *, cup3d_poisson_result *);

@@ -15,13 +15,15 @@ if has smoke; then echo "== smoke"
 if has tests; then echo "== pytest -m gpu"
   timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1 ; echo "pytest rc=$?" ; tail -25 $OUT/pytest_gpu.log | cut -c1-300; fi
 if has probe; then echo "== kernel probes"
-  timeout 300 python scripts/kernel_probe.py adv --size 512 > $OUT/probe_adv_512.jsonl 2>&1 ; cat $OUT/probe_adv_512.jsonl
-  timeout 300 python scripts/kernel_probe.py adv --size 256 --variants 0,10 > $OUT/probe_adv_256.jsonl 2>&1 ; cat $OUT/probe_adv_256.jsonl
+  timeout 300 python scripts/kernel_probe.py adv --size 512 --variants ${ADV_VARIANTS:-0,2,3,10} > $OUT/probe_adv_512.jsonl 2>&1 ; cat $OUT/probe_adv_512.jsonl
+  timeout 300 python scripts/kernel_probe.py adv --size 256 --variants 0 > $OUT/probe_adv_256.jsonl 2>&1 ; cat $OUT/probe_adv_256.jsonl
   timeout 300 python scripts/kernel_probe.py pre --size 256 > $OUT/probe_pre_256.jsonl 2>&1 ; cat $OUT/probe_pre_256.jsonl; fi
 if has bench; then echo "== bench 512 stencil-only"
   timeout 300 python bench.py --size 512 --steps 5 --warmup 1 --no-cpu --stencil-only > $OUT/bench_512_stencil.json 2> $OUT/bench_512_stencil.err ; tail -c 1200 $OUT/bench_512_stencil.json
   echo "== bench default (512 full + cpu baseline)"
-  timeout 1200 python bench.py > $OUT/bench_512.json 2> $OUT/bench_512.err ; echo "bench rc=$?" ; tail -c 4000 $OUT/bench_512.json ; tail -3 $OUT/bench_512.err; fi
+  timeout 1200 python bench.py > $OUT/bench_512.json 2> $OUT/bench_512.err ; echo "bench rc=$?" ; tail -c 4000 $OUT/bench_512.json ; tail -3 $OUT/bench_512.err
+  echo "== bench 512 full, direct block solve"
+  timeout 600 python bench.py --block-solver 1 --no-cpu > $OUT/bench_512_fdm.json 2> $OUT/bench_512_fdm.err ; tail -c 3000 $OUT/bench_512_fdm.json; fi
 if has trace; then echo "== rocprofv3 kernel trace (256^3 full step x2)"
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace -o t -- python $ROOT/bench.py --size 256 --steps 2 --warmup 1 --no-cpu > $ROOT/$OUT/trace.log 2>&1 )
   for f in $(find $OUT/trace -name "*kernel_stats.csv" | head -1); do cp $f $OUT/kernel_stats_256_full.csv; head -12 $f | cut -c1-200; done

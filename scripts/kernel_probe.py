@@ -70,18 +70,22 @@ def main():
         rng = np.random.default_rng(0)
         inputs = {"rhs": rhs, "noise": rng.uniform(-1, 1, rhs.shape)}
         for name, x in inputs.items():
-            for nofma in (0, 1):
-                check(lib().cup3d_debug_set_option(b"precond_no_fma", nofma))
+            for solver, fma in ((0, 0), (0, 1), (1, 0)):
+                check(lib().cup3d_debug_set_option(b"precond_fma", fma))
                 sim.upload("pres", x)
-                check(lib().cup3d_preconditioner(sim.handle))
+                check(lib().cup3d_preconditioner(sim.handle, solver))
+                ref = sim.download("pres") if (solver, fma) == (0, 0) else ref
+                err = float(np.abs(sim.download("pres") - ref).max() / np.abs(ref).max())
                 lib().cup3d_device_synchronize()
                 lib().cup3d_profile_reset()
                 for _ in range(a.reps):
                     sim.upload("pres", x)
-                    check(lib().cup3d_preconditioner(sim.handle))
-                n, ms = profile()["poisson_block_cg"]
-                print(json.dumps({"probe": "block_cg", "size": a.size, "input": name, "no_fma": nofma, "avg_ms": round(ms / n, 4)}))
-        check(lib().cup3d_debug_set_option(b"precond_no_fma", 0))
+                    check(lib().cup3d_preconditioner(sim.handle, solver))
+                key = "poisson_block_fdm" if solver else "poisson_block_cg"
+                n, ms = profile()[key]
+                print(json.dumps({"probe": key, "size": a.size, "input": name, "fma": fma, "avg_ms": round(ms / n, 4),
+                                  "max_rel_diff_vs_cg": err}))
+        check(lib().cup3d_debug_set_option(b"precond_fma", 0))
     else:
         bc = "periodic" if a.kernel == "adv" else "wall"
         sim = make(a.size, bc)
