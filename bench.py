@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--stencil-only", action="store_true", help="BASELINE configs[1]: periodic, advect-diffuse only")
     ap.add_argument("--block-solver", type=int, default=0, help="0: block CG as in the reference, 1: direct block solve")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second timed region with the other block solver")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -173,6 +174,7 @@ def main():
         one_step()
     fence()
     sec = time.perf_counter() - t0
+    main_iters = list(iters)
     if dist is not None:
         t = torch.tensor([sec], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -183,14 +185,38 @@ def main():
     lib().cup3d_profile_enable(0)
     prof = {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n.value)}
 
+    alt = None
+    if not a.stencil_only and not a.no_alt:
+        # same workload once more with the block preconditioner evaluated by the other method
+        # (cup3d_poisson_params.block_solver), reported next to the main number
+        sim.blockSolver = 1 - a.block_solver
+        sim.upload("vel", taylor_green_blocks(sim.grid, [ext] * 3, 1.0))
+        sim.fill("pres", 0.0)
+        sim.step, sim.dt = 21, 0.0
+        lib().cup3d_profile_enable(0)
+        one_step()
+        iters.clear()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            one_step()
+        fence()
+        sec2 = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([sec2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sec2 = float(t.item())
+        alt = {"block_preconditioner": ("block CG (reference algorithm)", "direct block solve (fast diagonalisation)")[sim.blockSolver],
+               "value": round(float(a.size) ** 3 * a.steps / sec2 / 1e6, 2), "unit": "Mcell-updates/s", "ms_per_step": round(sec2 / a.steps * 1e3, 3),
+               "bicgstab_iters_per_step": round(float(np.mean(iters)), 2), "warmup": 1, "steps": a.steps}
     if rank == 0:
-        report(a, sim, prof, sec, iters, world)
+        report(a, sim, prof, sec, main_iters, world, alt)
     if dist is not None:
         lib().cup3d_comm_finalize()
         dist.destroy_process_group()
 
 
-def report(a, sim, prof, sec, iters, world):
+def report(a, sim, prof, sec, iters, world, alt=None):
     cells = float(a.size) ** 3
     cells_local = sim.nblocks * 512.0
     value = cells * a.steps / sec / 1e6
@@ -226,6 +252,8 @@ def report(a, sim, prof, sec, iters, world):
         if dominant else None,
         "kernels": kernels,
     }
+    if alt is not None:
+        out["alt"] = alt
     if not a.no_cpu and world == 1:
         # the reference's OpenMP regions (one lab per thread, master-polled halo loop, 5594-5640) stop
         # scaling long before a 256-thread host is full: cap at 32 threads and say so in `cores`

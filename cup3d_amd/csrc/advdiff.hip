@@ -117,33 +117,78 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
 #pragma unroll
       for (int k = 0; k < CPT; ++k) told[k][c] = tp[c * 512 + k * NT + t];
   }
-  // ---- ghosts: 18 (face, component) units of 192 values, dealt round-robin to the waves.
-  // Every global load of the tile (centre, tmpV, ghosts: ~27 per thread) is issued before the
-  // first LDS write, so one memory latency is exposed per block instead of one per unit.
-  constexpr int UPW = (18 + NW - 1) / NW;  // units per wave
+  // ---- ghosts: 18 (face, component) units of 192 values.  Every global load of the tile
+  // (centre, tmpV, ghosts: ~27 per thread) is issued before the first LDS write, so ONE memory
+  // latency is exposed per block.  Units are dealt so that the face direction of a unit is a
+  // compile-time constant of the unrolled loop (x, y, z faces of components 0/1 in rounds 0-2,
+  // component 2 in the remaining rounds): the per-element index arithmetic then reduces to a few
+  // adds on per-thread constants computed once.
+  constexpr int UPW = (18 + NW - 1) / NW;  // rounds (units per wave)
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   double gv[UPW][3];
   int gl[UPW][3];
-  bool gflip[UPW];
+  bool gflip[UPW], gon[UPW];
+  // per-thread decode of element e = j*64 + lane of a y-face (24 = 3 rows x 8) and of an x-face (3 per row)
+  int yb[3], yl[3], yg[3], xb[3], xl[3], xg[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int e = j * 64 + lane;
+    const int zy = e / 24, r = e - 24 * zy, gr = r >> 3, xx8 = r & 7;
+    yb[j] = zy * 64 + xx8;                    // neighbour / own cell without the y term
+    yl[j] = zy * 196 + gr * kXYPitch + xx8 + 3;  // LDS slot for side 0 (ghost row gr-3)
+    yg[j] = gr;
+    const int row = e / 3, x3 = e - 3 * row;
+    xb[j] = row * 8;
+    xl[j] = (row >> 3) * 196 + ((row & 7) + 3) * kXYPitch + x3;  // LDS slot for side 0 (ghost column x3-3)
+    xg[j] = x3;
+  }
 #pragma unroll
   for (int i = 0; i < UPW; ++i) {
-    const int u = wave_s + i * NW;  // wave-uniform
-    if (VAR != 3 && u < 18) {
-      const int f = u / 3, c = u - 3 * f;
+    // unit of (wave, round): rounds 0..2 -> direction d = i, side = wave & 1, component wave >> 1 (NW = 4)
+    int d, side, c;
+    bool on = VAR != 3;
+    if (NW == 4) {
+      if (i < 3) { d = i; side = wave_s & 1; c = wave_s >> 1; }
+      else if (i == 3) { d = wave_s >> 1; side = wave_s & 1; c = 2; }
+      else { d = 2; side = wave_s & 1; c = 2; on = on && wave_s < 2; }
+    } else {  // NW = 8: rounds 0,1 -> faces 0..5 of components (0,1) spread over 8 waves + remainder
+      const int u = wave_s + i * NW;
+      on = on && u < 18;
+      const int f = u / 3;
+      d = f >> 1; side = f & 1; c = u - 3 * f;
+    }
+    gon[i] = on;
+    if (on) {
+      const int f = 2 * d + side;
       const int n = g.nbr[slot * 6 + f];
       // domain face: BlockLabBC, main.cpp:6513-6551.  wall (n == -3): every component negated
       // (6384-6394); freespace (n == -1): copy, normal component negated (6137-6153)
-      const bool flip = n < 0 && (n == -3 || c == (f >> 1));
-      const double *__restrict__ base = n >= kNbrHalo ? a.halo + ((size_t)(n - kNbrHalo) * 3 + c) * 192
-                                        : (n >= 0 ? a.vel + (size_t)n * 1536 + c * 512 : own + c * 512);
+      gflip[i] = n < 0 && (n == -3 || c == d);
+      const int src = n >= kNbrHalo ? 2 : (n >= 0 ? 1 : 0);  // halo slab / neighbour block / own face cell
+      const double *__restrict__ base = src == 2 ? a.halo + ((size_t)(n - kNbrHalo) * 3 + c) * 192
+                                        : (src == 1 ? a.vel + (size_t)n * 1536 + c * 512 : own + c * 512);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         int nb_cell, own_cell, lds, hal;
-        face_element(f, j * 64 + lane, nb_cell, own_cell, lds, hal);
-        gv[i][j] = base[n >= kNbrHalo ? hal : (n >= 0 ? nb_cell : own_cell)];  // consumed only after all loads are out
+        if (d == 2) {
+          nb_cell = (side ? j : 7 - j) * 64 + lane;
+          own_cell = (side ? 7 : 0) * 64 + lane;
+          lds = kXYSize + (side * 3 + j) * 64 + lane;
+          hal = j * 64 + lane;
+        } else if (d == 1) {
+          nb_cell = yb[j] + (side ? yg[j] : 5 + yg[j]) * 8;
+          own_cell = yb[j] + (side ? 56 : 0);
+          lds = yl[j] + (side ? 11 * kXYPitch : 0);
+          hal = (side ? yg[j] : 2 - yg[j]) * 64 + (yb[j] >> 6) * 8 + (yb[j] & 7);
+        } else {
+          nb_cell = xb[j] + (side ? xg[j] : 5 + xg[j]);
+          own_cell = xb[j] + (side ? 7 : 0);
+          lds = xl[j] + (side ? 11 : 0);
+          hal = (side ? xg[j] : 2 - xg[j]) * 64 + (xb[j] >> 3);
+        }
+        gv[i][j] = base[src == 2 ? hal : (src == 1 ? nb_cell : own_cell)];  // consumed only after all loads are out
         gl[i][j] = c * kCompStride + lds;
       }
-      gflip[i] = flip;
     }
   }
   const int xy = (y + 3) * kXYPitch + (x + 3);
@@ -153,7 +198,7 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
     for (int k = 0; k < CPT; ++k) tile[c * kCompStride + (z0 + k * NW) * 196 + xy] = uc[k][c];
 #pragma unroll
   for (int i = 0; i < UPW; ++i)
-    if (VAR != 3 && wave_s + i * NW < 18) {
+    if (gon[i]) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) tile[gl[i][j]] = gflip[i] ? -gv[i][j] : gv[i][j];
     }

@@ -20,15 +20,43 @@ __device__ __forceinline__ int block_slot(const GridDev &g) {
 }
 inline unsigned launch_groups(const GridDev &g) { return (unsigned)(8 * g.chunk); }
 
-// all 64 lanes receive the sum (commutative butterfly => identical in every lane)
+// ---- wavefront reductions on the DPP data path (no LDS crossbar round trips).
+// Classic GCN/CDNA reduction: xor-1 and xor-2 inside each quad (quad_perm), fold the two
+// quads of a half row (row_half_mirror), the two halves of a 16-lane row (row_mirror), then
+// carry row totals across rows with row_bcast15 / row_bcast31; lane 63 ends up with the
+// wavefront total, which is broadcast through the scalar unit (v_readlane).  ~6 dependent
+// VALU steps of a few cycles each instead of 6 ds_bpermute round trips (~100 cycles each):
+// the block-CG preconditioner is bound by exactly this latency.
+template <int CTRL, int ROW_MASK = 0xf, bool BOUND_CTRL = true>
+__device__ __forceinline__ double dpp_move(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  int lo = (int)b, hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, BOUND_CTRL);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, BOUND_CTRL);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double broadcast_lane63(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// all 64 lanes receive the same sum
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  v += dpp_move<0xB1>(v);              // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);              // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);             // row_half_mirror
+  v += dpp_move<0x140>(v);             // row_mirror: every lane of a row holds the row total
+  v += dpp_move<0x142, 0xa>(v);        // row_bcast15 into rows 1 and 3
+  v += dpp_move<0x143, 0xc>(v);        // row_bcast31 into rows 2 and 3: lane 63 = total
+  return broadcast_lane63(v);
 }
 __device__ __forceinline__ double wave_max(double v) {
+  v = fmax(v, dpp_move<0xB1>(v));
+  v = fmax(v, dpp_move<0x4E>(v));
+  v = fmax(v, dpp_move<0x141>(v));
+  v = fmax(v, dpp_move<0x140>(v));
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
+  for (int m = 32; m >= 16; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
   return v;
 }
 

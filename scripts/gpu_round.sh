@@ -22,11 +22,11 @@ if has bench; then echo "== bench 512 stencil-only"
   timeout 300 python bench.py --size 512 --steps 5 --warmup 1 --no-cpu --stencil-only > $OUT/bench_512_stencil.json 2> $OUT/bench_512_stencil.err ; tail -c 1200 $OUT/bench_512_stencil.json
   echo "== bench default (512 full + cpu baseline)"
   timeout 1200 python bench.py > $OUT/bench_512.json 2> $OUT/bench_512.err ; echo "bench rc=$?" ; tail -c 4000 $OUT/bench_512.json ; tail -3 $OUT/bench_512.err
-  echo "== bench 512 full, direct block solve"
-  timeout 600 python bench.py --block-solver 1 --no-cpu > $OUT/bench_512_fdm.json 2> $OUT/bench_512_fdm.err ; tail -c 3000 $OUT/bench_512_fdm.json; fi
-if has trace; then echo "== rocprofv3 kernel trace (256^3 full step x2)"
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace -o t -- python $ROOT/bench.py --size 256 --steps 2 --warmup 1 --no-cpu > $ROOT/$OUT/trace.log 2>&1 )
-  for f in $(find $OUT/trace -name "*kernel_stats.csv" | head -1); do cp $f $OUT/kernel_stats_256_full.csv; head -12 $f | cut -c1-200; done
+  fi
+if has trace; then echo "== rocprofv3 kernel trace of the default bench command (512^3 full step, no cpu baseline)"
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace -o t -- python $ROOT/bench.py --no-cpu --no-alt > $ROOT/$OUT/trace.log 2>&1 )
+  for f in $(find $OUT/trace -name "*kernel_stats.csv" | head -1); do cp $f $OUT/kernel_stats_512_full.csv; head -14 $f | cut -c1-200; done
+  grep -E "^\{" $OUT/trace.log | tail -c 1500
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace512 -o t -- python $ROOT/scripts/kernel_probe.py one --size 512 --kernel adv > $ROOT/$OUT/trace512.log 2>&1 )
   for f in $(find $OUT/trace512 -name "*kernel_stats.csv" | head -1); do cp $f $OUT/kernel_stats_512_adv.csv; head -6 $f | cut -c1-200; done
   rm -rf $OUT/trace/*/*.db $OUT/trace512/*/*.db 2>/dev/null; fi
