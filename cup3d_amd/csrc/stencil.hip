@@ -23,23 +23,34 @@ __device__ __forceinline__ void face1(int f, int lane, int &nb_cell, int &own_ce
 // scalar tile with zero-gradient domain faces (BlockLabNeumann3D, main.cpp:6561-6581)
 __device__ __forceinline__ void load_scalar_tile(const GridDev &g, int slot, const double *__restrict__ f, const double *__restrict__ halo,
                                                  double *tile, double c[2]) {
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const double *own = f + (size_t)slot * 512;
+  // all global loads (2 centre cells + up to 2 face elements per thread) are issued before the first LDS write
   c[0] = own[t];
   c[1] = own[256 + t];
+  double gv[2];
+  int gl[2];
+  bool gon[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int face = wave + 4 * i;
+    gon[i] = face < 6;
+    if (gon[i]) {
+      const int n = g.nbr[slot * 6 + face];
+      int nb_cell, own_cell, lds;
+      face1(face, lane, nb_cell, own_cell, lds);
+      const double *__restrict__ base = n >= kNbrHalo ? halo + (size_t)(n - kNbrHalo) * 64 : (n >= 0 ? f + (size_t)n * 512 : own);
+      gv[i] = base[n >= kNbrHalo ? lane : (n >= 0 ? nb_cell : own_cell)];
+      gl[i] = lds;
+    }
+  }
   const int x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
   tile[tix(x, y, z0)] = c[0];
   tile[tix(x, y, z0 + 4)] = c[1];
-  for (int face = wave; face < 6; face += 4) {
-    const int n = g.nbr[slot * 6 + face];
-    int nb_cell, own_cell, lds;
-    face1(face, lane, nb_cell, own_cell, lds);
-    double v;
-    if (n >= kNbrHalo) v = halo[(size_t)(n - kNbrHalo) * 64 + lane];
-    else if (n >= 0) v = f[(size_t)n * 512 + nb_cell];
-    else v = own[own_cell];
-    tile[lds] = v;
-  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if (gon[i]) tile[gl[i]] = gv[i];
 }
 
 // component c of a vector field, ghosts only on the two faces normal to axis c (all the
