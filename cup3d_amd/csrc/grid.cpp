@@ -51,7 +51,7 @@ Grid::Grid(const int bpd_[3], int level_max_, int level_, double maxextent_, con
   Z.resize(z_count);
   id2.resize(z_count);
   index.resize(3 * z_count);
-  std::vector<int32_t> slot_of_z(z_count);
+  slot_of_z.assign(z_count, -1);
   for (int64_t s = 0; s < z_count; ++s) {
     id2[s] = order[s].first;
     Z[s] = order[s].second;
@@ -111,6 +111,39 @@ Grid::Grid(const int bpd_[3], int level_max_, int level_, double maxextent_, con
     send_count[std::get<0>(t)]++;
     send_faces.push_back(std::get<3>(t));
   }
+}
+
+int32_t Grid::slot_of_index(int i, int j, int k) const {
+  const int64_t z = sfc->forward(level, i, j, k);
+  if (z < z_begin || z >= z_begin + z_count) return -1;
+  return slot_of_z[z - z_begin];
+}
+
+std::vector<int32_t> Grid::neighbours27() const {
+  std::vector<int32_t> out(27 * (size_t)nblocks());
+  for (int64_t s = 0; s < nblocks(); ++s) {
+    const int32_t *idx = &index[3 * s];
+    for (int cz = -1; cz <= 1; ++cz)
+      for (int cy = -1; cy <= 1; ++cy)
+        for (int cx = -1; cx <= 1; ++cx) {
+          const int code[3] = {cx, cy, cz};
+          bool skipped = false;
+          int c[3];
+          for (int d = 0; d < 3; ++d) {
+            const bool skin = idx[d] == 0 || idx[d] == nbd[d] - 1;
+            const int skip = idx[d] == 0 ? -1 : 1;  // main.cpp:3681-3686, 3696-3701
+            if (bc[d] != 1 && code[d] == skip && skin) skipped = true;
+            c[d] = (idx[d] + code[d] + nbd[d]) % nbd[d];
+          }
+          int32_t v = -1;
+          if (!skipped) {
+            v = slot_of_index(c[0], c[1], c[2]);
+            if (v < 0) v = -2;
+          }
+          out[27 * s + (cx + 1) + 3 * (cy + 1) + 9 * (cz + 1)] = v;
+        }
+  }
+  return out;
 }
 
 }  // namespace cup3d

@@ -41,6 +41,13 @@ struct Grid {
   int64_t n_recv_faces = 0;
   int32_t corner_slot = -1;  // local slot of the block with index (0,0,0), or -1 (mean constraint, main.cpp:9287-9289)
 
+  std::vector<int32_t> slot_of_z;  // Z - z_begin -> local slot
+  // local slot of the block at (i,j,k) of this level (periodic wrap NOT applied); -1 if owned by another rank
+  int32_t slot_of_index(int i, int j, int k) const;
+  // all 26 neighbours + self of every local block, code = (cx+1) + 3*(cy+1) + 9*(cz+1); -1 = not loaded
+  // (domain face with a boundary condition, BlockLab::load 3696-3701), -2 = owned by another rank
+  std::vector<int32_t> neighbours27() const;
+
   int64_t nblocks() const { return (int64_t)Z.size(); }
   int owner_of(int64_t z) const;
   static void partition(int64_t total, int rank, int nranks, int64_t *begin, int64_t *count);

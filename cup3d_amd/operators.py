@@ -237,6 +237,30 @@ class PressureProjection(Operator):
         return r
 
 
+class MeshAdaptation:
+    """Data-movement half of class MeshAdaptation (main.cpp:5023-5583) for whole-mesh transitions between
+    two uniform levels; the tagging decision is returned to the host, which owns the tree."""
+
+    def __init__(self, Rtol, Ctol):
+        self.tolerance_for_refinement, self.tolerance_for_compression = float(Rtol), float(Ctol)
+
+    def Tag(self, sim, field="tmpV"):
+        """TagLoadedBlock on every block (5566-5582) -> int8 states: 1 Refine, -1 Compress, 0 Leave."""
+        st = np.zeros(sim.nblocks, dtype=np.int8)
+        check(lib().cup3d_tag_blocks(sim.handle, FIELDS[field], self.tolerance_for_refinement, self.tolerance_for_compression, st))
+        return st
+
+    @staticmethod
+    def refine(coarse, fine, field):
+        """refine_1 + RefineBlocks (5227-5249, 5493-5565) of every block of `coarse` into `fine`."""
+        check(lib().cup3d_prolong(coarse.handle, fine.handle, FIELDS[field]))
+
+    @staticmethod
+    def compress(fine, coarse, field):
+        """compress (5272-5329) of every sibling octet of `fine` into `coarse`."""
+        check(lib().cup3d_restrict(fine.handle, coarse.handle, FIELDS[field]))
+
+
 def findMaxU(sim):
     """findMaxU, main.cpp:8603-8623."""
     out = C.c_double(0.0)

@@ -161,6 +161,18 @@ int cup3d_grad_p(cup3d_sim_t *, double dt);
  * chi/udef already resident (tmpV is zeroed exactly as at 15076-15078). */
 int cup3d_pressure_project(cup3d_sim_t *, double dt, int step, const cup3d_poisson_params *, cup3d_poisson_result *);
 
+/* ---------------------------------------------------------------------------
+ * Mesh-adaptation block operators (data movement of MeshAdaptation, main.cpp:5023-5583) for
+ * whole-mesh transitions between two uniform levels l (coarse) and l+1 (fine) of the same box.
+ * The integer decisions (which blocks to refine, 2:1 balancing, load balancing) stay on the host.
+ * ------------------------------------------------------------------------- */
+/* "restrict": MeshAdaptation::compress (5272-5329): every sibling octet of `fine` -> its parent block of `coarse` */
+int cup3d_restrict(cup3d_sim_t *fine, cup3d_sim_t *coarse, int field);
+/* "prolong": refine_1 + RefineBlocks (5227-5249, 5493-5565): every block of `coarse` -> its eight children in `fine` */
+int cup3d_prolong(cup3d_sim_t *coarse, cup3d_sim_t *fine, int field);
+/* TagLoadedBlock (5566-5582) + level clamps (5207-5211): states[nblocks] in {-1 Compress, 0 Leave, 1 Refine} (enum State, 320) */
+int cup3d_tag_blocks(cup3d_sim_t *, int field, double rtol, double ctol, signed char *states);
+
 /* per-kernel device time accounting (hipEvents on the compute stream) */
 int cup3d_profile_enable(int on);
 int cup3d_profile_reset(void);

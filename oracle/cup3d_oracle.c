@@ -760,3 +760,148 @@ void orc_project(const orc_grid *g, double *vel, double *pres, double *tmpV, dou
   for (long i = 0; i < 3 * N; i++) vel[i] += fac * tmpV[i];
   free(pOld);
 }
+
+/* ===================== mesh-adaptation block operators ===================== */
+/* Full tensorial [-1,2) tile of block b: centre, all 26 same-level neighbours, then the
+ * domain-face passes in the reference's order x-,x+,y-,y+,z-,z+ (BlockLab::load 3623-3743;
+ * BlockLabBC::_apply_bc 6513-6551 with applyBCfaceWall 6369-6429 / applyBCfaceOpen 6107-6231;
+ * BlockLabNeumann3D::_apply_bc 6561-6581 with Neumann3D 5929-6004).  Each pass fills the whole
+ * ghost slab behind the face -- interior part first, then the edge/corner strips -- from the
+ * face cell with the same transverse coordinates, which may themselves be ghosts filled earlier. */
+static void load_lab_full(const orc_grid *g, const double *f, int nc, int is_vector, long b, double *lab) {
+  const int w = 1, L = BS + 2;
+#define LAB(x, y, z, c) lab[((((long)(z) + w) * L + ((y) + w)) * L + ((x) + w)) * nc + (c)]
+  const int *idx = &g->index[3 * b];
+  for (long i = 0; i < (long)L * L * L * nc; i++) lab[i] = 0.0;
+  int skip[3], skin[3];
+  for (int d = 0; d < 3; d++) {
+    skin[d] = idx[d] == 0 || idx[d] == g->nb[d] - 1;
+    skip[d] = idx[d] == 0 ? -1 : 1; /* main.cpp:3681-3686 */
+  }
+  for (int cz = -1; cz <= 1; cz++)
+    for (int cy = -1; cy <= 1; cy++)
+      for (int cx = -1; cx <= 1; cx++) {
+        const int code[3] = {cx, cy, cz};
+        int skipped = 0;
+        for (int d = 0; d < 3; d++)
+          if (g->bc[d] != ORC_BC_PERIODIC && code[d] == skip[d] && skin[d]) skipped = 1; /* 3696-3701 */
+        if (skipped) continue;
+        int c[3];
+        for (int d = 0; d < 3; d++) c[d] = (idx[d] + code[d] + g->nb[d]) % g->nb[d];
+        const double *nb = f + g->slot_of[((long)c[2] * g->nb[1] + c[1]) * g->nb[0] + c[0]] * BS3 * nc;
+        const int s[3] = {cx < 0 ? -1 : (cx == 0 ? 0 : BS), cy < 0 ? -1 : (cy == 0 ? 0 : BS), cz < 0 ? -1 : (cz == 0 ? 0 : BS)};
+        const int e[3] = {cx < 0 ? 0 : (cx == 0 ? BS : BS + 1), cy < 0 ? 0 : (cy == 0 ? BS : BS + 1), cz < 0 ? 0 : (cz == 0 ? BS : BS + 1)};
+        for (int z = s[2]; z < e[2]; z++)
+          for (int y = s[1]; y < e[1]; y++)
+            for (int x = s[0]; x < e[0]; x++)
+              for (int k = 0; k < nc; k++)
+                LAB(x, y, z, k) = nb[(((z - cz * BS) * BS + (y - cy * BS)) * BS + (x - cx * BS)) * nc + k];
+      }
+  for (int d = 0; d < 3; d++) {
+    if (g->bc[d] == ORC_BC_PERIODIC) continue;
+    for (int side = 0; side < 2; side++) {
+      if (side == 0 ? idx[d] != 0 : idx[d] != g->nb[d] - 1) continue;
+      const int ghost = side ? BS : -1, face = side ? BS - 1 : 0, d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+      for (int a2 = -1; a2 <= BS; a2++)
+        for (int a1 = -1; a1 <= BS; a1++) {
+          int p[3], q[3];
+          p[d] = ghost; q[d] = face; p[d1] = q[d1] = a1; p[d2] = q[d2] = a2;
+          for (int k = 0; k < nc; k++) {
+            double v = LAB(q[0], q[1], q[2], k);
+            if (is_vector) {
+              if (g->bc[d] == ORC_BC_WALL) v = (-1.0) * v;
+              else if (k == d) v = (-1.) * v;
+            }
+            LAB(p[0], p[1], p[2], k) = v;
+          }
+        }
+    }
+  }
+#undef LAB
+}
+
+void orc_restrict(const orc_grid *fine, const orc_grid *coarse, const double *ff, double *cf, int nc) {
+  for (long pb = 0; pb < coarse->nblocks; pb++) {
+    const int *pi = &coarse->index[3 * pb];
+    double *dst = cf + pb * BS3 * nc;
+    for (int K = 0; K < 2; K++)
+      for (int J = 0; J < 2; J++)
+        for (int I = 0; I < 2; I++) {
+          const long cb = fine->slot_of[((long)(2 * pi[2] + K) * fine->nb[1] + (2 * pi[1] + J)) * fine->nb[0] + (2 * pi[0] + I)];
+          const double *b = ff + cb * BS3 * nc;
+#define B(i, j, k, c) b[(((k) * BS + (j)) * BS + (i)) * nc + (c)]
+          for (int k = 0; k < BS; k += 2)
+            for (int j = 0; j < BS; j += 2)
+              for (int i = 0; i < BS; i += 2)
+                for (int c = 0; c < nc; c++)
+                  dst[(((k / 2 + 4 * K) * BS + (j / 2 + 4 * J)) * BS + (i / 2 + 4 * I)) * nc + c] =
+                      0.125 * ((B(i, j, k, c) + B(i + 1, j + 1, k + 1, c)) + (B(i + 1, j, k, c) + B(i, j + 1, k + 1, c)) +
+                               (B(i, j + 1, k, c) + B(i + 1, j, k + 1, c)) + (B(i + 1, j + 1, k, c) + B(i, j, k + 1, c)));
+#undef B
+        }
+  }
+}
+
+void orc_prolong(const orc_grid *coarse, const orc_grid *fine, const double *cf, double *ff, int nc, int is_vector) {
+  const int L = BS + 2;
+  double *lab = (double *)malloc((size_t)L * L * L * nc * sizeof(double));
+#define Lb(x, y, z) lab[((((long)(z) + 1) * L + ((y) + 1)) * L + ((x) + 1)) * nc + c]
+  for (long pb = 0; pb < coarse->nblocks; pb++) {
+    load_lab_full(coarse, cf, nc, is_vector, pb, lab);
+    const int *pi = &coarse->index[3 * pb];
+    for (int K = 0; K < 2; K++)
+      for (int J = 0; J < 2; J++)
+        for (int I = 0; I < 2; I++) {
+          const long cb = fine->slot_of[((long)(2 * pi[2] + K) * fine->nb[1] + (2 * pi[1] + J)) * fine->nb[0] + (2 * pi[0] + I)];
+          double *b = ff + cb * BS3 * nc;
+#define B(i, j, k) b[(((k) * BS + (j)) * BS + (i)) * nc + c]
+          for (int k = 0; k < BS; k += 2)
+            for (int j = 0; j < BS; j += 2)
+              for (int i = 0; i < BS; i += 2)
+                for (int c = 0; c < nc; c++) {
+                  const int x = i / 2 + 4 * I, y = j / 2 + 4 * J, z = k / 2 + 4 * K;
+                  const double dudx = 0.5 * (Lb(x + 1, y, z) - Lb(x - 1, y, z));
+                  const double dudy = 0.5 * (Lb(x, y + 1, z) - Lb(x, y - 1, z));
+                  const double dudz = 0.5 * (Lb(x, y, z + 1) - Lb(x, y, z - 1));
+                  const double dudx2 = (Lb(x + 1, y, z) + Lb(x - 1, y, z)) - 2.0 * Lb(x, y, z);
+                  const double dudy2 = (Lb(x, y + 1, z) + Lb(x, y - 1, z)) - 2.0 * Lb(x, y, z);
+                  const double dudz2 = (Lb(x, y, z + 1) + Lb(x, y, z - 1)) - 2.0 * Lb(x, y, z);
+                  const double dudxdy = 0.25 * ((Lb(x + 1, y + 1, z) + Lb(x - 1, y - 1, z)) - (Lb(x + 1, y - 1, z) + Lb(x - 1, y + 1, z)));
+                  const double dudxdz = 0.25 * ((Lb(x + 1, y, z + 1) + Lb(x - 1, y, z - 1)) - (Lb(x + 1, y, z - 1) + Lb(x - 1, y, z + 1)));
+                  const double dudydz = 0.25 * ((Lb(x, y + 1, z + 1) + Lb(x, y - 1, z - 1)) - (Lb(x, y + 1, z - 1) + Lb(x, y - 1, z + 1)));
+                  const double u = Lb(x, y, z), q2 = 0.03125 * (dudx2 + dudy2 + dudz2);
+                  B(i, j, k) = u + 0.25 * (-(1.0) * dudx - dudy - dudz) + q2 + 0.0625 * (dudxdy + dudxdz + dudydz);
+                  B(i + 1, j, k) = u + 0.25 * (dudx - dudy - dudz) + q2 + 0.0625 * (-(1.0) * dudxdy - dudxdz + dudydz);
+                  B(i, j + 1, k) = u + 0.25 * (-(1.0) * dudx + dudy - dudz) + q2 + 0.0625 * (-(1.0) * dudxdy + dudxdz - dudydz);
+                  B(i + 1, j + 1, k) = u + 0.25 * (dudx + dudy - dudz) + q2 + 0.0625 * (dudxdy - dudxdz - dudydz);
+                  B(i, j, k + 1) = u + 0.25 * (-(1.0) * dudx - dudy + dudz) + q2 + 0.0625 * (dudxdy - dudxdz - dudydz);
+                  B(i + 1, j, k + 1) = u + 0.25 * (dudx - dudy + dudz) + q2 + 0.0625 * (-(1.0) * dudxdy + dudxdz - dudydz);
+                  B(i, j + 1, k + 1) = u + 0.25 * (-(1.0) * dudx + dudy + dudz) + q2 + 0.0625 * (-(1.0) * dudxdy - dudxdz + dudydz);
+                  B(i + 1, j + 1, k + 1) = u + 0.25 * (dudx + dudy + dudz) + q2 + 0.0625 * (dudxdy + dudxdz + dudydz);
+                }
+#undef B
+        }
+  }
+#undef Lb
+  free(lab);
+}
+
+void orc_tag(const orc_grid *g, const double *f, int nc, double rtol, double ctol, signed char *states) {
+  for (long b = 0; b < g->nblocks; b++) {
+    double Linf = 0.0;
+    for (int i = 0; i < BS3; i++) {
+      double m;
+      if (nc == 1) m = f[b * BS3 + i]; /* ScalarElement::magnitude = s, main.cpp:5783 */
+      else {
+        double s1 = 0.0;
+        for (int c = 0; c < nc; c++) s1 += f[(b * BS3 + i) * nc + c] * f[(b * BS3 + i) * nc + c];
+        m = sqrt(s1); /* VectorElement::magnitude, 5873-5879 */
+      }
+      Linf = fmax(Linf, fabs(m));
+    }
+    signed char st = Linf > rtol ? 1 : (Linf < ctol ? -1 : 0);
+    if (st == 1 && g->level == g->level_max - 1) st = 0; /* 5207-5211 */
+    if (st == -1 && g->level == 0) st = 0;
+    states[b] = st;
+  }
+}

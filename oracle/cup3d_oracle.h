@@ -71,6 +71,14 @@ void orc_grad_p(const orc_grid *, const double *pres, double *tmpV, double dt); 
 /* PressureProjection::operator(), main.cpp:15061-15160 (no obstacles: chi=0, udef=0) */
 void orc_project(const orc_grid *, double *vel, double *pres, double *tmpV, double *lhs, const double *chi,
                  double dt, int step, orc_solve_info *);
+/* --- mesh-adaptation block operators (uniform level l <-> l+1, whole mesh) ----------------- */
+/* "restrict": MeshAdaptation::compress, main.cpp:5290-5303 (8-cell mean, its association) */
+void orc_restrict(const orc_grid *fine, const orc_grid *coarse, const double *ffield, double *cfield, int nc);
+/* "prolong": refine_1 + RefineBlocks, main.cpp:5227-5249, 5493-5565: 2nd-order Taylor expansion from the tensorial
+ * [-1,2) lab (all 26 neighbours + domain-face rules of BlockLabBC / BlockLabNeumann3D incl. edge fills) */
+void orc_prolong(const orc_grid *coarse, const orc_grid *fine, const double *cfield, double *ffield, int nc, int is_vector);
+/* TagLoadedBlock (5566-5582) + the level clamps of TagBlocksVector (5207-5211): states[b] in {-1 Compress, 0 Leave, 1 Refine} */
+void orc_tag(const orc_grid *, const double *field, int nc, double rtol, double ctol, signed char *states);
 #ifdef __cplusplus
 }
 #endif

@@ -25,17 +25,66 @@
  *   op advdiff <dt> | lhs | precond | solve | project <dt> | maxu |
  *      steps <n> | forcing <dt> | rhs | divp | gradp   (the last three use `set dt`)
  *   hip on                 (ref_tool_hip only) route advdiff/project/steps through the HIP drop-in
+ *   amrtol <rt> <ct> | adapt | tagvel <rt> <ct> <file>   mesh-adaptation hooks (refine/compress everything)
  *   rep <n>                repeat every following `op` n times when timing
  * Every `op` prints one line `REF <op> seconds=<t> iters=<k> value=<v>`.
  */
 #include <chrono>
+/* every header the reference TU includes is pulled in FIRST, so that the access-specifier
+   override below (needed to reach MeshAdaptation's tolerances, main.cpp:5037-5038) touches the
+   reference's own classes only, not the standard library */
+#include <algorithm>
+#include <array>
+#include <cassert>
+#include <cctype>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <gsl/gsl_bspline.h>
+#include <gsl/gsl_linalg.h>
+#include <gsl/gsl_statistics.h>
+#include <iomanip>
+#include <ios>
+#include <iosfwd>
+#include <iostream>
+#include <limits>
+#include <list>
+#include <locale>
+#include <map>
+#include <math.h>
+#include <memory>
+#include <numeric>
+#include <omp.h>
+#include <queue>
+#include <random>
+#include <set>
+#include <sstream>
+#include <stack>
+#include <stdio.h>
+#include <string>
+#include <sys/stat.h>
+#include <sys/time.h>
+#include <type_traits>
+#include <unistd.h>
+#include <unordered_map>
+#include <utility>
+#include <vector>
 static long cup3d_stub_iallreduce7 = 0; /* one 7-double Iallreduce per BiCGSTAB iteration (main.cpp:14546) */
 #define CUP3D_STUB_COUNT_IALLREDUCE(n)                                         \
   do {                                                                         \
     if ((n) == 7) cup3d_stub_iallreduce7++;                                    \
   } while (0)
+#include <mpi.h>
 #define main cup3d_reference_main
+#define protected public
+#define private public
 #include CUP3D_REFERENCE_MAIN
+#undef private
+#undef protected
 #undef main
 #ifdef CUP3D_WITH_HIP
 /* the drop-in under test: HIP-backed operators behind the reference's own plugin surface */
@@ -197,6 +246,25 @@ int main(int argc, char **argv) {
 #else
       fprintf(stderr, "ref_tool: built without CUP3D_WITH_HIP\n"); exit(2);
 #endif
+    } else if (cmd == "amrtol") {
+      /* tolerance_for_refinement / tolerance_for_compression of the five MeshAdaptation objects
+         (main.cpp:5037-5038); `amrtol -1 -2` makes every block refine, `amrtol 1e300 1e299` compress */
+      double rt, ct; script >> rt >> ct;
+      sd.chi_amr->tolerance_for_refinement = sd.lhs_amr->tolerance_for_refinement = sd.pres_amr->tolerance_for_refinement = rt;
+      sd.vel_amr->tolerance_for_refinement = sd.tmpV_amr->tolerance_for_refinement = rt;
+      sd.chi_amr->tolerance_for_compression = sd.lhs_amr->tolerance_for_compression = sd.pres_amr->tolerance_for_compression = ct;
+      sd.vel_amr->tolerance_for_compression = sd.tmpV_amr->tolerance_for_compression = ct;
+    } else if (cmd == "adapt") {
+      S->adaptMesh(); /* main.cpp:15179-15194 */
+    } else if (cmd == "tagvel") {
+      /* MeshAdaptation::TagLoadedBlock on every vel block (main.cpp:5566-5582) with given tolerances -> int8 file */
+      double rt, ct; std::string path; script >> rt >> ct >> path;
+      const double r0 = sd.vel_amr->tolerance_for_refinement, c0 = sd.vel_amr->tolerance_for_compression;
+      sd.vel_amr->tolerance_for_refinement = rt; sd.vel_amr->tolerance_for_compression = ct;
+      std::vector<signed char> st;
+      for (auto &inf : sd.velInfo()) st.push_back((signed char)sd.vel_amr->TagLoadedBlock(sd.vel->getInfoAll(inf.level, inf.Z)));
+      sd.vel_amr->tolerance_for_refinement = r0; sd.vel_amr->tolerance_for_compression = c0;
+      write_file(path, st.data(), st.size());
     } else if (cmd == "rep") {
       script >> rep;
     } else if (cmd == "op") {

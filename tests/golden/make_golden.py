@@ -102,6 +102,31 @@ def traj_case():
     print("traj16_tgv dts", out["dts"], "iters", out["iters"])
 
 
+def adapt_cases():
+    """Whole-mesh refine then compress through the reference's own adaptMesh (main.cpp:15179-15194): every
+    block tagged Refine (tolerance -1), then every block tagged Compress (tolerance 1e300)."""
+    bpd, lmax = (2, 2, 2), 3
+    for name, bc, seed in (("adapt16_periodic", ("periodic",) * 3, 31), ("adapt16_mixed", ("wall", "freespace", "periodic"), 32),
+                           ("adapt16_wall", ("wall",) * 3, 33)):
+        rng = np.random.default_rng(seed)
+        velg, presg = rng.uniform(-1, 1, (16, 16, 16, 3)), rng.uniform(-1, 1, (16, 16, 16))
+        velg *= (0.35 + 0.65 * (np.arange(16) // 8))[None, None, :, None] * (0.6 + 0.4 * (np.arange(16) // 8))[:, None, None, None]  # per-block amplitudes
+        wd = O.tempfile.mkdtemp(prefix="golden_")
+        velg.tofile(os.path.join(wd, "vel_in.bin"))
+        presg.tofile(os.path.join(wd, "pres_in.bin"))
+        script = ["loadg vel vel_in.bin", "loadg pres pres_in.bin", "tagvel 1.0 0.5 tags.bin", "amrtol -1 -2", "adapt", "tables t1.bin",
+                  "dump vel v1.bin", "dump pres p1.bin", "amrtol 1e300 1e299", "adapt", "tables t2.bin", "dump vel v2.bin", "dump pres p2.bin"]
+        recs, wd = O.run_ref(script, O.ref_args(bpd, lmax, 0, EXT, bc), threads=1, workdir=wd)
+        t1, _ = O.read_tables(os.path.join(wd, "t1.bin"))
+        t2, _ = O.read_tables(os.path.join(wd, "t2.bin"))
+        out = dict(bpd=np.array(bpd), level_max=lmax, bc=np.array([O.BC[b] for b in bc]), extent=EXT, vel_in=velg, pres_in=presg,
+                   tag_rtol=1.0, tag_ctol=0.5, tags=np.fromfile(os.path.join(wd, "tags.bin"), dtype=np.int8), tables_fine=t1, tables_coarse=t2,
+                   vel_fine=O.read_blocks(os.path.join(wd, "v1.bin"), len(t1), 3), pres_fine=O.read_blocks(os.path.join(wd, "p1.bin"), len(t1), 1),
+                   vel_coarse=O.read_blocks(os.path.join(wd, "v2.bin"), len(t2), 3), pres_coarse=O.read_blocks(os.path.join(wd, "p2.bin"), len(t2), 1))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "blocks", len(t2), "->", len(t1), "->", len(t2), "tags", out["tags"])
+
+
 def sfc_cases():
     out = {}
     for bpd, lmax in SFC_CASES:
@@ -116,6 +141,7 @@ if __name__ == "__main__":
     if not O.have_ref_tool():
         sys.exit("oracle/_ref/ref_tool missing: run `make -C oracle ref` where /root/reference exists")
     sfc_cases()
+    adapt_cases()
     for c in FIELD_CASES:
         field_case(*c)
     traj_case()

@@ -78,6 +78,9 @@ def lib():
     L.orc_div_pressure.argtypes = [vp, _dp, _dp]
     L.orc_grad_p.argtypes = [vp, _dp, _dp, C.c_double]
     L.orc_project.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.POINTER(SolveInfo)]
+    L.orc_restrict.argtypes = [vp, vp, _dp, _dp, C.c_int]
+    L.orc_prolong.argtypes = [vp, vp, _dp, _dp, C.c_int, C.c_int]
+    L.orc_tag.argtypes = [vp, _dp, C.c_int, C.c_double, C.c_double, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]
     _lib = L
     return L
 
@@ -173,6 +176,29 @@ class OracleGrid:
         info = SolveInfo(tol, tol_rel, mean_constraint, 0, 0, 0.0, 0.0)
         lib().orc_project(self.g, vel, pres, tmpV, lhs, chi, dt, step, C.byref(info))
         return info, tmpV, lhs
+
+
+def restrict_field(fine, coarse, field):
+    """MeshAdaptation::compress of every sibling octet (fine level -> coarse level)."""
+    nc = 3 if field.ndim == 5 else 1
+    out = np.zeros((coarse.nb, 8, 8, 8, 3) if nc == 3 else (coarse.nb, 8, 8, 8))
+    lib().orc_restrict(fine.g, coarse.g, np.ascontiguousarray(field), out, nc)
+    return out
+
+
+def prolong_field(coarse, fine, field):
+    """refine_1 + RefineBlocks of every block (coarse level -> fine level)."""
+    nc = 3 if field.ndim == 5 else 1
+    out = np.zeros((fine.nb, 8, 8, 8, 3) if nc == 3 else (fine.nb, 8, 8, 8))
+    lib().orc_prolong(coarse.g, fine.g, np.ascontiguousarray(field), out, nc, 1 if nc == 3 else 0)
+    return out
+
+
+def tag_blocks(grid, field, rtol, ctol):
+    nc = 3 if field.ndim == 5 else 1
+    st = np.zeros(grid.nb, dtype=np.int8)
+    lib().orc_tag(grid.g, np.ascontiguousarray(field), nc, rtol, ctol, st)
+    return st
 
 
 # ------------------------------ compiled reference ------------------------------

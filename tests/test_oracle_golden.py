@@ -116,3 +116,32 @@ def test_partition():
                 assert a.value == covered
                 covered += n.value
             assert covered == total
+
+
+ADAPT_CASES = ["adapt16_periodic", "adapt16_mixed", "adapt16_wall"]
+
+
+def clamp_tags(raw, level, level_max):
+    """TagBlocksVector's clamps (main.cpp:5207-5211) applied to raw TagLoadedBlock states."""
+    st = raw.copy()
+    if level == level_max - 1:
+        st[st == 1] = 0
+    if level == 0:
+        st[st == -1] = 0
+    return st
+
+
+@pytest.mark.parametrize("name", ADAPT_CASES)
+def test_mesh_adaptation_block_operators(golden_dir, name):
+    """restrict (compress), prolong (RefineBlocks) and TagLoadedBlock against the reference's own adaptMesh."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    bc = [int(b) for b in z["bc"]]
+    g0 = O.OracleGrid(z["bpd"], int(z["level_max"]), 0, float(z["extent"]), bc)
+    g1 = O.OracleGrid(z["bpd"], int(z["level_max"]), 1, float(z["extent"]), bc)
+    assert np.array_equal(g1.tables, z["tables_fine"]) and np.array_equal(g0.tables, z["tables_coarse"])
+    v0, p0 = g0.to_blocks(z["vel_in"]), g0.to_blocks(z["pres_in"])
+    assert np.array_equal(O.prolong_field(g0, g1, v0), z["vel_fine"])
+    assert np.array_equal(O.prolong_field(g0, g1, p0), z["pres_fine"])
+    assert np.array_equal(O.restrict_field(g1, g0, z["vel_fine"]), z["vel_coarse"])
+    assert np.array_equal(O.restrict_field(g1, g0, z["pres_fine"]), z["pres_coarse"])
+    assert np.array_equal(O.tag_blocks(g0, v0, float(z["tag_rtol"]), float(z["tag_ctol"])), clamp_tags(z["tags"], 0, int(z["level_max"])))

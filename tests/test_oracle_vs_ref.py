@@ -50,3 +50,30 @@ def test_all_ops_bit_exact(bpd, lmax, lstart, bc, seed):
     assert info.iters == int([r for r in recs if r["op"] == "project"][0]["iters"])
     assert np.array_equal(v, O.read_blocks(os.path.join(wd, "prv.bin"), g.nb, 3))
     assert np.array_equal(p, O.read_blocks(os.path.join(wd, "prp.bin"), g.nb, 1))
+
+
+@pytest.mark.parametrize("bc", [("periodic", "periodic", "periodic"), ("wall", "freespace", "periodic"), ("freespace", "wall", "wall")])
+def test_mesh_adaptation_operators_bit_exact(bc):
+    """Whole-mesh refine / compress through the reference's adaptMesh vs the oracle's prolong / restrict."""
+    bpd, lmax = (2, 1, 2), 3
+    rng = np.random.default_rng(77)
+    g0, g1 = O.OracleGrid(bpd, lmax, 0, 2 * np.pi, bc), O.OracleGrid(bpd, lmax, 1, 2 * np.pi, bc)
+    NX, NY, NZ = g0.ncell
+    velg, presg = rng.uniform(-1, 1, (NZ, NY, NX, 3)), rng.uniform(-1, 1, (NZ, NY, NX))
+    wd = O.tempfile.mkdtemp(prefix="pin_")
+    velg.tofile(os.path.join(wd, "vel_in.bin"))
+    presg.tofile(os.path.join(wd, "pres_in.bin"))
+    script = ["loadg vel vel_in.bin", "loadg pres pres_in.bin", "tagvel 1.3 1.1 tags.bin", "amrtol -1 -2", "adapt", "tables t1.bin", "dump vel v1.bin",
+              "dump pres p1.bin", "amrtol 1e300 1e299", "adapt", "tables t2.bin", "dump vel v2.bin", "dump pres p2.bin"]
+    O.run_ref(script, O.ref_args(bpd, lmax, 0, 2 * np.pi, bc), threads=1, workdir=wd)
+    t1, _ = O.read_tables(os.path.join(wd, "t1.bin"))
+    t2, _ = O.read_tables(os.path.join(wd, "t2.bin"))
+    assert np.array_equal(t1, g1.tables) and np.array_equal(t2, g0.tables)
+    v1, p1 = O.read_blocks(os.path.join(wd, "v1.bin"), g1.nb, 3), O.read_blocks(os.path.join(wd, "p1.bin"), g1.nb, 1)
+    assert np.array_equal(O.prolong_field(g0, g1, g0.to_blocks(velg)), v1)
+    assert np.array_equal(O.prolong_field(g0, g1, g0.to_blocks(presg)), p1)
+    assert np.array_equal(O.restrict_field(g1, g0, v1), O.read_blocks(os.path.join(wd, "v2.bin"), g0.nb, 3))
+    assert np.array_equal(O.restrict_field(g1, g0, p1), O.read_blocks(os.path.join(wd, "p2.bin"), g0.nb, 1))
+    raw = np.fromfile(os.path.join(wd, "tags.bin"), dtype=np.int8)
+    raw[raw == -1] = 0  # level 0: TagBlocksVector's clamp
+    assert np.array_equal(O.tag_blocks(g0, g0.to_blocks(velg), 1.3, 1.1), raw)
