@@ -124,7 +124,8 @@ int halo_finish(Sim *s) {
 }
 
 int allreduce(Sim *s, double *d_buf, int n, bool is_max, hipStream_t st) {
-  if (s->grid->nranks == 1 || g_virtual_ranks) return CUP3D_OK;
+  // "force_allreduce": TEST SUPPORT, run the RCCL call on a 1-rank communicator to exercise the plumbing on one GPU
+  if ((s->grid->nranks == 1 && !(debug_option("force_allreduce") && comm())) || g_virtual_ranks) return CUP3D_OK;
   Comm *c = comm();
   if (!c) { set_error("multi-rank grid without cup3d_comm_init"); return CUP3D_ESTATE; }
   CUP3D_NCCL(c->AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, is_max ? ncclMax : ncclSum, c->comm, st));
@@ -150,7 +151,7 @@ int cup3d_comm_unique_id(void *id128) {
 
 int cup3d_comm_init(int rank, int nranks, const void *id128) {
   if (nranks < 1 || rank < 0 || rank >= nranks) return CUP3D_EINVAL;
-  if (nranks == 1) { g_comm.rank = 0; g_comm.nranks = 1; return CUP3D_OK; }
+  if (nranks == 1 && !debug_option("force_allreduce")) { g_comm.rank = 0; g_comm.nranks = 1; return CUP3D_OK; }
   if (!id128) return CUP3D_EINVAL;
   int rc = load_rccl();
   if (rc) return rc;

@@ -405,3 +405,25 @@ def test_medium_128_oracle_advect_diffuse_and_solver():
     assert iters_close(r.iterations, info.iters)
     assert_fields_close(sim.download("vel"), ref, np.abs(ref - before).max(), "velocity")
     assert_fields_close(sim.download("pres"), pref, np.abs(pref).max(), "pressure")
+
+
+def test_rccl_plumbing_on_one_rank():
+    """dlopen(librccl), ncclGetUniqueId, ncclCommInitRank and ncclAllReduce on the compute stream with a
+    1-rank communicator: the library's own RCCL path, exercised as far as one GPU allows."""
+    raw = (C.c_ubyte * 128)()
+    cu.capi.check(cu.lib().cup3d_debug_set_option(b"force_allreduce", 1))
+    try:
+        cu.capi.check(cu.lib().cup3d_comm_unique_id(raw))
+        assert any(raw)
+        cu.capi.check(cu.lib().cup3d_comm_init(0, 1, raw))
+        sim = cu.SimulationData(bpdx=2, bpdy=2, bpdz=2, levelMax=1, extent=1.0, BC_x="periodic", BC_y="periodic", BC_z="periodic")
+        rng = np.random.default_rng(2)
+        v = rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8, 3))
+        sim.upload("vel", v)
+        assert cu.findMaxU(sim) == np.abs(v).max()          # ncclAllReduce(MAX) of one double
+        sim.upload("lhs", rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8)))
+        r = cu.makePoissonSolver(sim).solve()                # ncclAllReduce(SUM) of 1, 2 and 7 doubles per iteration
+        assert 0 < r.iterations < 100
+    finally:
+        cu.lib().cup3d_comm_finalize()
+        cu.capi.check(cu.lib().cup3d_debug_set_option(b"force_allreduce", 0))
