@@ -79,6 +79,22 @@ void orc_restrict(const orc_grid *fine, const orc_grid *coarse, const double *ff
 void orc_prolong(const orc_grid *coarse, const orc_grid *fine, const double *cfield, double *ffield, int nc, int is_vector);
 /* TagLoadedBlock (5566-5582) + the level clamps of TagBlocksVector (5207-5211): states[b] in {-1 Compress, 0 Leave, 1 Refine} */
 void orc_tag(const orc_grid *, const double *field, int nc, double rtol, double ctol, signed char *states);
+/* --- multi-level (AMR) meshes: cup3d_oracle_amr.c ------------------------------------------- */
+typedef struct orc_mesh orc_mesh;
+orc_mesh *orc_mesh_create(int bx, int by, int bz, int level_max, double maxextent, const int bc[3], long nblocks,
+                          const int *levels, const long long *Zs);
+void orc_mesh_destroy(orc_mesh *);
+long orc_mesh_nblocks(const orc_mesh *);
+void orc_mesh_tables(const orc_mesh *, long long *out6); /* level,Z,index[3],blockID_2 in m_vInfo order */
+double orc_mesh_h(const orc_mesh *, long block);
+/* ghosted tiles of every block for stencil [s,e)^3 as BlockLab::load builds them (main.cpp:3623-4614):
+ * out [nb][L][L][L][nc], L = 8 + e - s - 1 */
+void orc_mesh_labs(const orc_mesh *, const double *field, int nc, int is_vector, int s, int e, int tensorial, double *out);
+/* the operators on multi-level meshes, each followed by the reference's flux correction at coarse/fine faces
+ * (compute<Lab>(kernel, g, g_corr), main.cpp:5584-5644; FluxCorrection 588-802) */
+void orc_mesh_advdiff_stage_rhs(const orc_mesh *, const double *vel, double *tmpV, double dt, double nu, const double uinf[3]);
+void orc_mesh_advect_diffuse(const orc_mesh *, double *vel, double *tmpV, double dt, double nu, const double uinf[3]);
+void orc_mesh_lhs(const orc_mesh *, const double *pres, double *lhs, int mean_constraint);
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,669 @@
+/* TEST INFRASTRUCTURE — CPU restatement of the reference's ghost reconstruction on
+ * multi-level (AMR) block meshes: BlockLab::load / post_load with SameLevelExchange,
+ * FineToCoarseExchange (restrict: 8-cell AverageDown), CoarseFineExchange + FillCoarseVersion
+ * (coarse shadow tile) and CoarseFineInterpolation (prolong: TestInterp and the
+ * finite-difference mode), slitvinov/CUP3D main.cpp:3623-4614, plus the domain-face rules on
+ * both tiles (5929-6004, 6107-6503).  Pinned against the reference's own tiles dumped by
+ * oracle/_ref/ref_tool (`lab` command) in tests/test_oracle_amr.py.  The product never links it.
+ *
+ * Conventions: a mesh is a list of leaf blocks (level, Z) sorted by blockID_2; fields are the
+ * reference's block memory [nb][8][8][8][nc].  The fine tile F covers fine-cell coordinates
+ * [s, 8+e-1)^3 relative to the block; the coarse shadow tile C covers coarse-cell coordinates
+ * [off, 4+eC-1)^3 (coarse cell X spans fine cells 2X, 2X+1), off = (s-1)/2 - 1, eC = e/2 + 2.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "cup3d_oracle.h"
+
+#define BS 8
+#define HB 4
+#define BS3 512
+
+struct orc_mesh {
+  orc_sfc *sfc;
+  int bpd[3], level_max, bc[3];
+  double maxextent;
+  long nblocks;
+  int *level;
+  long long *Z, *id2;
+  int *index;
+  int **slot_at; /* [level][(k*ny+j)*nx+i] -> slot or -1 */
+};
+
+typedef struct { long long id2; int level; long long Z; } mrec;
+static int cmp_mrec(const void *a, const void *b) {
+  const mrec *x = (const mrec *)a, *y = (const mrec *)b;
+  return (x->id2 > y->id2) - (x->id2 < y->id2);
+}
+
+orc_mesh *orc_mesh_create(int bx, int by, int bz, int level_max, double maxextent, const int bc[3], long nblocks,
+                          const int *levels, const long long *Zs) {
+  orc_mesh *m = (orc_mesh *)calloc(1, sizeof *m);
+  m->sfc = orc_sfc_create(bx, by, bz, level_max);
+  m->bpd[0] = bx; m->bpd[1] = by; m->bpd[2] = bz;
+  m->level_max = level_max; m->maxextent = maxextent; m->nblocks = nblocks;
+  for (int d = 0; d < 3; d++) m->bc[d] = bc[d];
+  m->level = (int *)malloc(nblocks * sizeof(int));
+  m->Z = (long long *)malloc(nblocks * sizeof(long long));
+  m->id2 = (long long *)malloc(nblocks * sizeof(long long));
+  m->index = (int *)malloc(nblocks * 3 * sizeof(int));
+  mrec *r = (mrec *)malloc(nblocks * sizeof(mrec));
+  for (long i = 0; i < nblocks; i++) {
+    int c[3];
+    orc_sfc_inverse(m->sfc, Zs[i], levels[i], c);
+    r[i].level = levels[i]; r[i].Z = Zs[i]; r[i].id2 = orc_sfc_encode(m->sfc, levels[i], c);
+  }
+  qsort(r, nblocks, sizeof(mrec), cmp_mrec);
+  m->slot_at = (int **)calloc(level_max, sizeof(int *));
+  for (int l = 0; l < level_max; l++) {
+    const long n = (long)(bx << l) * (by << l) * (bz << l);
+    m->slot_at[l] = (int *)malloc(n * sizeof(int));
+    for (long i = 0; i < n; i++) m->slot_at[l][i] = -1;
+  }
+  for (long s = 0; s < nblocks; s++) {
+    m->level[s] = r[s].level; m->Z[s] = r[s].Z; m->id2[s] = r[s].id2;
+    orc_sfc_inverse(m->sfc, r[s].Z, r[s].level, &m->index[3 * s]);
+    const int l = r[s].level, *c = &m->index[3 * s];
+    m->slot_at[l][((long)c[2] * (by << l) + c[1]) * (bx << l) + c[0]] = (int)s;
+  }
+  free(r);
+  return m;
+}
+void orc_mesh_destroy(orc_mesh *m) {
+  if (!m) return;
+  for (int l = 0; l < m->level_max; l++) free(m->slot_at[l]);
+  free(m->slot_at); orc_sfc_destroy(m->sfc); free(m->level); free(m->Z); free(m->id2); free(m->index); free(m);
+}
+long orc_mesh_nblocks(const orc_mesh *m) { return m->nblocks; }
+void orc_mesh_tables(const orc_mesh *m, long long *o) {
+  for (long s = 0; s < m->nblocks; s++) {
+    o[6 * s] = m->level[s]; o[6 * s + 1] = m->Z[s];
+    for (int d = 0; d < 3; d++) o[6 * s + 2 + d] = m->index[3 * s + d];
+    o[6 * s + 5] = m->id2[s];
+  }
+}
+double orc_mesh_h(const orc_mesh *m, long b) {
+  int mb = m->bpd[0] > m->bpd[1] ? m->bpd[0] : m->bpd[1];
+  if (m->bpd[2] > mb) mb = m->bpd[2];
+  return m->maxextent / (double)(mb * BS) / (double)(1 << m->level[b]);
+}
+
+static int nblk(const orc_mesh *m, int l, int d) { return m->bpd[d] << l; }
+/* leaf slot at (level l, block index c) with periodic wrap; -1 if not a leaf at that level */
+static int leaf_at(const orc_mesh *m, int l, const int c[3]) {
+  if (l < 0 || l >= m->level_max) return -1;
+  int w[3];
+  for (int d = 0; d < 3; d++) { const int n = nblk(m, l, d); w[d] = ((c[d] % n) + n) % n; }
+  return m->slot_at[l][((long)w[2] * nblk(m, l, 1) + w[1]) * nblk(m, l, 0) + w[0]];
+}
+/* TreePosition of (l, c): 1 Exists, -2 CheckCoarser, -1 CheckFiner (main.cpp:321-330) */
+static int tree_state(const orc_mesh *m, int l, const int c[3]) {
+  if (leaf_at(m, l, c) >= 0) return 1;
+  int w[3];
+  for (int d = 0; d < 3; d++) { const int n = nblk(m, l, d); w[d] = ((c[d] % n) + n) % n; }
+  for (int k = 1; k <= l; k++) {
+    const int p[3] = {w[0] >> k, w[1] >> k, w[2] >> k};
+    if (leaf_at(m, l - k, p) >= 0) return -2;
+  }
+  return -1;
+}
+
+/* ------------------------------------------------------------------ tiles */
+typedef struct {
+  int nc, is_vector, s, e, tens, use_avg; /* stencil [s,e)^3 */
+  int L, off, eC, Lc;
+  double *F, *C;
+} tile_t;
+#define FT(t, x, y, z, c) (t)->F[((((long)(z) - (t)->s) * (t)->L + ((y) - (t)->s)) * (t)->L + ((x) - (t)->s)) * (t)->nc + (c)]
+#define CT(t, x, y, z, c) (t)->C[((((long)(z) - (t)->off) * (t)->Lc + ((y) - (t)->off)) * (t)->Lc + ((x) - (t)->off)) * (t)->nc + (c)]
+
+static void tile_init(tile_t *t, int nc, int is_vector, int s, int e, int tens) {
+  t->nc = nc; t->is_vector = is_vector; t->s = s; t->e = e; t->tens = tens;
+  t->L = BS + e - s - 1;
+  t->off = (s - 1) / 2 + (-1);        /* main.cpp:3596 */
+  t->eC = e / 2 + 1 + 2 - 1;          /* main.cpp:3599 */
+  t->Lc = HB + t->eC - t->off - 1;
+  t->use_avg = tens || s < -2 || e > 3; /* main.cpp:3618-3621 (FiniteDifferences is always true) */
+  t->F = (double *)calloc((size_t)t->L * t->L * t->L * nc, sizeof(double));
+  t->C = (double *)calloc((size_t)t->Lc * t->Lc * t->Lc * nc, sizeof(double));
+}
+static void tile_free(tile_t *t) { free(t->F); free(t->C); }
+
+static inline double avg_down(double e0, double e1, double e2, double e3, double e4, double e5, double e6, double e7) {
+  return 0.125 * (e0 + e1 + e2 + e3 + e4 + e5 + e6 + e7); /* AverageDown, main.cpp:3877-3882 */
+}
+/* value of cell (gx,gy,gz) (global cell coordinates of level l, periodic wrap) if a level-l leaf holds it */
+static int cell_value(const orc_mesh *m, const double *f, int nc, int l, const long g[3], int c, double *out) {
+  int b[3], q[3];
+  for (int d = 0; d < 3; d++) {
+    const long n = (long)nblk(m, l, d) * BS;
+    const long w = ((g[d] % n) + n) % n;
+    b[d] = (int)(w / BS); q[d] = (int)(w % BS);
+  }
+  const int slot = leaf_at(m, l, b);
+  if (slot < 0) return 0;
+  *out = f[((long)slot * BS3 + (q[2] * BS + q[1]) * BS + q[0]) * nc + c];
+  return 1;
+}
+
+/* domain-face passes on the fine (coarse=0) or coarse shadow (coarse=1) tile, in the reference's order;
+ * each fills the whole ghost slab behind the face from the face cell with equal transverse coordinates */
+static void apply_bc(const orc_mesh *m, long b, tile_t *t, int coarse) {
+  const int l = m->level[b], *idx = &m->index[3 * b];
+  const int lo = coarse ? t->off : t->s, hi = coarse ? HB + t->eC - 1 : BS + t->e - 1, bs = coarse ? HB : BS;
+  for (int d = 0; d < 3; d++) {
+    if (m->bc[d] == ORC_BC_PERIODIC) continue;
+    for (int side = 0; side < 2; side++) {
+      if (side == 0 ? idx[d] != 0 : idx[d] != nblk(m, l, d) - 1) continue;
+      const int d1 = (d + 1) % 3, d2 = (d + 2) % 3, face = side ? bs - 1 : 0;
+      const int g0 = side ? bs : lo, g1 = side ? hi : 0;
+      for (int a2 = lo; a2 < hi; a2++)
+        for (int a1 = lo; a1 < hi; a1++)
+          for (int gg = g0; gg < g1; gg++) {
+            int p[3], q[3];
+            p[d] = gg; q[d] = face; p[d1] = q[d1] = a1; p[d2] = q[d2] = a2;
+            for (int c = 0; c < t->nc; c++) {
+              double v = coarse ? CT(t, q[0], q[1], q[2], c) : FT(t, q[0], q[1], q[2], c);
+              if (t->is_vector) {
+                if (m->bc[d] == ORC_BC_WALL) v = (-1.0) * v;
+                else if (c == d) v = (-1.) * v;
+              }
+              if (coarse) CT(t, p[0], p[1], p[2], c) = v; else FT(t, p[0], p[1], p[2], c) = v;
+            }
+          }
+    }
+  }
+}
+
+/* TestInterp, main.cpp:3883-3906: 8 fine values R[x+2y+4z] from the 3x3x3 coarse neighbourhood around (X,Y,Z) */
+static void test_interp(const tile_t *t, int X, int Y, int Z, int c, double R[8]) {
+#define Cc(i, j, k) CT(t, X - 1 + (i), Y - 1 + (j), Z - 1 + (k), c)
+  const double dudx = 0.125 * (Cc(2, 1, 1) - Cc(0, 1, 1));
+  const double dudy = 0.125 * (Cc(1, 2, 1) - Cc(1, 0, 1));
+  const double dudz = 0.125 * (Cc(1, 1, 2) - Cc(1, 1, 0));
+  const double dudxdy = 0.015625 * (Cc(0, 0, 1) + Cc(2, 2, 1) - Cc(2, 0, 1) - Cc(0, 2, 1));
+  const double dudxdz = 0.015625 * (Cc(0, 1, 0) + Cc(2, 1, 2) - Cc(2, 1, 0) - Cc(0, 1, 2));
+  const double dudydz = 0.015625 * (Cc(1, 0, 0) + Cc(1, 2, 2) - Cc(1, 2, 0) - Cc(1, 0, 2));
+  const double lap = Cc(1, 1, 1) + 0.03125 * (Cc(0, 1, 1) + Cc(2, 1, 1) + Cc(1, 0, 1) + Cc(1, 2, 1) + Cc(1, 1, 0) + Cc(1, 1, 2) + (-6.0) * Cc(1, 1, 1));
+#undef Cc
+  R[0] = lap - dudx - dudy - dudz + dudxdy + dudxdz + dudydz;
+  R[1] = lap + dudx - dudy - dudz - dudxdy - dudxdz + dudydz;
+  R[2] = lap - dudx + dudy - dudz - dudxdy + dudxdz - dudydz;
+  R[3] = lap + dudx + dudy - dudz + dudxdy - dudxdz - dudydz;
+  R[4] = lap - dudx - dudy + dudz + dudxdy - dudxdz - dudydz;
+  R[5] = lap + dudx - dudy + dudz - dudxdy + dudxdz - dudydz;
+  R[6] = lap - dudx + dudy + dudz - dudxdy - dudxdz + dudydz;
+  R[7] = lap + dudx + dudy + dudz + dudxdy + dudxdz + dudydz;
+}
+
+static const double d_coef_plus[9] = {-0.09375, 0.4375, 0.15625, 0.15625, -0.5625, 0.90625, -0.09375, 0.4375, 0.15625};  /* 3485-3488 */
+static const double d_coef_minus[9] = {0.15625, -0.5625, 0.90625, -0.09375, 0.4375, 0.15625, 0.15625, 0.4375, -0.09375};
+
+/* 1-D quadratic interpolation along axis `ax` at coarse position P (coordinates in C), main.cpp:4419-4441 */
+static double interp1d(const tile_t *t, const int P[3], int ax, const double *coef, int inner, int start, int c, int *pm) {
+  int A[3] = {P[0], P[1], P[2]}, B[3] = {P[0], P[1], P[2]};
+  double r;
+  if (inner) {
+    A[ax] = P[ax] - 1; B[ax] = P[ax] + 1;
+    r = (coef[6] * CT(t, A[0], A[1], A[2], c) + coef[8] * CT(t, B[0], B[1], B[2], c)) + coef[7] * CT(t, P[0], P[1], P[2], c);
+    pm[0] = P[ax] + 1; pm[1] = P[ax] - 1;
+  } else if (start) {
+    A[ax] = P[ax] + 2; B[ax] = P[ax] + 1;
+    r = (coef[0] * CT(t, A[0], A[1], A[2], c) + coef[1] * CT(t, B[0], B[1], B[2], c)) + coef[2] * CT(t, P[0], P[1], P[2], c);
+    pm[0] = P[ax] + 1; pm[1] = P[ax];
+  } else {
+    A[ax] = P[ax] - 2; B[ax] = P[ax] - 1;
+    r = (coef[3] * CT(t, A[0], A[1], A[2], c) + coef[4] * CT(t, B[0], B[1], B[2], c)) + coef[5] * CT(t, P[0], P[1], P[2], c);
+    pm[0] = P[ax]; pm[1] = P[ax] - 1;
+  }
+  return r;
+}
+
+/* BlockLab::load + post_load for block b: fills t->F (and t->C) */
+void orc_mesh_lab(const orc_mesh *m, const double *f, long b, tile_t *t) {
+  const int nc = t->nc, l = m->level[b], *idx = &m->index[3 * b];
+  const int s = t->s, e = t->e;
+  int N[3], skin[3], skip[3];
+  for (int d = 0; d < 3; d++) {
+    N[d] = nblk(m, l, d);
+    skin[d] = idx[d] == 0 || idx[d] == N[d] - 1;
+    skip[d] = idx[d] == 0 ? -1 : 1;
+  }
+  const double *own = f + (long)b * BS3 * nc;
+  for (int z = 0; z < BS; z++)
+    for (int y = 0; y < BS; y++)
+      for (int x = 0; x < BS; x++)
+        for (int c = 0; c < nc; c++) FT(t, x, y, z, c) = own[((z * BS + y) * BS + x) * nc + c];
+  int same_codes[26], nsame = 0, coarse_codes[27], ncoarse = 0, coarsened = 0;
+  for (int icode = 0; icode < 27; icode++) {
+    if (icode == 13) continue;
+    const int code[3] = {icode % 3 - 1, (icode / 3) % 3 - 1, icode / 9 - 1};
+    int skipped = 0;
+    for (int d = 0; d < 3; d++)
+      if (m->bc[d] != ORC_BC_PERIODIC && code[d] == skip[d] && skin[d]) skipped = 1;
+    if (skipped) continue;
+    const int nei[3] = {idx[0] + code[0], idx[1] + code[1], idx[2] + code[2]};
+    const int st = tree_state(m, l, nei);
+    if (st == 1) same_codes[nsame++] = icode;
+    else if (st == -2) {
+      coarse_codes[ncoarse++] = icode;
+      /* CoarseFineExchange, main.cpp:4066-4170: the coarse shadow region behind this code, from the coarser leaf */
+      int sC[3], eCc[3];
+      for (int d = 0; d < 3; d++) {
+        sC[d] = code[d] < 1 ? (code[d] < 0 ? t->off : 0) : HB;
+        eCc[d] = code[d] < 1 ? (code[d] < 0 ? 0 : HB) : HB + e / 2 + 2 - 1;
+      }
+      for (int Zc = sC[2]; Zc < eCc[2]; Zc++)
+        for (int Yc = sC[1]; Yc < eCc[1]; Yc++)
+          for (int Xc = sC[0]; Xc < eCc[0]; Xc++) {
+            const int P[3] = {Xc, Yc, Zc};
+            long g[3];
+            for (int d = 0; d < 3; d++) g[d] = (long)(idx[d] >> 1) * BS + (idx[d] & 1) * HB + P[d];
+            /* negative block indices: floor semantics of idx>>1 are fine since idx >= 0 */
+            for (int c = 0; c < nc; c++) {
+              double v;
+              if (cell_value(m, f, nc, l - 1, g, c, &v)) CT(t, Xc, Yc, Zc, c) = v;
+            }
+          }
+    }
+    if (!t->tens && !t->use_avg && abs(code[0]) + abs(code[1]) + abs(code[2]) > 1) continue;
+    int sF[3], eF[3];
+    for (int d = 0; d < 3; d++) {
+      sF[d] = code[d] < 1 ? (code[d] < 0 ? s : 0) : BS;
+      eF[d] = code[d] < 1 ? (code[d] < 0 ? 0 : BS) : BS + e - 1;
+    }
+    if (st == 1) { /* SameLevelExchange, 3823-3876 */
+      const double *nb = f + (long)leaf_at(m, l, nei) * BS3 * nc;
+      for (int z = sF[2]; z < eF[2]; z++)
+        for (int y = sF[1]; y < eF[1]; y++)
+          for (int x = sF[0]; x < eF[0]; x++)
+            for (int c = 0; c < nc; c++)
+              FT(t, x, y, z, c) = nb[(((z - code[2] * BS) * BS + (y - code[1] * BS)) * BS + (x - code[0] * BS)) * nc + c];
+    } else if (st == -1) { /* FineToCoarseExchange, 3907-4065: 8-cell mean of the finer leaves */
+      for (int z = sF[2]; z < eF[2]; z++)
+        for (int y = sF[1]; y < eF[1]; y++)
+          for (int x = sF[0]; x < eF[0]; x++)
+            for (int c = 0; c < nc; c++) {
+              double v[8];
+              int ok = 1;
+              for (int q = 0; q < 8 && ok; q++) { /* e0..e7: (dx,dy,dz) = (q>>2, (q>>1)&1, q&1) */
+                const long g[3] = {2 * ((long)idx[0] * BS + x) + (q >> 2), 2 * ((long)idx[1] * BS + y) + ((q >> 1) & 1), 2 * ((long)idx[2] * BS + z) + (q & 1)};
+                ok = cell_value(m, f, nc, l + 1, g, c, &v[q]);
+              }
+              if (ok) FT(t, x, y, z, c) = avg_down(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+            }
+    }
+  }
+  /* FillCoarseVersion for the same-level neighbours that touch a coarsened region, 3726-3738, 4171-4235 */
+  if (ncoarse > 0)
+    for (int i = 0; i < nsame; i++) {
+      const int icode = same_codes[i];
+      const int code[3] = {icode % 3 - 1, (icode / 3) % 3 - 1, icode / 9 - 1};
+      const int bidx[3] = {(idx[0] + code[0] + N[0]) % N[0], (idx[1] + code[1] + N[1]) % N[1], (idx[2] + code[2] + N[2]) % N[2]};
+      /* UseCoarseStencil, 3788-3822 */
+      int use = 0;
+      if (l != 0 && t->use_avg) {
+        int imin[3], imax[3];
+        for (int d = 0; d < 3; d++) {
+          imin[d] = idx[d] < bidx[d] ? 0 : -1;
+          imax[d] = idx[d] > bidx[d] ? 0 : +1;
+          if (m->bc[d] == ORC_BC_PERIODIC) {
+            if (idx[d] == 0 && bidx[d] == N[d] - 1) imin[d] = -1;
+            if (bidx[d] == 0 && idx[d] == N[d] - 1) imax[d] = +1;
+          } else {
+            if (idx[d] == 0 && bidx[d] == 0) imin[d] = 0;
+            if (idx[d] == N[d] - 1 && bidx[d] == N[d] - 1) imax[d] = 0;
+          }
+        }
+        for (int it = 0; it < ncoarse && !use; it++)
+          for (int i2 = imin[2]; i2 <= imax[2] && !use; i2++)
+            for (int i1 = imin[1]; i1 <= imax[1] && !use; i1++)
+              for (int i0 = imin[0]; i0 <= imax[0] && !use; i0++)
+                if (coarse_codes[it] == (i0 + 1) + 3 * (i1 + 1) + 9 * (i2 + 1)) use = 1;
+      }
+      if (!use) continue;
+      coarsened = 1;
+      /* only performed when SameLevelExchange loaded that neighbour (myblocks[icode] != nullptr): with use_avg all 26 are */
+      const double *nb = f + (long)leaf_at(m, l, bidx) * BS3 * nc;
+      int sC[3], eCc[3], start[3];
+      for (int d = 0; d < 3; d++) {
+        sC[d] = code[d] < 1 ? (code[d] < 0 ? t->off : 0) : HB;
+        eCc[d] = code[d] < 1 ? (code[d] < 0 ? 0 : HB) : HB + (e / 2 + 2) - 1;
+        start[d] = sC[d] + (code[d] > 0 ? code[d] : 0) * HB - code[d] * BS + (code[d] < 0 ? code[d] : 0) * (eCc[d] - sC[d]);
+      }
+      for (int Zc = sC[2]; Zc < eCc[2]; Zc++)
+        for (int Yc = sC[1]; Yc < eCc[1]; Yc++) {
+          if (code[1] == 0 && code[2] == 0 && Yc > 1 && Yc < HB - 2 && Zc > 1 && Zc < HB - 2) continue; /* never true for 4-cell blocks */
+          for (int Xc = sC[0]; Xc < eCc[0]; Xc++) {
+            const int XX = start[0] + 2 * (Xc - sC[0]), YY = start[1] + 2 * (Yc - sC[1]), ZZ = start[2] + 2 * (Zc - sC[2]);
+#define NB(a, bb, cc, c) nb[((((ZZ) + (cc)) * BS + ((YY) + (bb))) * BS + ((XX) + (a))) * nc + (c)]
+            for (int c = 0; c < nc; c++)
+              CT(t, Xc, Yc, Zc, c) = avg_down(NB(0, 0, 0, c), NB(0, 0, 1, c), NB(0, 1, 0, c), NB(0, 1, 1, c), NB(1, 0, 0, c), NB(1, 0, 1, c), NB(1, 1, 0, c), NB(1, 1, 1, c));
+#undef NB
+          }
+        }
+    }
+  /* post_load, 3746-3787 */
+  if (coarsened)
+    for (int k = 0; k < HB; k++)
+      for (int j = 0; j < HB; j++)
+        for (int i = 0; i < HB; i++) {
+          if (i > 1 && i < HB - 2 && j > 1 && j < HB - 2 && k > 1 && k < HB - 2) continue;
+          for (int c = 0; c < nc; c++)
+            CT(t, i, j, k, c) = avg_down(FT(t, 2 * i, 2 * j, 2 * k, c), FT(t, 2 * i + 1, 2 * j, 2 * k, c), FT(t, 2 * i, 2 * j + 1, 2 * k, c), FT(t, 2 * i + 1, 2 * j + 1, 2 * k, c),
+                                         FT(t, 2 * i, 2 * j, 2 * k + 1, c), FT(t, 2 * i + 1, 2 * j, 2 * k + 1, c), FT(t, 2 * i, 2 * j + 1, 2 * k + 1, c), FT(t, 2 * i + 1, 2 * j + 1, 2 * k + 1, c));
+        }
+  apply_bc(m, b, t, 1);
+  /* CoarseFineInterpolation, 4236-4614 */
+  for (int ii = 0; ii < ncoarse; ii++) {
+    const int icode = coarse_codes[ii];
+    const int code[3] = {icode % 3 - 1, (icode / 3) % 3 - 1, (icode / 9) % 3 - 1};
+    if (!t->tens && !t->use_avg && abs(code[0]) + abs(code[1]) + abs(code[2]) > 1) continue;
+    int sF[3], eF[3], sC[3];
+    for (int d = 0; d < 3; d++) {
+      sF[d] = code[d] < 1 ? (code[d] < 0 ? s : 0) : BS;
+      eF[d] = code[d] < 1 ? (code[d] < 0 ? 0 : BS) : BS + e - 1;
+      sC[d] = code[d] < 1 ? (code[d] < 0 ? ((s - 1) / 2) : 0) : HB;
+    }
+    if (t->use_avg)
+      for (int iz = sF[2]; iz < eF[2]; iz += 2) {
+        const int ZZ = (iz - sF[2] - (code[2] < 0 ? code[2] : 0) * ((eF[2] - sF[2]) % 2)) / 2 + sC[2];
+        const int izp = (abs(iz) % 2 == 1) ? -1 : 1, rzp = izp == 1 ? 1 : 0, rz = izp == 1 ? 0 : 1;
+        for (int iy = sF[1]; iy < eF[1]; iy += 2) {
+          const int YY = (iy - sF[1] - (code[1] < 0 ? code[1] : 0) * ((eF[1] - sF[1]) % 2)) / 2 + sC[1];
+          const int iyp = (abs(iy) % 2 == 1) ? -1 : 1, ryp = iyp == 1 ? 1 : 0, ry = iyp == 1 ? 0 : 1;
+          for (int ix = sF[0]; ix < eF[0]; ix += 2) {
+            const int XX = (ix - sF[0] - (code[0] < 0 ? code[0] : 0) * ((eF[0] - sF[0]) % 2)) / 2 + sC[0];
+            const int ixp = (abs(ix) % 2 == 1) ? -1 : 1, rxp = ixp == 1 ? 1 : 0, rx = ixp == 1 ? 0 : 1;
+            for (int c = 0; c < nc; c++) {
+              double R[8];
+              test_interp(t, XX, YY, ZZ, c, R);
+              for (int q = 0; q < 8; q++) {
+                const int px = (q & 1) ? ix + ixp : ix, py = (q & 2) ? iy + iyp : iy, pz = (q & 4) ? iz + izp : iz;
+                if (px < sF[0] || px >= eF[0] || py < sF[1] || py >= eF[1] || pz < sF[2] || pz >= eF[2]) continue;
+                FT(t, px, py, pz, c) = R[((q & 1) ? rxp : rx) + 2 * ((q & 2) ? ryp : ry) + 4 * ((q & 4) ? rzp : rz)];
+              }
+            }
+          }
+        }
+      }
+    if (abs(code[0]) + abs(code[1]) + abs(code[2]) == 1) {
+      int cf[3], mn[3], mx[3];
+      for (int d = 0; d < 3; d++) {
+        cf[d] = (code[d] < 0 ? code[d] : 0) * ((eF[d] - sF[d]) % 2);
+        mn[d] = sF[d] > -2 ? sF[d] : -2;
+        mx[d] = eF[d] < BS + 2 ? eF[d] : BS + 2;
+      }
+      const int ax = code[0] != 0 ? 0 : (code[1] != 0 ? 1 : 2);
+      const int a1 = ax == 0 ? 1 : 0, a2 = ax == 2 ? 1 : 2; /* the two tangential axes in the reference's order (y,z) / (x,z) / (x,y) */
+      for (int iz = mn[2]; iz < mx[2]; iz++)
+        for (int iy = mn[1]; iy < mx[1]; iy++)
+          for (int ix = mn[0]; ix < mx[0]; ix++) {
+            const int ip[3] = {ix, iy, iz};
+            int P[3], par[3], inner[3], start[3];
+            double dd[3];
+            const double *coef[3];
+            for (int d = 0; d < 3; d++) {
+              P[d] = (ip[d] - sF[d] - cf[d]) / 2 + sC[d]; /* absolute coarse coordinate (the reference subtracts offset for storage) */
+              par[d] = abs(ip[d] - sF[d] - cf[d]) % 2;
+              dd[d] = 0.25 * (2 * par[d] - 1);
+              coef[d] = dd[d] > 0 ? d_coef_plus : d_coef_minus;
+              inner[d] = P[d] != 0 && P[d] != HB - 1;
+              start[d] = P[d] == 0;
+            }
+            for (int c = 0; c < nc; c++) {
+              int pm1[2], pm2[2];
+              const double x1D = interp1d(t, P, a1, coef[a1], inner[a1], start[a1], c, pm1);
+              const double x2D = interp1d(t, P, a2, coef[a2], inner[a2], start[a2], c, pm2);
+              double mixed_coef = 1.0;
+              if (inner[a1]) mixed_coef *= 0.5;
+              if (inner[a2]) mixed_coef *= 0.5;
+              int Q[3] = {P[0], P[1], P[2]};
+              double vmm, vpp, vpm, vmp;
+              Q[a1] = pm1[1]; Q[a2] = pm2[1]; vmm = CT(t, Q[0], Q[1], Q[2], c);
+              Q[a1] = pm1[0]; Q[a2] = pm2[0]; vpp = CT(t, Q[0], Q[1], Q[2], c);
+              Q[a1] = pm1[0]; Q[a2] = pm2[1]; vpm = CT(t, Q[0], Q[1], Q[2], c);
+              Q[a1] = pm1[1]; Q[a2] = pm2[0]; vmp = CT(t, Q[0], Q[1], Q[2], c);
+              const double mixed = mixed_coef * dd[a1] * dd[a2] * ((vmm + vpp) - (vpm + vmp));
+              double a = (x1D + x2D) + mixed;
+              int pb[3], pc[3];
+              for (int d = 0; d < 3; d++) {
+                pb[d] = ip[d] + (-3 * code[d] + 1) / 2 - par[d] * abs(code[d]);
+                pc[d] = ip[d] + (-5 * code[d] + 1) / 2 - par[d] * abs(code[d]);
+              }
+              const double bv = FT(t, pb[0], pb[1], pb[2], c), cv = FT(t, pc[0], pc[1], pc[2], c);
+              const int ccc = code[0] + code[1] + code[2];
+              const int xyz = abs(code[0]) * par[0] + abs(code[1]) * par[1] + abs(code[2]) * par[2];
+              if (ccc == 1) a = (xyz == 0) ? (1.0 / 15.0) * (8.0 * a + (10.0 * bv - 3.0 * cv)) : (1.0 / 15.0) * (24.0 * a + (-15.0 * bv + 6 * cv));
+              else a = (xyz == 1) ? (1.0 / 15.0) * (8.0 * a + (10.0 * bv - 3.0 * cv)) : (1.0 / 15.0) * (24.0 * a + (-15.0 * bv + 6 * cv));
+              FT(t, ix, iy, iz, c) = a;
+            }
+          }
+    }
+  }
+  apply_bc(m, b, t, 0);
+}
+
+/* all tiles of a field: out [nb][L][L][L][nc] (x fastest), like ref_tool's `lab` command */
+void orc_mesh_labs(const orc_mesh *m, const double *f, int nc, int is_vector, int s, int e, int tens, double *out) {
+  tile_t t;
+  tile_init(&t, nc, is_vector, s, e, tens);
+  const size_t per = (size_t)t.L * t.L * t.L * nc;
+  for (long b = 0; b < m->nblocks; b++) {
+    /* the reference reuses one lab object: cells it does not fill keep the previous block's values; here they keep ours */
+    orc_mesh_lab(m, f, b, &t);
+    memcpy(out + b * per, t.F, per * sizeof(double));
+  }
+  tile_free(&t);
+}
+
+/* ======================= operators on multi-level meshes ======================= */
+/* compute<Lab>(kernel, g, g_corr) with flux correction (main.cpp:5584-5644, 588-802): every kernel below
+ * fills `out` per block and, for the faces whose same-level neighbour does not exist (FluxCorrection::prepare,
+ * 676-711), the face flux arrays face[b][f][64][fc]; fix_fluxes() then adds, on the coarse side of every
+ * coarse/fine face, the coarse face flux plus the four fine ones to the boundary cells (FillBlockCases 729-801). */
+typedef struct { int nf; double *v; char *stored; } faces_t; /* v: [nb][6][64][fc], stored: [nb][6] */
+
+static void faces_init(const orc_mesh *m, faces_t *F, int fc) {
+  F->nf = fc;
+  F->v = (double *)calloc((size_t)m->nblocks * 6 * 64 * fc, sizeof(double));
+  F->stored = (char *)calloc((size_t)m->nblocks * 6, 1);
+  for (long b = 0; b < m->nblocks; b++) {
+    const int l = m->level[b], *idx = &m->index[3 * b];
+    for (int f = 0; f < 6; f++) {
+      const int d = f >> 1, side = f & 1;
+      const int skin = idx[d] == 0 || idx[d] == nblk(m, l, d) - 1, skip = idx[d] == 0 ? -1 : 1;
+      if (m->bc[d] != ORC_BC_PERIODIC && (side ? 1 : -1) == skip && skin) continue;
+      int nei[3] = {idx[0], idx[1], idx[2]};
+      nei[d] += side ? 1 : -1;
+      if (tree_state(m, l, nei) != 1) F->stored[b * 6 + f] = 1;
+    }
+  }
+}
+static void faces_free(faces_t *F) { free(F->v); free(F->stored); }
+#define FACE(F, b, f, i, c) (F)->v[((((long)(b) * 6 + (f)) * 64) + (i)) * (F)->nf + (c)]
+
+/* out: block field with oc components; the face flux has fc (= oc) components.
+ * The grid is always a GridMPI, so the corrector that runs is FluxCorrectionMPI::FillBlockCases (main.cpp:2825-2935):
+ * every fine face is reduced 2x2 as (f00+f10)+(f01+f11) into the message (2848-2851), the coarse face accumulates
+ * it (FillCase 2579-2629), and the coarse boundary cells are then updated direction by direction - all x faces,
+ * then y, then z (FillCase_2, 2918-2926; called once per fine block, so three of the four calls add +0.0). */
+static void fix_fluxes(const orc_mesh *m, faces_t *F, double *out, int oc) {
+  for (int d = 0; d < 3; d++)
+    for (long b = 0; b < m->nblocks; b++) {
+      const int l = m->level[b], *idx = &m->index[3 * b];
+      for (int side = 0; side < 2; side++) {
+        const int f = 2 * d + side;
+        if (!F->stored[b * 6 + f]) continue;
+        int nei[3] = {idx[0], idx[1], idx[2]};
+        nei[d] += side ? 1 : -1;
+        if (tree_state(m, l, nei) != -1) continue; /* only the coarse side of a coarse/fine face is corrected */
+        const int of = f ^ 1;
+        const int dfast = d == 0 ? 1 : 0, dslow = d == 2 ? 1 : 2; /* face arrays: index = fast + 8*slow */
+        for (int B = 0; B < 4; B++) {
+          int fi[3];
+          for (int k = 0; k < 3; k++) fi[k] = 2 * idx[k];
+          fi[d] = 2 * idx[d] + (side ? 2 : -1);
+          fi[dfast] += B % 2;
+          fi[dslow] += B / 2;
+          const int fb = leaf_at(m, l + 1, fi);
+          if (fb < 0) continue;
+          const int base = (B % 2) * 4 + (B / 2) * 4 * 8;
+          for (int i1 = 0; i1 < 8; i1 += 2)
+            for (int i2 = 0; i2 < 8; i2 += 2)
+              for (int c = 0; c < oc; c++) {
+                const double avg = (FACE(F, fb, of, i2 + i1 * 8, c) + FACE(F, fb, of, i2 + 1 + i1 * 8, c)) +
+                                   (FACE(F, fb, of, i2 + (i1 + 1) * 8, c) + FACE(F, fb, of, i2 + 1 + (i1 + 1) * 8, c));
+                FACE(F, b, f, base + (i2 / 2) + (i1 / 2) * 8, c) += avg;
+              }
+        }
+        double *blk = out + (long)b * BS3 * oc;
+        const int j = side ? BS - 1 : 0;
+        for (int i1 = 0; i1 < 8; i1++)
+          for (int i2 = 0; i2 < 8; i2++) {
+            const int x = d == 0 ? j : i2, y = d == 1 ? j : (d == 0 ? i2 : i1), z = d == 2 ? j : i1;
+            for (int c = 0; c < oc; c++) {
+              double *v = &blk[((z * BS + y) * BS + x) * oc + c];
+              *v += FACE(F, b, f, i2 + i1 * 8, c);
+              *v += 0.0; /* the repeated FillCase_2 calls on the cleared face (turns -0.0 into +0.0) */
+            }
+          }
+      }
+    }
+}
+
+static inline double upwind5m(double U, double um3, double um2, double um1, double u, double up1, double up2, double up3) {
+  if (U > 0) return (-2 * um3 + 15 * um2 - 60 * um1 + 20 * u + 30 * up1 - 3 * up2) / 60.;
+  else return (2 * up3 - 15 * up2 + 60 * up1 - 20 * u - 30 * um1 + 3 * um2) / 60.;
+}
+
+/* KernelAdvectDiffuse incl. face fluxes (main.cpp:9484-9637) + flux correction on tmpV */
+void orc_mesh_advdiff_stage_rhs(const orc_mesh *m, const double *vel, double *tmpV, double dt, double nu, const double uinf[3]) {
+  faces_t F;
+  faces_init(m, &F, 3);
+  tile_t t;
+  tile_init(&t, 3, 1, -3, 4, 0);
+#define V(x, y, z, c) FT(&t, x, y, z, c)
+  for (long b = 0; b < m->nblocks; b++) {
+    orc_mesh_lab(m, vel, b, &t);
+    const double h = orc_mesh_h(m, b), h3 = h * h * h;
+    const double facA = -dt / h * h3 * 1.0, facD = (nu / h) * (dt / h) * h3 * 1.0;
+    double *o = tmpV + b * BS3 * 3;
+    for (int z = 0; z < BS; z++)
+      for (int y = 0; y < BS; y++)
+        for (int x = 0; x < BS; x++) {
+          const double uAbs[3] = {V(x, y, z, 0) + uinf[0], V(x, y, z, 1) + uinf[1], V(x, y, z, 2) + uinf[2]};
+          double dx[3], dy[3], dz[3], lap[3];
+          for (int c = 0; c < 3; c++) {
+            dx[c] = upwind5m(uAbs[0], V(x - 3, y, z, c), V(x - 2, y, z, c), V(x - 1, y, z, c), V(x, y, z, c), V(x + 1, y, z, c), V(x + 2, y, z, c), V(x + 3, y, z, c));
+            dy[c] = upwind5m(uAbs[1], V(x, y - 3, z, c), V(x, y - 2, z, c), V(x, y - 1, z, c), V(x, y, z, c), V(x, y + 1, z, c), V(x, y + 2, z, c), V(x, y + 3, z, c));
+            dz[c] = upwind5m(uAbs[2], V(x, y, z - 3, c), V(x, y, z - 2, c), V(x, y, z - 1, c), V(x, y, z, c), V(x, y, z + 1, c), V(x, y, z + 2, c), V(x, y, z + 3, c));
+          }
+          lap[0] = ((V(x + 1, y, z, 0) + V(x - 1, y, z, 0)) + ((V(x, y + 1, z, 0) + V(x, y - 1, z, 0)) + (V(x, y, z + 1, 0) + V(x, y, z - 1, 0)))) - 6 * V(x, y, z, 0);
+          lap[1] = ((V(x, y + 1, z, 1) + V(x, y - 1, z, 1)) + ((V(x, y, z + 1, 1) + V(x, y, z - 1, 1)) + (V(x + 1, y, z, 1) + V(x - 1, y, z, 1)))) - 6 * V(x, y, z, 1);
+          lap[2] = ((V(x, y, z + 1, 2) + V(x, y, z - 1, 2)) + ((V(x + 1, y, z, 2) + V(x - 1, y, z, 2)) + (V(x, y + 1, z, 2) + V(x, y - 1, z, 2)))) - 6 * V(x, y, z, 2);
+          const double duA = uAbs[0] * dx[0] + (uAbs[1] * dy[0] + uAbs[2] * dz[0]);
+          const double dvA = uAbs[1] * dy[1] + (uAbs[2] * dz[1] + uAbs[0] * dx[1]);
+          const double dwA = uAbs[2] * dz[2] + (uAbs[0] * dx[2] + uAbs[1] * dy[2]);
+          double *oc = o + ((z * BS + y) * BS + x) * 3;
+          oc[0] += facA * duA + facD * lap[0];
+          oc[1] += facA * dvA + facD * lap[1];
+          oc[2] += facA * dwA + facD * lap[2];
+        }
+    for (int f = 0; f < 6; f++) {
+      if (!F.stored[b * 6 + f]) continue;
+      const int d = f >> 1, side = f & 1;
+      for (int i1 = 0; i1 < 8; i1++)
+        for (int i2 = 0; i2 < 8; i2++) {
+          int p[3], q[3];
+          const int dfast = d == 0 ? 1 : 0, dslow = d == 2 ? 1 : 2;
+          p[dfast] = q[dfast] = i2; p[dslow] = q[dslow] = i1;
+          p[d] = side ? BS - 1 : 0; q[d] = side ? BS : -1;
+          for (int c = 0; c < 3; c++) FACE(&F, b, f, i2 + i1 * 8, c) = facD * (V(p[0], p[1], p[2], c) - V(q[0], q[1], q[2], c));
+        }
+    }
+  }
+#undef V
+  tile_free(&t);
+  fix_fluxes(m, &F, tmpV, 3);
+  faces_free(&F);
+}
+
+void orc_mesh_advect_diffuse(const orc_mesh *m, double *vel, double *tmpV, double dt, double nu, const double uinf[3]) {
+  const double alpha[3] = {1.0 / 3.0, 15.0 / 16.0, 8.0 / 15.0}, beta[3] = {-5.0 / 9.0, -153.0 / 128.0, 0.0};
+  memset(tmpV, 0, (size_t)m->nblocks * BS3 * 3 * sizeof(double));
+  for (int rk = 0; rk < 3; rk++) {
+    orc_mesh_advdiff_stage_rhs(m, vel, tmpV, dt, nu, uinf);
+    for (long b = 0; b < m->nblocks; b++) {
+      const double h = orc_mesh_h(m, b), ih3 = alpha[rk] / (h * h * h);
+      for (long i = b * BS3 * 3; i < (b + 1) * BS3 * 3; i++) { vel[i] += tmpV[i] * ih3; tmpV[i] *= beta[rk]; }
+    }
+  }
+}
+
+/* 7-point scalar kernels with their face fluxes */
+static void lhs_kernel_mesh(const orc_mesh *m, const double *pres, double *lhs) { /* KernelLHSPoisson, 9205-9268 */
+  faces_t F;
+  faces_init(m, &F, 1);
+  tile_t t;
+  tile_init(&t, 1, 0, -1, 2, 0);
+#define P(x, y, z) FT(&t, x, y, z, 0)
+  for (long b = 0; b < m->nblocks; b++) {
+    orc_mesh_lab(m, pres, b, &t);
+    const double h = orc_mesh_h(m, b);
+    double *o = lhs + b * BS3;
+    for (int z = 0; z < BS; z++)
+      for (int y = 0; y < BS; y++)
+        for (int x = 0; x < BS; x++)
+          o[(z * BS + y) * BS + x] = h * (P(x - 1, y, z) + P(x + 1, y, z) + P(x, y - 1, z) + P(x, y + 1, z) + P(x, y, z - 1) + P(x, y, z + 1) - 6.0 * P(x, y, z));
+    for (int f = 0; f < 6; f++) {
+      if (!F.stored[b * 6 + f]) continue;
+      const int d = f >> 1, side = f & 1, dfast = d == 0 ? 1 : 0, dslow = d == 2 ? 1 : 2;
+      for (int i1 = 0; i1 < 8; i1++)
+        for (int i2 = 0; i2 < 8; i2++) {
+          int p[3], q[3];
+          p[dfast] = q[dfast] = i2; p[dslow] = q[dslow] = i1;
+          p[d] = side ? BS - 1 : 0; q[d] = side ? BS : -1;
+          FACE(&F, b, f, i2 + i1 * 8, 0) = h * (P(p[0], p[1], p[2]) - P(q[0], q[1], q[2]));
+        }
+    }
+  }
+#undef P
+  tile_free(&t);
+  fix_fluxes(m, &F, lhs, 1);
+  faces_free(&F);
+}
+
+static long corner_block_mesh(const orc_mesh *m) {
+  for (long b = 0; b < m->nblocks; b++)
+    if (m->index[3 * b] == 0 && m->index[3 * b + 1] == 0 && m->index[3 * b + 2] == 0) return b;
+  return -1;
+}
+
+void orc_mesh_lhs(const orc_mesh *m, const double *pres, double *lhs, int mc) { /* ComputeLHS, 9273-9327 */
+  double avgP = 0;
+  if (mc <= 2 && mc > 0)
+    for (long b = 0; b < m->nblocks; b++) {
+      const double h = orc_mesh_h(m, b), h3 = h * h * h;
+      for (int i = 0; i < BS3; i++) avgP += pres[b * BS3 + i] * h3;
+    }
+  lhs_kernel_mesh(m, pres, lhs);
+  if (mc == 0) return;
+  /* `index` in the reference is the LAST block (in m_vInfo order) whose index is (0,0,0), 9287-9289 */
+  long corner = -1;
+  for (long b = 0; b < m->nblocks; b++)
+    if (m->index[3 * b] == 0 && m->index[3 * b + 1] == 0 && m->index[3 * b + 2] == 0) corner = b;
+  if (mc <= 2 && mc > 0) {
+    if (mc == 1 && corner >= 0) lhs[corner * BS3] = avgP;
+    else if (mc == 2)
+      for (long b = 0; b < m->nblocks; b++) {
+        const double h = orc_mesh_h(m, b), h3 = h * h * h;
+        for (int i = 0; i < BS3; i++) lhs[b * BS3 + i] += avgP * h3;
+      }
+  } else if (corner >= 0)
+    lhs[corner * BS3] = pres[corner * BS3];
+  (void)corner_block_mesh;
+}

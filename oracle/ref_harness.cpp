@@ -25,6 +25,8 @@
  *   op advdiff <dt> | lhs | precond | solve | project <dt> | maxu |
  *      steps <n> | forcing <dt> | rhs | divp | gradp   (the last three use `set dt`)
  *   hip on                 (ref_tool_hip only) route advdiff/project/steps through the HIP drop-in
+ *   lab <field> <s> <e> <tensorial> <file>   ghosted tiles of every block (BlockLab::load)
+ *   loadb <field> <file>   block-order load (multi-level meshes)
  *   amrtol <rt> <ct> | adapt | tagvel <rt> <ct> <file>   mesh-adaptation hooks (refine/compress everything)
  *   rep <n>                repeat every following `op` n times when timing
  * Every `op` prints one line `REF <op> seconds=<t> iters=<k> value=<v>`.
@@ -246,6 +248,37 @@ int main(int argc, char **argv) {
 #else
       fprintf(stderr, "ref_tool: built without CUP3D_WITH_HIP\n"); exit(2);
 #endif
+    } else if (cmd == "lab") {
+      /* `lab <vel|tmpV|pres|lhs|chi> <s> <e> <tensorial> <file>`: the ghosted tile BlockLab::load assembles
+         (main.cpp:3623-3787) for stencil [s,e)^3 of every block, [nb][L][L][L][nc], L = 8 + e - s - 1.
+         Cells the reference does not fill keep whatever the previous block left there. */
+      std::string fname, path; int ss, ee, tens; script >> fname >> ss >> ee >> tens >> path;
+      Field F = field_of(sd, fname);
+      const int L = 8 + ee - ss - 1;
+      std::vector<double> out;
+      auto dump_lab = [&](auto &lab, auto *grid, const std::vector<int> &comps) {
+        StencilInfo st(ss, ss, ss, ee, ee, ee, tens != 0, comps);
+        lab.prepare(*grid, st);
+        for (auto &inf : *F.infos) {
+          lab.load(inf, 0);
+          for (int z = ss; z < 8 + ee - 1; z++)
+            for (int y = ss; y < 8 + ee - 1; y++)
+              for (int x = ss; x < 8 + ee - 1; x++)
+                for (int c = 0; c < F.ncomp; c++) out.push_back(lab(x, y, z).member(c));
+        }
+      };
+      if (F.ncomp == 3) { VectorLab lab; dump_lab(lab, fname == "vel" ? sd.vel : sd.tmpV, {0, 1, 2}); }
+      else { ScalarLab lab; dump_lab(lab, fname == "pres" ? sd.pres : (fname == "lhs" ? sd.lhs : sd.chi), {0}); }
+      (void)L;
+      write_file(path, out.data(), out.size() * 8);
+    } else if (cmd == "loadb") {
+      /* `loadb <field> <file>`: block-order load [nb][8][8][8][nc] (works on multi-level meshes) */
+      std::string fname, path; script >> fname >> path;
+      Field F = field_of(sd, fname);
+      auto buf = read_file(path);
+      const size_t per = 512 * F.ncomp;
+      if (buf.size() != F.infos->size() * per * 8) { fprintf(stderr, "loadb %s: size mismatch\n", fname.c_str()); exit(2); }
+      for (size_t i = 0; i < F.infos->size(); i++) memcpy((*F.infos)[i].block, buf.data() + i * per * 8, per * 8);
     } else if (cmd == "amrtol") {
       /* tolerance_for_refinement / tolerance_for_compression of the five MeshAdaptation objects
          (main.cpp:5037-5038); `amrtol -1 -2` makes every block refine, `amrtol 1e300 1e299` compress */

@@ -81,9 +81,53 @@ static inline int MPI_Iallgather(const void *s, int n, MPI_Datatype t, void *r, 
 static inline int MPI_Bcast(void *, int, MPI_Datatype, int, MPI_Comm) { return 0; } /* used by the HIP drop-in shim only */
 static inline int MPI_Exscan(const void *, void *, int, MPI_Datatype, MPI_Op, MPI_Comm) { return 0; /* rank 0: recvbuf undefined by the standard */ }
 
-/* traffic to MPI_PROC_NULL is a no-op by the standard (LoadBalancer, main.cpp:4822-4835) */
-static inline int MPI_Isend(const void *, int, MPI_Datatype, int peer, int, MPI_Comm, MPI_Request *q) { if (peer != MPI_PROC_NULL) CUP3D_MPI_STUB_DIE("MPI_Isend"); *q = 0; return 0; }
-static inline int MPI_Irecv(void *, int, MPI_Datatype, int peer, int, MPI_Comm, MPI_Request *q) { if (peer != MPI_PROC_NULL) CUP3D_MPI_STUB_DIE("MPI_Irecv"); *q = 0; return 0; }
+/* traffic to MPI_PROC_NULL is a no-op by the standard (LoadBalancer, main.cpp:4822-4835); messages of
+ * rank 0 to itself (FluxCorrectionMPI 2898-2944, UpdateBoundary) are matched by tag through a small queue */
+typedef struct cup3d_stub_msg { int tag; size_t bytes; void *data; void *recvbuf; struct cup3d_stub_msg *next; } cup3d_stub_msg;
+static cup3d_stub_msg *cup3d_stub_sends = 0, *cup3d_stub_recvs = 0;
+static inline int MPI_Isend(const void *buf, int n, MPI_Datatype t, int peer, int tag, MPI_Comm, MPI_Request *q) {
+  *q = 0;
+  if (peer == MPI_PROC_NULL) return 0;
+  if (peer != 0 || t <= 0) CUP3D_MPI_STUB_DIE("MPI_Isend");
+  const size_t bytes = (size_t)n * (size_t)t;
+  for (cup3d_stub_msg **p = &cup3d_stub_recvs; *p; p = &(*p)->next)
+    if ((*p)->tag == tag) { /* a receive is already posted */
+      cup3d_stub_msg *r = *p;
+      if (bytes > r->bytes) CUP3D_MPI_STUB_DIE("MPI_Isend (truncation)");
+      memcpy(r->recvbuf, buf, bytes);
+      *p = r->next;
+      free(r);
+      return 0;
+    }
+  cup3d_stub_msg *m = (cup3d_stub_msg *)malloc(sizeof *m);
+  m->tag = tag; m->bytes = bytes; m->data = malloc(bytes ? bytes : 1); memcpy(m->data, buf, bytes); m->recvbuf = 0; m->next = 0;
+  cup3d_stub_msg **p = &cup3d_stub_sends;
+  while (*p) p = &(*p)->next;
+  *p = m;
+  return 0;
+}
+static inline int MPI_Irecv(void *buf, int n, MPI_Datatype t, int peer, int tag, MPI_Comm, MPI_Request *q) {
+  *q = 0;
+  if (peer == MPI_PROC_NULL) return 0;
+  if (peer != 0 || t <= 0) CUP3D_MPI_STUB_DIE("MPI_Irecv");
+  const size_t bytes = (size_t)n * (size_t)t;
+  for (cup3d_stub_msg **p = &cup3d_stub_sends; *p; p = &(*p)->next)
+    if ((*p)->tag == tag) { /* the matching send was posted first */
+      cup3d_stub_msg *m = *p;
+      if (m->bytes > bytes) CUP3D_MPI_STUB_DIE("MPI_Irecv (truncation)");
+      memcpy(buf, m->data, m->bytes);
+      *p = m->next;
+      free(m->data);
+      free(m);
+      return 0;
+    }
+  cup3d_stub_msg *r = (cup3d_stub_msg *)malloc(sizeof *r);
+  r->tag = tag; r->bytes = bytes; r->data = 0; r->recvbuf = buf; r->next = 0;
+  cup3d_stub_msg **p = &cup3d_stub_recvs;
+  while (*p) p = &(*p)->next;
+  *p = r;
+  return 0;
+}
 static inline int MPI_Probe(int, int, MPI_Comm, MPI_Status *) { CUP3D_MPI_STUB_DIE("MPI_Probe"); return 0; }
 static inline int MPI_Get_count(const MPI_Status *, MPI_Datatype, int *) { CUP3D_MPI_STUB_DIE("MPI_Get_count"); return 0; }
 static inline int MPI_Wait(MPI_Request *, MPI_Status *) { return 0; }

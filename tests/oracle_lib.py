@@ -81,6 +81,18 @@ def lib():
     L.orc_restrict.argtypes = [vp, vp, _dp, _dp, C.c_int]
     L.orc_prolong.argtypes = [vp, vp, _dp, _dp, C.c_int, C.c_int]
     L.orc_tag.argtypes = [vp, _dp, C.c_int, C.c_double, C.c_double, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]
+    L.orc_mesh_create.restype = vp
+    L.orc_mesh_create.argtypes = [C.c_int] * 4 + [C.c_double, _ip, C.c_long, _ip, _lp]
+    L.orc_mesh_destroy.argtypes = [vp]
+    L.orc_mesh_nblocks.restype = C.c_long
+    L.orc_mesh_nblocks.argtypes = [vp]
+    L.orc_mesh_tables.argtypes = [vp, _lp]
+    L.orc_mesh_h.restype = C.c_double
+    L.orc_mesh_h.argtypes = [vp, C.c_long]
+    L.orc_mesh_labs.argtypes = [vp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
+    L.orc_mesh_advdiff_stage_rhs.argtypes = [vp, _dp, _dp, C.c_double, C.c_double, _dp]
+    L.orc_mesh_advect_diffuse.argtypes = [vp, _dp, _dp, C.c_double, C.c_double, _dp]
+    L.orc_mesh_lhs.argtypes = [vp, _dp, _dp, C.c_int]
     _lib = L
     return L
 
@@ -176,6 +188,48 @@ class OracleGrid:
         info = SolveInfo(tol, tol_rel, mean_constraint, 0, 0, 0.0, 0.0)
         lib().orc_project(self.g, vel, pres, tmpV, lhs, chi, dt, step, C.byref(info))
         return info, tmpV, lhs
+
+
+class OracleMesh:
+    """Multi-level leaf-block mesh (levels, Zs in any order; stored in the reference's m_vInfo order)."""
+
+    def __init__(self, bpd, level_max, maxextent, bc, levels, Zs):
+        self.bpd = tuple(int(b) for b in bpd)
+        self.level_max, self.maxextent = int(level_max), float(maxextent)
+        self.bc = tuple(BC[b] if isinstance(b, str) else int(b) for b in bc)
+        lv = np.ascontiguousarray(levels, dtype=np.int32)
+        zs = np.ascontiguousarray(Zs, dtype=np.int64)
+        self.m = lib().orc_mesh_create(*self.bpd, self.level_max, self.maxextent, np.array(self.bc, dtype=np.int32), len(lv), lv, zs)
+        self.nb = lib().orc_mesh_nblocks(self.m)
+        self.tables = np.zeros((self.nb, 6), dtype=np.int64)
+        lib().orc_mesh_tables(self.m, self.tables)
+
+    def __del__(self):
+        try:
+            lib().orc_mesh_destroy(self.m)
+        except Exception:
+            pass
+
+    def labs(self, field, s, e, tensorial=False):
+        nc = 3 if field.ndim == 5 else 1
+        L = 8 + e - s - 1
+        out = np.zeros((self.nb, L, L, L, nc))
+        lib().orc_mesh_labs(self.m, np.ascontiguousarray(field), nc, 1 if nc == 3 else 0, s, e, 1 if tensorial else 0, out)
+        return out
+
+    def h(self, b):
+        return lib().orc_mesh_h(self.m, b)
+
+    def advect_diffuse(self, vel, dt, nu, uinf):
+        vel = np.ascontiguousarray(vel).copy()
+        tmpV = np.zeros_like(vel)
+        lib().orc_mesh_advect_diffuse(self.m, vel, tmpV, dt, nu, np.asarray(uinf, dtype=np.float64))
+        return vel, tmpV
+
+    def lhs(self, pres, mean_constraint=1):
+        out = np.zeros_like(pres)
+        lib().orc_mesh_lhs(self.m, np.ascontiguousarray(pres), out, mean_constraint)
+        return out
 
 
 def restrict_field(fine, coarse, field):
