@@ -489,46 +489,46 @@ static double precond_inner(double p[BS + 2][BS + 2][BS + 2], double Ax[BS][BS][
 }
 
 long orc_precond_total_iters = 0; /* diagnostic: block-CG iterations summed over blocks by the last orc_precond call */
+/* one block of getZImplParallel (main.cpp:14704-14745): blk <- approximate solve of the 8^3 Dirichlet problem; returns CG iterations */
+long orc_precond_block(double *pblk, double h) {
+  long total = 0;
+  double p[BS + 2][BS + 2][BS + 2], Ax[BS][BS][BS], r[BS][BS][BS];
+  memset(p, 0, sizeof p);
+  double(*blk)[BS][BS] = (double(*)[BS][BS])pblk;
+  const double invh = 1 / h;
+  double rrPartial[BS] = {0};
+  for (int iz = 0; iz < BS; iz++)
+    for (int iy = 0; iy < BS; iy++)
+      for (int ix = 0; ix < BS; ix++) {
+        r[iz][iy][ix] = invh * blk[iz][iy][ix];
+        rrPartial[ix] += r[iz][iy][ix] * r[iz][iy][ix];
+        p[iz + 1][iy + 1][ix + 1] = r[iz][iy][ix];
+        blk[iz][iy][ix] = 0;
+      }
+  double rr = 0;
+  for (int ix = 0; ix < BS; ix++) rr += rrPartial[ix];
+  const double sqrNorm0 = (double)1 / (BS3 * BS3) * rr;
+  if (sqrNorm0 < 1e-32) return 0;
+  for (int k = 0; k < 100; k++) {
+    rr = precond_inner(p, Ax, r, blk, sqrNorm0, rr);
+    total++;
+    if (rr <= 0) break;
+  }
+  return total;
+}
 void orc_precond(const orc_grid *g, double *pres) { /* getZImplParallel, main.cpp:14704-14745 */
   long total = 0;
-  static const double kRel = 1e-7 * 1e-7, kAbs = 1e-16 * 1e-16;
-  (void)kRel; (void)kAbs;
 #pragma omp parallel for reduction(+ : total)
-  for (long b = 0; b < g->nblocks; b++) {
-    double p[BS + 2][BS + 2][BS + 2], Ax[BS][BS][BS], r[BS][BS][BS];
-    memset(p, 0, sizeof p);
-    double(*blk)[BS][BS] = (double(*)[BS][BS])(pres + b * BS3);
-    const double invh = 1 / g->h;
-    double rrPartial[BS] = {0};
-    for (int iz = 0; iz < BS; iz++)
-      for (int iy = 0; iy < BS; iy++)
-        for (int ix = 0; ix < BS; ix++) {
-          r[iz][iy][ix] = invh * blk[iz][iy][ix];
-          rrPartial[ix] += r[iz][iy][ix] * r[iz][iy][ix];
-          p[iz + 1][iy + 1][ix + 1] = r[iz][iy][ix];
-          blk[iz][iy][ix] = 0;
-        }
-    double rr = 0;
-    for (int ix = 0; ix < BS; ix++) rr += rrPartial[ix];
-    const double sqrNorm0 = (double)1 / (BS3 * BS3) * rr;
-    if (sqrNorm0 < 1e-32) continue;
-    for (int k = 0; k < 100; k++) {
-      rr = precond_inner(p, Ax, r, blk, sqrNorm0, rr);
-      total++;
-      if (rr <= 0) break;
-    }
-  }
+  for (long b = 0; b < g->nblocks; b++) total += orc_precond_block(pres + b * BS3, g->h);
   orc_precond_total_iters = total;
 }
 
-static void solver_lhs(const orc_grid *g, const double *in, double *out, int mc) { orc_lhs(g, in, out, mc); } /* _lhs 9365-9393 */
-static void solver_precond(const orc_grid *g, const double *in, double *out, long N) {                          /* _preconditioner 9334-9364 */
-  memcpy(out, in, N * sizeof(double));
-  orc_precond(g, out);
-}
-
-void orc_solve(const orc_grid *g, double *lhs, double *pres, orc_solve_info *info) { /* PoissonSolverAMR::solve, main.cpp:14363-14616 */
-  const long N = g->nblocks * BS3;
+/* PoissonSolverAMR::solve, main.cpp:14363-14616, over any mesh: `op_lhs` is _lhs (9365-9393), `op_precond` is
+ * _preconditioner (9334-9364, in place), `corner` the first cell of the block whose index is (0,0,0) */
+void orc_solve_generic(void *g, long N, long corner, void (*op_lhs)(void *, const double *, double *, int),
+                       void (*op_precond)(void *, double *), double *lhs, double *pres, orc_solve_info *info) {
+#define solver_lhs(g, in, out, mc) op_lhs(g, in, out, mc)
+#define solver_precond(g, in, out, N) (memcpy(out, in, (N) * sizeof(double)), op_precond(g, out))
   const int mc = info->mean_constraint;
   const double eps = 1e-100, max_error = info->tol, max_rel_error = info->tol_rel;
   const int max_restarts = 100;
@@ -538,7 +538,7 @@ void orc_solve(const orc_grid *g, double *lhs, double *pres, orc_solve_info *inf
   double *phat = buf, *rhat = buf + N, *shat = buf + 2 * N, *what = buf + 3 * N, *zhat = buf + 4 * N, *qhat = buf + 5 * N,
          *s = buf + 6 * N, *w = buf + 7 * N, *z = buf + 8 * N, *t = buf + 9 * N, *v = buf + 10 * N, *q = buf + 11 * N,
          *r = buf + 12 * N, *y = buf + 13 * N, *x = buf + 14 * N, *r0 = buf + 15 * N, *b = buf + 16 * N, *x_opt = buf + 17 * N;
-  if (mc == 1 || mc > 2) lhs[corner_block(g) * BS3] = 0.0; /* 14404-14407 */
+  if (mc == 1 || mc > 2) lhs[corner] = 0.0; /* 14404-14407 */
   for (long j = 0; j < N; j++) { b[j] = lhs[j]; r[j] = lhs[j]; x[j] = pres[j]; }
   solver_lhs(g, x, r0, mc);
   for (long i = 0; i < N; i++) { r0[i] = r[i] - r0[i]; r[i] = r0[i]; }
@@ -658,6 +658,13 @@ void orc_solve(const orc_grid *g, double *lhs, double *pres, orc_solve_info *inf
   info->norm0 = init_norm;
   info->norm = norm;
   free(buf);
+#undef solver_lhs
+#undef solver_precond
+}
+static void uni_lhs(void *g, const double *in, double *out, int mc) { orc_lhs((const orc_grid *)g, in, out, mc); }
+static void uni_precond(void *g, double *io) { orc_precond((const orc_grid *)g, io); }
+void orc_solve(const orc_grid *g, double *lhs, double *pres, orc_solve_info *info) {
+  orc_solve_generic((void *)g, g->nblocks * BS3, corner_block(g) * BS3, uni_lhs, uni_precond, lhs, pres, info);
 }
 
 void orc_pressure_rhs(const orc_grid *g, const double *vel, const double *udef, const double *chi, double *lhs, double dt) {

@@ -65,6 +65,9 @@ void orc_precond(const orc_grid *, double *pres);
 /* PoissonSolverAMR::solve, main.cpp:14363-14616: rhs in lhs (clobbered), x0/result in pres */
 typedef struct { double tol, tol_rel; int mean_constraint; int iters; int restarts; double norm0, norm; } orc_solve_info;
 void orc_solve(const orc_grid *, double *lhs, double *pres, orc_solve_info *);
+long orc_precond_block(double *blk, double h); /* one 8^3 block of getZImplParallel; returns its CG iterations */
+void orc_solve_generic(void *mesh, long N, long corner, void (*op_lhs)(void *, const double *, double *, int),
+                       void (*op_precond)(void *, double *), double *lhs, double *pres, orc_solve_info *);
 void orc_pressure_rhs(const orc_grid *, const double *vel, const double *udef, const double *chi, double *lhs, double dt); /* 14849-14875 */
 void orc_div_pressure(const orc_grid *, const double *pres, double *tmpV);   /* 14769-14778 */
 void orc_grad_p(const orc_grid *, const double *pres, double *tmpV, double dt); /* 14990-14999 */
@@ -95,6 +98,14 @@ void orc_mesh_labs(const orc_mesh *, const double *field, int nc, int is_vector,
 void orc_mesh_advdiff_stage_rhs(const orc_mesh *, const double *vel, double *tmpV, double dt, double nu, const double uinf[3]);
 void orc_mesh_advect_diffuse(const orc_mesh *, double *vel, double *tmpV, double dt, double nu, const double uinf[3]);
 void orc_mesh_lhs(const orc_mesh *, const double *pres, double *lhs, int mean_constraint);
+void orc_mesh_precond(const orc_mesh *, double *pres);
+void orc_mesh_solve(const orc_mesh *, double *lhs, double *pres, orc_solve_info *);
+void orc_mesh_pressure_rhs(const orc_mesh *, const double *vel, const double *udef, const double *chi, double *lhs, double dt);
+void orc_mesh_div_pressure(const orc_mesh *, const double *pres, double *tmpV);
+void orc_mesh_grad_p(const orc_mesh *, const double *pres, double *tmpV, double dt);
+void orc_mesh_project(const orc_mesh *, double *vel, double *pres, double *tmpV, double *lhs, const double *chi, double dt, int step,
+                      orc_solve_info *);
+double orc_mesh_max_u(const orc_mesh *, const double *vel, const double uinf[3]);
 #ifdef __cplusplus
 }
 #endif

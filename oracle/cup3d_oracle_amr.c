@@ -667,3 +667,168 @@ void orc_mesh_lhs(const orc_mesh *m, const double *pres, double *lhs, int mc) { 
     lhs[corner * BS3] = pres[corner * BS3];
   (void)corner_block_mesh;
 }
+
+void orc_mesh_precond(const orc_mesh *m, double *pres) { /* getZImplParallel, main.cpp:14704-14745: invh of each block */
+#pragma omp parallel for
+  for (long b = 0; b < m->nblocks; b++) orc_precond_block(pres + b * BS3, orc_mesh_h(m, b));
+}
+
+static void mesh_lhs_cb(void *m, const double *in, double *out, int mc) { orc_mesh_lhs((const orc_mesh *)m, in, out, mc); }
+static void mesh_precond_cb(void *m, double *io) { orc_mesh_precond((const orc_mesh *)m, io); }
+void orc_mesh_solve(const orc_mesh *m, double *lhs, double *pres, orc_solve_info *info) {
+  long corner = -1;
+  for (long b = 0; b < m->nblocks; b++)
+    if (m->index[3 * b] == 0 && m->index[3 * b + 1] == 0 && m->index[3 * b + 2] == 0) corner = b;
+  orc_solve_generic((void *)m, m->nblocks * BS3, corner * BS3, mesh_lhs_cb, mesh_precond_cb, lhs, pres, info);
+}
+
+/* generic face loop helper: (p) inside face cell, (q) ghost cell behind face f at face index (i2,i1) */
+#define FACE_CELLS(f, i2, i1, p, q)                                        \
+  const int d_ = (f) >> 1, side_ = (f) & 1, df_ = d_ == 0 ? 1 : 0, ds_ = d_ == 2 ? 1 : 2; \
+  int p[3], q[3];                                                          \
+  p[df_] = q[df_] = (i2); p[ds_] = q[ds_] = (i1);                          \
+  p[d_] = side_ ? BS - 1 : 0; q[d_] = side_ ? BS : -1;
+
+/* KernelPressureRHS incl. faces, main.cpp:14849-14950; flux-corrected into lhs */
+void orc_mesh_pressure_rhs(const orc_mesh *m, const double *vel, const double *udef, const double *chi, double *lhs, double dt) {
+  faces_t F;
+  faces_init(m, &F, 1);
+  tile_t t, t2;
+  tile_init(&t, 3, 1, -1, 2, 0);
+  tile_init(&t2, 3, 1, -1, 2, 0);
+#define U(x, y, z, c) FT(&t, x, y, z, c)
+#define D(x, y, z, c) FT(&t2, x, y, z, c)
+  for (long b = 0; b < m->nblocks; b++) {
+    orc_mesh_lab(m, vel, b, &t);
+    orc_mesh_lab(m, udef, b, &t2);
+    const double h = orc_mesh_h(m, b), fac = 0.5 * h * h / dt;
+    for (int z = 0; z < BS; z++)
+      for (int y = 0; y < BS; y++)
+        for (int x = 0; x < BS; x++) {
+          const long i = b * BS3 + (z * BS + y) * BS + x;
+          double p = fac * (U(x + 1, y, z, 0) - U(x - 1, y, z, 0) + U(x, y + 1, z, 1) - U(x, y - 1, z, 1) + U(x, y, z + 1, 2) - U(x, y, z - 1, 2));
+          const double divUs = D(x + 1, y, z, 0) - D(x - 1, y, z, 0) + D(x, y + 1, z, 1) - D(x, y - 1, z, 1) + D(x, y, z + 1, 2) - D(x, y, z - 1, 2);
+          p += -chi[i] * fac * divUs;
+          lhs[i] = p;
+        }
+    for (int f = 0; f < 6; f++) {
+      if (!F.stored[b * 6 + f]) continue;
+      for (int i1 = 0; i1 < 8; i1++)
+        for (int i2 = 0; i2 < 8; i2++) {
+          FACE_CELLS(f, i2, i1, p, q)
+          const double c = chi[b * BS3 + (p[2] * BS + p[1]) * BS + p[0]];
+          const int comp = d_;
+          double v;
+          if (!side_) v = fac * (U(q[0], q[1], q[2], comp) + U(p[0], p[1], p[2], comp)) - c * fac * (D(q[0], q[1], q[2], comp) + D(p[0], p[1], p[2], comp));
+          else v = -fac * (U(q[0], q[1], q[2], comp) + U(p[0], p[1], p[2], comp)) + c * fac * (D(q[0], q[1], q[2], comp) + D(p[0], p[1], p[2], comp));
+          FACE(&F, b, f, i2 + i1 * 8, 0) = v;
+        }
+    }
+  }
+#undef U
+#undef D
+  tile_free(&t); tile_free(&t2);
+  fix_fluxes(m, &F, lhs, 1);
+  faces_free(&F);
+}
+
+/* KernelDivPressure incl. faces, main.cpp:14769-14834: writes tmpV.u[0]; correction on tmpV */
+void orc_mesh_div_pressure(const orc_mesh *m, const double *pres, double *tmpV) {
+  faces_t F;
+  faces_init(m, &F, 3);
+  tile_t t;
+  tile_init(&t, 1, 0, -1, 2, 0);
+#define P(x, y, z) FT(&t, x, y, z, 0)
+  for (long b = 0; b < m->nblocks; b++) {
+    orc_mesh_lab(m, pres, b, &t);
+    const double fac = orc_mesh_h(m, b);
+    for (int z = 0; z < BS; z++)
+      for (int y = 0; y < BS; y++)
+        for (int x = 0; x < BS; x++)
+          tmpV[(b * BS3 + (z * BS + y) * BS + x) * 3] =
+              fac * (P(x + 1, y, z) + P(x - 1, y, z) + P(x, y + 1, z) + P(x, y - 1, z) + P(x, y, z + 1) + P(x, y, z - 1) - 6.0 * P(x, y, z));
+    for (int f = 0; f < 6; f++) {
+      if (!F.stored[b * 6 + f]) continue;
+      for (int i1 = 0; i1 < 8; i1++)
+        for (int i2 = 0; i2 < 8; i2++) {
+          FACE_CELLS(f, i2, i1, p, q)
+          FACE(&F, b, f, i2 + i1 * 8, 0) = !side_ ? fac * (P(p[0], p[1], p[2]) - P(q[0], q[1], q[2])) : -fac * (P(q[0], q[1], q[2]) - P(p[0], p[1], p[2]));
+        }
+    }
+  }
+#undef P
+  tile_free(&t);
+  fix_fluxes(m, &F, tmpV, 3);
+  faces_free(&F);
+}
+
+/* KernelGradP incl. faces, main.cpp:14990-15055 */
+void orc_mesh_grad_p(const orc_mesh *m, const double *pres, double *tmpV, double dt) {
+  faces_t F;
+  faces_init(m, &F, 3);
+  tile_t t;
+  tile_init(&t, 1, 0, -1, 2, 0);
+#define P(x, y, z) FT(&t, x, y, z, 0)
+  for (long b = 0; b < m->nblocks; b++) {
+    orc_mesh_lab(m, pres, b, &t);
+    const double h = orc_mesh_h(m, b), fac = -0.5 * dt * h * h;
+    for (int z = 0; z < BS; z++)
+      for (int y = 0; y < BS; y++)
+        for (int x = 0; x < BS; x++) {
+          double *o = tmpV + (b * BS3 + (z * BS + y) * BS + x) * 3;
+          o[0] = fac * (P(x + 1, y, z) - P(x - 1, y, z));
+          o[1] = fac * (P(x, y + 1, z) - P(x, y - 1, z));
+          o[2] = fac * (P(x, y, z + 1) - P(x, y, z - 1));
+        }
+    for (int f = 0; f < 6; f++) {
+      if (!F.stored[b * 6 + f]) continue;
+      for (int i1 = 0; i1 < 8; i1++)
+        for (int i2 = 0; i2 < 8; i2++) {
+          FACE_CELLS(f, i2, i1, p, q)
+          FACE(&F, b, f, i2 + i1 * 8, d_) = !side_ ? fac * (P(q[0], q[1], q[2]) + P(p[0], p[1], p[2])) : -fac * (P(q[0], q[1], q[2]) + P(p[0], p[1], p[2]));
+        }
+    }
+  }
+#undef P
+  tile_free(&t);
+  fix_fluxes(m, &F, tmpV, 3);
+  faces_free(&F);
+}
+
+/* PressureProjection::operator(), main.cpp:15061-15160, on a multi-level mesh (no obstacles: udef = 0) */
+void orc_mesh_project(const orc_mesh *m, double *vel, double *pres, double *tmpV, double *lhs, const double *chi, double dt, int step,
+                      orc_solve_info *info) {
+  const long N = m->nblocks * BS3;
+  double *pOld = (double *)malloc(N * sizeof(double));
+  memcpy(pOld, pres, N * sizeof(double));
+  memset(tmpV, 0, 3 * N * sizeof(double));
+  orc_mesh_pressure_rhs(m, vel, tmpV, chi, lhs, dt);
+  if (step > 2) {
+    orc_mesh_div_pressure(m, pres, tmpV);
+    for (long i = 0; i < N; i++) { lhs[i] -= tmpV[3 * i]; pres[i] = 0; }
+  } else
+    memset(pres, 0, N * sizeof(double));
+  orc_mesh_solve(m, lhs, pres, info);
+  double avg = 0, avg1 = 0;
+  for (long b = 0; b < m->nblocks; b++) {
+    const double h = orc_mesh_h(m, b), vv = h * h * h;
+    for (long i = b * BS3; i < (b + 1) * BS3; i++) { avg += pres[i] * vv; avg1 += vv; }
+  }
+  avg = avg / avg1;
+  for (long i = 0; i < N; i++) pres[i] -= avg;
+  if (step > 2)
+    for (long i = 0; i < N; i++) pres[i] += pOld[i];
+  orc_mesh_grad_p(m, pres, tmpV, dt);
+  for (long b = 0; b < m->nblocks; b++) {
+    const double h = orc_mesh_h(m, b), fac = 1.0 / (h * h * h);
+    for (long i = b * BS3 * 3; i < (b + 1) * BS3 * 3; i++) vel[i] += fac * tmpV[i];
+  }
+  free(pOld);
+}
+
+double orc_mesh_max_u(const orc_mesh *m, const double *vel, const double uinf[3]) { /* findMaxU, main.cpp:8603-8623 */
+  double mx = 0;
+  for (long i = 0; i < m->nblocks * BS3; i++)
+    for (int c = 0; c < 3; c++) { const double a = fabs(vel[3 * i + c] + uinf[c]); if (a > mx) mx = a; }
+  return mx;
+}

@@ -127,6 +127,70 @@ def adapt_cases():
         print(name, "blocks", len(t2), "->", len(t1), "->", len(t2), "tags", out["tags"])
 
 
+def vortex_field(bpd):
+    """Localised Gaussian vortex on the level-0 cells: makes TagLoadedBlock refine a compact region."""
+    N = [b * 8 for b in bpd]
+    x = [(np.arange(n) + 0.5) * EXT / max(N) for n in N]
+    Z, Y, X = np.meshgrid(x[2], x[1], x[0], indexing="ij")
+    g = np.exp(-((X - 2.0) ** 2 + (Y - 2.0) ** 2 + (Z - 2.3) ** 2) / 0.5)
+    return np.stack([-(Y - 2.0) * g, (X - 2.0) * g, 0.3 * g], axis=-1) * 3
+
+
+def amr_mesh_script(wd, bpd, passes, rtol=2.0):
+    vortex_field(bpd).tofile(os.path.join(wd, "vel_in.bin"))
+    # chi is adapted without data transfer (new blocks hold uninitialised memory): clear it again afterwards
+    return ["zero chi", "loadg vel vel_in.bin", f"amrtol {rtol} 0.01"] + ["adapt"] * passes + ["zero chi"]
+
+
+AMR_CASES = [
+    # name, bpd, levelMax, bc, adapt passes, seed, full
+    ("amr_periodic_l01", (2, 2, 2), 3, ("periodic", "periodic", "periodic"), 1, 41, True),
+    ("amr_mixed_l12", (2, 2, 2), 3, ("freespace", "wall", "periodic"), 2, 42, False),
+]
+
+
+def amr_case(name, bpd, lmax, bc, passes, seed, full):
+    """Operators on a multi-level mesh produced by the reference's own adaptMesh; block-ordered random fields
+    are loaded into the adapted mesh (`loadb`)."""
+    wd = O.tempfile.mkdtemp(prefix="golden_")
+    pre = amr_mesh_script(wd, bpd, passes)
+    args = O.ref_args(bpd, lmax, 0, EXT, bc)
+    recs, wd = O.run_ref(pre + ["tables t1.bin"], args, threads=1, workdir=wd)
+    t1, _ = O.read_tables(os.path.join(wd, "t1.bin"))
+    nb = len(t1)
+    rng = np.random.default_rng(seed)
+    vel, pres, rhs = rng.uniform(-1, 1, (nb, 8, 8, 8, 3)), rng.uniform(-1, 1, (nb, 8, 8, 8)), rng.uniform(-1, 1, (nb, 8, 8, 8))
+    udef = rng.uniform(-1, 1, (nb, 8, 8, 8, 3))
+    chi = (rng.uniform(0, 1, (nb, 8, 8, 8)) > 0.7) * rng.uniform(0, 1, (nb, 8, 8, 8))
+    for n, a in (("velb", vel), ("presb", pres), ("rhsb", rhs), ("udefb", udef), ("chib", chi)):
+        a.tofile(os.path.join(wd, n + ".bin"))
+    dt, nu, uinf, step = 0.01, 0.02, (0.1, -0.2, 0.3), 5
+    script = pre + [
+        "loadb vel velb.bin", "loadb pres presb.bin", f"set nu {nu}", f"set uinfx {uinf[0]}", f"set uinfy {uinf[1]}", f"set uinfz {uinf[2]}",
+        "lab vel -3 4 0 lab_vel34.bin", "lab pres -1 2 0 lab_p12.bin", "lab vel -1 2 1 lab_v12t.bin",
+        f"op advdiff {dt}", "dump vel ad_vel.bin", "loadb pres presb.bin", "op lhs", "dump lhs lhs.bin",
+        "loadb pres presb.bin", "op precond", "dump pres precond.bin",
+        "loadb lhs rhsb.bin", "loadb pres presb.bin", "op solve", "dump pres solve.bin",
+        f"set dt {dt}", "loadb vel velb.bin", "loadb tmpV udefb.bin", "loadb chi chib.bin", "op rhs", "dump lhs rhs.bin",
+        "zero chi", "loadb pres presb.bin", "op divp", "dump tmpV divp.bin", "op gradp", "dump tmpV gradp.bin",
+        "loadb vel velb.bin", "loadb pres presb.bin", f"set step {step}", f"op project {dt}", "dump vel pr_vel.bin", "dump pres pr_pres.bin",
+    ]
+    recs, wd = O.run_ref(script, args, threads=1, workdir=wd)
+    rb = lambda f, nc: O.read_blocks(os.path.join(wd, f), nb, nc)  # noqa: E731
+    out = dict(bpd=np.array(bpd), level_max=lmax, bc=np.array([O.BC[b] for b in bc]), extent=EXT, tables=t1, dt=dt, nu=nu,
+               uinf=np.array(uinf), step=step, vel_in=vel, pres_in=pres, rhs_in=rhs, udef_in=udef, chi_in=chi,
+               ad_vel=rb("ad_vel.bin", 3), lhs=rb("lhs.bin", 1), rhs=rb("rhs.bin", 1), pr_vel=rb("pr_vel.bin", 3), pr_pres=rb("pr_pres.bin", 1),
+               solve_iters=[int(r["iters"]) for r in recs if r["op"] == "solve"][0],
+               pr_iters=[int(r["iters"]) for r in recs if r["op"] == "project"][0])
+    if full:
+        out.update(lab_vel34=np.fromfile(os.path.join(wd, "lab_vel34.bin")).reshape(nb, 14, 14, 14, 3),
+                   lab_p12=np.fromfile(os.path.join(wd, "lab_p12.bin")).reshape(nb, 10, 10, 10, 1),
+                   lab_v12t=np.fromfile(os.path.join(wd, "lab_v12t.bin")).reshape(nb, 10, 10, 10, 3),
+                   precond=rb("precond.bin", 1), solve=rb("solve.bin", 1), divp=rb("divp.bin", 3)[..., 0].copy(), gradp=rb("gradp.bin", 3))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "blocks", nb, "levels", sorted(set(t1[:, 0].tolist())), "solve iters", out["solve_iters"], "project iters", out["pr_iters"])
+
+
 def sfc_cases():
     out = {}
     for bpd, lmax in SFC_CASES:
@@ -142,6 +206,8 @@ if __name__ == "__main__":
         sys.exit("oracle/_ref/ref_tool missing: run `make -C oracle ref` where /root/reference exists")
     sfc_cases()
     adapt_cases()
+    for c in AMR_CASES:
+        amr_case(*c)
     for c in FIELD_CASES:
         field_case(*c)
     traj_case()

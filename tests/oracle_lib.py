@@ -93,6 +93,14 @@ def lib():
     L.orc_mesh_advdiff_stage_rhs.argtypes = [vp, _dp, _dp, C.c_double, C.c_double, _dp]
     L.orc_mesh_advect_diffuse.argtypes = [vp, _dp, _dp, C.c_double, C.c_double, _dp]
     L.orc_mesh_lhs.argtypes = [vp, _dp, _dp, C.c_int]
+    L.orc_mesh_precond.argtypes = [vp, _dp]
+    L.orc_mesh_solve.argtypes = [vp, _dp, _dp, C.POINTER(SolveInfo)]
+    L.orc_mesh_pressure_rhs.argtypes = [vp, _dp, _dp, _dp, _dp, C.c_double]
+    L.orc_mesh_div_pressure.argtypes = [vp, _dp, _dp]
+    L.orc_mesh_grad_p.argtypes = [vp, _dp, _dp, C.c_double]
+    L.orc_mesh_project.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.POINTER(SolveInfo)]
+    L.orc_mesh_max_u.restype = C.c_double
+    L.orc_mesh_max_u.argtypes = [vp, _dp, _dp]
     _lib = L
     return L
 
@@ -230,6 +238,40 @@ class OracleMesh:
         out = np.zeros_like(pres)
         lib().orc_mesh_lhs(self.m, np.ascontiguousarray(pres), out, mean_constraint)
         return out
+
+    def precond(self, pres):
+        lib().orc_mesh_precond(self.m, pres)
+
+    def solve(self, lhs, pres, tol=1e-6, tol_rel=1e-4, mean_constraint=1):
+        info = SolveInfo(tol, tol_rel, mean_constraint, 0, 0, 0.0, 0.0)
+        lib().orc_mesh_solve(self.m, lhs, pres, C.byref(info))
+        return info
+
+    def pressure_rhs(self, vel, udef, chi, dt):
+        out = np.zeros(vel.shape[:4])
+        lib().orc_mesh_pressure_rhs(self.m, vel, udef, chi, out, dt)
+        return out
+
+    def div_pressure(self, pres):
+        out = np.zeros(pres.shape + (3,))
+        lib().orc_mesh_div_pressure(self.m, pres, out)
+        return out
+
+    def grad_p(self, pres, dt):
+        out = np.zeros(pres.shape + (3,))
+        lib().orc_mesh_grad_p(self.m, pres, out, dt)
+        return out
+
+    def project(self, vel, pres, dt, step, tol=1e-6, tol_rel=1e-4, mean_constraint=1, chi=None):
+        tmpV = np.zeros_like(vel)
+        lhs = np.zeros_like(pres)
+        chi = np.zeros_like(pres) if chi is None else chi
+        info = SolveInfo(tol, tol_rel, mean_constraint, 0, 0, 0.0, 0.0)
+        lib().orc_mesh_project(self.m, vel, pres, tmpV, lhs, chi, dt, step, C.byref(info))
+        return info, tmpV, lhs
+
+    def max_u(self, vel, uinf=(0, 0, 0)):
+        return lib().orc_mesh_max_u(self.m, vel, np.asarray(uinf, dtype=np.float64))
 
 
 def restrict_field(fine, coarse, field):
