@@ -51,6 +51,9 @@ SIGNATURES = {
     "cup3d_sfc_encode": (C.c_longlong, [_vp, C.c_int, _ip]),
     "cup3d_sfc_info": (None, [_vp, C.c_int, _ip, _lp, _lp, _lp]),
     "cup3d_grid_create_uniform": (C.c_int, [_ip, C.c_int, C.c_int, C.c_double, _ip, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "cup3d_grid_create_mesh": (C.c_int, [_ip, C.c_int, C.c_double, _ip, C.c_long, _ip, _lp, C.POINTER(_vp)]),
+    "cup3d_grid_ninterface_faces": (C.c_long, [_vp]),
+    "cup3d_grid_interface": (C.c_int, [_vp, _vp, _vp, _vp]),
     "cup3d_grid_destroy": (None, [_vp]),
     "cup3d_grid_nblocks": (C.c_long, [_vp]),
     "cup3d_grid_nblocks_global": (C.c_long, [_vp]),
@@ -101,6 +104,7 @@ DEBUG_SIGNATURES = {
     "cup3d_debug_halo_pull": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int]),
     "cup3d_debug_advdiff_stage": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, _dp]),
     "cup3d_debug_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "cup3d_debug_amr_slabs": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
 }
 
 _lib = None

@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(256) k_tag(const double *__restrict__ f, int n
 
 static int child_table(const Sim *coarse, const Sim *fine, std::vector<int32_t> &tab) {
   const Grid *gc = coarse->grid, *gf = fine->grid;
+  if (gc->multilevel || gf->multilevel) { set_error("restrict/prolong/tag operate on uniform levels (whole-mesh transitions)"); return CUP3D_EINVAL; }
   bool same = gc->level + 1 == gf->level && gc->level_max == gf->level_max;
   for (int d = 0; d < 3; ++d) same = same && gc->bpd[d] == gf->bpd[d] && gc->bc[d] == gf->bc[d];
   if (!same) { set_error("restrict/prolong need two sims of the same box at levels l and l+1"); return CUP3D_EINVAL; }
@@ -214,6 +215,7 @@ int cup3d_tag_blocks(cup3d_sim_t *h, int field, double rtol, double ctol, signed
   int nc;
   const double *f = s->field(field, &nc);
   if (!f) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+  if (s->grid->multilevel) { set_error("restrict/prolong/tag operate on uniform levels (whole-mesh transitions)"); return CUP3D_EINVAL; }
   signed char *d_states;
   CUP3D_HIP(hipMalloc((void **)&d_states, (size_t)s->nb));
   {

@@ -93,7 +93,10 @@ __device__ __forceinline__ void face_element(int f, int e, int &nb_cell, int &ow
 // CPT = cells per thread (2 -> 256 threads, 1 -> 512 threads).  VAR: 0 production,
 // 1 IEEE division instead of div60 (A/B), 2/3 timing ablations with WRONG results
 // (2: no stencil arithmetic, 3: no ghost staging) -- cup3d_debug_set_option only.
-template <bool FIRST_STAGE, int CPT, int VAR>
+// AMR (multi-level meshes): spacing per block, face fluxes facD*(u_in - u_ghost) of the interface faces into g.flux
+// (main.cpp:9550-9637), and the stage is NOT fused with the Runge-Kutta update: tmpV receives the raw increment, which
+// k_flux_fix corrects before k_rk_update applies it (a.alpha is then the bare Williamson coefficient).
+template <bool FIRST_STAGE, int CPT, int VAR, bool AMR = false>
 __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
   constexpr int NT = 512 / CPT, NW = NT / 64;
   __shared__ double tile[3 * kCompStride];  // 46,848 B -> 3 workgroups per CU
@@ -205,9 +208,23 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
   __syncthreads();
 
   // ---- compute
-  const double h = g.h, h3 = h * h * h;
+  const double h = AMR ? g.hb[slot] : g.h, h3 = h * h * h;
   const double facA = -a.dt / h * h3 * 1.0;                 // main.cpp:9487 (coef = 1)
   const double facD = (a.nu / h) * (a.dt / h) * h3 * 1.0;   // main.cpp:9488
+  if (AMR && t < 192) {
+    const int c = t >> 6, a1 = lane & 7, a2 = lane >> 3;
+    const double *L = tile + c * kCompStride;
+    for (int f = 0; f < 6; ++f) {
+      const int n = g.nbr[slot * 6 + f];
+      if (n < kNbrHalo) continue;
+      const int d = f >> 1, side = f & 1;
+      int in, gh;
+      if (d == 0) { in = a2 * 196 + (a1 + 3) * kXYPitch + (side ? 10 : 3); gh = in + (side ? 1 : -1); }
+      else if (d == 1) { in = a2 * 196 + (side ? 10 : 3) * kXYPitch + a1 + 3; gh = in + (side ? kXYPitch : -kXYPitch); }
+      else { in = (side ? 7 : 0) * 196 + (a2 + 3) * kXYPitch + a1 + 3; gh = kXYSize + (side * 3) * 64 + lane; }
+      g.flux[((size_t)(n - kNbrHalo) * 3 + c) * 64 + lane] = facD * (L[in] - L[gh]);
+    }
+  }
   double *__restrict__ vout = a.vel_out + (size_t)slot * 1536;
   double *__restrict__ tout = a.tmp + (size_t)slot * 1536;
 #pragma unroll
@@ -256,6 +273,7 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double tn = (FIRST_STAGE ? 0.0 : told[k][c]) + res[c];  // o += ..., main.cpp:9546-9548
+      if (AMR) { tout[c * 512 + k * NT + t] = tn; continue; }
       vout[c * 512 + k * NT + t] = uc[k][c] + tn * a.alpha;          // V += tmpV*ih3, 9718-9720
       tout[c * 512 + k * NT + t] = tn * a.beta;                      // tmpV *= beta, 9721-9723
     }
@@ -279,6 +297,16 @@ __global__ void __launch_bounds__(64) k_pack_faces(const double *__restrict__ fi
       else cell = a2 * 64 + a1 * 8 + q;               // (y,z)
       out[(((size_t)s * nc + c) * w + gl) * 64 + lane] = field[((size_t)slot * nc + c) * 512 + cell];
     }
+}
+
+// multi-level meshes: V += tmpV*alpha/h^3 ; tmpV *= beta (main.cpp:9709-9725) after the flux correction of tmpV
+__global__ void __launch_bounds__(256) k_rk_update(const double *__restrict__ hb, const double *__restrict__ vel, double *__restrict__ tmp,
+                                                   double *__restrict__ vel_out, double alpha, double beta, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const double h = hb[i / 1536], ih3 = alpha / (h * h * h), tn = tmp[i];
+    vel_out[i] = vel[i] + tn * ih3;
+    tmp[i] = tn * beta;
+  }
 }
 
 int launch_pack(Sim *src, const double *field, int nc, int w, hipStream_t st) {
@@ -306,6 +334,22 @@ static int advdiff_stage(Sim *s, int rk, double dt, double nu, const double uinf
     a.dt = dt; a.nu = nu; a.u0 = uinf[0]; a.u1 = uinf[1]; a.u2 = uinf[2];
     a.alpha = alpha[rk] / (h * h * h);  // ih3, main.cpp:9711-9712
     a.beta = beta[rk];
+    if (s->grid->multilevel) {
+      GridDev g = s->gdev();
+      const dim3 G(launch_groups(g));
+      {
+        ProfileScope ps("advdiff_stage");
+        if (rk == 0) hipLaunchKernelGGL((k_advdiff<true, 2, 0, true>), G, dim3(256), 0, stream(), g, a);
+        else hipLaunchKernelGGL((k_advdiff<false, 2, 0, true>), G, dim3(256), 0, stream(), g, a);
+      }
+      CUP3D_HIP(hipGetLastError());
+      if ((rc = amr_flux_fix(s, 3, s->tmpV, 3))) return rc;  // compute(..., vel, tmpV) corrector, main.cpp:9708
+      ProfileScope ps("advdiff_update");
+      hipLaunchKernelGGL(k_rk_update, dim3(2048), dim3(256), 0, stream(), s->d_hb, s->vel, s->tmpV, s->vel2, alpha[rk], beta[rk], s->nb * 1536L);
+      CUP3D_HIP(hipGetLastError());
+      std::swap(s->vel, s->vel2);
+      return CUP3D_OK;
+    }
     for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
       GridDev g = split ? s->gdev(pass == 1, pass == 0) : s->gdev();
       if (pass == 1 && (rc = halo_finish(s))) return rc;

@@ -1,0 +1,242 @@
+// Multi-level (AMR) meshes on the device: ghost reconstruction at coarse/fine faces and flux correction.
+//
+// The stencil kernels never see the mesh hierarchy.  Before a kernel runs, two small kernels write, for every
+// interface face (a face whose same-level neighbour does not exist), the ghost slab the kernel will read -- in
+// the same slab format and through the same `nbr >= kNbrHalo` indirection as the RCCL halo slabs of a
+// multi-rank run:
+//   * neighbour finer  -> "restrict": 8-cell AverageDown of the fine leaves (BlockLab::FineToCoarseExchange,
+//     main.cpp:3907-4065, AverageDown 3877-3882);
+//   * neighbour coarser -> "prolong": BlockLab::CoarseFineInterpolation (4236-4614).  Only what a star-shaped
+//     stencil reads is built: layers 1-2 behind the face use the finite-difference mode (1-D quadratic
+//     interpolation along both tangential axes + mixed term on the coarse layer next to the face, blended with
+//     two own cells, 4374-4612); layer 3 (stencil [-3,4) only) uses TestInterp (3883-3906) on the 3x3x3 coarse
+//     neighbourhood, which needs the coarse shadow tile (m_CoarsenedBlock) behind the face including its
+//     tangential ghosts: coarser leaves copied (CoarseFineExchange 4066-4170), same-level neighbours averaged
+//     down (FillCoarseVersion 4171-4235), domain faces mirrored (_apply_bc on the coarse tile, 3781).
+// After the kernel, k_flux_fix applies FluxCorrectionMPI::FillBlockCases (2825-2935) to the coarse side.
+// All arithmetic keeps the reference's association (-ffp-contract=off): results are bit-identical to it.
+#include "sim.hpp"
+#include "tile.hpp"
+
+namespace cup3d {
+
+struct AmrDev {
+  const int32_t *faces;  // [ne][2]: 6*slot + face, kind
+  const int32_t *fine;   // [ne][4]
+  const int32_t *nbr27;  // [nb][27]
+  const int32_t *nbr;    // [nb][6]
+  const int32_t *index;  // [nb][3]
+};
+
+__device__ __forceinline__ double avg_down8(const double v[8]) {  // AverageDown, main.cpp:3877-3882
+  return 0.125 * (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7]);
+}
+// the 2x2x2 cells with low corner (x,y,z) of a block component, in AverageDown's argument order (x slowest)
+__device__ __forceinline__ double avg_block(const double *__restrict__ blk, int x, int y, int z) {
+  double v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = blk[(z + (q & 1)) * 64 + (y + ((q >> 1) & 1)) * 8 + (x + (q >> 2))];
+  return avg_down8(v);
+}
+
+// ---- neighbour finer: slab[(e*nc + c)*W + gl][a2*8 + a1]
+template <int W>
+__global__ void __launch_bounds__(64) k_ghost_restrict(AmrDev a, const int32_t *__restrict__ list, const double *__restrict__ field, int nc,
+                                                       double *__restrict__ slabs) {
+  const int e = list[blockIdx.x], lane = threadIdx.x;
+  const int sf = a.faces[2 * e], f = sf % 6, d = f >> 1, side = f & 1;
+  const int a1 = lane & 7, a2 = lane >> 3;
+  const int fe = a.fine[4 * e + (a1 >> 2) + 2 * (a2 >> 2)];
+  const int fslot = a.faces[2 * fe] / 6;
+  const int t1 = 2 * (a1 & 3), t2 = 2 * (a2 & 3);
+  for (int c = 0; c < nc; ++c) {
+    const double *__restrict__ blk = field + ((size_t)fslot * nc + c) * 512;
+#pragma unroll
+    for (int gl = 0; gl < W; ++gl) {
+      const int n0 = side ? 2 * gl : 6 - 2 * gl;
+      const int x = d == 0 ? n0 : t1, y = d == 1 ? n0 : (d == 0 ? t1 : t2), z = d == 2 ? n0 : t2;
+      slabs[(((size_t)e * nc + c) * W + gl) * 64 + lane] = avg_block(blk, x, y, z);
+    }
+  }
+}
+
+// ---- neighbour coarser
+__constant__ double kCoefPlus[9] = {-0.09375, 0.4375, 0.15625, 0.15625, -0.5625, 0.90625, -0.09375, 0.4375, 0.15625};   // d_coef_plus, 3485-3486
+__constant__ double kCoefMinus[9] = {0.15625, -0.5625, 0.90625, -0.09375, 0.4375, 0.15625, 0.15625, 0.4375, -0.09375};  // d_coef_minus, 3487-3488
+
+// 1-D quadratic interpolation at coarse position p (0..3) along one tangential axis of the 6x6 patch layer
+// (stride `st` between neighbours along that axis), main.cpp:4419-4441; pm = positions used by the mixed term
+__device__ __forceinline__ double interp1d(const double *__restrict__ P0, int p, int st, const double *__restrict__ coef, int &pp, int &pm) {
+  if (p != 0 && p != 3) {
+    pp = p + 1; pm = p - 1;
+    return (coef[6] * P0[-st] + coef[8] * P0[st]) + coef[7] * P0[0];
+  } else if (p == 0) {
+    pp = p + 1; pm = p;
+    return (coef[0] * P0[2 * st] + coef[1] * P0[st]) + coef[2] * P0[0];
+  }
+  pp = p; pm = p - 1;
+  return (coef[3] * P0[-2 * st] + coef[4] * P0[-st]) + coef[5] * P0[0];
+}
+
+template <int W>
+__global__ void __launch_bounds__(64) k_ghost_prolong(AmrDev a, const int32_t *__restrict__ list, const double *__restrict__ field, int nc,
+                                                      double *__restrict__ slabs) {
+  __shared__ double patch[W][36];  // coarse shadow tile behind the face: [layer][(Z+1)*6 + (Y+1)], Y/Z in [-1,4] along (a1,a2)
+  const int e = list[blockIdx.x], lane = threadIdx.x;
+  const int sf = a.faces[2 * e], slot = sf / 6, f = sf % 6, ax = f >> 1, side = f & 1;
+  const int ax1 = ax == 0 ? 1 : 0, ax2 = ax == 2 ? 1 : 2;  // tangential axes (fast, slow) = the reference's (y,z)/(x,z)/(x,y)
+  const int par[3] = {a.index[3 * slot] & 1, a.index[3 * slot + 1] & 1, a.index[3 * slot + 2] & 1};
+  const bool is_vector = nc == 3;
+  const int a1i = lane & 7, a2i = lane >> 3;
+  for (int c = 0; c < nc; ++c) {
+    __syncthreads();
+    // ---- coarse shadow values
+    for (int i = lane; i < W * 36; i += 64) {
+      const int L = i / 36, r = i - 36 * L;
+      int P[3], code[3];
+      P[ax] = side ? 4 + L : -1 - L;
+      P[ax1] = r % 6 - 1;
+      P[ax2] = r / 6 - 1;
+      code[ax] = side ? 1 : -1;
+      bool flip = false;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int t = k ? ax2 : ax1;
+        int rg = P[t] < 0 ? -1 : (P[t] > 3 ? 1 : 0);
+        if (rg != 0) {
+          const int n = a.nbr[slot * 6 + 2 * t + (rg > 0)];
+          if (n < 0) {  // domain face: _apply_bc on the coarse tile copies the face cell with the same transverse coordinates
+            P[t] = rg < 0 ? 0 : 3;
+            rg = 0;
+            if (is_vector && (n == -3 || c == t)) flip = !flip;  // wall: all components; freespace: the normal one
+          }
+        }
+        code[t] = rg;
+      }
+      const int v = a.nbr27[slot * 27 + (code[0] + 1) + 3 * (code[1] + 1) + 9 * (code[2] + 1)];
+      double val = 0.0;
+      if (v >= kNbrCoarser) {  // CoarseFineExchange: cell of the coarser leaf
+        const double *__restrict__ blk = field + ((size_t)(v - kNbrCoarser) * nc + c) * 512;
+        const int q0 = (par[0] * 4 + P[0] + 8) & 7, q1 = (par[1] * 4 + P[1] + 8) & 7, q2 = (par[2] * 4 + P[2] + 8) & 7;
+        val = blk[q2 * 64 + q1 * 8 + q0];
+      } else if (v >= 0) {  // FillCoarseVersion: same-level neighbour averaged down
+        const double *__restrict__ blk = field + ((size_t)v * nc + c) * 512;
+        val = avg_block(blk, 2 * P[0] - 8 * code[0], 2 * P[1] - 8 * code[1], 2 * P[2] - 8 * code[2]);
+      }
+      patch[L][r] = flip ? -val : val;
+    }
+    __syncthreads();
+    // ---- layers 1 (and 2): finite-difference mode
+    const double *__restrict__ own = field + ((size_t)slot * nc + c) * 512;
+    int cb[3], cc[3];
+    cb[ax] = side ? 7 : 0; cc[ax] = side ? 6 : 1;
+    cb[ax1] = cc[ax1] = a1i;
+    cb[ax2] = cc[ax2] = a2i;
+    const double bv = own[cb[2] * 64 + cb[1] * 8 + cb[0]], cv = own[cc[2] * 64 + cc[1] * 8 + cc[0]];
+    const int p1 = a1i >> 1, p2 = a2i >> 1;
+    const double dd1 = 0.25 * (2 * (a1i & 1) - 1), dd2 = 0.25 * (2 * (a2i & 1) - 1);
+    const double *coef1 = dd1 > 0 ? kCoefPlus : kCoefMinus, *coef2 = dd2 > 0 ? kCoefPlus : kCoefMinus;
+    const double *P0 = &patch[0][(p2 + 1) * 6 + (p1 + 1)];
+    int pp1, pm1, pp2, pm2;
+    const double x1D = interp1d(P0, p1, 1, coef1, pp1, pm1);
+    const double x2D = interp1d(P0, p2, 6, coef2, pp2, pm2);
+    double mixed_coef = 1.0;
+    if (p1 != 0 && p1 != 3) mixed_coef *= 0.5;
+    if (p2 != 0 && p2 != 3) mixed_coef *= 0.5;
+#define PC(i, j) patch[0][((j) + 1) * 6 + ((i) + 1)]
+    const double mixed = mixed_coef * dd1 * dd2 * ((PC(pm1, pm2) + PC(pp1, pp2)) - (PC(pp1, pm2) + PC(pm1, pp2)));
+#undef PC
+    const double av = (x1D + x2D) + mixed;
+    double *__restrict__ out = slabs + ((size_t)e * nc + c) * W * 64 + lane;
+    out[0] = (1.0 / 15.0) * (8.0 * av + (10.0 * bv - 3.0 * cv));  // 4601-4608
+    if (W == 3) {
+      out[64] = (1.0 / 15.0) * (24.0 * av + (-15.0 * bv + 6 * cv));
+      // ---- layer 3: TestInterp around the coarse cell two layers behind the face
+      auto Cc = [&](int i, int j, int k) -> double {
+        const int off[3] = {i, j, k};
+        const int L = side ? off[ax] : 2 - off[ax];
+        return patch[L][(p2 + off[ax2]) * 6 + (p1 + off[ax1])];
+      };
+      const double dudx = 0.125 * (Cc(2, 1, 1) - Cc(0, 1, 1));
+      const double dudy = 0.125 * (Cc(1, 2, 1) - Cc(1, 0, 1));
+      const double dudz = 0.125 * (Cc(1, 1, 2) - Cc(1, 1, 0));
+      const double dudxdy = 0.015625 * (Cc(0, 0, 1) + Cc(2, 2, 1) - Cc(2, 0, 1) - Cc(0, 2, 1));
+      const double dudxdz = 0.015625 * (Cc(0, 1, 0) + Cc(2, 1, 2) - Cc(2, 1, 0) - Cc(0, 1, 2));
+      const double dudydz = 0.015625 * (Cc(1, 0, 0) + Cc(1, 2, 2) - Cc(1, 2, 0) - Cc(1, 0, 2));
+      const double lap = Cc(1, 1, 1) + 0.03125 * (Cc(0, 1, 1) + Cc(2, 1, 1) + Cc(1, 0, 1) + Cc(1, 2, 1) + Cc(1, 1, 0) + Cc(1, 1, 2) + (-6.0) * Cc(1, 1, 1));
+      int bit[3];
+      bit[ax] = side ? 0 : 1;  // the fine layer is the upper child of the coarse cell below the block, the lower one above it
+      bit[ax1] = a1i & 1;
+      bit[ax2] = a2i & 1;
+      const double sx = bit[0] ? 1.0 : -1.0, sy = bit[1] ? 1.0 : -1.0, sz = bit[2] ? 1.0 : -1.0;
+      out[128] = lap + sx * dudx + sy * dudy + sz * dudz + (sx * sy) * dudxdy + (sx * sz) * dudxdz + (sy * sz) * dudydz;
+    }
+  }
+}
+
+// ---- flux correction of the coarse side, one launch per normal direction (x, then y, then z: FillCase_2 order).
+// out[cell] += own face flux + ((f00 + f10) + (f01 + f11)) of the fine faces; flux arrays [(e*nfc + c)][a2*8+a1]
+__global__ void __launch_bounds__(64) k_flux_fix(AmrDev a, const int32_t *__restrict__ list, const double *__restrict__ flux, int nfc,
+                                                 double *__restrict__ out, int out_nc) {
+  const int e = list[blockIdx.x], lane = threadIdx.x;
+  const int sf = a.faces[2 * e], slot = sf / 6, f = sf % 6, d = f >> 1, side = f & 1;
+  const int a1 = lane & 7, a2 = lane >> 3, j = side ? 7 : 0;
+  const int cell = d == 0 ? a2 * 64 + a1 * 8 + j : (d == 1 ? a2 * 64 + j * 8 + a1 : j * 64 + a2 * 8 + a1);
+  const int fe = a.fine[4 * e + (a1 >> 2) + 2 * (a2 >> 2)];
+  const int i2 = 2 * (a1 & 3), i1 = 2 * (a2 & 3);
+  for (int c = 0; c < nfc; ++c) {
+    const double *__restrict__ F = flux + ((size_t)fe * nfc + c) * 64;
+    const double avg = (F[i2 + i1 * 8] + F[i2 + 1 + i1 * 8]) + (F[i2 + (i1 + 1) * 8] + F[i2 + 1 + (i1 + 1) * 8]);
+    const double coarse = flux[((size_t)e * nfc + c) * 64 + lane] + avg;
+    double *__restrict__ o = out + ((size_t)slot * out_nc + c) * 512 + cell;
+    *o = (*o + coarse) + 0.0;  // + 0.0: the three further FillCase_2 calls on the cleared face
+  }
+}
+
+// ---- host side
+int amr_fill_ghosts(Sim *s, const double *field, int nc, int w, double *slabs) {
+  const Grid *g = s->grid;
+  AmrDev a{s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_nbr, s->d_index};
+  ProfileScope ps("amr_ghosts");
+  if (s->n_restrict) {
+    if (w == 3) hipLaunchKernelGGL(k_ghost_restrict<3>, dim3(s->n_restrict), dim3(64), 0, stream(), a, s->d_restrict_list, field, nc, slabs);
+    else hipLaunchKernelGGL(k_ghost_restrict<1>, dim3(s->n_restrict), dim3(64), 0, stream(), a, s->d_restrict_list, field, nc, slabs);
+  }
+  if (s->n_prolong) {
+    if (w == 3) hipLaunchKernelGGL(k_ghost_prolong<3>, dim3(s->n_prolong), dim3(64), 0, stream(), a, s->d_prolong_list, field, nc, slabs);
+    else hipLaunchKernelGGL(k_ghost_prolong<1>, dim3(s->n_prolong), dim3(64), 0, stream(), a, s->d_prolong_list, field, nc, slabs);
+  }
+  CUP3D_HIP(hipGetLastError());
+  (void)g;
+  return CUP3D_OK;
+}
+
+int amr_flux_fix(Sim *s, int nfc, double *out, int out_nc) {
+  AmrDev a{s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_nbr, s->d_index};
+  ProfileScope ps("amr_flux_fix");
+  for (int d = 0; d < 3; ++d) {
+    const unsigned n = (unsigned)s->grid->fix_faces[d].size();
+    if (n) hipLaunchKernelGGL(k_flux_fix, dim3(n), dim3(64), 0, stream(), a, s->d_fix_list[d], s->d_flux, nfc, out, out_nc);
+  }
+  CUP3D_HIP(hipGetLastError());
+  return CUP3D_OK;
+}
+
+}  // namespace cup3d
+
+using namespace cup3d;
+
+// TEST SUPPORT: the ghost slabs of every interface face for `field` and a w-deep stencil, [(e*nc + c)*w + gl][64]
+extern "C" int cup3d_debug_amr_slabs(cup3d_sim_t *h, int field, int w, double *out) {
+  if (!h || !out || (w != 1 && w != 3)) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  if (!s->grid->multilevel) { set_error("cup3d_debug_amr_slabs: not a multi-level mesh"); return CUP3D_EINVAL; }
+  int nc;
+  const double *f = s->field(field, &nc);
+  if (!f) return CUP3D_EINVAL;
+  int rc = amr_fill_ghosts(s, f, nc, w, s->halo_recv);
+  if (rc) return rc;
+  CUP3D_HIP(hipMemcpyAsync(out, s->halo_recv, (size_t)s->grid->n_amr_faces() * nc * w * 64 * sizeof(double), hipMemcpyDeviceToHost, stream()));
+  CUP3D_HIP(hipStreamSynchronize(stream()));
+  return CUP3D_OK;
+}

@@ -58,6 +58,30 @@ int cup3d_grid_create_uniform(const int bpd[3], int level_max, int level, double
   }
   return CUP3D_OK;
 }
+int cup3d_grid_create_mesh(const int bpd[3], int level_max, double maxextent, const int bc[3], long nleaves, const int32_t *levels,
+                           const int64_t *Zs, cup3d_grid_t **out) {
+  if (!bpd || !bc || !out || !levels || !Zs || level_max < 1) { set_error("cup3d_grid_create_mesh: bad argument"); return CUP3D_EINVAL; }
+  try {
+    *out = reinterpret_cast<cup3d_grid_t *>(new Grid(bpd, level_max, maxextent, bc, nleaves, levels, Zs));
+  } catch (const std::invalid_argument &e) {
+    set_error("cup3d_grid_create_mesh: %s", e.what());
+    return CUP3D_EINVAL;
+  } catch (const std::exception &e) {
+    set_error("cup3d_grid_create_mesh: %s", e.what());
+    return CUP3D_ENOMEM;
+  }
+  return CUP3D_OK;
+}
+long cup3d_grid_ninterface_faces(const cup3d_grid_t *g) { return (long)reinterpret_cast<const Grid *>(g)->n_amr_faces(); }
+int cup3d_grid_interface(const cup3d_grid_t *gh, int32_t *faces2, int32_t *fine4, int32_t *nbr27) {
+  if (!gh) return CUP3D_EINVAL;
+  const Grid *g = reinterpret_cast<const Grid *>(gh);
+  if (!g->multilevel) { set_error("cup3d_grid_interface: not a multi-level mesh"); return CUP3D_EINVAL; }
+  if (faces2) memcpy(faces2, g->amr_faces.data(), g->amr_faces.size() * sizeof(int32_t));
+  if (fine4) memcpy(fine4, g->amr_fine.data(), g->amr_fine.size() * sizeof(int32_t));
+  if (nbr27) memcpy(nbr27, g->nbr27.data(), g->nbr27.size() * sizeof(int32_t));
+  return CUP3D_OK;
+}
 void cup3d_grid_destroy(cup3d_grid_t *g) { delete reinterpret_cast<Grid *>(g); }
 long cup3d_grid_nblocks(const cup3d_grid_t *g) { return (long)reinterpret_cast<const Grid *>(g)->nblocks(); }
 long cup3d_grid_nblocks_global(const cup3d_grid_t *g) { return (long)reinterpret_cast<const Grid *>(g)->total_blocks; }
@@ -69,12 +93,13 @@ int cup3d_grid_tables(const cup3d_grid_t *gh, long long *t, double *geom) {
   if (!gh || !t || !geom) return CUP3D_EINVAL;
   const Grid *g = reinterpret_cast<const Grid *>(gh);
   for (int64_t s = 0; s < g->nblocks(); ++s) {
-    t[6 * s + 0] = g->level;
+    const double h = g->multilevel ? g->hb[s] : g->h;
+    t[6 * s + 0] = g->multilevel ? g->blevel[s] : g->level;
     t[6 * s + 1] = g->Z[s];
     for (int d = 0; d < 3; ++d) t[6 * s + 2 + d] = g->index[3 * s + d];
     t[6 * s + 5] = g->id2[s];
-    geom[4 * s] = g->h;
-    for (int d = 0; d < 3; ++d) geom[4 * s + 1 + d] = g->index[3 * s + d] * kBS * g->h;  // origin, main.cpp:1066-1068
+    geom[4 * s] = h;
+    for (int d = 0; d < 3; ++d) geom[4 * s + 1 + d] = g->index[3 * s + d] * kBS * h;  // origin, main.cpp:1066-1068
   }
   return CUP3D_OK;
 }

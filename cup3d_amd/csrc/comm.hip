@@ -65,6 +65,7 @@ static int load_rccl() {
 
 int halo_exchange(Sim *s, const double *field, int nc, int w) {
   const Grid *g = s->grid;
+  if (g->multilevel) return amr_fill_ghosts(s, field, nc, w, s->halo_recv);  // coarse/fine ghost slabs take the halo slabs' place
   if (g->nranks == 1 || g_virtual_ranks) return CUP3D_OK;
   Comm *c = comm();
   if (!c) { set_error("multi-rank grid without cup3d_comm_init"); return CUP3D_ESTATE; }
@@ -93,6 +94,7 @@ int halo_exchange(Sim *s, const double *field, int nc, int w) {
 // for the slabs before the boundary blocks are launched.
 int halo_begin(Sim *s, const double *field, int nc, int w) {
   const Grid *g = s->grid;
+  if (g->multilevel) return amr_fill_ghosts(s, field, nc, w, s->halo_recv);
   if (g->nranks == 1 || g_virtual_ranks) return CUP3D_OK;
   Comm *c = comm();
   if (!c) { set_error("multi-rank grid without cup3d_comm_init"); return CUP3D_ESTATE; }

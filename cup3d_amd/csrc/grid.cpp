@@ -113,6 +113,134 @@ Grid::Grid(const int bpd_[3], int level_max_, int level_, double maxextent_, con
   }
 }
 
+// ---------------------------------------------------------------- multi-level mesh
+Grid::Grid(const int bpd_[3], int level_max_, double maxextent_, const int bc_[3], int64_t nleaves, const int32_t *levels, const int64_t *Zs)
+    : level_max(level_max_), level(0), maxextent(maxextent_), rank(0), nranks(1) {
+  if (nleaves < 1 || !levels || !Zs) throw std::invalid_argument("empty leaf list");
+  for (int d = 0; d < 3; ++d) {
+    if (bpd_[d] < 1) throw std::invalid_argument("bpd must be >= 1");
+    if (bc_[d] < 0 || bc_[d] > 2) throw std::invalid_argument("bc must be freespace(0), periodic(1) or wall(2)");
+    bpd[d] = bpd_[d];
+    bc[d] = bc_[d];
+  }
+  multilevel = true;
+  sfc.reset(new HilbertCurve(bpd[0], bpd[1], bpd[2], level_max));
+  const int widest = std::max(bpd[0], std::max(bpd[1], bpd[2]));
+  const double h0 = maxextent / (double)(widest * kBS);
+  total_blocks = z_count = nleaves;
+  z_begin = 0;
+  // m_vInfo order: sorted by blockID_2 (FillPos, main.cpp:943-964)
+  std::vector<std::tuple<int64_t, int32_t, int64_t>> order(nleaves);
+  int lmin = level_max;
+  for (int64_t n = 0; n < nleaves; ++n) {
+    if (levels[n] < 0 || levels[n] >= level_max) throw std::invalid_argument("leaf level out of range");
+    int c[3];
+    sfc->inverse(Zs[n], levels[n], c);
+    order[n] = std::make_tuple(sfc->encode(levels[n], c), levels[n], Zs[n]);
+    lmin = std::min(lmin, (int)levels[n]);
+  }
+  std::sort(order.begin(), order.end());
+  level = lmin;
+  h = h0 / (double)(1 << level);
+  for (int d = 0; d < 3; ++d) nbd[d] = bpd[d] << level;
+  Z.resize(nleaves); id2.resize(nleaves); index.resize(3 * nleaves); blevel.resize(nleaves); hb.resize(nleaves);
+  // dense (level, i, j, k) -> slot maps
+  std::vector<std::vector<int32_t>> at(level_max);
+  auto dims = [&](int l, int d) { return bpd[d] << l; };
+  for (int l = 0; l < level_max; ++l) at[l].assign((size_t)dims(l, 0) * dims(l, 1) * dims(l, 2), -1);
+  auto key = [&](int l, const int c[3]) { return ((size_t)c[2] * dims(l, 1) + c[1]) * dims(l, 0) + c[0]; };
+  for (int64_t s = 0; s < nleaves; ++s) {
+    id2[s] = std::get<0>(order[s]);
+    blevel[s] = std::get<1>(order[s]);
+    Z[s] = std::get<2>(order[s]);
+    hb[s] = h0 / (double)(1 << blevel[s]);
+    int c[3];
+    sfc->inverse(Z[s], blevel[s], c);
+    for (int d = 0; d < 3; ++d) index[3 * s + d] = c[d];
+    if (at[blevel[s]][key(blevel[s], c)] != -1) throw std::invalid_argument("duplicate leaf");
+    at[blevel[s]][key(blevel[s], c)] = (int32_t)s;
+    if (c[0] == 0 && c[1] == 0 && c[2] == 0) corner_slot = (int32_t)s;  // the last one in m_vInfo order, main.cpp:9287-9289
+  }
+  // neighbour states of all 26 codes (BlockLab::load 3690-3712)
+  nbr27.assign(27 * (size_t)nleaves, kNbrSkipped);
+  for (int64_t s = 0; s < nleaves; ++s) {
+    const int l = blevel[s];
+    const int32_t *idx = &index[3 * s];
+    for (int icode = 0; icode < 27; ++icode) {
+      const int code[3] = {icode % 3 - 1, (icode / 3) % 3 - 1, icode / 9 - 1};
+      if (icode == 13) { nbr27[27 * s + icode] = (int32_t)s; continue; }
+      bool skipped = false;
+      int c[3];
+      for (int d = 0; d < 3; ++d) {
+        const int n = dims(l, d);
+        const bool skin = idx[d] == 0 || idx[d] == n - 1;
+        const int skip = idx[d] == 0 ? -1 : 1;
+        if (bc[d] != 1 && code[d] == skip && skin) skipped = true;
+        c[d] = (idx[d] + code[d] + n) % n;
+      }
+      if (skipped) continue;
+      int32_t v = at[l][key(l, c)];
+      if (v < 0) {
+        v = kNbrFiner;
+        for (int k = 1; k <= l; ++k) {
+          const int pc[3] = {c[0] >> k, c[1] >> k, c[2] >> k};
+          const int32_t a = at[l - k][key(l - k, pc)];
+          if (a >= 0) {
+            if (k > 1) throw std::invalid_argument("mesh is not 2:1 balanced");
+            v = kNbrCoarser + a;
+            break;
+          }
+        }
+      }
+      nbr27[27 * s + icode] = v;
+    }
+  }
+  // face neighbours; interface faces in (slot, face) order
+  nbr.assign(6 * (size_t)nleaves, 0);
+  std::vector<int32_t> face_e(6 * (size_t)nleaves, -1);
+  for (int64_t s = 0; s < nleaves; ++s)
+    for (int f = 0; f < 6; ++f) {
+      const int d = f >> 1, side = f & 1;
+      int code[3] = {0, 0, 0};
+      code[d] = side ? 1 : -1;
+      const int32_t v = nbr27[27 * s + (code[0] + 1) + 3 * (code[1] + 1) + 9 * (code[2] + 1)];
+      if (v == kNbrSkipped) nbr[6 * s + f] = -1 - bc[d];
+      else if (v >= 0 && v < kNbrCoarser) nbr[6 * s + f] = v;
+      else {
+        const int32_t e = (int32_t)n_amr_faces();
+        face_e[6 * s + f] = e;
+        nbr[6 * s + f] = kNbrHalo + e;
+        amr_faces.push_back((int32_t)(6 * s + f));
+        amr_faces.push_back(v == kNbrFiner ? 1 : 0);
+      }
+    }
+  amr_fine.assign(4 * (size_t)n_amr_faces(), -1);
+  for (int64_t e = 0; e < n_amr_faces(); ++e) {
+    if (amr_faces[2 * e + 1] != 1) continue;
+    const int64_t s = amr_faces[2 * e] / 6;
+    const int f = amr_faces[2 * e] % 6, d = f >> 1, side = f & 1, l = blevel[s];
+    const int dfast = d == 0 ? 1 : 0, dslow = d == 2 ? 1 : 2;
+    fix_faces[d].push_back((int32_t)e);
+    for (int B = 0; B < 4; ++B) {
+      int c[3];
+      for (int k = 0; k < 3; ++k) c[k] = 2 * index[3 * s + k];
+      c[d] = 2 * index[3 * s + d] + (side ? 2 : -1);
+      c[dfast] += B % 2;
+      c[dslow] += B / 2;
+      for (int k = 0; k < 3; ++k) { const int n = dims(l + 1, k); c[k] = (c[k] + n) % n; }
+      const int32_t fs = at[l + 1][key(l + 1, c)];
+      if (fs < 0) throw std::invalid_argument("mesh is not 2:1 balanced");
+      amr_fine[4 * e + B] = face_e[6 * (size_t)fs + (f ^ 1)];
+      if (amr_fine[4 * e + B] < 0) throw std::logic_error("interface face bookkeeping");
+    }
+  }
+  inner.resize(nleaves);
+  for (int64_t s = 0; s < nleaves; ++s) inner[s] = (int32_t)s;
+  send_count.assign(1, 0);
+  recv_count.assign(1, 0);
+  slot_of_z.clear();
+}
+
 int32_t Grid::slot_of_index(int i, int j, int k) const {
   const int64_t z = sfc->forward(level, i, j, k);
   if (z < z_begin || z >= z_begin + z_count) return -1;

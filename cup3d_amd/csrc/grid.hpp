@@ -18,9 +18,17 @@ namespace cup3d {
 constexpr int kBS = 8;             // _BS_ (Makefile:11)
 constexpr int kCells = 512;        // cells per block
 constexpr int32_t kNbrHalo = 0x40000000;
+// nbr27 entries of a multi-level mesh: [0, kNbrCoarser) same-level slot; kNbrCoarser + slot = the coarser leaf that
+// covers the neighbour position (TreePosition CheckCoarser); kNbrSkipped = not loaded (domain face with a boundary
+// condition, BlockLab::load 3696-3701); kNbrFiner = finer leaves there (CheckFiner)
+constexpr int32_t kNbrCoarser = 0x20000000;
+constexpr int32_t kNbrSkipped = -1, kNbrFiner = -3;
 
 struct Grid {
   Grid(const int bpd[3], int level_max, int level, double maxextent, const int bc[3], int rank, int nranks);
+  // multi-level (AMR) mesh on one rank: the leaves (level, Z) in any order -- what Grid::m_vInfo holds after
+  // MeshAdaptation::Adapt (main.cpp:5086-5159); the octree states follow from the leaf set (Tree(), 840-855)
+  Grid(const int bpd[3], int level_max, double maxextent, const int bc[3], int64_t nleaves, const int32_t *levels, const int64_t *Zs);
 
   std::unique_ptr<HilbertCurve> sfc;
   int bpd[3], level_max, level, bc[3];
@@ -40,6 +48,19 @@ struct Grid {
   std::vector<int32_t> send_faces;              // slot*6 + face of each slab sent, in send order
   int64_t n_recv_faces = 0;
   int32_t corner_slot = -1;  // local slot of the block with index (0,0,0), or -1 (mean constraint, main.cpp:9287-9289)
+
+  // ---- multi-level meshes only (multilevel == true; `level` is then the coarsest level present, `h` its spacing)
+  bool multilevel = false;
+  std::vector<int32_t> blevel;   // [nb] level of each block
+  std::vector<double> hb;        // [nb] grid spacing of each block (Info::h)
+  std::vector<int32_t> nbr27;    // [nb][27], code = (cx+1) + 3*(cy+1) + 9*(cz+1); see kNbrCoarser above
+  // interface faces = faces whose same-level neighbour does not exist (FluxCorrection::prepare 676-711): each one has a
+  // ghost slab produced on the device before a stencil kernel runs and a stored face-flux array.  nbr[6*slot+f] = kNbrHalo + e.
+  std::vector<int32_t> amr_faces;   // [ne][2]: 6*slot + face, kind (0: neighbour is coarser -> prolong; 1: finer -> restrict)
+  std::vector<int32_t> amr_fine;    // [ne][4]: interface-face index of the four finer blocks' opposite faces, quadrant
+                                    // B = (fast half) + 2*(slow half) of the face (FillCase 601-661); -1 for kind 0
+  std::vector<int32_t> fix_faces[3];  // interface faces of kind 1 with normal direction d (flux correction order x, y, z)
+  int64_t n_amr_faces() const { return (int64_t)amr_faces.size() / 2; }
 
   std::vector<int32_t> slot_of_z;  // Z - z_begin -> local slot
   // local slot of the block at (i,j,k) of this level (periodic wrap NOT applied); -1 if owned by another rank

@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
   const int l = threadIdx.x;
   const int base = ((l >> 3) + 1) * 10 + (l & 7) + 1;
   for (int i = l; i < 800; i += 64) P[i] = 0.0;
-  const double invh = 1 / g.h;  // main.cpp:14723
+  const double invh = 1 / block_h(g, slot);  // main.cpp:14723
   double r[8], p[8], x[8], Ax[8];
   double rr = 0;
 #pragma unroll
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
     sx += x[z];
   }
   if (block_sums) {  // sum(z*h^3) of this block for the mean constraint of the LHS that follows (9283-9294)
-    const double h3 = g.h * g.h * g.h;
+    const double hq = block_h(g, slot), h3 = hq * hq * hq;
     sx = wave_sum(sx * h3);
     if (l == 0) block_sums[slot] = sx;
   }
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(64) k_precond_fdm(GridDev g, const double *in,
   const int slot = block_slot(g);
   if (slot < 0) return;
   const int l = threadIdx.x, lo = l & 7, hi = l >> 3;
-  const double invh = 1 / g.h;
+  const double invh = 1 / block_h(g, slot);
   double v[8], w[8], scale[8];
   double rr = 0;
 #pragma unroll
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(64) k_precond_fdm(GridDev g, const double *in,
     sx += r;
   }
   if (block_sums) {
-    const double h3 = g.h * g.h * g.h;
+    const double hq = block_h(g, slot), h3 = hq * hq * hq;
     sx = wave_sum(sx * h3);
     if (l == 0) block_sums[slot] = sx;
   }
@@ -366,9 +366,13 @@ __global__ void __launch_bounds__(256) k_sub_divp(double *__restrict__ lhs, cons
   GRID_STRIDE(j, n) { lhs[j] -= tmpV[(j >> 9) * 1536 + (j & 511)]; pres[j] = 0; }
 }
 // sum(p*vv), sum(vv)   (15111-15121)
-__global__ void __launch_bounds__(256) k_mean_dots(const double *__restrict__ p, long n, double vv, double *__restrict__ partials) {
+__global__ void __launch_bounds__(256) k_mean_dots(const double *__restrict__ p, long n, double vv, const double *__restrict__ hb,
+                                                   double *__restrict__ partials) {
   double acc[2] = {0, 0};
-  GRID_STRIDE(j, n) { acc[0] += p[j] * vv; acc[1] += vv; }
+  GRID_STRIDE(j, n) {
+    if (hb) { const double h = hb[j >> 9]; vv = h * h * h; }
+    acc[0] += p[j] * vv; acc[1] += vv;
+  }
   emit_partials<2>(acc, partials);
 }
 // p -= avg ; (p += pOld)   (15127-15145)
@@ -557,7 +561,7 @@ int cup3d_pressure_project(cup3d_sim_t *h, double dt, int step, const cup3d_pois
   }
   TRY(solve(s, P, r));
   const double hh = s->grid->h, vv = hh * hh * hh;
-  { ProfileScope ps("project_pointwise"); LAUNCH_VEC(k_mean_dots, s->pres, N, vv, s->d_partials); }
+  { ProfileScope ps("project_pointwise"); LAUNCH_VEC(k_mean_dots, s->pres, N, vv, s->d_hb, s->d_partials); }
   Reducer red{s, G};
   TRY(red.begin(2)); TRY(red.wait());                        // MPI_Allreduce(2), 15123
   const double avg = s->h_red[0] / s->h_red[1];              // 15126

@@ -77,6 +77,8 @@ GridDev Sim::gdev(bool boundary_only, bool inner_only) const {
   GridDev g;
   g.nbr = d_nbr;
   g.h = grid->h;
+  g.hb = d_hb;
+  g.flux = d_flux;
   if (boundary_only) {
     g.list = d_boundary;
     g.nblocks = (int)grid->boundary.size();
@@ -266,6 +268,30 @@ int cup3d_sim_create(const cup3d_grid_t *gh, cup3d_sim_t **out) {
     if (!g->send_faces.empty()) { if ((rc = sim_alloc(&s->halo_send, g->send_faces.size() * slab, s))) return rc; }
     CUP3D_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
   }
+  if (g->multilevel) {
+    auto up = [&](int32_t **d, const std::vector<int32_t> &v) -> int {
+      if (v.empty()) { *d = nullptr; return CUP3D_OK; }
+      CUP3D_HIP(hipMalloc((void **)d, v.size() * sizeof(int32_t)));
+      CUP3D_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      return CUP3D_OK;
+    };
+    std::vector<int32_t> lr, lp;
+    for (int64_t e = 0; e < g->n_amr_faces(); ++e) (g->amr_faces[2 * e + 1] ? lr : lp).push_back((int32_t)e);
+    s->n_restrict = (unsigned)lr.size();
+    s->n_prolong = (unsigned)lp.size();
+    if ((rc = up(&s->d_amr_faces, g->amr_faces)) || (rc = up(&s->d_amr_fine, g->amr_fine)) || (rc = up(&s->d_nbr27, g->nbr27)) ||
+        (rc = up(&s->d_index, g->index)) || (rc = up(&s->d_restrict_list, lr)) || (rc = up(&s->d_prolong_list, lp)) ||
+        (rc = up(&s->d_fix_list[0], g->fix_faces[0])) || (rc = up(&s->d_fix_list[1], g->fix_faces[1])) || (rc = up(&s->d_fix_list[2], g->fix_faces[2]))) {
+      cup3d_sim_destroy((cup3d_sim_t *)s);
+      return rc;
+    }
+    if ((rc = sim_alloc(&s->d_hb, nb, s))) return rc;
+    CUP3D_HIP(hipMemcpy(s->d_hb, g->hb.data(), nb * sizeof(double), hipMemcpyHostToDevice));
+    const size_t ne = (size_t)std::max<int64_t>(g->n_amr_faces(), 1);
+    // ghost slabs: widest use = 3 components x 3 layers; the pressure RHS keeps a second set (udef) behind the first
+    if ((rc = sim_alloc(&s->halo_recv, ne * 9 * 64, s))) return rc;
+    if ((rc = sim_alloc(&s->d_flux, ne * 3 * 64, s))) return rc;
+  }
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_a, hipEventDisableTiming));
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_b, hipEventDisableTiming));
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_h1, hipEventDisableTiming));
@@ -279,12 +305,14 @@ void cup3d_sim_destroy(cup3d_sim_t *h) {
   if (!h) return;
   Sim *s = reinterpret_cast<Sim *>(h);
   hipStreamSynchronize(g_stream);
-  double *ptrs[] = {s->vel, s->vel2, s->tmpV, s->pres, s->lhs, s->chi, s->pold, s->d_partials, s->d_red, s->d_stage, s->halo_recv, s->halo_send};
+  double *ptrs[] = {s->vel, s->vel2, s->tmpV, s->pres, s->lhs, s->chi, s->pold, s->d_partials, s->d_red, s->d_stage, s->halo_recv, s->halo_send,
+                    s->d_hb, s->d_flux};
   for (double *p : ptrs) if (p) hipFree(p);
   for (double *p : s->sv) if (p) hipFree(p);
   if (s->h_red) hipHostFree(s->h_red);
   if (s->h_stage) hipHostFree(s->h_stage);
-  int32_t *ip[] = {s->d_nbr, s->d_inner, s->d_boundary, s->d_send_faces};
+  int32_t *ip[] = {s->d_nbr, s->d_inner, s->d_boundary, s->d_send_faces, s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_index,
+                   s->d_restrict_list, s->d_prolong_list, s->d_fix_list[0], s->d_fix_list[1], s->d_fix_list[2]};
   for (int32_t *p : ip) if (p) hipFree(p);
   if (s->comm_stream) hipStreamDestroy(s->comm_stream);
   if (s->ev_a) hipEventDestroy(s->ev_a);

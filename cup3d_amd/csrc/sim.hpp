@@ -49,7 +49,12 @@ struct GridDev {
   int nblocks;          // number of blocks this launch covers
   int chunk;            // ceil(nblocks / 8): blocks per XCD
   double h;
+  // multi-level meshes: per-block spacing (nullptr on uniform grids) and the face-flux arrays of the
+  // interface faces [(e*nc + c)][64] the kernel must fill (e = nbr - kNbrHalo); see amr.hip
+  const double *hb;
+  double *flux;
 };
+__device__ __forceinline__ double block_h(const GridDev &g, int slot) { return g.hb ? g.hb[slot] : g.h; }
 
 struct Sim {
   const Grid *grid = nullptr;
@@ -74,6 +79,11 @@ struct Sim {
   double *d_stage = nullptr;
   double *h_stage = nullptr;  // pinned
   size_t stage_blocks = 0;
+  // multi-level mesh tables (amr.hip); all nullptr / 0 on uniform grids
+  int32_t *d_amr_faces = nullptr, *d_amr_fine = nullptr, *d_nbr27 = nullptr, *d_index = nullptr;
+  int32_t *d_restrict_list = nullptr, *d_prolong_list = nullptr, *d_fix_list[3] = {nullptr, nullptr, nullptr};
+  unsigned n_restrict = 0, n_prolong = 0;
+  double *d_hb = nullptr, *d_flux = nullptr;
   // halo buffers (multi-rank)
   double *halo_recv = nullptr, *halo_send = nullptr;  // n faces x 3 comps x 3 layers x 64
   size_t bytes = 0;
@@ -93,6 +103,11 @@ int halo_begin(Sim *s, const double *field, int ncomp, int w);
 int halo_finish(Sim *s);
 // sum / max all-reduce of n doubles resident in device memory; no-op on one rank
 int allreduce(Sim *s, double *d_buf, int n, bool is_max, hipStream_t st);
+
+// multi-level meshes: ghost slabs of every interface face of `field` for a w-deep star stencil -> slabs;
+// flux correction of `out` (out_nc components per block, the first nfc corrected) from s->d_flux
+int amr_fill_ghosts(Sim *s, const double *field, int ncomp, int w, double *slabs);
+int amr_flux_fix(Sim *s, int nfc, double *out, int out_nc);
 
 // kernels' launchers shared across translation units
 int launch_lhs(Sim *s, const double *p, double *out, int mean_constraint);

@@ -20,6 +20,26 @@ __device__ __forceinline__ void face1(int f, int lane, int &nb_cell, int &own_ce
   else { nb_cell = a2 * 64 + a1 * 8 + qn; own_cell = a2 * 64 + a1 * 8 + qo; lds = tix(g, a1, a2); }
 }
 
+// Multi-level meshes: face-flux arrays of the interface faces of this block (KernelLHSPoisson 9216-9267 and friends).
+// fn(c, in, ghost, side, d) -> flux of component c given the LDS indices of the face cell and of the ghost behind it.
+template <int NFC, class Fn>
+__device__ __forceinline__ void write_face_fluxes(const GridDev &g, int slot, Fn fn) {
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int face = wave + 4 * i;
+    if (face >= 6) continue;
+    const int n = g.nbr[slot * 6 + face];
+    if (n < kNbrHalo) continue;
+    int nb_cell, own_cell, ghost;
+    face1(face, lane, nb_cell, own_cell, ghost);
+    const int in = tix(own_cell & 7, (own_cell >> 3) & 7, own_cell >> 6);
+#pragma unroll
+    for (int c = 0; c < NFC; ++c) g.flux[((size_t)(n - kNbrHalo) * NFC + c) * 64 + lane] = fn(c, in, ghost, face & 1, face >> 1);
+  }
+}
+
 // scalar tile with zero-gradient domain faces (BlockLabNeumann3D, main.cpp:6561-6581)
 __device__ __forceinline__ void load_scalar_tile(const GridDev &g, int slot, const double *__restrict__ f, const double *__restrict__ halo,
                                                  double *tile, double c[2]) {
@@ -88,13 +108,14 @@ __global__ void __launch_bounds__(256) k_lhs(GridDev g, const double *__restrict
   load_scalar_tile(g, slot, p, halo, tile, c);
   __syncthreads();
   const int t = threadIdx.x, x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
-  const double h = g.h;
+  const double h = block_h(g, slot);
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int z = z0 + 4 * k, b = tix(x, y, z);
     out[(size_t)slot * 512 + k * 256 + t] =
         h * (tile[b - 1] + tile[b + 1] + tile[b - 10] + tile[b + 10] + tile[b - 100] + tile[b + 100] - 6.0 * c[k]);
   }
+  if (g.flux) write_face_fluxes<1>(g, slot, [&](int, int in, int gh, int, int) { return h * (tile[in] - tile[gh]); });
   if (block_sums) {
     const double h3 = h * h * h;
     const double s = group_sum<4>(c[0] * h3 + c[1] * h3, red);
@@ -120,8 +141,13 @@ __global__ void k_lhs_corner(double *__restrict__ out, const double *__restrict_
   if (mode == 1) out[(size_t)corner_slot * 512] = avg[0];          // LHS(0,0,0) = avgP
   else out[(size_t)corner_slot * 512] = in[(size_t)corner_slot * 512];  // bMeanConstraint > 2
 }
-__global__ void __launch_bounds__(256) k_lhs_add_mean(double *__restrict__ out, long n, const double *__restrict__ avg, double h3) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] += avg[0] * h3;  // 9314
+__global__ void __launch_bounds__(256) k_lhs_add_mean(double *__restrict__ out, long n, const double *__restrict__ avg, double h3,
+                                                      const double *__restrict__ hb) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    double v = h3;
+    if (hb) { const double h = hb[i >> 9]; v = h * h * h; }
+    out[i] += avg[0] * v;  // 9314
+  }
 }
 
 // ---- KernelPressureRHS (main.cpp:14849-14875)
@@ -139,7 +165,7 @@ __global__ void __launch_bounds__(256) k_pressure_rhs(GridDev g, const double *_
     for (int c = 0; c < 3; ++c) load_normal_tile(g, slot, udef, halo_u, c, tu + c * kT);
   __syncthreads();
   const int t = threadIdx.x, x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
-  const double h = g.h, fac = 0.5 * h * h / dt;
+  const double h = block_h(g, slot), fac = 0.5 * h * h / dt;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int b = tix(x, y, z0 + 4 * k);
@@ -150,6 +176,17 @@ __global__ void __launch_bounds__(256) k_pressure_rhs(GridDev g, const double *_
     }
     out[(size_t)slot * 512 + k * 256 + t] = p;
   }
+  if (g.flux)  // main.cpp:14892-14945: the normal component of (u - chi*udef) summed across the face
+    write_face_fluxes<1>(g, slot, [&](int, int in, int gh, int side, int d) {
+      const double su = tv[d * kT + gh] + tv[d * kT + in];
+      double v = side ? -fac * su : fac * su;
+      if (chi) {
+        const int x_ = in % 10 - 1, y_ = (in / 10) % 10 - 1, z_ = in / 100 - 1;
+        const double cu = chi[(size_t)slot * 512 + z_ * 64 + y_ * 8 + x_] * fac * (tu[d * kT + gh] + tu[d * kT + in]);
+        v = side ? v + cu : v - cu;
+      }
+      return v;
+    });
 }
 
 // ---- KernelDivPressure (main.cpp:14769-14778): tmpV.u[0] = h*lap(p)
@@ -161,13 +198,15 @@ __global__ void __launch_bounds__(256) k_div_pressure(GridDev g, const double *_
   load_scalar_tile(g, slot, p, halo, tile, c);
   __syncthreads();
   const int t = threadIdx.x, x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
-  const double fac = g.h;
+  const double fac = block_h(g, slot);
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int b = tix(x, y, z0 + 4 * k);
     tmpV[(size_t)slot * 1536 + k * 256 + t] =
         fac * (tile[b + 1] + tile[b - 1] + tile[b + 10] + tile[b - 10] + tile[b + 100] + tile[b - 100] - 6.0 * c[k]);
   }
+  if (g.flux)  // main.cpp:14795-14833
+    write_face_fluxes<1>(g, slot, [&](int, int in, int gh, int side, int) { return side ? -fac * (tile[gh] - tile[in]) : fac * (tile[in] - tile[gh]); });
 }
 
 // ---- KernelGradP (main.cpp:14990-14999), optionally fused with vel += tmpV/h^3 (15147-15159)
@@ -180,7 +219,7 @@ __global__ void __launch_bounds__(256) k_grad_p(GridDev g, const double *__restr
   load_scalar_tile(g, slot, p, halo, tile, c);
   __syncthreads();
   const int t = threadIdx.x, x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
-  const double h = g.h, fac = -0.5 * dt * h * h, ih3 = 1.0 / (h * h * h);
+  const double h = block_h(g, slot), fac = -0.5 * dt * h * h, ih3 = 1.0 / (h * h * h);
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int b = tix(x, y, z0 + 4 * k);
@@ -192,6 +231,19 @@ __global__ void __launch_bounds__(256) k_grad_p(GridDev g, const double *__restr
     if (vel) {
       vel[o] += ih3 * gx; vel[o + 512] += ih3 * gy; vel[o + 1024] += ih3 * gz;
     }
+  }
+  if (g.flux)  // main.cpp:15016-15054: only the component normal to the face is non-zero
+    write_face_fluxes<3>(g, slot, [&](int c_, int in, int gh, int side, int d) {
+      const double v = side ? -fac * (tile[gh] + tile[in]) : fac * (tile[gh] + tile[in]);
+      return c_ == d ? v : 0.0;
+    });
+}
+
+// vel += tmpV / h^3 (main.cpp:15147-15159) as its own pass: on multi-level meshes tmpV is flux-corrected first
+__global__ void __launch_bounds__(256) k_add_scaled(const double *__restrict__ hb, const double *__restrict__ tmpV, double *__restrict__ vel, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const double h = hb[i / 1536];
+    vel[i] += (1.0 / (h * h * h)) * tmpV[i];
   }
 }
 
@@ -211,6 +263,7 @@ int launch_lhs(Sim *s, const double *p, double *out, int mc) {
     hipLaunchKernelGGL(k_lhs, dim3(launch_groups(g)), dim3(256), 0, stream(), g, p, s->halo_recv, out, (need_sum && !have_sums) ? block_sums : nullptr);
   }
   CUP3D_HIP(hipGetLastError());
+  if (s->grid->multilevel && (rc = amr_flux_fix(s, 1, out, 1))) return rc;  // compute(..., lhs) corrector, main.cpp:9298
   if (mc == 0) return CUP3D_OK;
   const int corner = s->grid->corner_slot;
   if (need_sum) {
@@ -222,7 +275,7 @@ int launch_lhs(Sim *s, const double *p, double *out, int mc) {
       if (corner >= 0) hipLaunchKernelGGL(k_lhs_corner, dim3(1), dim3(1), 0, stream(), out, p, s->d_red + 8, corner, 1);
     } else {
       const double h = s->grid->h;
-      hipLaunchKernelGGL(k_lhs_add_mean, dim3(2048), dim3(256), 0, stream(), out, s->nb * 512L, s->d_red + 8, h * h * h);
+      hipLaunchKernelGGL(k_lhs_add_mean, dim3(2048), dim3(256), 0, stream(), out, s->nb * 512L, s->d_red + 8, h * h * h, s->d_hb);
     }
   } else if (corner >= 0) {
     hipLaunchKernelGGL(k_lhs_corner, dim3(1), dim3(1), 0, stream(), out, p, s->d_red + 8, corner, 3);
@@ -249,7 +302,10 @@ int cup3d_pressure_rhs(cup3d_sim_t *h, double dt) {
   int rc;
   const bool obst = s->chi_nonzero;
   double *halo_u = nullptr;
-  if (obst && s->grid->nranks > 1) {
+  if (obst && s->grid->multilevel) {
+    halo_u = s->halo_recv + (size_t)s->grid->n_amr_faces() * 3 * 64;
+    if ((rc = amr_fill_ghosts(s, s->tmpV, 3, 1, halo_u))) return rc;
+  } else if (obst && s->grid->nranks > 1) {
     // udef slabs go to the second half of the receive buffer (each exchange uses <= 3*64 per face of 9*64)
     if ((rc = halo_exchange(s, s->tmpV, 3, 1))) return rc;
     halo_u = s->halo_recv + (size_t)s->grid->n_recv_faces * 3 * 64;
@@ -260,6 +316,7 @@ int cup3d_pressure_rhs(cup3d_sim_t *h, double dt) {
   ProfileScope ps("pressure_rhs");
   hipLaunchKernelGGL(k_pressure_rhs, dim3(launch_groups(g)), dim3(256), 0, stream(), g, s->vel, s->tmpV, obst ? s->chi : nullptr, s->halo_recv, halo_u, dt, s->lhs);
   CUP3D_HIP(hipGetLastError());
+  if (s->grid->multilevel) return amr_flux_fix(s, 1, s->lhs, 1);
   return CUP3D_OK;
 }
 
@@ -272,6 +329,7 @@ int cup3d_div_pressure(cup3d_sim_t *h) {
   ProfileScope ps("div_pressure");
   hipLaunchKernelGGL(k_div_pressure, dim3(launch_groups(g)), dim3(256), 0, stream(), g, s->pres, s->halo_recv, s->tmpV);
   CUP3D_HIP(hipGetLastError());
+  if (s->grid->multilevel) return amr_flux_fix(s, 1, s->tmpV, 3);  // only tmpV.u[0] carries the result
   return CUP3D_OK;
 }
 
@@ -280,8 +338,14 @@ static int grad_p(Sim *s, double dt, bool update_vel) {
   if (rc) return rc;
   GridDev g = s->gdev();
   ProfileScope ps("grad_p");
-  hipLaunchKernelGGL(k_grad_p, dim3(launch_groups(g)), dim3(256), 0, stream(), g, s->pres, s->halo_recv, dt, s->tmpV, update_vel ? s->vel : nullptr);
+  const bool ml = s->grid->multilevel;
+  hipLaunchKernelGGL(k_grad_p, dim3(launch_groups(g)), dim3(256), 0, stream(), g, s->pres, s->halo_recv, dt, s->tmpV, (update_vel && !ml) ? s->vel : nullptr);
   CUP3D_HIP(hipGetLastError());
+  if (ml) {
+    if ((rc = amr_flux_fix(s, 3, s->tmpV, 3))) return rc;
+    if (update_vel) hipLaunchKernelGGL(k_add_scaled, dim3(2048), dim3(256), 0, stream(), s->d_hb, s->tmpV, s->vel, s->nb * 1536L);
+    CUP3D_HIP(hipGetLastError());
+  }
   return CUP3D_OK;
 }
 int cup3d_grad_p(cup3d_sim_t *h, double dt) {

@@ -24,14 +24,22 @@ class Grid:
     """Block topology of one rank (host only): GridMPI ownership + m_vInfo order + face
     neighbours + halo plan.  Works without a GPU."""
 
-    def __init__(self, bpd, levelMax, level, maxextent, bc, rank=0, nranks=1):
+    def __init__(self, bpd, levelMax, level, maxextent, bc, rank=0, nranks=1, leaves=None):
+        """Uniform grid at `level`, or -- with leaves=(levels, Zs) -- the multi-level mesh made of those leaf blocks
+        (what MeshAdaptation leaves in m_vInfo; one rank)."""
         self.bpd = np.array(bpd, dtype=np.int32)
         self.bc = np.array([BC[b] if isinstance(b, str) else int(b) for b in bc], dtype=np.int32)
         self.levelMax, self.level, self.maxextent = int(levelMax), int(level), float(maxextent)
         self.rank, self.nranks = int(rank), int(nranks)
+        self.multilevel = leaves is not None
         h = C.c_void_p()
-        check(lib().cup3d_grid_create_uniform(self.bpd, self.levelMax, self.level, self.maxextent, self.bc,
-                                              self.rank, self.nranks, C.byref(h)))
+        if self.multilevel:
+            lv = np.ascontiguousarray(leaves[0], dtype=np.int32)
+            zs = np.ascontiguousarray(leaves[1], dtype=np.int64)
+            check(lib().cup3d_grid_create_mesh(self.bpd, self.levelMax, self.maxextent, self.bc, len(lv), lv, zs, C.byref(h)))
+        else:
+            check(lib().cup3d_grid_create_uniform(self.bpd, self.levelMax, self.level, self.maxextent, self.bc,
+                                                  self.rank, self.nranks, C.byref(h)))
         self.handle = h
         self.nblocks = lib().cup3d_grid_nblocks(h)
         self.nblocks_global = lib().cup3d_grid_nblocks_global(h)
@@ -47,6 +55,16 @@ class Grid:
             lib().cup3d_grid_destroy(self.handle)
         except Exception:
             pass
+
+    def interface(self):
+        """Multi-level meshes: (faces[ne,2] = 6*slot+face, kind; fine4[ne,4]; nbr27[nb,27]), see cup3d_grid_interface."""
+        ne = lib().cup3d_grid_ninterface_faces(self.handle)
+        faces = np.zeros((max(ne, 1), 2), dtype=np.int32)
+        fine = np.zeros((max(ne, 1), 4), dtype=np.int32)
+        n27 = np.zeros((self.nblocks, 27), dtype=np.int32)
+        check(lib().cup3d_grid_interface(self.handle, faces.ctypes.data_as(C.c_void_p), fine.ctypes.data_as(C.c_void_p),
+                                         n27.ctypes.data_as(C.c_void_p)))
+        return faces[:ne], fine[:ne], n27
 
     def neighbours(self):
         nbr = np.zeros((self.nblocks, 6), dtype=np.int32)
@@ -80,7 +98,7 @@ class SimulationData:
     def __init__(self, bpdx=1, bpdy=1, bpdz=1, levelMax=1, levelStart=None, extent=1.0, nu=0.0, CFL=0.1,
                  BC_x="freespace", BC_y="freespace", BC_z="freespace", uinf=(0.0, 0.0, 0.0), uMax_forced=0.0,
                  poissonTol=1e-6, poissonTolRel=1e-4, bMeanConstraint=1, poissonSolver="hip_iterative", rampup=100,
-                 blockSolver=0,
+                 blockSolver=0, leaves=None,
                  rank=0, nranks=1, device=None):
         if device is not None or not capi._device_ready:
             capi.device_init(0 if device is None else device)
@@ -88,7 +106,8 @@ class SimulationData:
         self.levelMax = levelMax
         self.levelStart = levelMax - 1 if levelStart is None else levelStart
         self.maxextent = float(extent)
-        self.grid = Grid((bpdx, bpdy, bpdz), levelMax, self.levelStart, self.maxextent, (BC_x, BC_y, BC_z), rank, nranks)
+        # leaves=(levels, Zs): run on that multi-level mesh instead of the uniform grid at levelStart
+        self.grid = Grid((bpdx, bpdy, bpdz), levelMax, self.levelStart, self.maxextent, (BC_x, BC_y, BC_z), rank, nranks, leaves=leaves)
         # extents / hmin as in _preprocessArguments, main.cpp:15394-15415
         aux = 1 << (levelMax - 1)
         nfe = [bpdx * aux * 8, bpdy * aux * 8, bpdz * aux * 8]

@@ -64,6 +64,20 @@ typedef struct cup3d_grid cup3d_grid_t;
  * Z range of GridMPI's constructor. */
 int cup3d_grid_create_uniform(const int bpd[3], int level_max, int level, double maxextent, const int bc[3],
                               int rank, int nranks, cup3d_grid_t **out);
+/* multi-level (AMR) mesh on one rank from its leaf blocks (level, Z) in any order: the block set Grid::m_vInfo holds
+ * after MeshAdaptation::Adapt (main.cpp:5086-5159).  Blocks are ordered by blockID_2; the octree states
+ * (Exists / CheckCoarser / CheckFiner, 321-330) follow from the leaf set; the mesh must be 2:1 balanced. */
+int cup3d_grid_create_mesh(const int bpd[3], int level_max, double maxextent, const int bc[3], long nleaves,
+                           const int32_t *levels, const int64_t *Zs, cup3d_grid_t **out);
+/* interface faces of a multi-level mesh (faces whose same-level neighbour does not exist, FluxCorrection::prepare
+ * 676-711): faces2[e] = {6*slot + face, kind} with kind 0 = neighbour coarser, 1 = neighbour finer; fine4[e] = interface-face
+ * indices of the four finer blocks' opposite faces (FillCase 601-661), -1 for kind 0; nbr27[slot][27] = neighbour states
+ * (same-level slot, CUP3D_NBR_COARSER + slot, CUP3D_NBR_SKIPPED, CUP3D_NBR_FINER).  Any output may be NULL. */
+#define CUP3D_NBR_COARSER 0x20000000
+#define CUP3D_NBR_SKIPPED (-1)
+#define CUP3D_NBR_FINER (-3)
+long cup3d_grid_ninterface_faces(const cup3d_grid_t *);
+int cup3d_grid_interface(const cup3d_grid_t *, int32_t *faces2, int32_t *fine4, int32_t *nbr27);
 void cup3d_grid_destroy(cup3d_grid_t *);
 long cup3d_grid_nblocks(const cup3d_grid_t *);        /* local blocks = m_vInfo.size() */
 long cup3d_grid_nblocks_global(const cup3d_grid_t *);

@@ -92,6 +92,16 @@ double orc_mesh_h(const orc_mesh *m, long b) {
 }
 
 static int nblk(const orc_mesh *m, int l, int d) { return m->bpd[d] << l; }
+#ifdef _OPENMP
+#include <omp.h>
+static int mesh_threads(const orc_mesh *m) { /* small meshes: a team per 8 blocks at most (big hosts have 256 cores) */
+  long t = m->nblocks / 8, mx = omp_get_max_threads();
+  if (t < 1) t = 1;
+  return (int)(t < mx ? t : mx);
+}
+#else
+static int mesh_threads(const orc_mesh *m) { (void)m; return 1; }
+#endif
 /* leaf slot at (level l, block index c) with periodic wrap; -1 if not a leaf at that level */
 static int leaf_at(const orc_mesh *m, int l, const int c[3]) {
   if (l < 0 || l >= m->level_max) return -1;
@@ -544,9 +554,12 @@ static inline double upwind5m(double U, double um3, double um2, double um1, doub
 void orc_mesh_advdiff_stage_rhs(const orc_mesh *m, const double *vel, double *tmpV, double dt, double nu, const double uinf[3]) {
   faces_t F;
   faces_init(m, &F, 3);
+#define V(x, y, z, c) FT(&t, x, y, z, c)
+#pragma omp parallel num_threads(mesh_threads(m))
+  {
   tile_t t;
   tile_init(&t, 3, 1, -3, 4, 0);
-#define V(x, y, z, c) FT(&t, x, y, z, c)
+#pragma omp for schedule(dynamic, 1)
   for (long b = 0; b < m->nblocks; b++) {
     orc_mesh_lab(m, vel, b, &t);
     const double h = orc_mesh_h(m, b), h3 = h * h * h;
@@ -586,8 +599,9 @@ void orc_mesh_advdiff_stage_rhs(const orc_mesh *m, const double *vel, double *tm
         }
     }
   }
-#undef V
   tile_free(&t);
+  }
+#undef V
   fix_fluxes(m, &F, tmpV, 3);
   faces_free(&F);
 }
@@ -608,9 +622,12 @@ void orc_mesh_advect_diffuse(const orc_mesh *m, double *vel, double *tmpV, doubl
 static void lhs_kernel_mesh(const orc_mesh *m, const double *pres, double *lhs) { /* KernelLHSPoisson, 9205-9268 */
   faces_t F;
   faces_init(m, &F, 1);
+#define P(x, y, z) FT(&t, x, y, z, 0)
+#pragma omp parallel num_threads(mesh_threads(m))
+  {
   tile_t t;
   tile_init(&t, 1, 0, -1, 2, 0);
-#define P(x, y, z) FT(&t, x, y, z, 0)
+#pragma omp for schedule(dynamic, 1)
   for (long b = 0; b < m->nblocks; b++) {
     orc_mesh_lab(m, pres, b, &t);
     const double h = orc_mesh_h(m, b);
@@ -631,8 +648,9 @@ static void lhs_kernel_mesh(const orc_mesh *m, const double *pres, double *lhs) 
         }
     }
   }
-#undef P
   tile_free(&t);
+  }
+#undef P
   fix_fluxes(m, &F, lhs, 1);
   faces_free(&F);
 }
@@ -669,7 +687,7 @@ void orc_mesh_lhs(const orc_mesh *m, const double *pres, double *lhs, int mc) { 
 }
 
 void orc_mesh_precond(const orc_mesh *m, double *pres) { /* getZImplParallel, main.cpp:14704-14745: invh of each block */
-#pragma omp parallel for
+#pragma omp parallel for num_threads(mesh_threads(m))
   for (long b = 0; b < m->nblocks; b++) orc_precond_block(pres + b * BS3, orc_mesh_h(m, b));
 }
 
@@ -693,11 +711,14 @@ void orc_mesh_solve(const orc_mesh *m, double *lhs, double *pres, orc_solve_info
 void orc_mesh_pressure_rhs(const orc_mesh *m, const double *vel, const double *udef, const double *chi, double *lhs, double dt) {
   faces_t F;
   faces_init(m, &F, 1);
+#define U(x, y, z, c) FT(&t, x, y, z, c)
+#define D(x, y, z, c) FT(&t2, x, y, z, c)
+#pragma omp parallel num_threads(mesh_threads(m))
+  {
   tile_t t, t2;
   tile_init(&t, 3, 1, -1, 2, 0);
   tile_init(&t2, 3, 1, -1, 2, 0);
-#define U(x, y, z, c) FT(&t, x, y, z, c)
-#define D(x, y, z, c) FT(&t2, x, y, z, c)
+#pragma omp for schedule(dynamic, 1)
   for (long b = 0; b < m->nblocks; b++) {
     orc_mesh_lab(m, vel, b, &t);
     orc_mesh_lab(m, udef, b, &t2);
@@ -725,9 +746,10 @@ void orc_mesh_pressure_rhs(const orc_mesh *m, const double *vel, const double *u
         }
     }
   }
+  tile_free(&t); tile_free(&t2);
+  }
 #undef U
 #undef D
-  tile_free(&t); tile_free(&t2);
   fix_fluxes(m, &F, lhs, 1);
   faces_free(&F);
 }
@@ -736,9 +758,12 @@ void orc_mesh_pressure_rhs(const orc_mesh *m, const double *vel, const double *u
 void orc_mesh_div_pressure(const orc_mesh *m, const double *pres, double *tmpV) {
   faces_t F;
   faces_init(m, &F, 3);
+#define P(x, y, z) FT(&t, x, y, z, 0)
+#pragma omp parallel num_threads(mesh_threads(m))
+  {
   tile_t t;
   tile_init(&t, 1, 0, -1, 2, 0);
-#define P(x, y, z) FT(&t, x, y, z, 0)
+#pragma omp for schedule(dynamic, 1)
   for (long b = 0; b < m->nblocks; b++) {
     orc_mesh_lab(m, pres, b, &t);
     const double fac = orc_mesh_h(m, b);
@@ -756,8 +781,9 @@ void orc_mesh_div_pressure(const orc_mesh *m, const double *pres, double *tmpV) 
         }
     }
   }
-#undef P
   tile_free(&t);
+  }
+#undef P
   fix_fluxes(m, &F, tmpV, 3);
   faces_free(&F);
 }
@@ -766,9 +792,12 @@ void orc_mesh_div_pressure(const orc_mesh *m, const double *pres, double *tmpV) 
 void orc_mesh_grad_p(const orc_mesh *m, const double *pres, double *tmpV, double dt) {
   faces_t F;
   faces_init(m, &F, 3);
+#define P(x, y, z) FT(&t, x, y, z, 0)
+#pragma omp parallel num_threads(mesh_threads(m))
+  {
   tile_t t;
   tile_init(&t, 1, 0, -1, 2, 0);
-#define P(x, y, z) FT(&t, x, y, z, 0)
+#pragma omp for schedule(dynamic, 1)
   for (long b = 0; b < m->nblocks; b++) {
     orc_mesh_lab(m, pres, b, &t);
     const double h = orc_mesh_h(m, b), fac = -0.5 * dt * h * h;
@@ -789,8 +818,9 @@ void orc_mesh_grad_p(const orc_mesh *m, const double *pres, double *tmpV, double
         }
     }
   }
-#undef P
   tile_free(&t);
+  }
+#undef P
   fix_fluxes(m, &F, tmpV, 3);
   faces_free(&F);
 }

@@ -345,3 +345,64 @@ def read_tables(path):
     t = raw[:nb * 48].view(np.int64).reshape(nb, 6)
     g = raw[nb * 48:].view(np.float64).reshape(nb, 4)
     return t, g
+
+
+def build_balanced_mesh(bpd, level_max, bc, refine):
+    """Leaves (levels, Zs) of a 2:1-balanced multi-level mesh made without the reference: start from the level-0
+    blocks, split the leaves listed in `refine` = [(level, i, j, k), ...] in that order, and after each split
+    keep splitting coarser leaves until no leaf touches (26-neighbourhood, periodic wrap where the BC is periodic)
+    a leaf more than one level away -- the invariant MeshAdaptation::ValidStates (main.cpp:5330-5492) maintains."""
+    bcs = [BC[b] if isinstance(b, str) else int(b) for b in bc]
+    leaves = {(0, i, j, k) for i in range(bpd[0]) for j in range(bpd[1]) for k in range(bpd[2])}
+
+    def split(leaf):
+        l, i, j, k = leaf
+        assert l + 1 < level_max
+        leaves.remove(leaf)
+        for q in range(8):
+            leaves.add((l + 1, 2 * i + (q & 1), 2 * j + ((q >> 1) & 1), 2 * k + (q >> 2)))
+
+    def covering(l, c):
+        for up in range(l + 1):
+            cand = (l - up, c[0] >> up, c[1] >> up, c[2] >> up)
+            if cand in leaves:
+                return cand
+        return None  # finer leaves there
+
+    def balance():
+        changed = True
+        while changed:
+            changed = False
+            for leaf in sorted(leaves, key=lambda t: -t[0]):
+                l = leaf[0]
+                for code in range(27):
+                    d = (code % 3 - 1, (code // 3) % 3 - 1, code // 9 - 1)
+                    c, ok = [], True
+                    for a in range(3):
+                        n = bpd[a] << l
+                        v = leaf[1 + a] + d[a]
+                        if v < 0 or v >= n:
+                            if bcs[a] != 1:
+                                ok = False
+                            v %= n
+                        c.append(v)
+                    if not ok:
+                        continue
+                    cov = covering(l, c)
+                    if cov is not None and cov[0] < l - 1:
+                        split(cov)
+                        changed = True
+                        break
+                if changed:
+                    break
+
+    for leaf in refine:
+        if tuple(leaf) in leaves:  # may already have been split by the balancing
+            split(tuple(leaf))
+            balance()
+    sfc = lib().orc_sfc_create(int(bpd[0]), int(bpd[1]), int(bpd[2]), int(level_max))
+    out = sorted(leaves)
+    levels = np.array([t[0] for t in out], dtype=np.int32)
+    Zs = np.array([lib().orc_sfc_forward(sfc, t[0], t[1], t[2], t[3]) for t in out], dtype=np.int64)
+    lib().orc_sfc_destroy(sfc)
+    return levels, Zs
