@@ -103,17 +103,27 @@ private:
       }
       device_ready = true;
     }
-    // this round: single-level meshes (every block at the same level)
     const int level = I.empty() ? sim.levelStart : I[0].level;
-    for (const Info &b : I)
-      if (b.level != level) {
-        fprintf(stderr, "cup3d_hip: multi-level (AMR) meshes are not supported by the device path yet\n");
+    bool uniform = true;
+    for (const Info &b : I) uniform = uniform && b.level == level;
+    const int bpd[3] = {sim.bpdx, sim.bpdy, sim.bpdz};
+    const int bc[3] = {(int)sim.BCx_flag, (int)sim.BCy_flag, (int)sim.BCz_flag};  // enum BCflag == CUP3D_BC_*
+    if (uniform) {
+      CUP3D_HIP_CALL(cup3d_grid_create_uniform(bpd, sim.levelMax, level, sim.maxextent, bc, rank, size, &grid));
+    } else {
+      // multi-level mesh after MeshAdaptation: the leaves of m_vInfo; coarse/fine ghosts and flux correction run on the
+      // device (amr.hip).  One rank this round: cross-rank coarse/fine faces need the flux-correction messages of
+      // FluxCorrectionMPI (main.cpp:2825-2935) on RCCL.
+      if (size > 1) {
+        fprintf(stderr, "cup3d_hip: multi-level (AMR) meshes are supported on one rank only\n");
         fflush(0);
         MPI_Abort(sim.comm, 1);
       }
-    const int bpd[3] = {sim.bpdx, sim.bpdy, sim.bpdz};
-    const int bc[3] = {(int)sim.BCx_flag, (int)sim.BCy_flag, (int)sim.BCz_flag};  // enum BCflag == CUP3D_BC_*
-    CUP3D_HIP_CALL(cup3d_grid_create_uniform(bpd, sim.levelMax, level, sim.maxextent, bc, rank, size, &grid));
+      std::vector<int32_t> lv(I.size());
+      std::vector<int64_t> zs(I.size());
+      for (size_t i = 0; i < I.size(); ++i) { lv[i] = I[i].level; zs[i] = I[i].Z; }
+      CUP3D_HIP_CALL(cup3d_grid_create_mesh(bpd, sim.levelMax, sim.maxextent, bc, (long)I.size(), lv.data(), zs.data(), &grid));
+    }
     // the device topology must be the reference's own: same blocks, same order, same h
     const long nb = cup3d_grid_nblocks(grid);
     std::vector<long long> tab(6 * (size_t)nb);
