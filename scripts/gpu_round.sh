@@ -20,6 +20,10 @@ if has probe; then echo "== kernel probes"
   timeout 300 python scripts/kernel_probe.py adv --size 512 --variants ${ADV_VARIANTS:-0,2,3,10} > $OUT/probe_adv_512.jsonl 2>&1 ; cat $OUT/probe_adv_512.jsonl
   timeout 300 python scripts/kernel_probe.py adv --size 256 --variants 0 > $OUT/probe_adv_256.jsonl 2>&1 ; cat $OUT/probe_adv_256.jsonl
   timeout 300 python scripts/kernel_probe.py pre --size 256 > $OUT/probe_pre_256.jsonl 2>&1 ; cat $OUT/probe_pre_256.jsonl; fi
+if has benchq; then echo "== bench 512 (no cpu baseline)"
+  timeout 300 python bench.py --size 512 --steps 5 --warmup 1 --no-cpu --stencil-only > $OUT/benchq_512_stencil.json 2> $OUT/benchq_512_stencil.err ; tail -c 1500 $OUT/benchq_512_stencil.json
+  timeout 600 python bench.py --no-cpu > $OUT/benchq_512.json 2> $OUT/benchq_512.err ; echo "bench rc=$?" ; tail -c 3000 $OUT/benchq_512.json ; tail -3 $OUT/benchq_512.err
+  fi
 if has bench; then echo "== bench 512 stencil-only"
   timeout 300 python bench.py --size 512 --steps 5 --warmup 1 --no-cpu --stencil-only > $OUT/bench_512_stencil.json 2> $OUT/bench_512_stencil.err ; tail -c 1200 $OUT/bench_512_stencil.json
   echo "== bench default (512 full + cpu baseline)"

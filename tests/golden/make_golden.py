@@ -138,8 +138,9 @@ def vortex_field(bpd):
 
 def amr_mesh_script(wd, bpd, passes, rtol=2.0):
     vortex_field(bpd).tofile(os.path.join(wd, "vel_in.bin"))
-    # chi is adapted without data transfer (new blocks hold uninitialised memory): clear it again afterwards
-    return ["zero chi", "loadg vel vel_in.bin", f"amrtol {rtol} 0.01"] + ["adapt"] * passes + ["zero chi"]
+    # chi is adapted without data transfer (new blocks hold uninitialised memory, which GradChiOnTmp would read at the
+    # next adaptMesh, main.cpp:8541-8600): clear it after every pass
+    return ["zero chi", "loadg vel vel_in.bin", f"amrtol {rtol} 0.01"] + ["adapt", "zero chi"] * passes
 
 
 AMR_CASES = [
