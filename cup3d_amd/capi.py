@@ -15,6 +15,7 @@ FIELD_CHI, FIELD_PRES, FIELD_VEL, FIELD_TMPV, FIELD_LHS = 0, 1, 2, 3, 4
 FIELD_NCOMP = {FIELD_CHI: 1, FIELD_PRES: 1, FIELD_VEL: 3, FIELD_TMPV: 3, FIELD_LHS: 1}
 BC = {"freespace": 0, "periodic": 1, "wall": 2}
 NBR_HALO = 0x40000000
+NBR_COARSER = 0x20000000
 
 
 class Cup3dError(RuntimeError):

@@ -862,3 +862,32 @@ double orc_mesh_max_u(const orc_mesh *m, const double *vel, const double uinf[3]
     for (int c = 0; c < 3; c++) { const double a = fabs(vel[3 * i + c] + uinf[c]); if (a > mx) mx = a; }
   return mx;
 }
+
+/* neighbour states of all 27 codes of every block as BlockLab::load sees them (3690-3712): out[b][code] = slot of the
+ * same-level leaf (Exists), -100 - slot of the coarser leaf (CheckCoarser), -3 (CheckFiner), -1 skipped (domain face) */
+void orc_mesh_states(const orc_mesh *m, int *out) {
+  for (long b = 0; b < m->nblocks; b++) {
+    const int l = m->level[b], *idx = &m->index[3 * b];
+    for (int icode = 0; icode < 27; icode++) {
+      const int code[3] = {icode % 3 - 1, (icode / 3) % 3 - 1, icode / 9 - 1};
+      int skipped = 0, nei[3];
+      for (int d = 0; d < 3; d++) {
+        const int n = nblk(m, l, d), skin = idx[d] == 0 || idx[d] == n - 1, skip = idx[d] == 0 ? -1 : 1;
+        if (m->bc[d] != ORC_BC_PERIODIC && code[d] == skip && skin) skipped = 1;
+        nei[d] = idx[d] + code[d];
+      }
+      int v = -1;
+      if (!skipped) {
+        const int st = tree_state(m, l, nei);
+        if (st == 1) v = leaf_at(m, l, nei);
+        else if (st == -1) v = -3;
+        else {
+          int w[3];
+          for (int d = 0; d < 3; d++) { const int n = nblk(m, l, d); w[d] = (((nei[d] % n) + n) % n) >> 1; }
+          v = -100 - leaf_at(m, l - 1, w);
+        }
+      }
+      out[b * 27 + icode] = v;
+    }
+  }
+}

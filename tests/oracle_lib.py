@@ -99,6 +99,7 @@ def lib():
     L.orc_mesh_div_pressure.argtypes = [vp, _dp, _dp]
     L.orc_mesh_grad_p.argtypes = [vp, _dp, _dp, C.c_double]
     L.orc_mesh_project.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.POINTER(SolveInfo)]
+    L.orc_mesh_states.argtypes = [vp, _ip]
     L.orc_mesh_max_u.restype = C.c_double
     L.orc_mesh_max_u.argtypes = [vp, _dp, _dp]
     _lib = L
@@ -272,6 +273,11 @@ class OracleMesh:
 
     def max_u(self, vel, uinf=(0, 0, 0)):
         return lib().orc_mesh_max_u(self.m, vel, np.asarray(uinf, dtype=np.float64))
+
+    def states(self):
+        out = np.zeros((self.nb, 27), dtype=np.int32)
+        lib().orc_mesh_states(self.m, out)
+        return out
 
 
 def restrict_field(fine, coarse, field):

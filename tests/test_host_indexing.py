@@ -155,3 +155,92 @@ def test_compute_fails_loudly_without_gpu():
         cu.device_init(0)
     with pytest.raises(cu.Cup3dError):
         cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=1)
+
+
+# ------------------------------------------------------------------ multi-level meshes (host topology only)
+def _mesh_cases(golden_dir):
+    import os
+    for name in ("amr_periodic_l01", "amr_mixed_l12"):
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        t = g["tables"]
+        yield name, tuple(int(b) for b in g["bpd"]), int(g["level_max"]), tuple(int(b) for b in g["bc"]), t[:, 0].copy(), t[:, 1].copy(), t
+    bpd, lmax, bc = (2, 2, 2), 3, (2, 0, 2)
+    lv, zs = O.build_balanced_mesh(bpd, lmax, bc, [(0, 0, 0, 0), (1, 0, 0, 0)])
+    yield "synthetic_l012", bpd, lmax, bc, lv, zs, None
+
+
+def test_mesh_topology_matches_reference_tables_and_oracle_states(golden_dir):
+    for name, bpd, lmax, bc, lv, zs, tables in _mesh_cases(golden_dir):
+        rng = np.random.default_rng(1)
+        perm = rng.permutation(len(lv))  # leaves may come in any order
+        g = cu.Grid(bpd, lmax, 0, 2 * np.pi, bc, leaves=(lv[perm], zs[perm]))
+        m = O.OracleMesh(bpd, lmax, 2 * np.pi, bc, lv, zs)
+        assert np.array_equal(g.tables, m.tables), name                       # m_vInfo order, index, blockID_2
+        if tables is not None:
+            assert np.array_equal(g.tables, tables), name                     # ... as the reference's adaptMesh left them
+        assert np.array_equal(g.geom[:, 0], np.array([m.h(b) for b in range(m.nb)]))
+        faces, fine, n27 = g.interface()
+        st = m.states()
+        same = st >= 0
+        assert np.array_equal(n27 >= 0, (st >= 0) | (st <= -100))
+        assert np.array_equal(n27[same], st[same])
+        coarser = st <= -100
+        assert np.array_equal(n27[coarser] - cu.capi.NBR_COARSER, -100 - st[coarser])
+        assert np.array_equal(n27 == -3, st == -3) and np.array_equal(n27 == -1, st == -1)
+        # face table: same-level slot, boundary code, or interface face e (numbered in (slot, face) order)
+        nbr = g.neighbours()
+        face_codes = [12, 14, 10, 16, 4, 22]  # x-,x+,y-,y+,z-,z+ in the 27-code numbering
+        e = 0
+        for s in range(g.nblocks):
+            for f in range(6):
+                v = st[s, face_codes[f]]
+                if v >= 0:
+                    assert nbr[s, f] == v
+                elif v == -1:
+                    assert nbr[s, f] == -1 - bc[f >> 1]
+                else:
+                    assert nbr[s, f] == cu.capi.NBR_HALO + e
+                    assert faces[e, 0] == 6 * s + f and faces[e, 1] == (1 if v == -3 else 0)
+                    e += 1
+        assert e == len(faces)
+        # every coarse-side face points at the four opposite fine faces, quadrant by quadrant
+        lev, idx = g.tables[:, 0], g.tables[:, 2:5]
+        for ei, (sf, kind) in enumerate(faces):
+            if kind == 0:
+                assert (fine[ei] == -1).all()
+                continue
+            s, f = sf // 6, sf % 6
+            d, side = f >> 1, f & 1
+            dfast, dslow = (1 if d == 0 else 0), (1 if d == 2 else 2)
+            for B in range(4):
+                fs, ff = faces[fine[ei, B], 0] // 6, faces[fine[ei, B], 0] % 6
+                assert ff == f ^ 1 and faces[fine[ei, B], 1] == 0 and lev[fs] == lev[s] + 1
+                exp = 2 * idx[s].copy()
+                exp[d] += 2 if side else -1
+                exp[dfast] += B % 2
+                exp[dslow] += B // 2
+                n = np.array(bpd) << int(lev[fs])
+                assert np.array_equal(idx[fs], exp % n)
+
+
+def test_mesh_rejects_unbalanced_and_duplicate_leaves():
+    h = C.c_void_p()
+    bpd = np.array([2, 2, 2], dtype=np.int32)
+    bc = np.array([1, 1, 1], dtype=np.int32)
+    lv, zs = O.build_balanced_mesh((2, 2, 2), 3, (1, 1, 1), [(0, 0, 0, 0)])
+    dup = (np.concatenate([lv, lv[:1]]).astype(np.int32), np.concatenate([zs, zs[:1]]).astype(np.int64))
+    assert L.cup3d_grid_create_mesh(bpd, 3, 1.0, bc, len(dup[0]), dup[0], dup[1], C.byref(h)) == -1
+    assert b"duplicate" in L.cup3d_last_error()
+    # split a level-1 leaf twice without balancing: a level-3... (levelMax 4) leaf next to level-0 blocks
+    sfc = O.lib().orc_sfc_create(2, 2, 2, 4)
+    leaves = {(0, i, j, k) for i in range(2) for j in range(2) for k in range(2)}
+    for leaf in [(0, 0, 0, 0), (1, 1, 1, 1)]:
+        leaves.remove(leaf)
+        l, i, j, k = leaf
+        leaves |= {(l + 1, 2 * i + (q & 1), 2 * j + ((q >> 1) & 1), 2 * k + (q >> 2)) for q in range(8)}
+    out = sorted(leaves)
+    lv = np.array([t[0] for t in out], dtype=np.int32)
+    zs = np.array([O.lib().orc_sfc_forward(sfc, *t) for t in out], dtype=np.int64)
+    O.lib().orc_sfc_destroy(sfc)
+    assert L.cup3d_grid_create_mesh(bpd, 4, 1.0, bc, len(lv), lv, zs, C.byref(h)) == -1
+    assert b"2:1" in L.cup3d_last_error()
