@@ -51,4 +51,20 @@ for k, v in acc.items():
 PY
     done
   done; fi
+if has pmc2; then echo "== rocprofv3 PMC passes (one pressure projection at 512^3): FETCH_SIZE, WRITE_SIZE in separate runs"
+  for C in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $ROOT/$OUT/pmc2_$C -o p -- python $ROOT/scripts/kernel_probe.py one --size 512 --kernel solve > $ROOT/$OUT/pmc2_$C.log 2>&1 )
+    for f in $(find $OUT/pmc2_$C -name "*counter_collection.csv" | head -1); do python - "$f" $C <<'PY' | tee -a $OUT/pmc2_summary.txt
+import csv, sys, collections
+f, c = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if r.get("Counter_Name") == c:
+        acc[r["Kernel_Name"][:70]].append(float(r["Counter_Value"]))
+for k, v in sorted(acc.items()):
+    print(c, k, "launches", len(v), "mean_KB", round(sum(v) / len(v), 1))
+PY
+    done
+    rm -rf $OUT/pmc2_$C
+  done; fi
 echo "== done"
