@@ -95,6 +95,7 @@ SIGNATURES = {
     "cup3d_restrict": (C.c_int, [_vp, _vp, C.c_int]),
     "cup3d_prolong": (C.c_int, [_vp, _vp, C.c_int]),
     "cup3d_tag_blocks": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]),
+    "cup3d_compute_vorticity": (C.c_int, [_vp]),
     "cup3d_profile_enable": (C.c_int, [C.c_int]),
     "cup3d_profile_reset": (C.c_int, []),
     "cup3d_profile_read": (C.c_int, [C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),

@@ -215,18 +215,24 @@ int cup3d_tag_blocks(cup3d_sim_t *h, int field, double rtol, double ctol, signed
   int nc;
   const double *f = s->field(field, &nc);
   if (!f) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
-  if (s->grid->multilevel) { set_error("restrict/prolong/tag operate on uniform levels (whole-mesh transitions)"); return CUP3D_EINVAL; }
+  const Grid *gr = s->grid;
   signed char *d_states;
   CUP3D_HIP(hipMalloc((void **)&d_states, (size_t)s->nb));
   {
     ProfileScope ps("tag_blocks");
-    hipLaunchKernelGGL(k_tag, dim3((unsigned)s->nb), dim3(256), 0, stream(), f, nc, rtol, ctol, s->grid->level == s->grid->level_max - 1 ? 1 : 0,
-                       s->grid->level == 0 ? 1 : 0, d_states);
+    // multi-level meshes: the level clamps differ per block and are applied on the host below
+    hipLaunchKernelGGL(k_tag, dim3((unsigned)s->nb), dim3(256), 0, stream(), f, nc, rtol, ctol,
+                       (!gr->multilevel && gr->level == gr->level_max - 1) ? 1 : 0, (!gr->multilevel && gr->level == 0) ? 1 : 0, d_states);
   }
   CUP3D_HIP(hipGetLastError());
   CUP3D_HIP(hipMemcpyAsync(states, d_states, (size_t)s->nb, hipMemcpyDeviceToHost, stream()));
   CUP3D_HIP(hipStreamSynchronize(stream()));
   CUP3D_HIP(hipFree(d_states));
+  if (gr->multilevel)
+    for (int64_t b = 0; b < s->nb; ++b) {  // TagBlocksVector, main.cpp:5207-5211
+      if (states[b] == 1 && gr->blevel[b] == gr->level_max - 1) states[b] = 0;
+      if (states[b] == -1 && gr->blevel[b] == 0) states[b] = 0;
+    }
   return CUP3D_OK;
 }
 

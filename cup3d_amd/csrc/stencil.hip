@@ -96,6 +96,52 @@ __device__ __forceinline__ void load_normal_tile(const GridDev &g, int slot, con
   }
 }
 
+// all three components with ghosts behind all six faces (VectorLab with BlockLabBC: wall negates every component,
+// freespace the one normal to the face, main.cpp:6137-6153, 6384-6394)
+__device__ __forceinline__ void load_vector_tile(const GridDev &g, int slot, const double *__restrict__ f, const double *__restrict__ halo, double *tile) {
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const double *own = f + (size_t)slot * 1536;
+  const int x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    tile[c * kT + tix(x, y, z0)] = own[c * 512 + t];
+    tile[c * kT + tix(x, y, z0 + 4)] = own[c * 512 + 256 + t];
+  }
+  for (int u = wave; u < 18; u += 4) {  // (face, component) units of 64 ghosts
+    const int face = u / 3, c = u - 3 * face;
+    const int n = g.nbr[slot * 6 + face];
+    int nb_cell, own_cell, lds;
+    face1(face, lane, nb_cell, own_cell, lds);
+    double v;
+    if (n >= kNbrHalo) v = halo[((size_t)(n - kNbrHalo) * 3 + c) * 64 + lane];
+    else if (n >= 0) v = f[(size_t)n * 1536 + c * 512 + nb_cell];
+    else { v = own[c * 512 + own_cell]; if (n == -3 || c == (face >> 1)) v = -v; }
+    tile[c * kT + lds] = v;
+  }
+}
+
+// ---- ComputeVorticity (main.cpp:8624-8746): tmpV = curl(vel) * (h^2/2) / h^3.  The reference's face-flux branch is dead code
+// (it reads the BlockCase from the velocity grid's Info, which never has one), so there is nothing to flux-correct.
+__global__ void __launch_bounds__(256) k_vorticity(GridDev g, const double *__restrict__ vel, const double *__restrict__ halo, double *__restrict__ tmpV) {
+  __shared__ double tv[3 * kT];
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  load_vector_tile(g, slot, vel, halo, tv);
+  __syncthreads();
+  const int t = threadIdx.x, x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
+  const double h = block_h(g, slot), inv2h = .5 * h * h, fac = 1.0 / (h * h * h);
+  const double *U = tv, *V = tv + kT, *W = tv + 2 * kT;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int b = tix(x, y, z0 + 4 * k);
+    const size_t o = (size_t)slot * 1536 + k * 256 + t;
+    tmpV[o] = (inv2h * ((W[b + 10] - W[b - 10]) - (V[b + 100] - V[b - 100]))) * fac;
+    tmpV[o + 512] = (inv2h * ((U[b + 100] - U[b - 100]) - (W[b + 1] - W[b - 1]))) * fac;
+    tmpV[o + 1024] = (inv2h * ((V[b + 1] - V[b - 1]) - (U[b + 10] - U[b - 10]))) * fac;
+  }
+}
+
 // ---- KernelLHSPoisson (main.cpp:9205-9215) + the per-block partial of sum(p*h^3) that
 // ComputeLHS needs for the mean constraint (9283-9294)
 __global__ void __launch_bounds__(256) k_lhs(GridDev g, const double *__restrict__ p, const double *__restrict__ halo, double *__restrict__ out,
@@ -330,6 +376,18 @@ int cup3d_div_pressure(cup3d_sim_t *h) {
   hipLaunchKernelGGL(k_div_pressure, dim3(launch_groups(g)), dim3(256), 0, stream(), g, s->pres, s->halo_recv, s->tmpV);
   CUP3D_HIP(hipGetLastError());
   if (s->grid->multilevel) return amr_flux_fix(s, 1, s->tmpV, 3);  // only tmpV.u[0] carries the result
+  return CUP3D_OK;
+}
+
+int cup3d_compute_vorticity(cup3d_sim_t *h) {
+  if (!h) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  int rc = halo_exchange(s, s->vel, 3, 1);
+  if (rc) return rc;
+  GridDev g = s->gdev();
+  ProfileScope ps("vorticity");
+  hipLaunchKernelGGL(k_vorticity, dim3(launch_groups(g)), dim3(256), 0, stream(), g, s->vel, s->halo_recv, s->tmpV);
+  CUP3D_HIP(hipGetLastError());
   return CUP3D_OK;
 }
 

@@ -187,6 +187,13 @@ class AdvectionDiffusion(Operator):
         check(lib().cup3d_advect_diffuse(s.handle, dt, s.nu, s.uinf))
 
 
+class ComputeVorticity(Operator):
+    """ComputeVorticity::operator()(dt), main.cpp:8726-8746: tmpV <- curl(vel) (the input of adaptMesh's tagging)."""
+
+    def __call__(self, dt=0):
+        check(lib().cup3d_compute_vorticity(self.sim.handle))
+
+
 class ExternalForcing(Operator):
     """ExternalForcing::operator()(dt), main.cpp:10581-10596."""
 

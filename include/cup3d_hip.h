@@ -184,8 +184,12 @@ int cup3d_pressure_project(cup3d_sim_t *, double dt, int step, const cup3d_poiss
 int cup3d_restrict(cup3d_sim_t *fine, cup3d_sim_t *coarse, int field);
 /* "prolong": refine_1 + RefineBlocks (5227-5249, 5493-5565): every block of `coarse` -> its eight children in `fine` */
 int cup3d_prolong(cup3d_sim_t *coarse, cup3d_sim_t *fine, int field);
-/* TagLoadedBlock (5566-5582) + level clamps (5207-5211): states[nblocks] in {-1 Compress, 0 Leave, 1 Refine} (enum State, 320) */
+/* TagLoadedBlock (5566-5582) + level clamps (5207-5211): states[nblocks] in {-1 Compress, 0 Leave, 1 Refine} (enum State, 320);
+ * any mesh (uniform or multi-level).  With ComputeVorticity this is the device half of Simulation::adaptMesh's decision input
+ * (15180-15183, obstacle-free: GradChiOnTmp only reads chi); ValidStates' 2:1 balancing of the tags stays on the host. */
 int cup3d_tag_blocks(cup3d_sim_t *, int field, double rtol, double ctol, signed char *states);
+/* ComputeVorticity::operator() (8726-8746, KernelVorticity 8624-8645): tmpV <- curl(vel); any mesh */
+int cup3d_compute_vorticity(cup3d_sim_t *);
 
 /* per-kernel device time accounting (hipEvents on the compute stream) */
 int cup3d_profile_enable(int on);

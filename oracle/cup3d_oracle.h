@@ -106,6 +106,8 @@ void orc_mesh_grad_p(const orc_mesh *, const double *pres, double *tmpV, double 
 void orc_mesh_project(const orc_mesh *, double *vel, double *pres, double *tmpV, double *lhs, const double *chi, double dt, int step,
                       orc_solve_info *);
 double orc_mesh_max_u(const orc_mesh *, const double *vel, const double uinf[3]);
+void orc_mesh_vorticity(const orc_mesh *, const double *vel, double *tmpV); /* ComputeVorticity, main.cpp:8624-8746 */
+void orc_mesh_tag(const orc_mesh *, const double *field, int nc, double rtol, double ctol, signed char *states);
 void orc_mesh_states(const orc_mesh *, int *out27); /* octree states of the 27 neighbour positions of every block */
 #ifdef __cplusplus
 }

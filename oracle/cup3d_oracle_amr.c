@@ -891,3 +891,52 @@ void orc_mesh_states(const orc_mesh *m, int *out) {
     }
   }
 }
+
+/* ComputeVorticity::operator(), main.cpp:8726-8746: KernelVorticity (8624-8724) followed by tmpV *= 1/h^3.
+ * The kernel's face-flux branch (8646-8722) is dead code in the reference: it looks for the BlockCase in `info.auxiliary` of
+ * the VELOCITY grid's Info, which is always nullptr (Info::setup 395; only flux-corrected grids get one, and vel never is
+ * one), so the faces stay zero and FluxCorrectionMPI adds 0 to the coarse cells: the result is the plain curl of the ghosted
+ * tile.  (Confirmed against the compiled reference on two- and three-level meshes.)  A uniform grid is the single-level
+ * special case of a mesh. */
+void orc_mesh_vorticity(const orc_mesh *m, const double *vel, double *tmpV) {
+#define L(x, y, z, c) FT(&t, x, y, z, c)
+#pragma omp parallel num_threads(mesh_threads(m))
+  {
+  tile_t t;
+  tile_init(&t, 3, 1, -1, 2, 0);
+#pragma omp for schedule(dynamic, 1)
+  for (long b = 0; b < m->nblocks; b++) {
+    orc_mesh_lab(m, vel, b, &t);
+    const double h = orc_mesh_h(m, b), inv2h = .5 * h * h, fac = 1.0 / (h * h * h);
+    for (int z = 0; z < BS; z++)
+      for (int y = 0; y < BS; y++)
+        for (int x = 0; x < BS; x++) {
+          double *o = tmpV + (b * BS3 + (z * BS + y) * BS + x) * 3;
+          o[0] = inv2h * ((L(x, y + 1, z, 2) - L(x, y - 1, z, 2)) - (L(x, y, z + 1, 1) - L(x, y, z - 1, 1)));
+          o[1] = inv2h * ((L(x, y, z + 1, 0) - L(x, y, z - 1, 0)) - (L(x + 1, y, z, 2) - L(x - 1, y, z, 2)));
+          o[2] = inv2h * ((L(x + 1, y, z, 1) - L(x - 1, y, z, 1)) - (L(x, y + 1, z, 0) - L(x, y - 1, z, 0)));
+          for (int c = 0; c < 3; c++) o[c] *= fac;
+        }
+  }
+  tile_free(&t);
+  }
+#undef L
+}
+
+/* TagLoadedBlock (5566-5582) with the level clamps of TagBlocksVector (5207-5211) on every block of a mesh */
+void orc_mesh_tag(const orc_mesh *m, const double *f, int nc, double rtol, double ctol, signed char *states) {
+  for (long b = 0; b < m->nblocks; b++) {
+    double Linf = 0.0;
+    for (int i = 0; i < BS3; i++) {
+      const double *e = f + ((long)b * BS3 + i) * nc;
+      const double mag = nc == 3 ? sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) : e[0]; /* magnitude(), 5783 / 5873-5879 */
+      Linf = fmax(Linf, fabs(mag));
+    }
+    signed char s = 0;
+    if (Linf > rtol) s = 1;
+    else if (Linf < ctol) s = -1;
+    if (s == 1 && m->level[b] == m->level_max - 1) s = 0;
+    if (s == -1 && m->level[b] == 0) s = 0;
+    states[b] = s;
+  }
+}

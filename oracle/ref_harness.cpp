@@ -298,6 +298,21 @@ int main(int argc, char **argv) {
       for (auto &inf : sd.velInfo()) st.push_back((signed char)sd.vel_amr->TagLoadedBlock(sd.vel->getInfoAll(inf.level, inf.Z)));
       sd.vel_amr->tolerance_for_refinement = r0; sd.vel_amr->tolerance_for_compression = c0;
       write_file(path, st.data(), st.size());
+    } else if (cmd == "tagtmp") {
+      /* what tmpV_amr->Tag() decides per block (TagBlocksVector 5196-5226: TagLoadedBlock + the level clamps), before
+         ValidStates balances the result -> int8 file */
+      double rt, ct; std::string path; script >> rt >> ct >> path;
+      const double r0 = sd.tmpV_amr->tolerance_for_refinement, c0 = sd.tmpV_amr->tolerance_for_compression;
+      sd.tmpV_amr->tolerance_for_refinement = rt; sd.tmpV_amr->tolerance_for_compression = ct;
+      std::vector<signed char> st;
+      for (auto &inf : sd.tmpVInfo()) {
+        int s = (int)sd.tmpV_amr->TagLoadedBlock(sd.tmpV->getInfoAll(inf.level, inf.Z));
+        if (s == (int)Refine && inf.level == sd.levelMax - 1) s = (int)Leave;
+        if (s == (int)Compress && inf.level == 0) s = (int)Leave;
+        st.push_back((signed char)(s == (int)Refine ? 1 : (s == (int)Compress ? -1 : 0)));
+      }
+      sd.tmpV_amr->tolerance_for_refinement = r0; sd.tmpV_amr->tolerance_for_compression = c0;
+      write_file(path, st.data(), st.size());
     } else if (cmd == "rep") {
       script >> rep;
     } else if (cmd == "op") {
@@ -310,6 +325,7 @@ int main(int argc, char **argv) {
         const double t0 = now();
         if (op == "advdiff") { sd.dt = arg; if (hip_adv) (*hip_adv)(arg); else advdiff(arg); }
         else if (op == "lhs") lhsop(0);
+        else if (op == "vorticity") { ComputeVorticity w(sd); w(0); } /* first half of adaptMesh, main.cpp:15180-15181 */
         else if (op == "precond") {
 #pragma omp parallel
           { poisson_kernels::getZImplParallel(sd.presInfo()); }

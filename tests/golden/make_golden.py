@@ -192,6 +192,39 @@ def amr_case(name, bpd, lmax, bc, passes, seed, full):
     print(name, "blocks", nb, "levels", sorted(set(t1[:, 0].tolist())), "solve iters", out["solve_iters"], "project iters", out["pr_iters"])
 
 
+def vorticity_cases():
+    """ComputeVorticity + the per-block tags of tmpV_amr->Tag() (the decision input of adaptMesh) on the velocity inputs of
+    existing cases: one uniform grid and the two multi-level meshes.  Stores only the outputs."""
+    out = {}
+    for name in ("f16_mixed", "amr_periodic_l01", "amr_mixed_l12"):
+        g = np.load(os.path.join(HERE, name + ".npz"))
+        bpd, lmax = tuple(int(b) for b in g["bpd"]), int(g["level_max"])
+        bc = tuple(O.BC_NAMES[int(b)] for b in g["bc"])
+        wd = O.tempfile.mkdtemp(prefix="golden_")
+        if name.startswith("amr"):
+            passes = [c for c in AMR_CASES if c[0] == name][0][4]
+            pre, lstart = amr_mesh_script(wd, bpd, passes), 0
+            g["vel_in"].tofile(os.path.join(wd, "v.bin"))
+            pre += ["loadb vel v.bin"]
+        else:
+            lstart = int(g["level"])
+            g["vel_in"].tofile(os.path.join(wd, "v.bin"))
+            pre = ["zero chi", "loadg vel v.bin"]
+        args = O.ref_args(bpd, lmax, lstart, EXT, bc)
+        recs, wd = O.run_ref(pre + ["tables t.bin", "op vorticity", "dump tmpV w.bin"], args, threads=1, workdir=wd)
+        t, _ = O.read_tables(os.path.join(wd, "t.bin"))
+        assert np.array_equal(t, g["tables"]), name
+        w = O.read_blocks(os.path.join(wd, "w.bin"), len(t), 3)
+        linf = np.sqrt((w ** 2).sum(axis=-1)).reshape(len(t), -1).max(axis=1)
+        rt, ct = float(np.quantile(linf, 0.6)), float(np.quantile(linf, 0.3))  # a mix of Refine / Leave / Compress
+        recs, wd = O.run_ref(pre + ["op vorticity", f"tagtmp {rt!r} {ct!r} tags.bin"], args, threads=1, workdir=wd)
+        out[name + "_vort"] = w
+        out[name + "_tags"] = np.fromfile(os.path.join(wd, "tags.bin"), dtype=np.int8)
+        out[name + "_tol"] = np.array([rt, ct])
+        print(name, "vorticity max", np.abs(out[name + "_vort"]).max(), "tags", {int(k): int((out[name + "_tags"] == k).sum()) for k in (-1, 0, 1)})
+    np.savez_compressed(os.path.join(HERE, "vorticity.npz"), **out)
+
+
 def sfc_cases():
     out = {}
     for bpd, lmax in SFC_CASES:
@@ -212,3 +245,4 @@ if __name__ == "__main__":
     for c in FIELD_CASES:
         field_case(*c)
     traj_case()
+    vorticity_cases()

@@ -100,6 +100,8 @@ def lib():
     L.orc_mesh_grad_p.argtypes = [vp, _dp, _dp, C.c_double]
     L.orc_mesh_project.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.POINTER(SolveInfo)]
     L.orc_mesh_states.argtypes = [vp, _ip]
+    L.orc_mesh_vorticity.argtypes = [vp, _dp, _dp]
+    L.orc_mesh_tag.argtypes = [vp, _dp, C.c_int, C.c_double, C.c_double, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]
     L.orc_mesh_max_u.restype = C.c_double
     L.orc_mesh_max_u.argtypes = [vp, _dp, _dp]
     _lib = L
@@ -273,6 +275,17 @@ class OracleMesh:
 
     def max_u(self, vel, uinf=(0, 0, 0)):
         return lib().orc_mesh_max_u(self.m, vel, np.asarray(uinf, dtype=np.float64))
+
+    def vorticity(self, vel):
+        out = np.zeros_like(vel)
+        lib().orc_mesh_vorticity(self.m, np.ascontiguousarray(vel), out)
+        return out
+
+    def tag(self, field, rtol, ctol):
+        nc = 3 if field.ndim == 5 else 1
+        st = np.zeros(self.nb, dtype=np.int8)
+        lib().orc_mesh_tag(self.m, np.ascontiguousarray(field), nc, rtol, ctol, st)
+        return st
 
     def states(self):
         out = np.zeros((self.nb, 27), dtype=np.int32)

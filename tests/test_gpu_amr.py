@@ -122,6 +122,15 @@ def test_stencil_operators_bitexact(golden_dir, name):
     check(lib().cup3d_grad_p(sim.handle, dt))
     assert np.array_equal(sim.download("tmpV"), m.grad_p(f["pres"], dt))
     assert sim_max_u(sim, uinf) == m.max_u(f["vel"], uinf)
+    # adaptMesh's decision input: ComputeVorticity -> tmpV, then the per-block tags (TagLoadedBlock + level clamps)
+    sim.upload("vel", f["vel"])
+    cu.ComputeVorticity(sim)(0)
+    w = m.vorticity(f["vel"])
+    assert np.array_equal(sim.download("tmpV"), w)
+    linf = np.sqrt((w ** 2).sum(axis=-1)).reshape(m.nb, -1).max(axis=1)
+    rt, ct = float(np.quantile(linf, 0.6)), float(np.quantile(linf, 0.3))
+    tags = cu.MeshAdaptation(rt, ct).Tag(sim, "tmpV")
+    assert np.array_equal(tags, m.tag(w, rt, ct)) and len(set(tags.tolist())) >= 2
 
 
 def sim_max_u(sim, uinf):

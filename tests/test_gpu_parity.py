@@ -139,6 +139,18 @@ def test_golden_stencil_operators_bit_exact(golden_dir, name):
     sim.upload("chi", g.to_blocks(z["chi_in"]))
     cu.capi.check(cu.lib().cup3d_pressure_rhs(sim.handle, dt))
     assert np.array_equal(sim.download("lhs"), z["rhs"])
+    # ComputeVorticity + block tags (the decision input of adaptMesh); a uniform grid is a one-level mesh for the oracle
+    sim.upload("vel", vel)
+    cu.ComputeVorticity(sim)(0)
+    t = z["tables"]
+    m = O.OracleMesh(tuple(z["bpd"]), int(z["level_max"]), float(z["extent"]), tuple(int(b) for b in z["bc"]), t[:, 0], t[:, 1])
+    w = m.vorticity(vel)
+    assert np.array_equal(sim.download("tmpV"), w)
+    if name == "f16_mixed":
+        assert np.array_equal(w, load(golden_dir, "vorticity")["f16_mixed_vort"])  # ... and the reference's own output
+    linf = np.sqrt((w ** 2).sum(axis=-1)).reshape(m.nb, -1).max(axis=1)
+    rt, ct = float(np.quantile(linf, 0.6)), float(np.quantile(linf, 0.3))
+    assert np.array_equal(cu.MeshAdaptation(rt, ct).Tag(sim, "tmpV"), m.tag(w, rt, ct))
 
 
 @pytest.mark.parametrize("block_solver", [0, 1])
