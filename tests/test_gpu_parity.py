@@ -224,6 +224,34 @@ def test_trajectory_against_reference(golden_dir, block_solver):
         assert_fields_close(sim.download("pres"), z["pres"][n], max(1e-3, np.abs(z["pres"][n]).max()), "pressure")
 
 
+def test_trajectory_64_cubed_ten_steps():
+    """a 64^3 Taylor-Green trajectory, 10 full steps of the reference's loop (calcMaxTimestep,
+    AdvectionDiffusion, ExternalForcing, PressureProjection), device vs oracle, both solving to 1e-9 / 1e-8 (below that the
+    reference's BiCGSTAB stagnates at this size and runs into its 1000-iteration cap)."""
+    bpd, lmax, level, ext, nu, cfl, rampup, umax = (1, 1, 1), 4, 3, 2 * np.pi, 0.01, 0.3, 4, 1.0
+    bc = ("periodic", "periodic", "wall")
+    o = O.OracleGrid(bpd, lmax, level, ext, bc)
+    sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=lmax, levelStart=level, extent=ext, nu=nu, CFL=cfl, rampup=rampup,
+                            uMax_forced=umax, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], poissonTol=1e-9, poissonTolRel=1e-8)
+    vel = o.taylor_green([ext] * 3, umax)
+    pres = np.zeros((o.nb, 8, 8, 8))
+    sim.upload("vel", vel)
+    S = cu.Simulation(sim)
+    dt, coefU = 0.0, np.array([1.5, -2.0, 0.5])
+    for n in range(10):
+        dt = O.lib().orc_calc_dt(o.h, o.max_u(vel), nu, cfl, n, rampup, dt, coefU)
+        dt_dev = S.calcMaxTimestep()
+        assert abs(dt_dev - dt) <= 1e-9 * dt
+        S.advance(dt_dev)
+        tmpV = np.zeros_like(vel)
+        o.advect_diffuse(vel, tmpV, dt, nu)
+        O.lib().orc_external_forcing(o.g, vel, umax, nu, ext, dt)
+        info, _, _ = o.project(vel, pres, dt, n, tol=1e-9, tol_rel=1e-8)
+        assert iters_close(sim.last_poisson.iterations, info.iters)
+    assert np.abs(sim.download("vel") - vel).max() <= 1e-7
+    assert np.abs(sim.download("pres") - pres).max() <= 1e-5 * max(np.abs(pres).max(), 1e-12)
+
+
 @pytest.mark.parametrize("bpd,lmax,level,bc", [
     ((4, 4, 4), 1, 0, ("periodic", "periodic", "periodic")),
     ((1, 1, 1), 3, 2, ("wall", "wall", "wall")),
