@@ -108,7 +108,12 @@ void orc_mesh_project(const orc_mesh *, double *vel, double *pres, double *tmpV,
 double orc_mesh_max_u(const orc_mesh *, const double *vel, const double uinf[3]);
 void orc_mesh_vorticity(const orc_mesh *, const double *vel, double *tmpV); /* ComputeVorticity, main.cpp:8624-8746 */
 void orc_mesh_tag(const orc_mesh *, const double *field, int nc, double rtol, double ctol, signed char *states);
-void orc_mesh_states(const orc_mesh *, int *out27); /* octree states of the 27 neighbour positions of every block */
+void orc_mesh_states(const orc_mesh *, int *out27);
+/* mesh adaptation (one rank): ValidStates 5330-5492 (in/out states), the leaf set after Adapt 5086-5159, and the field data
+ * on the adapted mesh (RefineBlocks 5493-5565 from the old mesh's tensorial tiles, compress 5272-5329, copies) */
+void orc_mesh_valid_states(const orc_mesh *, signed char *states);
+long orc_mesh_adapted_leaves(const orc_mesh *, const signed char *states, int *levels, long long *Zs);
+void orc_mesh_transfer(const orc_mesh *old_mesh, const orc_mesh *new_mesh, const double *f_old, double *f_new, int nc, int is_vector); /* octree states of the 27 neighbour positions of every block */
 #ifdef __cplusplus
 }
 #endif

@@ -940,3 +940,167 @@ void orc_mesh_tag(const orc_mesh *m, const double *f, int nc, double rtol, doubl
     states[b] = s;
   }
 }
+
+/* ======================= mesh adaptation on multi-level meshes ======================= */
+/* MeshAdaptation::ValidStates, main.cpp:5330-5492, one rank (UpdateBoundary is a no-op then): in/out states[nb] in
+ * {-1 Compress, 0 Leave, 1 Refine}, m_vInfo order.  Refinement propagates to coarser neighbours level by level (finest
+ * first), a block next to finer blocks or to a refining same-level block may not compress, and an octet compresses only
+ * if all eight siblings exist and agree. */
+void orc_mesh_valid_states(const orc_mesh *m, signed char *st) {
+  const int lmax = m->level_max;
+  for (long b = 0; b < m->nblocks; b++)
+    if ((st[b] == 1 && m->level[b] == lmax - 1) || (st[b] == -1 && m->level[b] == 0)) st[b] = 0;
+  for (int lv = lmax - 1; lv >= 0; lv--) {
+    for (long b = 0; b < m->nblocks; b++) {
+      if (!(m->level[b] == lv && st[b] != 1 && m->level[b] != lmax - 1)) continue;
+      const int *idx = &m->index[3 * b];
+      for (int icode = 0; icode < 27; icode++) {
+        if (st[b] == 1) break;
+        if (icode == 13) continue;
+        const int code[3] = {icode % 3 - 1, (icode / 3) % 3 - 1, (icode / 9) % 3 - 1};
+        int skipped = 0, nei[3];
+        for (int d = 0; d < 3; d++) {
+          const int n = nblk(m, lv, d), skin = idx[d] == 0 || idx[d] == n - 1, skip = idx[d] == 0 ? -1 : 1;
+          if (m->bc[d] != ORC_BC_PERIODIC && code[d] == skip && skin) skipped = 1;
+          nei[d] = idx[d] + code[d];
+        }
+        if (skipped) continue;
+        if (tree_state(m, lv, nei) != -1) continue; /* CheckFiner */
+        if (st[b] == -1) st[b] = 0;
+        const int tmp = abs(code[0]) + abs(code[1]) + abs(code[2]);
+        const int Bstep = tmp == 2 ? 3 : (tmp == 3 ? 4 : 1);
+        for (int B = 0; B <= 3; B += Bstep) {
+          const int aux = (abs(code[0]) == 1) ? (B % 2) : (B / 2);
+          const int fi[3] = {2 * idx[0] + (code[0] > 0 ? code[0] : 0) + code[0] + (B % 2) * (1 - abs(code[0]) > 0 ? 1 - abs(code[0]) : 0),
+                             2 * idx[1] + (code[1] > 0 ? code[1] : 0) + code[1] + aux * (1 - abs(code[1]) > 0 ? 1 - abs(code[1]) : 0),
+                             2 * idx[2] + (code[2] > 0 ? code[2] : 0) + code[2] + (B / 2) * (1 - abs(code[2]) > 0 ? 1 - abs(code[2]) : 0)};
+          const int fb = leaf_at(m, lv + 1, fi);
+          if (fb >= 0 && st[fb] == 1) { st[b] = 1; break; }
+        }
+      }
+    }
+    if (lv == 0) break;
+    for (long b = 0; b < m->nblocks; b++) {
+      if (!(m->level[b] == lv && st[b] == -1)) continue;
+      const int *idx = &m->index[3 * b];
+      for (int icode = 0; icode < 27; icode++) {
+        if (icode == 13) continue;
+        const int code[3] = {icode % 3 - 1, (icode / 3) % 3 - 1, (icode / 9) % 3 - 1};
+        int skipped = 0, nei[3];
+        for (int d = 0; d < 3; d++) {
+          const int n = nblk(m, lv, d), skin = idx[d] == 0 || idx[d] == n - 1, skip = idx[d] == 0 ? -1 : 1;
+          if (m->bc[d] != ORC_BC_PERIODIC && code[d] == skip && skin) skipped = 1;
+          nei[d] = idx[d] + code[d];
+        }
+        if (skipped) continue;
+        const int nb_ = leaf_at(m, lv, nei);
+        if (nb_ >= 0 && st[nb_] == 1) { st[b] = 0; break; }
+      }
+    }
+  }
+  /* sibling agreement, 5451-5491 (the reference walks the blocks sequentially and clears the octet through the
+   * all-blocks table; the net effect is: an octet keeps Compress only if all eight siblings exist and are Compress) */
+  for (long b = 0; b < m->nblocks; b++) {
+    if (st[b] != -1) continue;
+    const int l = m->level[b], *idx = &m->index[3 * b];
+    int all = 1;
+    for (int q = 0; q < 8 && all; q++) {
+      const int s[3] = {2 * (idx[0] / 2) + (q & 1), 2 * (idx[1] / 2) + ((q >> 1) & 1), 2 * (idx[2] / 2) + (q >> 2)};
+      const int sb = leaf_at(m, l, s);
+      if (sb < 0 || st[sb] != -1) all = 0;
+    }
+    if (!all) st[b] = -2; /* marked; cleared below so that the test above keeps seeing the original states */
+  }
+  for (long b = 0; b < m->nblocks; b++)
+    if (st[b] == -2) st[b] = 0;
+}
+
+/* the leaf set after MeshAdaptation::Adapt (5086-5159) applied the (valid) states: Refine -> eight children, an octet of
+ * Compress -> its parent, Leave -> unchanged.  levels/Zs must hold nblocks + 7*nrefine entries; returns the new count. */
+long orc_mesh_adapted_leaves(const orc_mesh *m, const signed char *st, int *levels, long long *Zs) {
+  long n = 0;
+  for (long b = 0; b < m->nblocks; b++) {
+    const int l = m->level[b], *idx = &m->index[3 * b];
+    if (st[b] == 1) {
+      for (int q = 0; q < 8; q++) {
+        levels[n] = l + 1;
+        Zs[n++] = orc_sfc_forward(m->sfc, l + 1, 2 * idx[0] + (q & 1), 2 * idx[1] + ((q >> 1) & 1), 2 * idx[2] + (q >> 2));
+      }
+    } else if (st[b] == -1) {
+      if (idx[0] % 2 == 0 && idx[1] % 2 == 0 && idx[2] % 2 == 0) {
+        levels[n] = l - 1;
+        Zs[n++] = orc_sfc_forward(m->sfc, l - 1, idx[0] / 2, idx[1] / 2, idx[2] / 2);
+      }
+    } else {
+      levels[n] = l;
+      Zs[n++] = m->Z[b];
+    }
+  }
+  return n;
+}
+
+/* field data on the adapted mesh (refine_1 + RefineBlocks 5227-5249, 5493-5565 from the parent's tensorial [-1,2) tile on
+ * the OLD mesh; compress 5272-5329; unchanged blocks copied) */
+void orc_mesh_transfer(const orc_mesh *mo, const orc_mesh *mn, const double *fo, double *fn, int nc, int is_vector) {
+  tile_t t;
+  tile_init(&t, nc, is_vector, -1, 2, 1);
+#define Lb(x, y, z) FT(&t, x, y, z, c)
+  for (long b = 0; b < mn->nblocks; b++) {
+    const int l = mn->level[b], *idx = &mn->index[3 * b];
+    double *out = fn + b * BS3 * nc;
+    const int same = leaf_at(mo, l, idx);
+    if (same >= 0) { memcpy(out, fo + (long)same * BS3 * nc, BS3 * nc * sizeof(double)); continue; }
+    const int pidx[3] = {idx[0] >> 1, idx[1] >> 1, idx[2] >> 1};
+    const int par = l > 0 ? leaf_at(mo, l - 1, pidx) : -1;
+    if (par >= 0) { /* this block is child (I,J,K) of a refined parent */
+      const int I = idx[0] & 1, J = idx[1] & 1, K = idx[2] & 1;
+      orc_mesh_lab(mo, fo, par, &t);
+#define B(i, j, k) out[(((k) * BS + (j)) * BS + (i)) * nc + c]
+      for (int k = 0; k < BS; k += 2)
+        for (int j = 0; j < BS; j += 2)
+          for (int i = 0; i < BS; i += 2)
+            for (int c = 0; c < nc; c++) {
+              const int x = i / 2 + 4 * I, y = j / 2 + 4 * J, z = k / 2 + 4 * K;
+              const double dudx = 0.5 * (Lb(x + 1, y, z) - Lb(x - 1, y, z));
+              const double dudy = 0.5 * (Lb(x, y + 1, z) - Lb(x, y - 1, z));
+              const double dudz = 0.5 * (Lb(x, y, z + 1) - Lb(x, y, z - 1));
+              const double dudx2 = (Lb(x + 1, y, z) + Lb(x - 1, y, z)) - 2.0 * Lb(x, y, z);
+              const double dudy2 = (Lb(x, y + 1, z) + Lb(x, y - 1, z)) - 2.0 * Lb(x, y, z);
+              const double dudz2 = (Lb(x, y, z + 1) + Lb(x, y, z - 1)) - 2.0 * Lb(x, y, z);
+              const double dudxdy = 0.25 * ((Lb(x + 1, y + 1, z) + Lb(x - 1, y - 1, z)) - (Lb(x + 1, y - 1, z) + Lb(x - 1, y + 1, z)));
+              const double dudxdz = 0.25 * ((Lb(x + 1, y, z + 1) + Lb(x - 1, y, z - 1)) - (Lb(x + 1, y, z - 1) + Lb(x - 1, y, z + 1)));
+              const double dudydz = 0.25 * ((Lb(x, y + 1, z + 1) + Lb(x, y - 1, z - 1)) - (Lb(x, y + 1, z - 1) + Lb(x, y - 1, z + 1)));
+              const double u = Lb(x, y, z), q2 = 0.03125 * (dudx2 + dudy2 + dudz2);
+              B(i, j, k) = u + 0.25 * (-(1.0) * dudx - dudy - dudz) + q2 + 0.0625 * (dudxdy + dudxdz + dudydz);
+              B(i + 1, j, k) = u + 0.25 * (dudx - dudy - dudz) + q2 + 0.0625 * (-(1.0) * dudxdy - dudxdz + dudydz);
+              B(i, j + 1, k) = u + 0.25 * (-(1.0) * dudx + dudy - dudz) + q2 + 0.0625 * (-(1.0) * dudxdy + dudxdz - dudydz);
+              B(i + 1, j + 1, k) = u + 0.25 * (dudx + dudy - dudz) + q2 + 0.0625 * (dudxdy - dudxdz - dudydz);
+              B(i, j, k + 1) = u + 0.25 * (-(1.0) * dudx - dudy + dudz) + q2 + 0.0625 * (dudxdy - dudxdz - dudydz);
+              B(i + 1, j, k + 1) = u + 0.25 * (dudx - dudy + dudz) + q2 + 0.0625 * (-(1.0) * dudxdy + dudxdz - dudydz);
+              B(i, j + 1, k + 1) = u + 0.25 * (-(1.0) * dudx + dudy + dudz) + q2 + 0.0625 * (-(1.0) * dudxdy - dudxdz + dudydz);
+              B(i + 1, j + 1, k + 1) = u + 0.25 * (dudx + dudy + dudz) + q2 + 0.0625 * (dudxdy + dudxdz + dudydz);
+            }
+#undef B
+      continue;
+    }
+    /* parent of a compressed octet */
+    for (int q = 0; q < 8; q++) {
+      const int I = q & 1, J = (q >> 1) & 1, K = q >> 2;
+      const int ci[3] = {2 * idx[0] + I, 2 * idx[1] + J, 2 * idx[2] + K};
+      const int cb = leaf_at(mo, l + 1, ci);
+      if (cb < 0) { fprintf(stderr, "orc_mesh_transfer: block without a source\n"); abort(); }
+      const double *src = fo + (long)cb * BS3 * nc;
+#define S(i, j, k, c) src[(((k) * BS + (j)) * BS + (i)) * nc + (c)]
+      for (int k = 0; k < BS; k += 2)
+        for (int j = 0; j < BS; j += 2)
+          for (int i = 0; i < BS; i += 2)
+            for (int c = 0; c < nc; c++)
+              out[(((k / 2 + 4 * K) * BS + (j / 2 + 4 * J)) * BS + (i / 2 + 4 * I)) * nc + c] =
+                  0.125 * ((S(i, j, k, c) + S(i + 1, j + 1, k + 1, c)) + (S(i + 1, j, k, c) + S(i, j + 1, k + 1, c)) +
+                           (S(i, j + 1, k, c) + S(i + 1, j, k + 1, c)) + (S(i + 1, j + 1, k, c) + S(i, j, k + 1, c)));
+#undef S
+    }
+  }
+#undef Lb
+  tile_free(&t);
+}

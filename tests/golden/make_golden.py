@@ -225,6 +225,43 @@ def vorticity_cases():
     np.savez_compressed(os.path.join(HERE, "vorticity.npz"), **out)
 
 
+def octet_fields(t, seed):
+    """Block-ordered random fields whose amplitude is shared by the eight siblings of an octet (and scaled with the block
+    size), so that whole octets get the same vorticity tag and compression survives ValidStates."""
+    rng = np.random.default_rng(seed)
+    amp = {}
+    a = np.array([amp.setdefault((int(l), int(i) // 2, int(j) // 2, int(k) // 2), rng.choice([0.02, 0.3, 1.0])) for l, _, i, j, k, _ in t])
+    nb = len(t)
+    vel = rng.uniform(-1, 1, (nb, 8, 8, 8, 3)) * (a / 2.0 ** t[:, 0])[:, None, None, None, None]
+    return vel, rng.uniform(-1, 1, (nb, 8, 8, 8))
+
+
+def amr_adapt_case(name, bpd, lmax, bc, passes, seed, qr=0.75, qc=0.4):
+    """One full Simulation::adaptMesh (main.cpp:15179-15194) of the reference on a multi-level mesh: vorticity tags,
+    ValidStates, refine / compress of vel and pres."""
+    wd = O.tempfile.mkdtemp(prefix="golden_")
+    pre = amr_mesh_script(wd, bpd, passes)
+    args = O.ref_args(bpd, lmax, 0, EXT, bc)
+    _, wd = O.run_ref(pre + ["tables t.bin"], args, threads=1, workdir=wd)
+    t, _ = O.read_tables(os.path.join(wd, "t.bin"))
+    vel, pres = octet_fields(t, seed)
+    vel.tofile(os.path.join(wd, "velb.bin"))
+    pres.tofile(os.path.join(wd, "presb.bin"))
+    _, wd = O.run_ref(pre + ["loadb vel velb.bin", "op vorticity", "dump tmpV w.bin"], args, threads=1, workdir=wd)
+    w = O.read_blocks(os.path.join(wd, "w.bin"), len(t), 3)
+    linf = np.sqrt((w ** 2).sum(axis=-1)).reshape(len(t), -1).max(axis=1)
+    rt, ct = float(np.quantile(linf, qr)), float(np.quantile(linf, qc))
+    _, wd = O.run_ref(pre + ["loadb vel velb.bin", "loadb pres presb.bin", "op vorticity", f"tagtmp {rt!r} {ct!r} tags.bin", f"amrtol {rt!r} {ct!r}",
+                             "adapt", "tables t2.bin", "dump vel v2.bin", "dump pres p2.bin"], args, threads=1, workdir=wd)
+    t2, _ = O.read_tables(os.path.join(wd, "t2.bin"))
+    tags = np.fromfile(os.path.join(wd, "tags.bin"), dtype=np.int8)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), bpd=np.array(bpd), level_max=lmax, bc=np.array([O.BC[b] for b in bc]), extent=EXT,
+                        tables=t, vel_in=vel, pres_in=pres, tol=np.array([rt, ct]), tags=tags, tables_new=t2,
+                        vel_new=O.read_blocks(os.path.join(wd, "v2.bin"), len(t2), 3), pres_new=O.read_blocks(os.path.join(wd, "p2.bin"), len(t2), 1))
+    print(name, "blocks", len(t), "->", len(t2), "tags", {int(k): int((tags == k).sum()) for k in (-1, 0, 1)},
+          "levels", sorted(set(t[:, 0].tolist())), "->", sorted(set(t2[:, 0].tolist())))
+
+
 def sfc_cases():
     out = {}
     for bpd, lmax in SFC_CASES:
@@ -242,6 +279,7 @@ if __name__ == "__main__":
     adapt_cases()
     for c in AMR_CASES:
         amr_case(*c)
+    amr_adapt_case("amr_adapt_mixed", (2, 2, 2), 3, ("freespace", "wall", "periodic"), 2, 12)
     for c in FIELD_CASES:
         field_case(*c)
     traj_case()

@@ -100,6 +100,11 @@ def lib():
     L.orc_mesh_grad_p.argtypes = [vp, _dp, _dp, C.c_double]
     L.orc_mesh_project.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.POINTER(SolveInfo)]
     L.orc_mesh_states.argtypes = [vp, _ip]
+    _bp = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
+    L.orc_mesh_valid_states.argtypes = [vp, _bp]
+    L.orc_mesh_adapted_leaves.restype = C.c_long
+    L.orc_mesh_adapted_leaves.argtypes = [vp, _bp, _ip, _lp]
+    L.orc_mesh_transfer.argtypes = [vp, vp, _dp, _dp, C.c_int, C.c_int]
     L.orc_mesh_vorticity.argtypes = [vp, _dp, _dp]
     L.orc_mesh_tag.argtypes = [vp, _dp, C.c_int, C.c_double, C.c_double, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]
     L.orc_mesh_max_u.restype = C.c_double
@@ -286,6 +291,25 @@ class OracleMesh:
         st = np.zeros(self.nb, dtype=np.int8)
         lib().orc_mesh_tag(self.m, np.ascontiguousarray(field), nc, rtol, ctol, st)
         return st
+
+    def valid_states(self, tags):
+        st = np.ascontiguousarray(tags, dtype=np.int8).copy()
+        lib().orc_mesh_valid_states(self.m, st)
+        return st
+
+    def adapted(self, states):
+        """The mesh MeshAdaptation::Adapt produces from (valid) states."""
+        st = np.ascontiguousarray(states, dtype=np.int8)
+        n = self.nb + 7 * int((st == 1).sum())
+        lv, zs = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int64)
+        n = lib().orc_mesh_adapted_leaves(self.m, st, lv, zs)
+        return OracleMesh(self.bpd, self.level_max, self.maxextent, self.bc, lv[:n], zs[:n])
+
+    def transfer(self, new_mesh, field):
+        nc = 3 if field.ndim == 5 else 1
+        out = np.zeros((new_mesh.nb, 8, 8, 8, 3) if nc == 3 else (new_mesh.nb, 8, 8, 8))
+        lib().orc_mesh_transfer(self.m, new_mesh.m, np.ascontiguousarray(field), out, nc, 1 if nc == 3 else 0)
+        return out
 
     def states(self):
         out = np.zeros((self.nb, 27), dtype=np.int32)
