@@ -15,6 +15,9 @@
 //     down (FillCoarseVersion 4171-4235), domain faces mirrored (_apply_bc on the coarse tile, 3781).
 // After the kernel, k_flux_fix applies FluxCorrectionMPI::FillBlockCases (2825-2935) to the coarse side.
 // All arithmetic keeps the reference's association (-ffp-contract=off): results are bit-identical to it.
+#include <memory>
+#include <stdexcept>
+
 #include "sim.hpp"
 #include "tile.hpp"
 
@@ -193,6 +196,227 @@ __global__ void __launch_bounds__(64) k_flux_fix(AmrDev a, const int32_t *__rest
   }
 }
 
+// ---- mesh adaptation: the eight children of a refined block (refine_1 + RefineBlocks, main.cpp:5227-5249, 5493-5565).
+// One workgroup per refined parent builds the parent's tensorial [-1,2) tile on the OLD mesh in LDS exactly as BlockLab::load
+// does -- same-level neighbours copied, finer ones averaged down, coarser ones interpolated from the coarse shadow tile
+// (faces: finite-difference mode, edges and corners: TestInterp), domain faces last -- and expands it.
+struct RefineTab {
+  const int32_t *items;  // [n][9]: parent slot (old mesh), eight child slots (new mesh, child = I + 2J + 4K)
+  const int32_t *finer;  // [n][27][8]: old-mesh slot of the finer leaf behind code for the octant (bits of x,y,z >= 4), -1 unused
+};
+__device__ __forceinline__ int lix10(int x, int y, int z) { return ((z + 1) * 10 + (y + 1)) * 10 + (x + 1); }
+__device__ __forceinline__ int cix8(int X, int Y, int Z) { return ((Z + 2) * 8 + (Y + 2)) * 8 + (X + 2); }
+
+template <int NC>
+__global__ void __launch_bounds__(256) k_refine(AmrDev a, RefineTab tab, const double *__restrict__ src, double *__restrict__ dst) {
+  __shared__ double lab[NC * 1000];
+  __shared__ double Ct[NC * 512];  // coarse shadow tile, coarse cells [-2,6)^3
+  const int it = blockIdx.x, t = threadIdx.x;
+  const int pb = tab.items[9 * it];
+  const int32_t *n27 = a.nbr27 + 27 * pb;
+  const int32_t *fin = tab.finer + (size_t)it * 27 * 8;
+  const int par[3] = {a.index[3 * pb] & 1, a.index[3 * pb + 1] & 1, a.index[3 * pb + 2] & 1};
+  bool has_coarse = false;
+  for (int i = 0; i < 27; ++i) has_coarse = has_coarse || n27[i] >= kNbrCoarser;
+  // A. centre, same-level neighbours (SameLevelExchange), finer neighbours (FineToCoarseExchange)
+  for (int e = t; e < 1000; e += 256) {
+    const int l[3] = {e % 10 - 1, (e / 10) % 10 - 1, e / 100 - 1};
+    int code[3], loc[3], fl[3], q = 0;
+    for (int d = 0; d < 3; ++d) {
+      code[d] = l[d] < 0 ? -1 : (l[d] > 7 ? 1 : 0);
+      loc[d] = l[d] - 8 * code[d];
+      fl[d] = code[d] < 0 ? 6 : (code[d] > 0 ? 0 : (2 * l[d]) & 7);
+      if (code[d] == 0 && l[d] >= 4) q |= 1 << d;
+    }
+    const int icode = (code[0] + 1) + 3 * (code[1] + 1) + 9 * (code[2] + 1);
+    const int n = n27[icode];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      double v = 0.0;
+      if (n >= 0 && n < kNbrCoarser) v = src[((size_t)n * NC + c) * 512 + (loc[2] * 8 + loc[1]) * 8 + loc[0]];
+      else if (n == kNbrFiner) v = avg_block(src + ((size_t)fin[icode * 8 + q] * NC + c) * 512, fl[0], fl[1], fl[2]);
+      lab[c * 1000 + e] = v;
+    }
+  }
+  __syncthreads();
+  if (has_coarse) {
+    // B. coarse shadow tile: own block averaged down (post_load 3750-3778), coarser leaves copied (CoarseFineExchange),
+    //    same-level neighbours averaged down (FillCoarseVersion)
+    for (int e = t; e < 512; e += 256) {
+      const int P[3] = {e % 8 - 2, (e / 8) % 8 - 2, e / 64 - 2};
+      int code[3];
+      for (int d = 0; d < 3; ++d) code[d] = P[d] < 0 ? -1 : (P[d] > 3 ? 1 : 0);
+      const int icode = (code[0] + 1) + 3 * (code[1] + 1) + 9 * (code[2] + 1);
+      const int n = n27[icode];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        double v = 0.0;
+        if (icode == 13) {
+          const double *L = lab + c * 1000;
+          double w[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) w[q] = L[lix10(2 * P[0] + (q & 1), 2 * P[1] + ((q >> 1) & 1), 2 * P[2] + (q >> 2))];  // x fastest here
+          v = avg_down8(w);
+        } else if (n >= kNbrCoarser) {
+          v = src[((size_t)(n - kNbrCoarser) * NC + c) * 512 + ((par[2] * 4 + P[2] + 8) & 7) * 64 + ((par[1] * 4 + P[1] + 8) & 7) * 8 + ((par[0] * 4 + P[0] + 8) & 7)];
+        } else if (n >= 0) {
+          v = avg_block(src + ((size_t)n * NC + c) * 512, 2 * P[0] - 8 * code[0], 2 * P[1] - 8 * code[1], 2 * P[2] - 8 * code[2]);
+        }
+        Ct[c * 512 + e] = v;
+      }
+    }
+    __syncthreads();
+    // C. domain faces on the coarse tile (_apply_bc(info, t, true), 3781): both ghost layers behind the face, every
+    //    transverse position, from the face cell; order x-,x+,y-,y+,z-,z+
+    for (int f = 0; f < 6; ++f) {
+      const int n = a.nbr[pb * 6 + f];
+      if (n >= 0) continue;
+      const int d = f >> 1, side = f & 1, d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+      if (t < 128) {
+        int p[3], q[3];
+        p[d] = side ? 4 + (t >> 6) : -1 - (t >> 6);
+        q[d] = side ? 3 : 0;
+        p[d1] = q[d1] = (t & 7) - 2;
+        p[d2] = q[d2] = ((t >> 3) & 7) - 2;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          double v = Ct[c * 512 + cix8(q[0], q[1], q[2])];
+          if (NC == 3 && (n == -3 || c == d)) v = -v;
+          Ct[c * 512 + cix8(p[0], p[1], p[2])] = v;
+        }
+      }
+      __syncthreads();
+    }
+    // D. CoarseFineInterpolation (4236-4614) of the ghosts behind coarser neighbours
+    for (int e = t; e < 1000; e += 256) {
+      const int l[3] = {e % 10 - 1, (e / 10) % 10 - 1, e / 100 - 1};
+      int code[3], X[3], bit[3], ncode = 0;
+      for (int d = 0; d < 3; ++d) {
+        code[d] = l[d] < 0 ? -1 : (l[d] > 7 ? 1 : 0);
+        ncode += code[d] != 0;
+        X[d] = code[d] < 0 ? -1 : (code[d] > 0 ? 4 : l[d] >> 1);
+        bit[d] = code[d] < 0 ? 1 : (code[d] > 0 ? 0 : l[d] & 1);
+      }
+      if (ncode == 0 || n27[(code[0] + 1) + 3 * (code[1] + 1) + 9 * (code[2] + 1)] < kNbrCoarser) continue;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const double *C0 = Ct + c * 512;
+        double v;
+        if (ncode == 1) {  // face: finite-difference mode
+          const int ax = code[0] ? 0 : (code[1] ? 1 : 2), ax1 = ax == 0 ? 1 : 0, ax2 = ax == 2 ? 1 : 2;
+          const int st1 = ax1 == 0 ? 1 : 8, st2 = ax2 == 1 ? 8 : 64;
+          const int p1 = X[ax1], p2 = X[ax2];
+          const double dd1 = 0.25 * (2 * bit[ax1] - 1), dd2 = 0.25 * (2 * bit[ax2] - 1);
+          const double *coef1 = dd1 > 0 ? kCoefPlus : kCoefMinus, *coef2 = dd2 > 0 ? kCoefPlus : kCoefMinus;
+          const double *P0 = C0 + cix8(X[0], X[1], X[2]);
+          int pp1, pm1, pp2, pm2;
+          const double x1D = interp1d(P0, p1, st1, coef1, pp1, pm1);
+          const double x2D = interp1d(P0, p2, st2, coef2, pp2, pm2);
+          double mixed_coef = 1.0;
+          if (p1 != 0 && p1 != 3) mixed_coef *= 0.5;
+          if (p2 != 0 && p2 != 3) mixed_coef *= 0.5;
+#define PC(i, j) P0[((i) - p1) * st1 + ((j) - p2) * st2]
+          const double mixed = mixed_coef * dd1 * dd2 * ((PC(pm1, pm2) + PC(pp1, pp2)) - (PC(pp1, pm2) + PC(pm1, pp2)));
+#undef PC
+          const double av = (x1D + x2D) + mixed;
+          int cb[3] = {l[0], l[1], l[2]}, cc[3] = {l[0], l[1], l[2]};
+          cb[ax] = code[ax] > 0 ? 7 : 0;
+          cc[ax] = code[ax] > 0 ? 6 : 1;
+          const double bv = lab[c * 1000 + lix10(cb[0], cb[1], cb[2])], cv = lab[c * 1000 + lix10(cc[0], cc[1], cc[2])];
+          v = (1.0 / 15.0) * (8.0 * av + (10.0 * bv - 3.0 * cv));
+        } else {  // edge / corner: TestInterp
+          auto Cc = [&](int i, int j, int k) -> double { return C0[cix8(X[0] - 1 + i, X[1] - 1 + j, X[2] - 1 + k)]; };
+          const double dudx = 0.125 * (Cc(2, 1, 1) - Cc(0, 1, 1));
+          const double dudy = 0.125 * (Cc(1, 2, 1) - Cc(1, 0, 1));
+          const double dudz = 0.125 * (Cc(1, 1, 2) - Cc(1, 1, 0));
+          const double dudxdy = 0.015625 * (Cc(0, 0, 1) + Cc(2, 2, 1) - Cc(2, 0, 1) - Cc(0, 2, 1));
+          const double dudxdz = 0.015625 * (Cc(0, 1, 0) + Cc(2, 1, 2) - Cc(2, 1, 0) - Cc(0, 1, 2));
+          const double dudydz = 0.015625 * (Cc(1, 0, 0) + Cc(1, 2, 2) - Cc(1, 2, 0) - Cc(1, 0, 2));
+          const double lap = Cc(1, 1, 1) + 0.03125 * (Cc(0, 1, 1) + Cc(2, 1, 1) + Cc(1, 0, 1) + Cc(1, 2, 1) + Cc(1, 1, 0) + Cc(1, 1, 2) + (-6.0) * Cc(1, 1, 1));
+          const double sx = bit[0] ? 1.0 : -1.0, sy = bit[1] ? 1.0 : -1.0, sz = bit[2] ? 1.0 : -1.0;
+          v = lap + sx * dudx + sy * dudy + sz * dudz + (sx * sy) * dudxdy + (sx * sz) * dudxdz + (sy * sz) * dudydz;
+        }
+        lab[c * 1000 + e] = v;
+      }
+    }
+    __syncthreads();
+  }
+  // E. domain faces on the fine tile, order x-,x+,y-,y+,z-,z+ (as k_prolong)
+  for (int f = 0; f < 6; ++f) {
+    const int n = a.nbr[pb * 6 + f];
+    if (n >= 0) continue;
+    const int d = f >> 1, side = f & 1, ghost = side ? 8 : -1, face = side ? 7 : 0, d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+    if (t < 100) {
+      int p[3], q[3];
+      p[d] = ghost; q[d] = face;
+      p[d1] = q[d1] = t % 10 - 1;
+      p[d2] = q[d2] = t / 10 - 1;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        double v = lab[c * 1000 + lix10(q[0], q[1], q[2])];
+        if (NC == 3 && (n == -3 || c == d)) v = -v;
+        lab[c * 1000 + lix10(p[0], p[1], p[2])] = v;
+      }
+    }
+    __syncthreads();
+  }
+  // F. RefineBlocks, 5493-5565
+  for (int k = 0; k < 2; ++k) {
+    const int cell = k * 256 + t, x = cell & 7, y = (cell >> 3) & 7, z = cell >> 6;
+    const int fs = tab.items[9 * it + 1 + (z >> 2) * 4 + (y >> 2) * 2 + (x >> 2)];
+    const int i = 2 * (x & 3), j = 2 * (y & 3), kk = 2 * (z & 3);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const double *L = lab + c * 1000;
+#define Lb(a_, b_, c_) L[lix10(x + (a_), y + (b_), z + (c_))]
+      const double dudx = 0.5 * (Lb(1, 0, 0) - Lb(-1, 0, 0));
+      const double dudy = 0.5 * (Lb(0, 1, 0) - Lb(0, -1, 0));
+      const double dudz = 0.5 * (Lb(0, 0, 1) - Lb(0, 0, -1));
+      const double dudx2 = (Lb(1, 0, 0) + Lb(-1, 0, 0)) - 2.0 * Lb(0, 0, 0);
+      const double dudy2 = (Lb(0, 1, 0) + Lb(0, -1, 0)) - 2.0 * Lb(0, 0, 0);
+      const double dudz2 = (Lb(0, 0, 1) + Lb(0, 0, -1)) - 2.0 * Lb(0, 0, 0);
+      const double dudxdy = 0.25 * ((Lb(1, 1, 0) + Lb(-1, -1, 0)) - (Lb(1, -1, 0) + Lb(-1, 1, 0)));
+      const double dudxdz = 0.25 * ((Lb(1, 0, 1) + Lb(-1, 0, -1)) - (Lb(1, 0, -1) + Lb(-1, 0, 1)));
+      const double dudydz = 0.25 * ((Lb(0, 1, 1) + Lb(0, -1, -1)) - (Lb(0, 1, -1) + Lb(0, -1, 1)));
+      const double u = Lb(0, 0, 0), q2 = 0.03125 * (dudx2 + dudy2 + dudz2);
+#undef Lb
+      double *b = dst + ((size_t)fs * NC + c) * 512;
+#define B(a_, b_, c_) b[((kk + (c_)) * 8 + (j + (b_))) * 8 + (i + (a_))]
+      B(0, 0, 0) = u + 0.25 * (-(1.0) * dudx - dudy - dudz) + q2 + 0.0625 * (dudxdy + dudxdz + dudydz);
+      B(1, 0, 0) = u + 0.25 * (dudx - dudy - dudz) + q2 + 0.0625 * (-(1.0) * dudxdy - dudxdz + dudydz);
+      B(0, 1, 0) = u + 0.25 * (-(1.0) * dudx + dudy - dudz) + q2 + 0.0625 * (-(1.0) * dudxdy + dudxdz - dudydz);
+      B(1, 1, 0) = u + 0.25 * (dudx + dudy - dudz) + q2 + 0.0625 * (dudxdy - dudxdz - dudydz);
+      B(0, 0, 1) = u + 0.25 * (-(1.0) * dudx - dudy + dudz) + q2 + 0.0625 * (dudxdy - dudxdz - dudydz);
+      B(1, 0, 1) = u + 0.25 * (dudx - dudy + dudz) + q2 + 0.0625 * (-(1.0) * dudxdy + dudxdz - dudydz);
+      B(0, 1, 1) = u + 0.25 * (-(1.0) * dudx + dudy + dudz) + q2 + 0.0625 * (-(1.0) * dudxdy - dudxdz + dudydz);
+      B(1, 1, 1) = u + 0.25 * (dudx + dudy + dudz) + q2 + 0.0625 * (dudxdy + dudxdz + dudydz);
+#undef B
+    }
+  }
+}
+
+// unchanged blocks: copy; parents of compressed octets: compress (5272-5329) -- pairs[n][2] = dst slot, src slot;
+// octets[n][9] = dst slot, eight src slots (child = I + 2J + 4K)
+__global__ void __launch_bounds__(256) k_copy_blocks(const int32_t *__restrict__ pairs, const double *__restrict__ src, double *__restrict__ dst, int nc) {
+  const int d = pairs[2 * blockIdx.x], s = pairs[2 * blockIdx.x + 1];
+  for (int i = threadIdx.x; i < 512 * nc; i += 256) dst[(size_t)d * 512 * nc + i] = src[(size_t)s * 512 * nc + i];
+}
+__global__ void __launch_bounds__(256) k_compress_blocks(const int32_t *__restrict__ octets, const double *__restrict__ src, double *__restrict__ dst, int nc) {
+  const int pb = octets[9 * blockIdx.x], t = threadIdx.x;
+  for (int k = 0; k < 2; ++k) {
+    const int cell = k * 256 + t, cx = cell & 7, cy = (cell >> 3) & 7, cz = cell >> 6;
+    const int fs = octets[9 * blockIdx.x + 1 + (cz >> 2) * 4 + (cy >> 2) * 2 + (cx >> 2)];
+    const int i = 2 * (cx & 3), j = 2 * (cy & 3), kk = 2 * (cz & 3);
+    for (int c = 0; c < nc; ++c) {
+      const double *b = src + ((size_t)fs * nc + c) * 512;
+#define B(a_, b_, c_) b[((kk + (c_)) * 8 + (j + (b_))) * 8 + (i + (a_))]
+      dst[((size_t)pb * nc + c) * 512 + cell] =
+          0.125 * ((B(0, 0, 0) + B(1, 1, 1)) + (B(1, 0, 0) + B(0, 1, 1)) + (B(0, 1, 0) + B(1, 0, 1)) + (B(1, 1, 0) + B(0, 0, 1)));  // 5298-5302
+#undef B
+    }
+  }
+}
+
 // ---- host side
 int amr_fill_ghosts(Sim *s, const double *field, int nc, int w, double *slabs) {
   const Grid *g = s->grid;
@@ -225,6 +449,104 @@ int amr_flux_fix(Sim *s, int nfc, double *out, int out_nc) {
 }  // namespace cup3d
 
 using namespace cup3d;
+
+namespace {
+struct DevInts {
+  int32_t *p = nullptr;
+  int upload(const std::vector<int32_t> &v) {
+    if (v.empty()) return CUP3D_OK;
+    CUP3D_HIP(hipMalloc((void **)&p, v.size() * sizeof(int32_t)));
+    CUP3D_HIP(hipMemcpyAsync(p, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream()));
+    return CUP3D_OK;
+  }
+  ~DevInts() { if (p) hipFree(p); }
+};
+}  // namespace
+
+extern "C" int cup3d_adapt_transfer(cup3d_sim_t *src_h, cup3d_sim_t *dst_h, int field) {
+  if (!src_h || !dst_h) return CUP3D_EINVAL;
+  Sim *src = reinterpret_cast<Sim *>(src_h), *dst = reinterpret_cast<Sim *>(dst_h);
+  int nc, nc2;
+  const double *fs = src->field(field, &nc);
+  double *fd = dst->field(field, &nc2);
+  if (!fs || !fd) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+  std::unique_ptr<Grid> mo_tmp, mn_tmp;
+  const Grid *mo = src->grid, *mn = dst->grid;
+  std::vector<int32_t> pairs, octets, items, finer;
+  try {
+    if (!mo->multilevel) { mo_tmp = mo->as_mesh(); mo = mo_tmp.get(); }
+    if (!mn->multilevel) { mn_tmp = mn->as_mesh(); mn = mn_tmp.get(); }
+    for (int d = 0; d < 3; ++d)
+      if (mo->bpd[d] != mn->bpd[d] || mo->bc[d] != mn->bc[d] || mo->level_max != mn->level_max) throw std::invalid_argument("the two meshes belong to different boxes");
+    std::vector<int32_t> item_of(mo->nblocks(), -1);
+    for (int64_t b = 0; b < mn->nblocks(); ++b) {
+      const int l = mn->blevel[b];
+      const int idx[3] = {mn->index[3 * b], mn->index[3 * b + 1], mn->index[3 * b + 2]};
+      const int32_t same = mo->leaf(l, idx);
+      if (same >= 0) { pairs.push_back((int32_t)b); pairs.push_back(same); continue; }
+      const int pidx[3] = {idx[0] >> 1, idx[1] >> 1, idx[2] >> 1};
+      const int32_t par = l > 0 ? mo->leaf(l - 1, pidx) : -1;
+      if (par >= 0) {
+        if (item_of[par] < 0) {
+          item_of[par] = (int32_t)(items.size() / 9);
+          items.push_back(par);
+          for (int q = 0; q < 8; ++q) items.push_back(-1);
+        }
+        items[9 * (size_t)item_of[par] + 1 + (idx[0] & 1) + 2 * (idx[1] & 1) + 4 * (idx[2] & 1)] = (int32_t)b;
+        continue;
+      }
+      octets.push_back((int32_t)b);
+      for (int q = 0; q < 8; ++q) {
+        const int ci[3] = {2 * idx[0] + (q & 1), 2 * idx[1] + ((q >> 1) & 1), 2 * idx[2] + (q >> 2)};
+        const int32_t cb = l + 1 < mo->level_max ? mo->leaf(l + 1, ci) : -1;
+        if (cb < 0) throw std::invalid_argument("a block of the new mesh is neither a block, a child nor the parent of blocks of the old mesh");
+        octets.push_back(cb);
+      }
+    }
+    for (size_t i = 0; i < items.size(); ++i)
+      if (items[i] < 0) throw std::invalid_argument("a refined block lacks some of its children in the new mesh");
+    // finer leaves behind every code of the refined parents, by octant of the parent
+    finer.assign(items.size() / 9 * 27 * 8, -1);
+    for (size_t it = 0; it < items.size() / 9; ++it) {
+      const int32_t pb = items[9 * it];
+      const int l = mo->blevel[pb];
+      for (int icode = 0; icode < 27; ++icode) {
+        if (mo->nbr27[27 * (size_t)pb + icode] != kNbrFiner) continue;
+        const int code[3] = {icode % 3 - 1, (icode / 3) % 3 - 1, icode / 9 - 1};
+        for (int q = 0; q < 8; ++q) {
+          int fi[3];
+          bool used = true;
+          for (int d = 0; d < 3; ++d) {
+            const int bit = (q >> d) & 1;
+            if (code[d] != 0 && bit) used = false;
+            fi[d] = 2 * mo->index[3 * (size_t)pb + d] + (code[d] < 0 ? -1 : (code[d] > 0 ? 2 : bit));
+          }
+          if (used) finer[(it * 27 + icode) * 8 + q] = mo->leaf(l + 1, fi);
+        }
+      }
+    }
+  } catch (const std::exception &e) {
+    set_error("cup3d_adapt_transfer: %s", e.what());
+    return CUP3D_EINVAL;
+  }
+  DevInts d_pairs, d_octets, d_items, d_finer, d_n27, d_nbr, d_index;
+  int rc;
+  if ((rc = d_pairs.upload(pairs)) || (rc = d_octets.upload(octets)) || (rc = d_items.upload(items)) || (rc = d_finer.upload(finer))) return rc;
+  ProfileScope ps("adapt_transfer");
+  if (!pairs.empty()) hipLaunchKernelGGL(k_copy_blocks, dim3((unsigned)(pairs.size() / 2)), dim3(256), 0, stream(), d_pairs.p, fs, fd, nc);
+  if (!octets.empty()) hipLaunchKernelGGL(k_compress_blocks, dim3((unsigned)(octets.size() / 9)), dim3(256), 0, stream(), d_octets.p, fs, fd, nc);
+  if (!items.empty()) {
+    if ((rc = d_n27.upload(mo->nbr27)) || (rc = d_nbr.upload(mo->nbr)) || (rc = d_index.upload(mo->index))) return rc;
+    AmrDev a{nullptr, nullptr, d_n27.p, d_nbr.p, d_index.p};
+    RefineTab tab{d_items.p, d_finer.p};
+    const unsigned n = (unsigned)(items.size() / 9);
+    if (nc == 3) hipLaunchKernelGGL(k_refine<3>, dim3(n), dim3(256), 0, stream(), a, tab, fs, fd);
+    else hipLaunchKernelGGL(k_refine<1>, dim3(n), dim3(256), 0, stream(), a, tab, fs, fd);
+  }
+  CUP3D_HIP(hipGetLastError());
+  CUP3D_HIP(hipStreamSynchronize(stream()));  // the index tables above are freed on return
+  return CUP3D_OK;
+}
 
 // TEST SUPPORT: the ghost slabs of every interface face for `field` and a w-deep stencil, [(e*nc + c)*w + gl][64]
 extern "C" int cup3d_debug_amr_slabs(cup3d_sim_t *h, int field, int w, double *out) {

@@ -4,7 +4,9 @@
 #include <cmath>
 #include <cstring>
 #include <exception>
+#include <memory>
 #include <stdexcept>
+#include <vector>
 
 #include "../../include/cup3d_hip.h"
 #include "grid.hpp"
@@ -80,6 +82,35 @@ int cup3d_grid_interface(const cup3d_grid_t *gh, int32_t *faces2, int32_t *fine4
   if (faces2) memcpy(faces2, g->amr_faces.data(), g->amr_faces.size() * sizeof(int32_t));
   if (fine4) memcpy(fine4, g->amr_fine.data(), g->amr_fine.size() * sizeof(int32_t));
   if (nbr27) memcpy(nbr27, g->nbr27.data(), g->nbr27.size() * sizeof(int32_t));
+  return CUP3D_OK;
+}
+int cup3d_grid_valid_states(const cup3d_grid_t *gh, signed char *states) {
+  if (!gh || !states) return CUP3D_EINVAL;
+  const Grid *g = reinterpret_cast<const Grid *>(gh);
+  try {
+    if (g->multilevel) g->valid_states(reinterpret_cast<int8_t *>(states));
+    else g->as_mesh()->valid_states(reinterpret_cast<int8_t *>(states));
+  } catch (const std::exception &e) {
+    set_error("cup3d_grid_valid_states: %s", e.what());
+    return CUP3D_EINVAL;
+  }
+  return CUP3D_OK;
+}
+int cup3d_grid_adapted(const cup3d_grid_t *gh, const signed char *states, cup3d_grid_t **out) {
+  if (!gh || !states || !out) return CUP3D_EINVAL;
+  const Grid *g = reinterpret_cast<const Grid *>(gh);
+  try {
+    std::unique_ptr<Grid> tmp;
+    const Grid *m = g;
+    if (!g->multilevel) { tmp = g->as_mesh(); m = tmp.get(); }
+    std::vector<int32_t> lv;
+    std::vector<int64_t> zs;
+    m->adapted_leaves(reinterpret_cast<const int8_t *>(states), lv, zs);
+    *out = reinterpret_cast<cup3d_grid_t *>(new Grid(g->bpd, g->level_max, g->maxextent, g->bc, (int64_t)lv.size(), lv.data(), zs.data()));
+  } catch (const std::exception &e) {
+    set_error("cup3d_grid_adapted: %s", e.what());
+    return CUP3D_EINVAL;
+  }
   return CUP3D_OK;
 }
 void cup3d_grid_destroy(cup3d_grid_t *g) { delete reinterpret_cast<Grid *>(g); }

@@ -145,7 +145,8 @@ Grid::Grid(const int bpd_[3], int level_max_, double maxextent_, const int bc_[3
   for (int d = 0; d < 3; ++d) nbd[d] = bpd[d] << level;
   Z.resize(nleaves); id2.resize(nleaves); index.resize(3 * nleaves); blevel.resize(nleaves); hb.resize(nleaves);
   // dense (level, i, j, k) -> slot maps
-  std::vector<std::vector<int32_t>> at(level_max);
+  std::vector<std::vector<int32_t>> &at = at_;
+  at.assign(level_max, std::vector<int32_t>());
   auto dims = [&](int l, int d) { return bpd[d] << l; };
   for (int l = 0; l < level_max; ++l) at[l].assign((size_t)dims(l, 0) * dims(l, 1) * dims(l, 2), -1);
   auto key = [&](int l, const int c[3]) { return ((size_t)c[2] * dims(l, 1) + c[1]) * dims(l, 0) + c[0]; };
@@ -239,6 +240,96 @@ Grid::Grid(const int bpd_[3], int level_max_, double maxextent_, const int bc_[3
   send_count.assign(1, 0);
   recv_count.assign(1, 0);
   slot_of_z.clear();
+}
+
+int32_t Grid::leaf(int l, const int c[3]) const {
+  if (l < 0 || l >= level_max || at_.empty()) return -1;
+  int w[3];
+  for (int d = 0; d < 3; ++d) { const int n = bpd[d] << l; w[d] = ((c[d] % n) + n) % n; }
+  return at_[l][((size_t)w[2] * (bpd[1] << l) + w[1]) * (bpd[0] << l) + w[0]];
+}
+
+std::unique_ptr<Grid> Grid::as_mesh() const {
+  if (nranks != 1) throw std::invalid_argument("mesh adaptation is supported on one rank");
+  std::vector<int32_t> lv(nblocks());
+  for (int64_t s = 0; s < nblocks(); ++s) lv[s] = multilevel ? blevel[s] : level;
+  return std::unique_ptr<Grid>(new Grid(bpd, level_max, maxextent, bc, nblocks(), lv.data(), Z.data()));
+}
+
+void Grid::valid_states(int8_t *st) const {
+  if (!multilevel) throw std::invalid_argument("valid_states needs a multi-level mesh object (Grid::as_mesh)");
+  const int64_t nb = nblocks();
+  for (int64_t b = 0; b < nb; ++b)
+    if ((st[b] == 1 && blevel[b] == level_max - 1) || (st[b] == -1 && blevel[b] == 0)) st[b] = 0;
+  for (int lv = level_max - 1; lv >= 0; --lv) {
+    // refinement propagates from finer neighbours; a block next to finer blocks may not compress (5352-5409)
+    for (int64_t b = 0; b < nb; ++b) {
+      if (!(blevel[b] == lv && st[b] != 1 && blevel[b] != level_max - 1)) continue;
+      const int32_t *idx = &index[3 * b];
+      for (int icode = 0; icode < 27; ++icode) {
+        if (st[b] == 1) break;
+        if (icode == 13 || nbr27[27 * b + icode] != kNbrFiner) continue;
+        if (st[b] == -1) st[b] = 0;
+        const int code[3] = {icode % 3 - 1, (icode / 3) % 3 - 1, icode / 9 - 1};
+        const int tmp = std::abs(code[0]) + std::abs(code[1]) + std::abs(code[2]);
+        const int Bstep = tmp == 2 ? 3 : (tmp == 3 ? 4 : 1);
+        for (int B = 0; B <= 3; B += Bstep) {
+          const int aux = std::abs(code[0]) == 1 ? B % 2 : B / 2;
+          const int fi[3] = {2 * idx[0] + std::max(code[0], 0) + code[0] + (B % 2) * std::max(0, 1 - std::abs(code[0])),
+                             2 * idx[1] + std::max(code[1], 0) + code[1] + aux * std::max(0, 1 - std::abs(code[1])),
+                             2 * idx[2] + std::max(code[2], 0) + code[2] + (B / 2) * std::max(0, 1 - std::abs(code[2]))};
+          const int32_t fb = leaf(lv + 1, fi);
+          if (fb >= 0 && st[fb] == 1) { st[b] = 1; break; }
+        }
+      }
+    }
+    if (lv == 0) break;
+    // no compression next to a refining block of the same level (5413-5448)
+    for (int64_t b = 0; b < nb; ++b) {
+      if (!(blevel[b] == lv && st[b] == -1)) continue;
+      for (int icode = 0; icode < 27; ++icode) {
+        const int32_t v = nbr27[27 * b + icode];
+        if (icode != 13 && v >= 0 && v < kNbrCoarser && st[v] == 1) { st[b] = 0; break; }
+      }
+    }
+  }
+  // an octet compresses only if all eight siblings exist and agree (5451-5491)
+  std::vector<int8_t> veto(nb, 0);
+  for (int64_t b = 0; b < nb; ++b) {
+    if (st[b] != -1) continue;
+    const int32_t *idx = &index[3 * b];
+    for (int q = 0; q < 8; ++q) {
+      const int s[3] = {2 * (idx[0] / 2) + (q & 1), 2 * (idx[1] / 2) + ((q >> 1) & 1), 2 * (idx[2] / 2) + (q >> 2)};
+      const int32_t sb = leaf(blevel[b], s);
+      if (sb < 0 || st[sb] != -1) { veto[b] = 1; break; }
+    }
+  }
+  for (int64_t b = 0; b < nb; ++b)
+    if (veto[b]) st[b] = 0;
+}
+
+void Grid::adapted_leaves(const int8_t *st, std::vector<int32_t> &levels, std::vector<int64_t> &Zs) const {
+  if (!multilevel) throw std::invalid_argument("adapted_leaves needs a multi-level mesh object (Grid::as_mesh)");
+  levels.clear();
+  Zs.clear();
+  for (int64_t b = 0; b < nblocks(); ++b) {
+    const int l = blevel[b];
+    const int32_t *idx = &index[3 * b];
+    if (st[b] == 1) {
+      for (int q = 0; q < 8; ++q) {
+        levels.push_back(l + 1);
+        Zs.push_back(sfc->forward(l + 1, 2 * idx[0] + (q & 1), 2 * idx[1] + ((q >> 1) & 1), 2 * idx[2] + (q >> 2)));
+      }
+    } else if (st[b] == -1) {
+      if (idx[0] % 2 == 0 && idx[1] % 2 == 0 && idx[2] % 2 == 0) {
+        levels.push_back(l - 1);
+        Zs.push_back(sfc->forward(l - 1, idx[0] / 2, idx[1] / 2, idx[2] / 2));
+      }
+    } else {
+      levels.push_back(l);
+      Zs.push_back(Z[b]);
+    }
+  }
 }
 
 int32_t Grid::slot_of_index(int i, int j, int k) const {

@@ -61,6 +61,15 @@ struct Grid {
                                     // B = (fast half) + 2*(slow half) of the face (FillCase 601-661); -1 for kind 0
   std::vector<int32_t> fix_faces[3];  // interface faces of kind 1 with normal direction d (flux correction order x, y, z)
   int64_t n_amr_faces() const { return (int64_t)amr_faces.size() / 2; }
+  std::vector<std::vector<int32_t>> at_;  // [level][(k*ny + j)*nx + i] -> slot of the leaf there, or -1
+  // slot of the leaf (l, c) with periodic wrap, -1 if there is none at that level (multi-level meshes)
+  int32_t leaf(int l, const int c[3]) const;
+  // MeshAdaptation::ValidStates (main.cpp:5330-5492) on one rank: in/out states[nb] in {-1 Compress, 0 Leave, 1 Refine}
+  void valid_states(int8_t *states) const;
+  // leaves after MeshAdaptation::Adapt (5086-5159) applied the valid states
+  void adapted_leaves(const int8_t *states, std::vector<int32_t> &levels, std::vector<int64_t> &Zs) const;
+  // the same blocks as a multi-level mesh object (for uniform one-rank grids; a multi-level grid returns a copy of itself)
+  std::unique_ptr<Grid> as_mesh() const;
 
   std::vector<int32_t> slot_of_z;  // Z - z_begin -> local slot
   // local slot of the block at (i,j,k) of this level (periodic wrap NOT applied); -1 if owned by another rank

@@ -56,6 +56,22 @@ class Grid:
         except Exception:
             pass
 
+    def valid_states(self, tags):
+        """MeshAdaptation::ValidStates (main.cpp:5330-5492) of per-block tags -> the states Adapt will act on."""
+        st = np.ascontiguousarray(tags, dtype=np.int8).copy()
+        check(lib().cup3d_grid_valid_states(self.handle, st))
+        return st
+
+    def adapted_leaves(self, states):
+        """(levels, Zs) of the mesh MeshAdaptation::Adapt (5086-5159) produces from valid states."""
+        h = C.c_void_p()
+        check(lib().cup3d_grid_adapted(self.handle, np.ascontiguousarray(states, dtype=np.int8), C.byref(h)))
+        n = lib().cup3d_grid_nblocks(h)
+        t, geom = np.zeros((n, 6), dtype=np.int64), np.zeros((n, 4))
+        check(lib().cup3d_grid_tables(h, t, geom))
+        lib().cup3d_grid_destroy(h)
+        return t[:, 0].astype(np.int32), t[:, 1].copy()
+
     def interface(self):
         """Multi-level meshes: (faces[ne,2] = 6*slot+face, kind; fine4[ne,4]; nbr27[nb,27]), see cup3d_grid_interface."""
         ne = lib().cup3d_grid_ninterface_faces(self.handle)
@@ -156,6 +172,22 @@ class SimulationData:
 
     def fill(self, field, value):
         check(lib().cup3d_sim_fill(self.handle, FIELDS[field], float(value)))
+
+    def adapted(self, states):
+        """A new SimulationData on the mesh that MeshAdaptation::Adapt produces from (valid) `states`, with vel and pres
+        moved over on the device (refine / compress / copy; chi, lhs and tmpV are adapted without data in the reference
+        too, 15188-15190) and the run state carried along.  Simulation::adaptMesh's second half (15184-15193)."""
+        lv, zs = self.grid.adapted_leaves(states)
+        new = SimulationData(bpdx=self.bpdx, bpdy=self.bpdy, bpdz=self.bpdz, levelMax=self.levelMax, levelStart=self.levelStart,
+                             extent=self.maxextent, nu=self.nu, CFL=self.CFL, BC_x=self.BCx_flag, BC_y=self.BCy_flag, BC_z=self.BCz_flag,
+                             uinf=self.uinf, uMax_forced=self.uMax_forced, poissonTol=self.PoissonErrorTol, poissonTolRel=self.PoissonErrorTolRel,
+                             bMeanConstraint=self.bMeanConstraint, poissonSolver=self.poissonSolver, rampup=self.rampup,
+                             blockSolver=self.blockSolver, leaves=(lv, zs))
+        for f in ("vel", "pres"):
+            check(lib().cup3d_adapt_transfer(self.handle, new.handle, FIELDS[f]))
+        new.dt, new.dt_old, new.time, new.step, new.coefU = self.dt, self.dt_old, self.time, self.step, self.coefU.copy()
+        new.uMax_measured = self.uMax_measured
+        return new
 
     def poisson_params(self):
         p = PoissonParams()
@@ -304,6 +336,16 @@ class Simulation:
         if sim.uMax_forced > 0:
             self.pipeline.append(ExternalForcing(sim))
         self.pipeline.append(PressureProjection(sim))
+
+    def adaptMesh(self, Rtol, Ctol):
+        """Simulation::adaptMesh (15179-15194) without obstacles: vorticity -> tags -> ValidStates -> Adapt.  Replaces
+        self.sim (and the operators bound to it) when the mesh changes; returns the valid states."""
+        s = self.sim
+        ComputeVorticity(s)(0)
+        st = s.grid.valid_states(MeshAdaptation(Rtol, Ctol).Tag(s, "tmpV"))
+        if (st != 0).any():
+            self.__init__(s.adapted(st))
+        return st
 
     def calcMaxTimestep(self):
         s = self.sim

@@ -78,6 +78,13 @@ int cup3d_grid_create_mesh(const int bpd[3], int level_max, double maxextent, co
 #define CUP3D_NBR_FINER (-3)
 long cup3d_grid_ninterface_faces(const cup3d_grid_t *);
 int cup3d_grid_interface(const cup3d_grid_t *, int32_t *faces2, int32_t *fine4, int32_t *nbr27);
+/* Mesh adaptation decisions (integer contract; one rank).  cup3d_grid_valid_states = MeshAdaptation::ValidStates
+ * (main.cpp:5330-5492): in/out states[nblocks] in {-1 Compress, 0 Leave, 1 Refine} (e.g. from cup3d_tag_blocks):
+ * refinement propagates to coarser neighbours to keep the mesh 2:1 balanced, unbalanced or partial compressions are
+ * dropped.  cup3d_grid_adapted = the mesh MeshAdaptation::Adapt (5086-5159) produces from valid states (a new grid object,
+ * always of the multi-level kind); cup3d_adapt_transfer (below) moves the field data. */
+int cup3d_grid_valid_states(const cup3d_grid_t *, signed char *states);
+int cup3d_grid_adapted(const cup3d_grid_t *, const signed char *states, cup3d_grid_t **out);
 void cup3d_grid_destroy(cup3d_grid_t *);
 long cup3d_grid_nblocks(const cup3d_grid_t *);        /* local blocks = m_vInfo.size() */
 long cup3d_grid_nblocks_global(const cup3d_grid_t *);
@@ -188,6 +195,11 @@ int cup3d_prolong(cup3d_sim_t *coarse, cup3d_sim_t *fine, int field);
  * any mesh (uniform or multi-level).  With ComputeVorticity this is the device half of Simulation::adaptMesh's decision input
  * (15180-15183, obstacle-free: GradChiOnTmp only reads chi); ValidStates' 2:1 balancing of the tags stays on the host. */
 int cup3d_tag_blocks(cup3d_sim_t *, int field, double rtol, double ctol, signed char *states);
+/* field `field` of `src` onto the mesh of `dst` (MeshAdaptation::Adapt for one grid, basic = false): blocks present in both
+ * are copied, children of a refined block come from refine_1 + RefineBlocks (5227-5249, 5493-5565: 2nd-order Taylor
+ * expansion from the parent's tensorial [-1,2) tile on the OLD mesh, coarse/fine ghosts included), the parent of a
+ * compressed octet from compress (5272-5329).  Every block of dst must be a block, a child or the parent of blocks of src. */
+int cup3d_adapt_transfer(cup3d_sim_t *src, cup3d_sim_t *dst, int field);
 /* ComputeVorticity::operator() (8726-8746, KernelVorticity 8624-8645): tmpV <- curl(vel); any mesh */
 int cup3d_compute_vorticity(cup3d_sim_t *);
 

@@ -221,3 +221,66 @@ def test_time_steps_on_a_fixed_mesh(golden_dir):
     assert np.abs(sim.download("vel") - v).max() <= 1e-9
     assert np.abs(sim.download("pres") - p).max() <= 1e-6 * max(np.abs(p).max(), 1e-30)
     del t
+
+
+# ------------------------------------------------------------------ mesh adaptation (Simulation::adaptMesh)
+def _octet_fields(tables, seed):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as M
+    return M.octet_fields(tables, seed)
+
+
+def test_adapt_mesh_golden(golden_dir):
+    """One full adaptMesh of the reference on a two-level mesh (vorticity tags, ValidStates, refine + compress of vel and
+    pres): every stage bit-exact on the device."""
+    g = np.load(os.path.join(golden_dir, "amr_adapt_mixed.npz"))
+    t = g["tables"]
+    bpd, lmax, bc = tuple(int(b) for b in g["bpd"]), int(g["level_max"]), tuple(BCN[int(b)] for b in g["bc"])
+    sim = cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=0, extent=float(g["extent"]), BC_x=bc[0], BC_y=bc[1],
+                            BC_z=bc[2], leaves=(t[:, 0], t[:, 1]))
+    sim.upload("vel", g["vel_in"]); sim.upload("pres", g["pres_in"])
+    S = cu.Simulation(sim)
+    rt, ct = g["tol"]
+    cu.ComputeVorticity(sim)(0)
+    assert np.array_equal(cu.MeshAdaptation(rt, ct).Tag(sim, "tmpV"), g["tags"])
+    st = S.adaptMesh(rt, ct)
+    assert (st == 1).sum() > 0 and (st == -1).sum() >= 8
+    new = S.sim
+    assert new is not sim and np.array_equal(new.grid.tables, g["tables_new"])
+    assert np.array_equal(new.download("vel"), g["vel_new"])
+    assert np.array_equal(new.download("pres"), g["pres_new"])
+    # the adapted simulation keeps running: one step on the new mesh against the oracle
+    m2 = O.OracleMesh(bpd, lmax, float(g["extent"]), bc, g["tables_new"][:, 0], g["tables_new"][:, 1])
+    new.nu, dt = 0.01, 0.002
+    cu.AdvectionDiffusion(new)(dt)
+    v, _ = m2.advect_diffuse(g["vel_new"], dt, 0.01, (0, 0, 0))
+    assert np.array_equal(new.download("vel"), v)
+
+
+@pytest.mark.parametrize("case", ["synthetic_l012", "uniform_l1", "amr_periodic_l01"])
+def test_adapt_transfer_against_oracle(golden_dir, case):
+    if case == "uniform_l1":   # a uniform grid as the source: refine a few blocks of an 8^3-block level
+        bpd, lmax, bc = (2, 2, 2), 3, ("periodic", "wall", "freespace")
+        g0 = cu.Grid(bpd, lmax, 1, EXT, bc)
+        lv, zs = g0.tables[:, 0].astype(np.int32), g0.tables[:, 1].copy()
+        kw = dict(levelStart=1)
+    else:
+        bpd, lmax, bc, lv, zs = synthetic_mesh() if case == "synthetic_l012" else golden_mesh(golden_dir, case)
+        kw = dict(levelStart=0, leaves=(lv, zs))
+    m = O.OracleMesh(bpd, lmax, EXT, bc, lv, zs)
+    sim = cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, extent=EXT, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], **kw)
+    assert np.array_equal(sim.grid.tables, m.tables)
+    vel, pres = _octet_fields(m.tables, 21)
+    sim.upload("vel", vel); sim.upload("pres", pres)
+    w = m.vorticity(vel)
+    linf = np.sqrt((w ** 2).sum(axis=-1)).reshape(m.nb, -1).max(axis=1)
+    rt, ct = float(np.quantile(linf, 0.7)), float(np.quantile(linf, 0.4))
+    S = cu.Simulation(sim)
+    st = S.adaptMesh(rt, ct)
+    st_o = m.valid_states(m.tag(w, rt, ct))
+    assert np.array_equal(st, st_o) and (st == 1).sum() > 0
+    m2 = m.adapted(st_o)
+    assert np.array_equal(S.sim.grid.tables, m2.tables)
+    assert np.array_equal(S.sim.download("vel"), m.transfer(m2, vel))
+    assert np.array_equal(S.sim.download("pres"), m.transfer(m2, pres))

@@ -244,3 +244,36 @@ def test_mesh_rejects_unbalanced_and_duplicate_leaves():
     O.lib().orc_sfc_destroy(sfc)
     assert L.cup3d_grid_create_mesh(bpd, 4, 1.0, bc, len(lv), lv, zs, C.byref(h)) == -1
     assert b"2:1" in L.cup3d_last_error()
+
+
+def test_valid_states_and_adapted_mesh_match_reference(golden_dir):
+    """Integer contract of MeshAdaptation: ValidStates (5330-5492) and the block list Adapt (5086-5159) leaves behind."""
+    import os
+    g = np.load(os.path.join(golden_dir, "amr_adapt_mixed.npz"))
+    t = g["tables"]
+    bpd, lmax, bc = tuple(int(b) for b in g["bpd"]), int(g["level_max"]), tuple(int(b) for b in g["bc"])
+    grid = cu.Grid(bpd, lmax, 0, float(g["extent"]), bc, leaves=(t[:, 0], t[:, 1]))
+    m = O.OracleMesh(bpd, lmax, float(g["extent"]), bc, t[:, 0], t[:, 1])
+    st = grid.valid_states(g["tags"])
+    assert np.array_equal(st, m.valid_states(g["tags"]))
+    lv, zs = grid.adapted_leaves(st)
+    new = cu.Grid(bpd, lmax, 0, float(g["extent"]), bc, leaves=(lv, zs))
+    assert np.array_equal(new.tables, g["tables_new"])          # what the reference's adaptMesh produced
+    # random tags on more meshes against the oracle (itself pinned to the reference by tests/test_oracle_amr.py)
+    rng = np.random.default_rng(3)
+    for name, bpd, lmax, bc, lv, zs, _ in _mesh_cases(golden_dir):
+        grid = cu.Grid(bpd, lmax, 0, 2 * np.pi, bc, leaves=(lv, zs))
+        m = O.OracleMesh(bpd, lmax, 2 * np.pi, bc, lv, zs)
+        for trial in range(6):
+            tags = rng.choice(np.array([-1, 0, 1], dtype=np.int8), size=grid.nblocks, p=[(0.7, 0.2, 0.1), (0.2, 0.5, 0.3)][trial % 2])
+            st = grid.valid_states(tags)
+            assert np.array_equal(st, m.valid_states(tags)), (name, trial)
+            lv2, zs2 = grid.adapted_leaves(st)
+            assert np.array_equal(cu.Grid(bpd, lmax, 0, 2 * np.pi, bc, leaves=(lv2, zs2)).tables, m.adapted(st).tables)   # also checks 2:1 balance
+    # a uniform one-rank grid is accepted too (viewed as a one-level mesh)
+    u = cu.Grid((2, 2, 2), 3, 1, 1.0, (1, 1, 1))
+    tags = np.zeros(u.nblocks, dtype=np.int8)
+    tags[5] = 1
+    st = u.valid_states(tags)
+    lv2, zs2 = u.adapted_leaves(st)
+    assert len(lv2) == u.nblocks + 7 and set(lv2.tolist()) == {1, 2}
