@@ -284,3 +284,50 @@ def test_adapt_transfer_against_oracle(golden_dir, case):
     assert np.array_equal(S.sim.grid.tables, m2.tables)
     assert np.array_equal(S.sim.download("vel"), m.transfer(m2, vel))
     assert np.array_equal(S.sim.download("pres"), m.transfer(m2, pres))
+
+
+def test_adaptive_time_loop_block_lists_and_fields(golden_dir):
+    """SURVEY 8c (iv): the reference's time loop WITH mesh adaptation every step (Simulation::advance 15306-15326: adaptMesh,
+    then the pipeline), device vs oracle, both solving to 1e-9 / 1e-8: the block lists (level, Z) agree bit-exactly at every
+    step and the fields to solver round-off."""
+    bpd, lmax, bc, ext, nu, cfl = (2, 2, 2), 3, ("periodic", "wall", "freespace"), 2 * np.pi, 0.05, 0.3
+    g0 = cu.Grid(bpd, lmax, 0, ext, bc)
+    lv, zs = g0.tables[:, 0].astype(np.int32), g0.tables[:, 1].copy()
+    m = O.OracleMesh(bpd, lmax, ext, bc, lv, zs)
+    geom = g0.geom
+    ax = np.arange(8) + 0.5
+    vel = np.zeros((m.nb, 8, 8, 8, 3))
+    for b in range(m.nb):   # a compact vortex: refinement stays local
+        h = geom[b, 0]
+        Z, Y, X = np.meshgrid(geom[b, 3] + ax * h, geom[b, 2] + ax * h, geom[b, 1] + ax * h, indexing="ij")
+        gss = np.exp(-((X - 2.5) ** 2 + (Y - 3.0) ** 2 + (Z - 3.2) ** 2) / 0.8)
+        vel[b, ..., 0], vel[b, ..., 1], vel[b, ..., 2] = -(Y - 3.0) * gss, (X - 2.5) * gss, 0.2 * gss
+    pres = np.zeros((m.nb, 8, 8, 8))
+    sim = cu.SimulationData(bpdx=2, bpdy=2, bpdz=2, levelMax=lmax, levelStart=0, extent=ext, nu=nu, CFL=cfl, rampup=3, BC_x=bc[0], BC_y=bc[1],
+                            BC_z=bc[2], poissonTol=1e-9, poissonTolRel=1e-8)
+    sim.upload("vel", vel)
+    S = cu.Simulation(sim)
+    w = m.vorticity(vel)
+    linf = np.sqrt((w ** 2).sum(axis=-1)).reshape(m.nb, -1).max(axis=1)
+    rt, ct = float(np.quantile(linf, 0.6)), float(np.quantile(linf, 0.4))   # the mesh grows 8 -> 29 -> 85 -> 92 blocks
+    dt, coefU, nblocks = 0.0, np.array([1.5, -2.0, 0.5]), []
+    for n in range(6):
+        # oracle: adaptMesh, calcMaxTimestep, AdvectionDiffusion, PressureProjection
+        st = m.valid_states(m.tag(m.vorticity(vel), rt, ct))
+        if (st != 0).any():
+            m2 = m.adapted(st)
+            vel, pres, m = m.transfer(m2, vel), m.transfer(m2, pres), m2
+        dt = O.lib().orc_calc_dt(sim.hmin, m.max_u(vel), nu, cfl, n, 3, dt, coefU)
+        vel, _ = m.advect_diffuse(vel, dt, nu, (0, 0, 0))
+        m.project(vel, pres, dt, n, tol=1e-9, tol_rel=1e-8)
+        # device
+        st_dev = S.adaptMesh(rt, ct)
+        assert np.array_equal(st_dev, st), n
+        assert np.array_equal(S.sim.grid.tables, m.tables), n       # the block list, bit-exactly
+        dt_dev = S.calcMaxTimestep()
+        assert abs(dt_dev - dt) <= 1e-9 * dt
+        S.advance(dt_dev)
+        nblocks.append(m.nb)
+        assert np.abs(S.sim.download("vel") - vel).max() <= 1e-7, n
+    assert len(set(nblocks)) >= 3 and len(set(m.tables[:, 0].tolist())) >= 2   # the mesh kept changing and is multi-level
+    assert np.abs(S.sim.download("pres") - pres).max() <= 1e-5 * max(np.abs(pres).max(), 1e-12)
