@@ -379,6 +379,15 @@ def test_sharded_blocks_equal_single_rank(nranks, bc):
             cu.capi.check(cu.lib().cup3d_pressure_rhs(s.handle, dt))
             s.grid.scatter_to_global(s.download("lhs"), got_r)
         assert np.array_equal(got_r, rhs_ref)
+        # vector 1-deep exchange read on ALL faces: ComputeVorticity (slabs still current from the pull above)
+        t = o.tables
+        mo = O.OracleMesh(bpd, lmax, ext, bc, t[:, 0], t[:, 1])
+        vort_ref = o.to_global(mo.vorticity(o.to_blocks(velg)))
+        got_w = np.zeros_like(vort_ref)
+        for s in sims:
+            cu.ComputeVorticity(s)(0)
+            s.grid.scatter_to_global(s.download("tmpV"), got_w)
+        assert np.array_equal(got_w, vort_ref)
     finally:
         cu.lib().cup3d_debug_virtual_ranks(0)
 
