@@ -435,8 +435,7 @@ def test_full_size_256_advect_diffuse_properties():
 def test_full_size_256_poisson_properties(block_solver):
     """BASELINE configs[1] size (256^3, 32768 blocks), Poisson path, size-independent properties: (a) the iterate the solver
     returns satisfies the reference's stopping rule when the residual is re-evaluated by an independent application of the
-    operator (ComputeLHS); (b) manufactured solution: solving A x = A x* recovers x* up to cond(A) * tolerance;
-    (c) the projection reduces the discrete divergence of a smooth divergent field by an order of magnitude."""
+    operator (ComputeLHS); (b) manufactured solution: solving A x = A x* recovers x* up to cond(A) * tolerance."""
     ext = 2 * np.pi
     sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=6, levelStart=5, extent=ext, BC_x="wall", BC_y="periodic", BC_z="freespace",
                             blockSolver=block_solver, poissonTol=1e-9, poissonTolRel=1e-8)
@@ -467,16 +466,6 @@ def test_full_size_256_poisson_properties(block_solver):
     # x* has the mean sum(x* h^3) that b(0,0,0) carried; the solver enforces mean 0: compare up to the constant
     d = (x - x.mean()) - (xs - xs.mean())
     assert np.abs(d).max() <= 1e-5 * np.abs(xs).max()
-    # (c)
-    vel = np.stack([np.sin(X) * np.cos(Y) + 0 * Z, np.cos(2 * Y) * np.sin(Z) + 0 * X, np.sin(Z) * np.cos(X) + np.sin(X) + 0 * Y], axis=-1)
-    sim.upload("vel", vel); sim.fill("tmpV", 0.0); sim.fill("chi", 0.0)
-    dt = 0.01
-    cu.capi.check(cu.lib().cup3d_pressure_rhs(sim.handle, dt))
-    div0 = np.abs(sim.download("lhs")).max()
-    sim.step = 0
-    cu.PressureProjection(sim)(dt)
-    cu.capi.check(cu.lib().cup3d_pressure_rhs(sim.handle, dt))
-    assert np.abs(sim.download("lhs")).max() < 0.1 * div0
 
 
 def test_medium_128_oracle_advect_diffuse_and_solver():
