@@ -93,6 +93,90 @@ def cpu_baseline(size_cpu, steps, threads):
                       f"{sec:.2f} s, {its / steps:.1f} BiCGSTAB its/step"}
 
 
+def run_amr(a):
+    """--amr: the same step on a multi-level mesh the device builds itself.  A compact vortex on a uniform level; a few passes of
+    Simulation.adaptMesh (vorticity tags -> ValidStates -> refine/compress on the device) refine around it; then K steps on the
+    frozen mesh are timed.  One GPU.  Reported beside the headline, not instead of it."""
+    import cup3d_amd as cu
+    from cup3d_amd.capi import ProfileEntry, lib
+    cu.device_init(0)
+    ext, lmax, lstart = 2 * np.pi, a.amr_levels + a.amr_base, a.amr_base
+    sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=lmax, levelStart=lstart, extent=ext, nu=0.002, CFL=0.3, BC_x="wall", BC_y="wall",
+                            BC_z="wall", rampup=0, blockSolver=a.block_solver)
+    g = sim.grid
+    ax = np.arange(8) + 0.5
+    X = (g.index[:, 0, None] * 8 + ax[None, :])[:, None, None, :] * g.h
+    Y = (g.index[:, 1, None] * 8 + ax[None, :])[:, None, :, None] * g.h
+    Z = (g.index[:, 2, None] * 8 + ax[None, :])[:, :, None, None] * g.h
+    gss = np.exp(-((X - 2.6) ** 2 + (Y - 3.1) ** 2 + (Z - 3.4) ** 2) / 0.6)
+    vel = np.stack([-(Y - 3.1) * gss, (X - 2.6) * gss, 0.3 * gss + 0 * X], axis=-1)
+    sim.upload("vel", np.ascontiguousarray(vel))
+    del vel, gss, X, Y, Z
+    S = cu.Simulation(sim)
+    t0 = time.perf_counter()
+    history = [int(sim.nblocks)]
+    for _ in range(a.amr_levels - 1):
+        cu.ComputeVorticity(S.sim)(0)
+        w = S.sim.download("tmpV")
+        linf = np.sqrt((w ** 2).sum(axis=-1)).reshape(S.sim.nblocks, -1).max(axis=1)
+        S.adaptMesh(float(np.quantile(linf, 1.0 - a.amr_fraction)), -1.0)   # refine the top fraction, never compress
+        history.append(int(S.sim.nblocks))
+    lib().cup3d_device_synchronize()
+    adapt_s = time.perf_counter() - t0
+    sim = S.sim
+    sim.step = 21
+    iters = []
+
+    def one_step():
+        S.advance(S.calcMaxTimestep())
+        iters.append(sim.last_poisson.iterations)
+
+    for _ in range(a.warmup):
+        one_step()
+    iters.clear()
+    lib().cup3d_profile_enable(1)
+    lib().cup3d_profile_reset()
+    lib().cup3d_device_synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    lib().cup3d_device_synchronize()
+    sec = time.perf_counter() - t0
+    ents = (ProfileEntry * 64)()
+    n = C.c_int(0)
+    lib().cup3d_profile_read(ents, 64, C.byref(n))
+    prof = {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n.value)}
+    total_ms = sum(ms for _, ms in prof.values()) or 1.0
+    cells = sim.nblocks * 512.0
+    t = sim.grid.tables
+    kernels = []
+    for name, (launches, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+        if not launches:
+            continue
+        e = {"kernel": name, "launches": launches, "avg_ms": round(ms / launches, 5), "share": round(ms / total_ms, 4)}
+        if name in ALGO_BYTES:
+            # the unfused AMR advect-diffuse stage reads vel and tmpV and writes tmpV only (72 B/cell); k_rk_update is its own entry
+            bpc = 72.0 if name == "advdiff_stage" else ALGO_BYTES[name]
+            ach = bpc * cells / (ms / launches * 1e-3) / 1e9
+            e.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None})
+        kernels.append(e)
+    with_roof = [k for k in kernels if "achieved" in k]
+    out = {"metric": "Mcell-updates/s (advect+diffuse+Poisson), multi-level AMR mesh", "value": round(cells * a.steps / sec / 1e6, 2),
+           "unit": "Mcell-updates/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(sec / a.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"compact vortex in an all-wall box, uniform level {lstart} refined {a.amr_levels - 1}x around it by Simulation.adaptMesh "
+                                  f"(top {a.amr_fraction:.0%} of the blocks by vorticity each pass), frozen mesh while timing",
+                      "blocks": int(sim.nblocks), "cells": int(cells), "blocks_per_level": {int(l): int((t[:, 0] == l).sum()) for l in sorted(set(t[:, 0].tolist()))},
+                      "interface_faces": int(lib().cup3d_grid_ninterface_faces(sim.grid.handle)), "block_history": history,
+                      "finest_uniform_equivalent_cells": int((8 << (lmax - 1)) ** 3), "mesh_build_seconds": round(adapt_s, 3),
+                      "bicgstab_iters_per_step": round(float(np.mean(iters)), 2),
+                      "block_preconditioner": ("block CG (reference algorithm)", "direct block solve (fast diagonalisation)")[a.block_solver]},
+           "roofline": ({k: with_roof[0][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": with_roof[0]["kernel"]}) if with_roof else None,
+           "kernels": kernels}
+    print(json.dumps(out))
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,7 +189,13 @@ def main():
     ap.add_argument("--stencil-only", action="store_true", help="BASELINE configs[1]: periodic, advect-diffuse only")
     ap.add_argument("--block-solver", type=int, default=0, help="0: block CG as in the reference, 1: direct block solve")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed region with the other block solver")
+    ap.add_argument("--amr", action="store_true", help="time the step on a multi-level mesh built on the device (see run_amr)")
+    ap.add_argument("--amr-base", type=int, default=4, help="--amr: uniform starting level (16^3 blocks at 4)")
+    ap.add_argument("--amr-levels", type=int, default=3, help="--amr: number of levels of the final mesh")
+    ap.add_argument("--amr-fraction", type=float, default=0.3, help="--amr: fraction of the blocks refined per pass")
     a = ap.parse_args()
+    if a.amr:
+        return run_amr(a)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -24,6 +24,10 @@ if has benchq; then echo "== bench 512 (no cpu baseline)"
   timeout 300 python bench.py --size 512 --steps 5 --warmup 1 --no-cpu --stencil-only > $OUT/benchq_512_stencil.json 2> $OUT/benchq_512_stencil.err ; tail -c 1500 $OUT/benchq_512_stencil.json
   timeout 600 python bench.py --no-cpu > $OUT/benchq_512.json 2> $OUT/benchq_512.err ; echo "bench rc=$?" ; tail -c 3000 $OUT/benchq_512.json ; tail -3 $OUT/benchq_512.err
   fi
+if has amr; then echo "== bench --amr (multi-level mesh built on the device)"
+  timeout 600 python bench.py --amr --steps 5 --warmup 1 > $OUT/bench_amr.json 2> $OUT/bench_amr.err ; echo "bench rc=$?" ; tail -c 3500 $OUT/bench_amr.json ; tail -3 $OUT/bench_amr.err
+  timeout 600 python bench.py --amr --steps 5 --warmup 1 --block-solver 1 > $OUT/bench_amr_fdm.json 2> $OUT/bench_amr_fdm.err ; tail -c 600 $OUT/bench_amr_fdm.json | head -c 600
+  fi
 if has bench; then echo "== bench 512 stencil-only"
   timeout 300 python bench.py --size 512 --steps 5 --warmup 1 --no-cpu --stencil-only > $OUT/bench_512_stencil.json 2> $OUT/bench_512_stencil.err ; tail -c 1200 $OUT/bench_512_stencil.json
   echo "== bench default (512 full + cpu baseline)"
