@@ -13,7 +13,7 @@ echo "== host: $(nproc) cpus" ; rocminfo 2>/dev/null | grep -m1 -E "gfx9"
 if has smoke; then echo "== smoke"
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1 ; echo "smoke rc=$?" ; tail -3 $OUT/smoke.log; fi
 if has quick; then echo "== pytest quick: ${QUICK:-tests/test_gpu_adapt.py}"
-  timeout 600 python -m pytest ${QUICK:-tests/test_gpu_adapt.py} -m gpu -q --durations=12 > $OUT/pytest_quick.log 2>&1 ; echo "pytest rc=$?" ; tail -30 $OUT/pytest_quick.log | cut -c1-250; fi
+  timeout ${QUICK_TIMEOUT:-300} python -m pytest ${QUICK:-tests/test_gpu_adapt.py} -m gpu -q --durations=12 > $OUT/pytest_quick.log 2>&1 ; echo "pytest rc=$?" ; tail -30 $OUT/pytest_quick.log | cut -c1-250; fi
 if has tests; then echo "== pytest -m gpu"
   timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1 ; echo "pytest rc=$?" ; tail -25 $OUT/pytest_gpu.log | cut -c1-300; fi
 if has probe; then echo "== kernel probes"

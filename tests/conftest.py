@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# The CPU oracle's OpenMP regions are tiny at test sizes; on a 256-thread host a 256-wide team makes every region cost
+# milliseconds (fork/join + per-thread tile allocation), which turned a 20 s test into > 10 minutes.  Must be set before
+# libgomp loads (i.e. before tests/oracle_lib.py dlopens the oracle).
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
