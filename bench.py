@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--amr-fraction", type=float, default=0.3, help="--amr: fraction of the blocks refined per pass")
     a = ap.parse_args()
     if a.amr:
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            sys.exit("bench.py --amr runs on one GPU (multi-level meshes are single-rank this round)")
         return run_amr(a)
 
     rank = int(os.environ.get("RANK", "0"))

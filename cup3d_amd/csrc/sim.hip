@@ -264,8 +264,8 @@ int cup3d_sim_create(const cup3d_grid_t *gh, cup3d_sim_t **out) {
       return rc;
     }
     const size_t slab = 3 * 3 * 64;  // widest exchange: 3 components x 3 layers
-    if (g->n_recv_faces) { if ((rc = sim_alloc(&s->halo_recv, (size_t)g->n_recv_faces * slab, s))) return rc; }
-    if (!g->send_faces.empty()) { if ((rc = sim_alloc(&s->halo_send, g->send_faces.size() * slab, s))) return rc; }
+    if (g->n_recv_faces) { if ((rc = sim_alloc(&s->halo_recv, (size_t)g->n_recv_faces * slab, s))) { cup3d_sim_destroy((cup3d_sim_t *)s); return rc; } }
+    if (!g->send_faces.empty()) { if ((rc = sim_alloc(&s->halo_send, g->send_faces.size() * slab, s))) { cup3d_sim_destroy((cup3d_sim_t *)s); return rc; } }
     CUP3D_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
   }
   if (g->multilevel) {
@@ -285,12 +285,12 @@ int cup3d_sim_create(const cup3d_grid_t *gh, cup3d_sim_t **out) {
       cup3d_sim_destroy((cup3d_sim_t *)s);
       return rc;
     }
-    if ((rc = sim_alloc(&s->d_hb, nb, s))) return rc;
+    if ((rc = sim_alloc(&s->d_hb, nb, s))) { cup3d_sim_destroy((cup3d_sim_t *)s); return rc; }
     CUP3D_HIP(hipMemcpy(s->d_hb, g->hb.data(), nb * sizeof(double), hipMemcpyHostToDevice));
     const size_t ne = (size_t)std::max<int64_t>(g->n_amr_faces(), 1);
     // ghost slabs: widest use = 3 components x 3 layers; the pressure RHS keeps a second set (udef) behind the first
-    if ((rc = sim_alloc(&s->halo_recv, ne * 9 * 64, s))) return rc;
-    if ((rc = sim_alloc(&s->d_flux, ne * 3 * 64, s))) return rc;
+    if ((rc = sim_alloc(&s->halo_recv, ne * 9 * 64, s))) { cup3d_sim_destroy((cup3d_sim_t *)s); return rc; }
+    if ((rc = sim_alloc(&s->d_flux, ne * 3 * 64, s))) { cup3d_sim_destroy((cup3d_sim_t *)s); return rc; }
   }
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_a, hipEventDisableTiming));
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_b, hipEventDisableTiming));
