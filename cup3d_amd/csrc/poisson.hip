@@ -236,7 +236,10 @@ int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
 }
 
 // ------------------------------------------------------------------ fused BiCGSTAB vector kernels
-struct Vecs { double *v[NVEC]; };
+struct Vecs {
+  double *v[NVEC];
+  const double *xin;  // where the second loop reads x from: v[X_], or the x_opt snapshot right after one was taken (see solve())
+};
 
 template <int K>
 __device__ __forceinline__ void emit_partials(double (&acc)[K], double *__restrict__ partials) {
@@ -321,7 +324,7 @@ __global__ void __launch_bounds__(256) k_loop2(Vecs V, long n, double alpha, dou
   double acc[7] = {0, 0, 0, 0, 0, 0, 0};
   GRID_STRIDE2(j, n) {
     const double2 qhat = LD2(V.v[QHAT]), y = LD2(V.v[Y_]), r0 = LD2(V.v[R0]);
-    const double2 x = LD2(V.v[X_]) + alpha * LD2(V.v[PHAT]) + omega * qhat;
+    const double2 x = LD2(V.xin) + alpha * LD2(V.v[PHAT]) + omega * qhat;
     const double2 r = LD2(V.v[Q_]) - omega * y;
     const double2 rhat = qhat - omega * (LD2(V.v[WHAT]) - alpha * LD2(V.v[ZHAT]));
     const double2 w = y - omega * (LD2(V.v[T_]) - alpha * LD2(V.v[V_]));
@@ -338,7 +341,7 @@ __global__ void __launch_bounds__(256) k_loop2(Vecs V, long n, double alpha, dou
 }
 // k % 50 == 0 variants   (14518-14537)
 __global__ void __launch_bounds__(256) k_loop2_x(Vecs V, long n, double alpha, double omega) {
-  GRID_STRIDE(j, n) V.v[X_][j] = V.v[X_][j] + alpha * V.v[PHAT][j] + omega * V.v[QHAT][j];
+  GRID_STRIDE(j, n) V.v[X_][j] = V.xin[j] + alpha * V.v[PHAT][j] + omega * V.v[QHAT][j];
 }
 __global__ void __launch_bounds__(256) k_true_resid(Vecs V, long n) {
   GRID_STRIDE(j, n) V.v[R_][j] = V.v[B_][j] - V.v[R_][j];
@@ -420,6 +423,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   s->block_solver = P.block_solver;
   Vecs V;
   for (int i = 0; i < NVEC; ++i) V.v[i] = s->sv[i];
+  V.xin = V.v[X_];
   const long N = s->nb * 512L;
   const unsigned G = vec_groups(N);
   const int mc = P.mean_constraint;
@@ -461,6 +465,9 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       LAUNCH_VEC(k_loop2, V, N, alpha, omega, s->d_partials);
     } else {
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_loop2_x, V, N, alpha, omega); }
+    }
+    V.xin = V.v[X_];  // x now lives in v[X_] again
+    if (k % 50 == 0) {
       TRY(LHS(X_, R_));
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_true_resid, V, N); }
       TRY(PRE(R_, RHAT)); TRY(LHS(RHAT, W_));
@@ -493,10 +500,12 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       omega = 0.0;
     }
     if (norm < min_norm) {                                              // 14594-14600
+      // x_opt = x without the copy (16 B/cell in two iterations out of three): the buffer that holds x becomes the
+      // snapshot, and the next update of x reads it and writes the other buffer (x is read once and written once there anyway)
       use_xopt = true;
       min_norm = norm;
-      ProfileScope ps("bicgstab_vector");
-      LAUNCH_VEC(k_copy, V.v[X_], V.v[XOPT], N);
+      std::swap(V.v[XOPT], V.v[X_]);
+      V.xin = V.v[XOPT];
     }
     if (norm < P.tol || norm / (init_norm + eps) < P.tol_rel) break;   // 14601
   }
