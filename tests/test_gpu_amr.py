@@ -331,3 +331,74 @@ def test_adaptive_time_loop_block_lists_and_fields(golden_dir):
         assert np.abs(S.sim.download("vel") - vel).max() <= 1e-7, n
     assert len(set(nblocks)) >= 3 and len(set(m.tables[:, 0].tolist())) >= 2   # the mesh kept changing and is multi-level
     assert np.abs(S.sim.download("pres") - pres).max() <= 1e-5 * max(np.abs(pres).max(), 1e-12)
+
+
+# ------------------------------------------------------------------ randomised meshes
+def random_mesh(seed):
+    """A multi-level mesh grown by the ORACLE's adaptMesh from level 0 under random octet-amplitude fields (refinement and
+    compression), random box shape (incl. one block across a periodic direction), boundary conditions and depth."""
+    rng = np.random.default_rng(seed)
+    bpd = tuple(int(v) for v in rng.choice([1, 2, 3], 3))
+    if bpd == (1, 1, 1):
+        bpd = (2, 1, 2)
+    lmax, bc, passes = int(rng.choice([3, 4])), tuple(str(b) for b in rng.choice(["periodic", "wall", "freespace"], 3)), int(rng.choice([2, 3]))
+    g0 = cu.Grid(bpd, lmax, 0, EXT, bc)
+    m = O.OracleMesh(bpd, lmax, EXT, bc, g0.tables[:, 0].astype(np.int32), g0.tables[:, 1].copy())
+    for p in range(passes):
+        vel, _ = _octet_fields(m.tables, seed + p)
+        w = m.vorticity(vel)
+        linf = np.sqrt((w ** 2).sum(axis=-1)).reshape(m.nb, -1).max(axis=1)
+        st = m.valid_states(m.tag(w, float(np.quantile(linf, 0.6)), float(np.quantile(linf, 0.3))))
+        if (st != 0).any():
+            m = m.adapted(st)
+    return bpd, lmax, bc, m
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606, 707, 808])
+def test_random_meshes_everything_bitexact(seed):
+    bpd, lmax, bc, m = random_mesh(seed)
+    if m.nb > 1200 or len(set(m.tables[:, 0].tolist())) < 2:
+        pytest.skip("mesh too large / single level for this seed")
+    lv, zs = m.tables[:, 0].astype(np.int32), m.tables[:, 1].copy()
+    sim = cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=0, extent=EXT, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2],
+                            leaves=(lv, zs), nu=0.02, uinf=(0.1, -0.2, 0.3))
+    assert np.array_equal(sim.grid.tables, m.tables)
+    rng = np.random.default_rng(seed)
+    vel, pres = rng.uniform(-1, 1, (m.nb, 8, 8, 8, 3)), rng.uniform(-1, 1, (m.nb, 8, 8, 8))
+    faces, _, _ = sim.grid.interface()
+    # ghost slabs
+    for field, arr, w, s, e in (("vel", vel, 3, -3, 4), ("pres", pres, 1, -1, 2)):
+        sim.upload(field, arr)
+        nc = 3 if field == "vel" else 1
+        got = np.zeros((len(faces), nc, w, 64))
+        check(lib().cup3d_debug_amr_slabs(sim.handle, FIELDS[field], w, got))
+        labs = m.labs(arr, s, e, False)
+        for ei, (sf, kind) in enumerate(faces):
+            for gl in range(w):
+                assert np.array_equal(got[ei, :, gl, :], slab_from_tile(labs[sf // 6], s, sf % 6, gl)), (field, ei, kind, gl)
+    # operators
+    dt = 0.01
+    cu.AdvectionDiffusion(sim)(dt)
+    v, _ = m.advect_diffuse(vel, dt, 0.02, (0.1, -0.2, 0.3))
+    assert np.array_equal(sim.download("vel"), v)
+    sim.bMeanConstraint = 0
+    sim.upload("pres", pres)
+    cu.ComputeLHS(sim)(0)
+    assert np.array_equal(sim.download("lhs"), m.lhs(pres, 0))
+    check(lib().cup3d_grad_p(sim.handle, dt))
+    assert np.array_equal(sim.download("tmpV"), m.grad_p(pres, dt))
+    # adaptMesh
+    velo, preso = _octet_fields(m.tables, seed + 50)
+    sim.upload("vel", velo); sim.upload("pres", preso)
+    w = m.vorticity(velo)
+    linf = np.sqrt((w ** 2).sum(axis=-1)).reshape(m.nb, -1).max(axis=1)
+    rt, ct = float(np.quantile(linf, 0.7)), float(np.quantile(linf, 0.35))
+    S = cu.Simulation(sim)
+    st = S.adaptMesh(rt, ct)
+    st_o = m.valid_states(m.tag(w, rt, ct))
+    assert np.array_equal(st, st_o)
+    if (st != 0).any():
+        m2 = m.adapted(st_o)
+        assert np.array_equal(S.sim.grid.tables, m2.tables)
+        assert np.array_equal(S.sim.download("vel"), m.transfer(m2, velo))
+        assert np.array_equal(S.sim.download("pres"), m.transfer(m2, preso))
