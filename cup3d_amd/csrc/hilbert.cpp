@@ -84,7 +84,11 @@ HilbertCurve::HilbertCurve(int bx, int by, int bz, int level_max) : level_max_(l
   while ((1 << base_bits_) < widest) ++base_bits_;
   const int64_t ncell = (int64_t)bx * by * bz;
   const int64_t cube = (int64_t)1 << (3 * base_bits_);
-  full_cube_ = (ncell == cube);
+  // The reference indexes with the enclosing cube's curve whenever no cube cell outside the box precedes a box cell on the
+  // curve (`isRegular`, main.cpp:216-234) -- true for full cubes, but also for boxes such as 1x1x2 or 1x2x2 that happen to be
+  // a prefix of the curve -- and compacts the curve otherwise.
+  full_cube_ = true;
+  bool seen_outside = false;
   rank_of_cell_.assign(ncell, -1);
   cell_of_rank_.assign(3 * ncell, -1);
   // Walk the enclosing cube along the curve; box cells keep their relative order.
@@ -92,7 +96,8 @@ HilbertCurve::HilbertCurve(int bx, int by, int bz, int level_max) : level_max_(l
   for (int64_t h = 0; h < cube; ++h) {
     int64_t c[3];
     cube_coords(h, base_bits_, c);
-    if (c[0] >= bx || c[1] >= by || c[2] >= bz) continue;
+    if (c[0] >= bx || c[1] >= by || c[2] >= bz) { seen_outside = true; continue; }
+    if (seen_outside) full_cube_ = false;
     rank_of_cell_[(c[2] * by + c[1]) * bx + c[0]] = next;
     cell_of_rank_[3 * next + 0] = (int32_t)c[0];
     cell_of_rank_[3 * next + 1] = (int32_t)c[1];

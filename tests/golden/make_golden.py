@@ -26,7 +26,8 @@ FIELD_CASES = [
     ("f16_mixed", (2, 2, 2), 1, 0, ("freespace", "wall", "periodic"), 13),
     ("f24x16x8_mixed", (3, 2, 1), 1, 0, ("periodic", "freespace", "wall"), 14),
 ]
-SFC_CASES = [((1, 1, 1), 4), ((2, 2, 2), 3), ((2, 1, 1), 3), ((3, 2, 1), 2), ((4, 4, 4), 1)]
+SFC_CASES = [((1, 1, 1), 4), ((2, 2, 2), 3), ((2, 1, 1), 3), ((3, 2, 1), 2), ((4, 4, 4), 1),
+             ((1, 1, 2), 3), ((1, 2, 2), 3), ((1, 3, 1), 2), ((2, 1, 3), 2)]  # 1x1x2 and 1x2x2 are curve prefixes: 'regular' without being cubes
 
 
 def field_case(name, bpd, lmax, lstart, bc, seed):

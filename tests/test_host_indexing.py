@@ -277,3 +277,14 @@ def test_valid_states_and_adapted_mesh_match_reference(golden_dir):
     st = u.valid_states(tags)
     lv2, zs2 = u.adapted_leaves(st)
     assert len(lv2) == u.nblocks + 7 and set(lv2.tolist()) == {1, 2}
+
+
+def test_block_tables_for_every_small_box_shape():
+    """Product topology vs oracle for every box up to 4x4x3 level-0 blocks (the reference treats boxes that are a prefix of the
+    enclosing cube's Hilbert curve, e.g. 1x1x2 and 1x2x2, as 'regular': main.cpp:216-234)."""
+    import itertools
+    for bpd in itertools.product([1, 2, 3, 4], [1, 2, 3, 4], [1, 2, 3]):
+        for lmax, lev in ((1, 0), (2, 1), (3, 2)):
+            g = cu.Grid(bpd, lmax, lev, 1.0, (1, 1, 1))
+            o = O.OracleGrid(bpd, lmax, lev, 1.0, (1, 1, 1))
+            assert np.array_equal(g.tables, o.tables), (bpd, lmax, lev)
