@@ -259,6 +259,8 @@ def test_trajectory_64_cubed_ten_steps():
     ((1, 1, 1), 3, 2, ("wall", "wall", "wall")),
     ((1, 2, 3), 2, 1, ("freespace", "periodic", "wall")),
     ((8, 8, 8), 1, 0, ("periodic", "wall", "periodic")),
+    ((1, 1, 2), 1, 0, ("periodic", "periodic", "periodic")),   # one block across a periodic direction: a block is its own neighbour
+    ((1, 2, 2), 2, 1, ("periodic", "freespace", "wall")),      # a box the reference indexes as 'regular' although it is no cube
 ])
 def test_oracle_random_fields(bpd, lmax, level, bc):
     """Fresh seeded inputs against the oracle (pinned to the reference by tests/test_oracle_*.py)."""
