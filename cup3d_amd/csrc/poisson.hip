@@ -26,9 +26,9 @@ enum { PHAT, RHAT, SHAT, WHAT, ZHAT, QHAT, S_, W_, Z_, T_, V_, Q_, R_, Y_, X_, R
 
 // ------------------------------------------------------------------ block-local CG
 // One wavefront per 8^3 block: lane = (x,y) column, the 8 z-values of r, p, x, Ap in
-// registers; z-neighbours come from registers, x/y-neighbours from a 10x10-pitched LDS
-// copy of p whose border stays 0 (the zero Dirichlet halo of the reference's
-// PaddedBlock).  Two wave reductions per CG iteration (p.Ap and r.r).
+// registers; z-neighbours come from registers, x/y-neighbours from an LDS copy of p with
+// zero rows above and below (the zero Dirichlet halo of the reference's PaddedBlock).
+// Two wave reductions per CG iteration (p.Ap and r.r).
 // FMA = contract a*b+c where the reference has a separate multiply and add (tuning variant
 // only: the production launch keeps the reference's association).
 template <bool FMA>
@@ -36,14 +36,21 @@ __device__ __forceinline__ double mad(double a, double b, double c) {
   if constexpr (FMA) return __builtin_fma(a, b, c);
   else return a * b + c;
 }
+// LDS layout: [z][row = y + 1 (rows 0 and 9 stay zero)][x], pitch 8 doubles and NO x halo.  With the 10x10-pitched tile of the
+// first version half of all LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50, and the waves
+// spent 35 % of their cycles in SQ_WAIT_INST_LDS: profiles/r01/pmc_block_preconditioner_sq.txt): a 64-bit access is served 32
+// lanes at a time, and four 8-wide rows at pitch 10 overlap in banks, while at pitch 8 the four rows tile the 32 bank pairs
+// exactly.  The price is that the x-1 / x+1 reads of the lanes at x = 0 / 7 fetch a cell of the neighbouring row, which is
+// multiplied by 0 (one FP64 multiply per side and plane; exact for the others, which are multiplied by 1).
 template <bool FMA>
 __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, double *out, double *__restrict__ block_sums) {
-  __shared__ double P[8 * 100];
+  __shared__ double P[8 * 80];
   const int slot = block_slot(g);
   if (slot < 0) return;
   const int l = threadIdx.x;
-  const int base = ((l >> 3) + 1) * 10 + (l & 7) + 1;
-  for (int i = l; i < 800; i += 64) P[i] = 0.0;
+  const int base = ((l >> 3) + 1) * 8 + (l & 7);
+  for (int i = l; i < 640; i += 64) P[i] = 0.0;
+  const double ml = (l & 7) == 0 ? 0.0 : 1.0, mr = (l & 7) == 7 ? 0.0 : 1.0;
   const double invh = 1 / block_h(g, slot);  // main.cpp:14723
   double r[8], p[8], x[8], Ax[8];
   double rr = 0;
@@ -61,14 +68,14 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
     __syncthreads();
     for (int k = 0; k < 100; ++k) {                         // 14739
 #pragma unroll
-      for (int z = 0; z < 8; ++z) P[z * 100 + base] = p[z];
+      for (int z = 0; z < 8; ++z) P[z * 80 + base] = p[z];
       __syncthreads();
       double a2 = 0;
 #pragma unroll
       for (int z = 0; z < 8; ++z) {                         // kernelPoissonGetZInner, 14662-14682
-        double t = mad<FMA>(-6.0, p[z], P[z * 100 + base - 1] + P[z * 100 + base + 1]);
-        t += P[z * 100 + base - 10];
-        t += P[z * 100 + base + 10];
+        double t = mad<FMA>(-6.0, p[z], P[z * 80 + base - 1] * ml + P[z * 80 + base + 1] * mr);
+        t += P[z * 80 + base - 8];
+        t += P[z * 80 + base + 8];
         t += z > 0 ? p[z - 1] : 0.0;
         t += z < 7 ? p[z + 1] : 0.0;
         Ax[z] = t;

@@ -71,4 +71,22 @@ PY
     done
     rm -rf $OUT/pmc2_$C
   done; fi
+if has pmc3; then echo "== rocprofv3 SQ counters of the block preconditioners (256^3, solver-like input)"
+  for SET in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES SQ_LDS_IDX_ACTIVE"; do
+    TAGC=$(echo $SET | cut -d" " -f1)
+    ( cd /tmp && timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $ROOT/$OUT/pmc3_$TAGC -o p -- python $ROOT/scripts/kernel_probe.py pre --size 256 --reps 2 > $ROOT/$OUT/pmc3_$TAGC.log 2>&1 )
+    for f in $(find $OUT/pmc3_$TAGC -name "*counter_collection.csv" | head -1); do python - "$f" <<'PY' | tee -a $OUT/pmc3_summary.txt
+import csv, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"][:48]
+    if "k_precond" in k:
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in sorted(acc.items()):
+    for c, v in sorted(d.items()):
+        print(k, c, "launches", len(v), "mean", round(sum(v) / len(v), 1), "last", v[-1])
+PY
+    done
+    rm -rf $OUT/pmc3_$TAGC
+  done; fi
 echo "== done"
