@@ -233,9 +233,11 @@ int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
     return CUP3D_OK;
   }
   ProfileScope ps("poisson_block_cg");
-  // default: the reference's association (no FMA contraction); measured on MI355X the kernel is bound by the
-  // latency of its two dependent wave reductions per iteration, not by FP64 issue (FMA: 0.827 vs 0.845 ms at 256^3)
-  if (debug_option("precond_fma")) hipLaunchKernelGGL(k_precond<true>, dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, sums);
+  // Production contracts a*b+c into FMAs here (and only here): the result of this kernel sits behind two wave reductions per
+  // iteration whose summation order already differs from the CPU's, FMA moves it by ~1e-15 relative (the CG's own truncation
+  // is 1e-7), and with the conflict-free LDS layout the kernel is VALU-issue/dependency bound, where the contraction is worth
+  // 10 % (0.571 vs 0.634 ms at 256^3).  cup3d_debug_set_option("precond_no_fma", 1) selects the uncontracted association.
+  if (!debug_option("precond_no_fma")) hipLaunchKernelGGL(k_precond<true>, dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, sums);
   else hipLaunchKernelGGL(k_precond<false>, dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, sums);
   CUP3D_HIP(hipGetLastError());
   s->sums_of = want_sums ? out : nullptr;  // block sums of `out` are fresh: the next LHS of `out` reuses them
