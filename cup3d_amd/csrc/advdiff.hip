@@ -20,9 +20,15 @@
 namespace cup3d {
 
 constexpr int kXYPitch = 14;                    // x and y extended by the 3-deep ghosts
-constexpr int kXYSize = 8 * 14 * 14;            // centre + x/y ghosts: [z 8][y 14][x 14]
-constexpr int kZGSize = 6 * 64;                 // z ghost planes: [-1,-2,-3, 8,9,10][y][x]
-constexpr int kCompStride = kXYSize + kZGSize;  // 1952 doubles per component
+// LDS bank discipline: a 64-bit LDS access is served 32 lanes at a time over 32 bank pairs.  The compute phase maps a
+// half-wave to 8 x by 4 z cells at one y (see k_advdiff), so every stencil read of a half-wave is "base + x + z*kPlane"; with
+// kPlane = 8 (mod 32) the four z rows tile the 32 bank pairs exactly, for every shift along x, y or z.  (The first version mapped
+// a half-wave to 8 x by 4 y at pitch 14: every read was a 2-way conflict.)  The z ghost planes get pitch 72 for the same reason.
+constexpr int kPlane = 14 * 14 + 4;             // 200: one z plane [y 14][x 14] + 4 pad
+constexpr int kXYSize = 8 * kPlane;             // centre + x/y ghosts: [z 8][y 14][x 14]
+constexpr int kZPitch = 72;                     // pitch of the z ghost planes
+constexpr int kZGSize = 6 * kZPitch;            // z ghost planes: [-1,-2,-3, 8,9,10][y][x]
+constexpr int kCompStride = kXYSize + kZGSize;  // 2032 doubles per component
 
 struct AdvArgs {
   const double *vel;   // [nb][3][512] in
@@ -71,21 +77,21 @@ __device__ __forceinline__ void face_element(int f, int e, int &nb_cell, int &ow
     const int gl = e >> 6, a = e & 63;
     nb_cell = (side ? gl : 7 - gl) * 64 + a;
     own_cell = (side ? 7 : 0) * 64 + a;
-    lds = kXYSize + (side * 3 + gl) * 64 + a;
+    lds = kXYSize + (side * 3 + gl) * kZPitch + a;
     halo = gl * 64 + a;
   } else if (d == 1) {
     const int z = e / 24, r = e - 24 * z, gr = r >> 3, x = r & 7;
     const int ys = side ? gr : 5 + gr, yg = side ? 8 + gr : gr - 3, gl = side ? gr : 2 - gr;
     nb_cell = z * 64 + ys * 8 + x;
     own_cell = z * 64 + (side ? 7 : 0) * 8 + x;
-    lds = (z * kXYPitch + (yg + 3)) * kXYPitch + (x + 3);
+    lds = z * kPlane + (yg + 3) * kXYPitch + (x + 3);
     halo = gl * 64 + z * 8 + x;
   } else {
     const int row = e / 3, xx = e - 3 * row, z = row >> 3, y = row & 7;
     const int xs = side ? xx : 5 + xx, xg = side ? 8 + xx : xx - 3, gl = side ? xx : 2 - xx;
     nb_cell = row * 8 + xs;
     own_cell = row * 8 + (side ? 7 : 0);
-    lds = (z * kXYPitch + (y + 3)) * kXYPitch + (xg + 3);
+    lds = z * kPlane + (y + 3) * kXYPitch + (xg + 3);
     halo = gl * 64 + z * 8 + y;
   }
 }
@@ -99,26 +105,30 @@ __device__ __forceinline__ void face_element(int f, int e, int &nb_cell, int &ow
 template <bool FIRST_STAGE, int CPT, int VAR, bool AMR = false>
 __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
   constexpr int NT = 512 / CPT, NW = NT / 64;
-  __shared__ double tile[3 * kCompStride];  // 46,848 B -> 3 workgroups per CU
+  __shared__ double tile[3 * kCompStride];  // 48,768 B -> 3 workgroups per CU
   const int slot = block_slot(g);
   if (slot < 0) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const double *__restrict__ own = a.vel + (size_t)slot * 1536;
 
   // ---- stage the tile: centre (each thread's own cells stay in registers too)
-  const int x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;  // cells (x,y,z0 + k*NW)
+  // cells of this thread: (x, y, z0 + 4k).  A half-wave holds 8 x by 4 z at one y (bank discipline above); the two halves of a
+  // wave hold y and y+1, i.e. the two 64 B halves of the same 128 B lines in global memory.
+  static_assert(CPT == 2, "the lane -> cell map below is written for 256 threads x 2 cells");
+  const int x = lane & 7, z0 = (lane >> 3) & 3, y = 2 * wave + (lane >> 5);
+  const int cell0 = z0 * 64 + y * 8 + x;  // second cell: + 256
   double uc[CPT][3];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) uc[k][c] = own[c * 512 + k * NT + t];
+    for (int k = 0; k < CPT; ++k) uc[k][c] = own[c * 512 + k * 256 + cell0];
   double told[CPT][3];
   if (!FIRST_STAGE) {
     const double *__restrict__ tp = a.tmp + (size_t)slot * 1536;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int k = 0; k < CPT; ++k) told[k][c] = tp[c * 512 + k * NT + t];
+      for (int k = 0; k < CPT; ++k) told[k][c] = tp[c * 512 + k * 256 + cell0];
   }
   // ---- ghosts: 18 (face, component) units of 192 values.  Every global load of the tile
   // (centre, tmpV, ghosts: ~27 per thread) is issued before the first LDS write, so ONE memory
@@ -138,11 +148,11 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
     const int e = j * 64 + lane;
     const int zy = e / 24, r = e - 24 * zy, gr = r >> 3, xx8 = r & 7;
     yb[j] = zy * 64 + xx8;                    // neighbour / own cell without the y term
-    yl[j] = zy * 196 + gr * kXYPitch + xx8 + 3;  // LDS slot for side 0 (ghost row gr-3)
+    yl[j] = zy * kPlane + gr * kXYPitch + xx8 + 3;  // LDS slot for side 0 (ghost row gr-3)
     yg[j] = gr;
     const int row = e / 3, x3 = e - 3 * row;
     xb[j] = row * 8;
-    xl[j] = (row >> 3) * 196 + ((row & 7) + 3) * kXYPitch + x3;  // LDS slot for side 0 (ghost column x3-3)
+    xl[j] = (row >> 3) * kPlane + ((row & 7) + 3) * kXYPitch + x3;  // LDS slot for side 0 (ghost column x3-3)
     xg[j] = x3;
   }
 #pragma unroll
@@ -176,7 +186,7 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
         if (d == 2) {
           nb_cell = (side ? j : 7 - j) * 64 + lane;
           own_cell = (side ? 7 : 0) * 64 + lane;
-          lds = kXYSize + (side * 3 + j) * 64 + lane;
+          lds = kXYSize + (side * 3 + j) * kZPitch + lane;
           hal = j * 64 + lane;
         } else if (d == 1) {
           nb_cell = yb[j] + (side ? yg[j] : 5 + yg[j]) * 8;
@@ -198,7 +208,7 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) tile[c * kCompStride + (z0 + k * NW) * 196 + xy] = uc[k][c];
+    for (int k = 0; k < CPT; ++k) tile[c * kCompStride + (z0 + 4 * k) * kPlane + xy] = uc[k][c];
 #pragma unroll
   for (int i = 0; i < UPW; ++i)
     if (gon[i]) {
@@ -219,9 +229,9 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
       if (n < kNbrHalo) continue;
       const int d = f >> 1, side = f & 1;
       int in, gh;
-      if (d == 0) { in = a2 * 196 + (a1 + 3) * kXYPitch + (side ? 10 : 3); gh = in + (side ? 1 : -1); }
-      else if (d == 1) { in = a2 * 196 + (side ? 10 : 3) * kXYPitch + a1 + 3; gh = in + (side ? kXYPitch : -kXYPitch); }
-      else { in = (side ? 7 : 0) * 196 + (a2 + 3) * kXYPitch + a1 + 3; gh = kXYSize + (side * 3) * 64 + lane; }
+      if (d == 0) { in = a2 * kPlane + (a1 + 3) * kXYPitch + (side ? 10 : 3); gh = in + (side ? 1 : -1); }
+      else if (d == 1) { in = a2 * kPlane + (side ? 10 : 3) * kXYPitch + a1 + 3; gh = in + (side ? kXYPitch : -kXYPitch); }
+      else { in = (side ? 7 : 0) * kPlane + (a2 + 3) * kXYPitch + a1 + 3; gh = kXYSize + (side * 3) * kZPitch + lane; }
       g.flux[((size_t)(n - kNbrHalo) * 3 + c) * 64 + lane] = facD * (L[in] - L[gh]);
     }
   }
@@ -229,12 +239,12 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
   double *__restrict__ tout = a.tmp + (size_t)slot * 1536;
 #pragma unroll
   for (int k = 0; k < CPT; ++k) {
-    const int z = z0 + NW * k;
+    const int z = z0 + 4 * k;
     if (VAR == 2) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        vout[c * 512 + k * NT + t] = uc[k][c] + tile[c * kCompStride + ((t * 7 + c) % kCompStride)];
-        tout[c * 512 + k * NT + t] = FIRST_STAGE ? 0.0 : told[k][c];
+        vout[c * 512 + k * 256 + cell0] = uc[k][c] + tile[c * kCompStride + ((t * 7 + c) % kCompStride)];
+        tout[c * 512 + k * 256 + cell0] = FIRST_STAGE ? 0.0 : told[k][c];
       }
       continue;
     }
@@ -242,9 +252,9 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
 #pragma unroll
     for (int dz = -3; dz <= 3; ++dz) {
       const int zz = z + dz;
-      zo[dz + 3] = (zz >= 0 && zz < 8) ? zz * 196 + xy : kXYSize + (zz < 0 ? -1 - zz : zz - 5) * 64 + y * 8 + x;
+      zo[dz + 3] = (zz >= 0 && zz < 8) ? zz * kPlane + xy : kXYSize + (zz < 0 ? -1 - zz : zz - 5) * kZPitch + y * 8 + x;
     }
-    const int b = z * 196 + xy;
+    const int b = z * kPlane + xy;
     const double ua0 = uc[k][0] + a.u0, ua1 = uc[k][1] + a.u1, ua2 = uc[k][2] + a.u2;  // uAbs, 9492-9494
     const bool p0 = ua0 > 0, p1 = ua1 > 0, p2 = ua2 > 0;
     double res[3];
@@ -273,9 +283,9 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double tn = (FIRST_STAGE ? 0.0 : told[k][c]) + res[c];  // o += ..., main.cpp:9546-9548
-      if (AMR) { tout[c * 512 + k * NT + t] = tn; continue; }
-      vout[c * 512 + k * NT + t] = uc[k][c] + tn * a.alpha;          // V += tmpV*ih3, 9718-9720
-      tout[c * 512 + k * NT + t] = tn * a.beta;                      // tmpV *= beta, 9721-9723
+      if (AMR) { tout[c * 512 + k * 256 + cell0] = tn; continue; }
+      vout[c * 512 + k * 256 + cell0] = uc[k][c] + tn * a.alpha;          // V += tmpV*ih3, 9718-9720
+      tout[c * 512 + k * 256 + cell0] = tn * a.beta;                      // tmpV *= beta, 9721-9723
     }
   }
 }
@@ -363,8 +373,6 @@ static int advdiff_stage(Sim *s, int rk, double dt, double nu, const double uinf
         case 1: ADV2(2, 1); break;
         case 2: ADV2(2, 2); break;
         case 3: ADV2(2, 3); break;
-        case 10: ADV2(1, 0); break;
-        case 11: ADV2(1, 1); break;
         default: set_error("unknown advdiff_variant"); return CUP3D_EINVAL;
       }
 #undef ADV2

@@ -17,7 +17,7 @@ if has quick; then echo "== pytest quick: ${QUICK:-tests/test_gpu_adapt.py}"
 if has tests; then echo "== pytest -m gpu"
   timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1 ; echo "pytest rc=$?" ; tail -25 $OUT/pytest_gpu.log | cut -c1-300; fi
 if has probe; then echo "== kernel probes"
-  timeout 300 python scripts/kernel_probe.py adv --size 512 --variants ${ADV_VARIANTS:-0,2,3,10} > $OUT/probe_adv_512.jsonl 2>&1 ; cat $OUT/probe_adv_512.jsonl
+  timeout 300 python scripts/kernel_probe.py adv --size 512 --variants ${ADV_VARIANTS:-0,2,3} > $OUT/probe_adv_512.jsonl 2>&1 ; cat $OUT/probe_adv_512.jsonl
   timeout 300 python scripts/kernel_probe.py adv --size 256 --variants 0 > $OUT/probe_adv_256.jsonl 2>&1 ; cat $OUT/probe_adv_256.jsonl
   timeout 300 python scripts/kernel_probe.py pre --size 256 > $OUT/probe_pre_256.jsonl 2>&1 ; cat $OUT/probe_pre_256.jsonl; fi
 if has benchq; then echo "== bench 512 (no cpu baseline)"

@@ -39,7 +39,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["adv", "pre", "one"])
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--variants", default="0,1,2,3,10,11")
+    ap.add_argument("--variants", default="0,1,2,3")
     ap.add_argument("--kernel", default="adv")
     ap.add_argument("--reps", type=int, default=4)
     a = ap.parse_args()
