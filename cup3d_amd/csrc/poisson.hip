@@ -44,6 +44,8 @@ __device__ __forceinline__ double mad(double a, double b, double c) {
 // multiplied by 0 (one FP64 multiply per side and plane; exact for the others, which are multiplied by 1).
 template <bool FMA>
 __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, double *out, double *__restrict__ block_sums) {
+  // (86 VGPRs -> 5 waves/SIMD.  Forcing 6 with amdgpu_waves_per_eu spills five values that are reloaded every iteration: 0.476
+  //  vs 0.431 ms at 256^3, so the natural allocation stays.)
   __shared__ double P[8 * 80];
   const int slot = block_slot(g);
   if (slot < 0) return;
