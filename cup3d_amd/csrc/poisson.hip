@@ -396,7 +396,8 @@ __global__ void __launch_bounds__(256) k_shift_mean(double *__restrict__ p, cons
 
 static unsigned vec_groups(long n) {
   long g = (n + 255) / 256;
-  return (unsigned)(g > 2048 ? 2048 : g);
+  const int cap = debug_option("vec_groups") > 0 ? debug_option("vec_groups") : 2048;  // tuning knob; <= Sim::max_groups
+  return (unsigned)(g > cap ? cap : g);
 }
 
 struct Reducer {

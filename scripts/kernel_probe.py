@@ -37,7 +37,7 @@ def make(size, bc="periodic"):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["adv", "pre", "one"])
+    ap.add_argument("what", choices=["adv", "pre", "one", "loops"])
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--variants", default="0,1,2,3")
     ap.add_argument("--kernel", default="adv")
@@ -62,6 +62,23 @@ def main():
             print(json.dumps({"probe": "advdiff", "size": a.size, "variant": v, "avg_ms": round(avg, 4),
                               "GBps_algorithmic": round(96 * cells / avg / 1e6, 1), "frac_8TBs": round(96 * cells / avg / 1e6 / 8000, 4)}))
         check(lib().cup3d_debug_set_option(b"advdiff_variant", 0))
+    elif a.what == "loops":
+        # grid size of the fused BiCGSTAB vector loops (cup3d_debug_set_option "vec_groups")
+        sim = make(a.size, "wall")
+        sim.step = 21
+        dt = 0.3 * sim.grid.h
+        vel0 = sim.download("vel")
+        for vg in [int(x) for x in a.variants.split(",")]:
+            check(lib().cup3d_debug_set_option(b"vec_groups", vg))
+            sim.upload("vel", vel0); sim.fill("pres", 0.0)
+            lib().cup3d_device_synchronize()
+            lib().cup3d_profile_reset()
+            r = cu.PressureProjection(sim)(dt)
+            p = profile()
+            print(json.dumps({"probe": "bicgstab_loops", "size": a.size, "vec_groups": vg, "iterations": r.iterations,
+                              "loop1_ms": round(p["bicgstab_loop1"][1] / p["bicgstab_loop1"][0], 4),
+                              "loop2_ms": round(p["bicgstab_loop2"][1] / p["bicgstab_loop2"][0], 4)}))
+        check(lib().cup3d_debug_set_option(b"vec_groups", 0))
     elif a.what == "pre":
         sim = make(a.size, "wall")
         # solver-like inputs: the pressure RHS of the initial field, then A M^-1 of it, then noise
