@@ -8,8 +8,19 @@
 
 namespace cup3d {
 
-constexpr int kT = 1000;  // [10][10][10]
-__device__ __forceinline__ int tix(int x, int y, int z) { return (z + 1) * 100 + (y + 1) * 10 + (x + 1); }
+// LDS bank discipline (as in advdiff.hip): a half-wave computes 8 x by 4 z cells at one y, and the z-plane stride is
+// 104 = 8 (mod 32), so the four rows of a half-wave tile the 32 bank pairs of a 64-bit LDS access for every stencil shift.
+constexpr int kTP = 104;       // z-plane stride: [10][10] + 4 pad
+constexpr int kT = 10 * kTP;   // one component: [10 planes][10][10]
+__device__ __forceinline__ int tix(int x, int y, int z) { return (z + 1) * kTP + (y + 1) * 10 + (x + 1); }
+// the two cells of thread t: (x, y, z0) and (x, y, z0 + 4); cell0 = z0*64 + y*8 + x is the first one's index in the block
+__device__ __forceinline__ void thread_cells(int t, int &x, int &y, int &z0, int &cell0) {
+  const int lane = t & 63;
+  x = lane & 7;
+  z0 = (lane >> 3) & 3;
+  y = 2 * (t >> 6) + (lane >> 5);
+  cell0 = z0 * 64 + y * 8 + x;
+}
 
 // 1-deep face slab element `lane` of face f: neighbour cell, own face cell, LDS slot
 __device__ __forceinline__ void face1(int f, int lane, int &nb_cell, int &own_cell, int &lds) {
@@ -47,8 +58,10 @@ __device__ __forceinline__ void load_scalar_tile(const GridDev &g, int slot, con
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const double *own = f + (size_t)slot * 512;
   // all global loads (2 centre cells + up to 2 face elements per thread) are issued before the first LDS write
-  c[0] = own[t];
-  c[1] = own[256 + t];
+  int x, y, z0, cell0;
+  thread_cells(t, x, y, z0, cell0);
+  c[0] = own[cell0];
+  c[1] = own[256 + cell0];
   double gv[2];
   int gl[2];
   bool gon[2];
@@ -65,7 +78,6 @@ __device__ __forceinline__ void load_scalar_tile(const GridDev &g, int slot, con
       gl[i] = lds;
     }
   }
-  const int x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
   tile[tix(x, y, z0)] = c[0];
   tile[tix(x, y, z0 + 4)] = c[1];
 #pragma unroll
@@ -80,9 +92,10 @@ __device__ __forceinline__ void load_normal_tile(const GridDev &g, int slot, con
                                                  int c, double *tile) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const double *own = f + (size_t)slot * 1536 + c * 512;
-  const int x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
-  tile[tix(x, y, z0)] = own[t];
-  tile[tix(x, y, z0 + 4)] = own[256 + t];
+  int x, y, z0, cell0;
+  thread_cells(t, x, y, z0, cell0);
+  tile[tix(x, y, z0)] = own[cell0];
+  tile[tix(x, y, z0 + 4)] = own[256 + cell0];
   if (wave < 2) {
     const int face = 2 * c + wave;
     const int n = g.nbr[slot * 6 + face];
@@ -102,11 +115,12 @@ __device__ __forceinline__ void load_vector_tile(const GridDev &g, int slot, con
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const double *own = f + (size_t)slot * 1536;
-  const int x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
+  int x, y, z0, cell0;
+  thread_cells(t, x, y, z0, cell0);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    tile[c * kT + tix(x, y, z0)] = own[c * 512 + t];
-    tile[c * kT + tix(x, y, z0 + 4)] = own[c * 512 + 256 + t];
+    tile[c * kT + tix(x, y, z0)] = own[c * 512 + cell0];
+    tile[c * kT + tix(x, y, z0 + 4)] = own[c * 512 + 256 + cell0];
   }
   for (int u = wave; u < 18; u += 4) {  // (face, component) units of 64 ghosts
     const int face = u / 3, c = u - 3 * face;
@@ -129,15 +143,17 @@ __global__ void __launch_bounds__(256) k_vorticity(GridDev g, const double *__re
   if (slot < 0) return;
   load_vector_tile(g, slot, vel, halo, tv);
   __syncthreads();
-  const int t = threadIdx.x, x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
+  const int t = threadIdx.x;
+  int x, y, z0, cell0;
+  thread_cells(t, x, y, z0, cell0);
   const double h = block_h(g, slot), inv2h = .5 * h * h, fac = 1.0 / (h * h * h);
   const double *U = tv, *V = tv + kT, *W = tv + 2 * kT;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int b = tix(x, y, z0 + 4 * k);
-    const size_t o = (size_t)slot * 1536 + k * 256 + t;
-    tmpV[o] = (inv2h * ((W[b + 10] - W[b - 10]) - (V[b + 100] - V[b - 100]))) * fac;
-    tmpV[o + 512] = (inv2h * ((U[b + 100] - U[b - 100]) - (W[b + 1] - W[b - 1]))) * fac;
+    const size_t o = (size_t)slot * 1536 + k * 256 + cell0;
+    tmpV[o] = (inv2h * ((W[b + 10] - W[b - 10]) - (V[b + kTP] - V[b - kTP]))) * fac;
+    tmpV[o + 512] = (inv2h * ((U[b + kTP] - U[b - kTP]) - (W[b + 1] - W[b - 1]))) * fac;
     tmpV[o + 1024] = (inv2h * ((V[b + 1] - V[b - 1]) - (U[b + 10] - U[b - 10]))) * fac;
   }
 }
@@ -153,13 +169,15 @@ __global__ void __launch_bounds__(256) k_lhs(GridDev g, const double *__restrict
   double c[2];
   load_scalar_tile(g, slot, p, halo, tile, c);
   __syncthreads();
-  const int t = threadIdx.x, x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
+  const int t = threadIdx.x;
+  int x, y, z0, cell0;
+  thread_cells(t, x, y, z0, cell0);
   const double h = block_h(g, slot);
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int z = z0 + 4 * k, b = tix(x, y, z);
-    out[(size_t)slot * 512 + k * 256 + t] =
-        h * (tile[b - 1] + tile[b + 1] + tile[b - 10] + tile[b + 10] + tile[b - 100] + tile[b + 100] - 6.0 * c[k]);
+    out[(size_t)slot * 512 + k * 256 + cell0] =
+        h * (tile[b - 1] + tile[b + 1] + tile[b - 10] + tile[b + 10] + tile[b - kTP] + tile[b + kTP] - 6.0 * c[k]);
   }
   if (g.flux) write_face_fluxes<1>(g, slot, [&](int, int in, int gh, int, int) { return h * (tile[in] - tile[gh]); });
   if (block_sums) {
@@ -210,24 +228,26 @@ __global__ void __launch_bounds__(256) k_pressure_rhs(GridDev g, const double *_
 #pragma unroll
     for (int c = 0; c < 3; ++c) load_normal_tile(g, slot, udef, halo_u, c, tu + c * kT);
   __syncthreads();
-  const int t = threadIdx.x, x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
+  const int t = threadIdx.x;
+  int x, y, z0, cell0;
+  thread_cells(t, x, y, z0, cell0);
   const double h = block_h(g, slot), fac = 0.5 * h * h / dt;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int b = tix(x, y, z0 + 4 * k);
-    double p = fac * (tv[b + 1] - tv[b - 1] + tv[kT + b + 10] - tv[kT + b - 10] + tv[2 * kT + b + 100] - tv[2 * kT + b - 100]);
+    double p = fac * (tv[b + 1] - tv[b - 1] + tv[kT + b + 10] - tv[kT + b - 10] + tv[2 * kT + b + kTP] - tv[2 * kT + b - kTP]);
     if (chi) {
-      const double divUs = tu[b + 1] - tu[b - 1] + tu[kT + b + 10] - tu[kT + b - 10] + tu[2 * kT + b + 100] - tu[2 * kT + b - 100];
-      p += -chi[(size_t)slot * 512 + k * 256 + t] * fac * divUs;
+      const double divUs = tu[b + 1] - tu[b - 1] + tu[kT + b + 10] - tu[kT + b - 10] + tu[2 * kT + b + kTP] - tu[2 * kT + b - kTP];
+      p += -chi[(size_t)slot * 512 + k * 256 + cell0] * fac * divUs;
     }
-    out[(size_t)slot * 512 + k * 256 + t] = p;
+    out[(size_t)slot * 512 + k * 256 + cell0] = p;
   }
   if (g.flux)  // main.cpp:14892-14945: the normal component of (u - chi*udef) summed across the face
     write_face_fluxes<1>(g, slot, [&](int, int in, int gh, int side, int d) {
       const double su = tv[d * kT + gh] + tv[d * kT + in];
       double v = side ? -fac * su : fac * su;
       if (chi) {
-        const int x_ = in % 10 - 1, y_ = (in / 10) % 10 - 1, z_ = in / 100 - 1;
+        const int x_ = (in % kTP) % 10 - 1, y_ = (in % kTP) / 10 - 1, z_ = in / kTP - 1;
         const double cu = chi[(size_t)slot * 512 + z_ * 64 + y_ * 8 + x_] * fac * (tu[d * kT + gh] + tu[d * kT + in]);
         v = side ? v + cu : v - cu;
       }
@@ -243,13 +263,15 @@ __global__ void __launch_bounds__(256) k_div_pressure(GridDev g, const double *_
   double c[2];
   load_scalar_tile(g, slot, p, halo, tile, c);
   __syncthreads();
-  const int t = threadIdx.x, x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
+  const int t = threadIdx.x;
+  int x, y, z0, cell0;
+  thread_cells(t, x, y, z0, cell0);
   const double fac = block_h(g, slot);
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int b = tix(x, y, z0 + 4 * k);
-    tmpV[(size_t)slot * 1536 + k * 256 + t] =
-        fac * (tile[b + 1] + tile[b - 1] + tile[b + 10] + tile[b - 10] + tile[b + 100] + tile[b - 100] - 6.0 * c[k]);
+    tmpV[(size_t)slot * 1536 + k * 256 + cell0] =
+        fac * (tile[b + 1] + tile[b - 1] + tile[b + 10] + tile[b - 10] + tile[b + kTP] + tile[b - kTP] - 6.0 * c[k]);
   }
   if (g.flux)  // main.cpp:14795-14833
     write_face_fluxes<1>(g, slot, [&](int, int in, int gh, int side, int) { return side ? -fac * (tile[gh] - tile[in]) : fac * (tile[in] - tile[gh]); });
@@ -264,15 +286,17 @@ __global__ void __launch_bounds__(256) k_grad_p(GridDev g, const double *__restr
   double c[2];
   load_scalar_tile(g, slot, p, halo, tile, c);
   __syncthreads();
-  const int t = threadIdx.x, x = t & 7, y = (t >> 3) & 7, z0 = t >> 6;
+  const int t = threadIdx.x;
+  int x, y, z0, cell0;
+  thread_cells(t, x, y, z0, cell0);
   const double h = block_h(g, slot), fac = -0.5 * dt * h * h, ih3 = 1.0 / (h * h * h);
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int b = tix(x, y, z0 + 4 * k);
     const double gx = fac * (tile[b + 1] - tile[b - 1]);
     const double gy = fac * (tile[b + 10] - tile[b - 10]);
-    const double gz = fac * (tile[b + 100] - tile[b - 100]);
-    const size_t o = (size_t)slot * 1536 + k * 256 + t;
+    const double gz = fac * (tile[b + kTP] - tile[b - kTP]);
+    const size_t o = (size_t)slot * 1536 + k * 256 + cell0;
     tmpV[o] = gx; tmpV[o + 512] = gy; tmpV[o + 1024] = gz;
     if (vel) {
       vel[o] += ih3 * gx; vel[o + 512] += ih3 * gy; vel[o + 1024] += ih3 * gz;
