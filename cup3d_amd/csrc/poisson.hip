@@ -275,8 +275,25 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const double *__restric
 #define GRID_STRIDE(j, n) for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < (n); j += (long)gridDim.x * 256)
 // 16 B per lane (double2): n is a multiple of 512
 #define GRID_STRIDE2(j, n) for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < (n) / 2; j += (long)gridDim.x * 256)
-#define LD2(v) (reinterpret_cast<const double2 *>(v)[j])
-#define ST2(v, val) (reinterpret_cast<double2 *>(v)[j] = (val))
+// NT: nontemporal (streaming) accesses -- every vector is touched once per launch and the 19 GB working set cannot stay in L2
+template <bool NT>
+__device__ __forceinline__ double2 ld2(const double *v, long j) {
+  if constexpr (!NT) return reinterpret_cast<const double2 *>(v)[j];
+  const double *p = v + 2 * j;
+  double2 r;
+  r.x = __builtin_nontemporal_load(p);
+  r.y = __builtin_nontemporal_load(p + 1);
+  return r;
+}
+template <bool NT>
+__device__ __forceinline__ void st2(double *v, long j, double2 val) {
+  if constexpr (!NT) { reinterpret_cast<double2 *>(v)[j] = val; return; }
+  double *p = v + 2 * j;
+  __builtin_nontemporal_store(val.x, p);
+  __builtin_nontemporal_store(val.y, p + 1);
+}
+#define LD2(v) ld2<NT>(v, j)
+#define ST2(v, val) st2<NT>(v, j, val)
 __device__ __forceinline__ double2 operator+(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ double2 operator-(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ double2 operator*(double s, double2 a) { return make_double2(s * a.x, s * a.y); }
@@ -297,6 +314,7 @@ __global__ void __launch_bounds__(256) k_dots_r0(Vecs V, long n, double *__restr
   emit_partials<2>(acc, partials);
 }
 // first fused loop, k % 50 != 0   (14454-14464)
+template <bool NT>
 __global__ void __launch_bounds__(256) k_loop1(Vecs V, long n, double alpha, double beta, double omega, double *__restrict__ partials) {
   double acc[2] = {0, 0};
   GRID_STRIDE2(j, n) {
@@ -331,6 +349,7 @@ __global__ void __launch_bounds__(256) k_loop1_tail(Vecs V, long n, double alpha
   emit_partials<2>(acc, partials);
 }
 // second fused loop, k % 50 != 0   (14503-14515)
+template <bool NT>
 __global__ void __launch_bounds__(256) k_loop2(Vecs V, long n, double alpha, double omega, double *__restrict__ partials) {
   double acc[7] = {0, 0, 0, 0, 0, 0, 0};
   GRID_STRIDE2(j, n) {
@@ -396,7 +415,10 @@ __global__ void __launch_bounds__(256) k_shift_mean(double *__restrict__ p, cons
 
 static unsigned vec_groups(long n) {
   long g = (n + 255) / 256;
-  const int cap = debug_option("vec_groups") > 0 ? debug_option("vec_groups") : 2048;  // tuning knob; <= Sim::max_groups
+  // One 256-thread workgroup per CU: with 18 concurrent streams per loop, fewer in-flight wavefronts keep the DRAM pages of each
+  // stream open longer -- measured at 512^3 (profiles/r01/probe_bicgstab_loops_512.jsonl): 2048 groups 3.50 / 3.42 ms for the two
+  // fused loops, 512 groups 3.18 / 2.86, 256 groups 3.08 / 2.82 (6.3 / 6.1 TB/s, the copy ceiling of the chip).
+  const int cap = debug_option("vec_groups") > 0 ? debug_option("vec_groups") : 256;  // tuning knob; <= Sim::max_groups
   return (unsigned)(g > cap ? cap : g);
 }
 
@@ -462,7 +484,8 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   for (k = 0; k < P.max_iter; ++k) {
     if (k % 50 != 0) {
       ProfileScope ps("bicgstab_loop1");
-      LAUNCH_VEC(k_loop1, V, N, alpha, beta, omega, s->d_partials);
+      if (!debug_option("loops_no_nt")) LAUNCH_VEC(k_loop1<true>, V, N, alpha, beta, omega, s->d_partials);
+      else LAUNCH_VEC(k_loop1<false>, V, N, alpha, beta, omega, s->d_partials);
     } else {
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_loop1_phat, V, N, beta, omega); }
       TRY(LHS(PHAT, S_)); TRY(PRE(S_, SHAT)); TRY(LHS(SHAT, Z_));
@@ -474,7 +497,8 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     omega = s->h_red[0] / (s->h_red[1] + eps);  // 14493
     if (k % 50 != 0) {
       ProfileScope ps("bicgstab_loop2");
-      LAUNCH_VEC(k_loop2, V, N, alpha, omega, s->d_partials);
+      if (!debug_option("loops_no_nt")) LAUNCH_VEC(k_loop2<true>, V, N, alpha, omega, s->d_partials);
+      else LAUNCH_VEC(k_loop2<false>, V, N, alpha, omega, s->d_partials);
     } else {
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_loop2_x, V, N, alpha, omega); }
     }

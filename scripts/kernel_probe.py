@@ -69,16 +69,20 @@ def main():
         dt = 0.3 * sim.grid.h
         vel0 = sim.download("vel")
         for vg in [int(x) for x in a.variants.split(",")]:
+            nt = 1 if vg < 0 else 0   # negative grid size: nontemporal variant of the two fused loops
+            check(lib().cup3d_debug_set_option(b"loops_no_nt", 0 if nt else 1))
+            vg = abs(vg)
             check(lib().cup3d_debug_set_option(b"vec_groups", vg))
             sim.upload("vel", vel0); sim.fill("pres", 0.0)
             lib().cup3d_device_synchronize()
             lib().cup3d_profile_reset()
             r = cu.PressureProjection(sim)(dt)
             p = profile()
-            print(json.dumps({"probe": "bicgstab_loops", "size": a.size, "vec_groups": vg, "iterations": r.iterations,
+            print(json.dumps({"probe": "bicgstab_loops", "size": a.size, "vec_groups": vg, "nt": nt, "iterations": r.iterations,
                               "loop1_ms": round(p["bicgstab_loop1"][1] / p["bicgstab_loop1"][0], 4),
                               "loop2_ms": round(p["bicgstab_loop2"][1] / p["bicgstab_loop2"][0], 4)}))
         check(lib().cup3d_debug_set_option(b"vec_groups", 0))
+        check(lib().cup3d_debug_set_option(b"loops_no_nt", 0))
     elif a.what == "pre":
         sim = make(a.size, "wall")
         # solver-like inputs: the pressure RHS of the initial field, then A M^-1 of it, then noise
