@@ -413,6 +413,10 @@ __global__ void __launch_bounds__(256) k_shift_mean(double *__restrict__ p, cons
   GRID_STRIDE(j, n) { double v = p[j] - avg; if (pold) v += pold[j]; p[j] = v; }
 }
 
+static unsigned vec_groups_simple(long n) {
+  long g = (n + 255) / 256;
+  return (unsigned)(g > 2048 ? 2048 : g);
+}
 static unsigned vec_groups(long n) {
   long g = (n + 255) / 256;
   // One 256-thread workgroup per CU: with 18 concurrent streams per loop, fewer in-flight wavefronts keep the DRAM pages of each
@@ -450,6 +454,8 @@ static int ensure_vectors(Sim *s) {
 }
 
 #define LAUNCH_VEC(kern, ...) hipLaunchKernelGGL(kern, dim3(G), dim3(256), 0, stream(), __VA_ARGS__)
+// few-stream pointwise kernels without partial sums: these want the wide grid (0.88 vs 1.26 ms for k_loop1_phat at 512^3)
+#define LAUNCH_VEC_S(kern, ...) hipLaunchKernelGGL(kern, dim3(Gs), dim3(256), 0, stream(), __VA_ARGS__)
 #define TRY(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
 static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *res) {
@@ -459,7 +465,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   for (int i = 0; i < NVEC; ++i) V.v[i] = s->sv[i];
   V.xin = V.v[X_];
   const long N = s->nb * 512L;
-  const unsigned G = vec_groups(N);
+  const unsigned G = vec_groups(N), Gs = vec_groups_simple(N);
   const int mc = P.mean_constraint;
   const double eps = 1e-100;
   Reducer red{s, G};
@@ -468,9 +474,9 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
 
   if ((mc == 1 || mc > 2) && s->grid->corner_slot >= 0)  // rhs(0,0,0) = 0, 14404-14407
     hipLaunchKernelGGL(k_set_one, dim3(1), dim3(1), 0, stream(), s->lhs, (size_t)s->grid->corner_slot * 512, 0.0);
-  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_solver_init, V, s->lhs, s->pres, N); }
+  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_solver_init, V, s->lhs, s->pres, N); }
   TRY(LHS(X_, R0));
-  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_resid0, V, N); }
+  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_resid0, V, N); }
   TRY(PRE(R0, RHAT)); TRY(LHS(RHAT, W_)); TRY(PRE(W_, WHAT)); TRY(LHS(WHAT, T_));
   { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots_r0, V, N, s->d_partials); }
   TRY(red.begin(2)); TRY(red.wait());
@@ -487,7 +493,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       if (!debug_option("loops_no_nt")) LAUNCH_VEC(k_loop1<true>, V, N, alpha, beta, omega, s->d_partials);
       else LAUNCH_VEC(k_loop1<false>, V, N, alpha, beta, omega, s->d_partials);
     } else {
-      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_loop1_phat, V, N, beta, omega); }
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_loop1_phat, V, N, beta, omega); }
       TRY(LHS(PHAT, S_)); TRY(PRE(S_, SHAT)); TRY(LHS(SHAT, Z_));
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_loop1_tail, V, N, alpha, s->d_partials); }
     }
@@ -500,12 +506,12 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       if (!debug_option("loops_no_nt")) LAUNCH_VEC(k_loop2<true>, V, N, alpha, omega, s->d_partials);
       else LAUNCH_VEC(k_loop2<false>, V, N, alpha, omega, s->d_partials);
     } else {
-      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_loop2_x, V, N, alpha, omega); }
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_loop2_x, V, N, alpha, omega); }
     }
     V.xin = V.v[X_];  // x now lives in v[X_] again
     if (k % 50 == 0) {
       TRY(LHS(X_, R_));
-      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_true_resid, V, N); }
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_true_resid, V, N); }
       TRY(PRE(R_, RHAT)); TRY(LHS(RHAT, W_));
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots7, V, N, s->d_partials); }
     }
@@ -524,7 +530,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     const bool serious_breakdown = r0r * r0r < 1e-16 * norm_1 * norm_2;  // 14566
     if (serious_breakdown && restarts < P.max_restarts) {               // 14567-14593
       restarts++;
-      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_copy, V.v[R_], V.v[R0], N); }
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_copy, V.v[R_], V.v[R0], N); }
       TRY(PRE(R0, RHAT)); TRY(LHS(RHAT, W_));
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots_r0, V, N, s->d_partials); }
       TRY(red.begin(2));
@@ -545,7 +551,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     }
     if (norm < P.tol || norm / (init_norm + eps) < P.tol_rel) break;   // 14601
   }
-  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_copy, use_xopt ? V.v[XOPT] : V.v[X_], s->pres, N); }  // 14605-14615
+  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_copy, use_xopt ? V.v[XOPT] : V.v[X_], s->pres, N); }  // 14605-14615
   CUP3D_HIP(hipGetLastError());
   if (res) {
     res->iterations = k < P.max_iter ? k + 1 : P.max_iter;
@@ -591,16 +597,16 @@ int cup3d_pressure_project(cup3d_sim_t *h, double dt, int step, const cup3d_pois
   cup3d_poisson_default_params(&P);
   if (pp) P = *pp;
   const long N = s->nb * 512L;
-  const unsigned G = vec_groups(N);
+  const unsigned G = vec_groups(N), Gs = vec_groups_simple(N);
   const bool second_order = step > 2;  // sim.step > sim.step_2nd_start (= 2), main.cpp:15087, 15355
-  if (second_order) { ProfileScope ps("project_pointwise"); LAUNCH_VEC(k_copy, s->pres, s->pold, N); }  // pOld, 15075
+  if (second_order) { ProfileScope ps("project_pointwise"); LAUNCH_VEC_S(k_copy, s->pres, s->pold, N); }  // pOld, 15075
   // tmpV = 0 (15076-15078) matters only as the udef lab of KernelPressureRHS; without
   // obstacles the RHS kernel does not read it (adding -0*fac*0 is the identity).
   TRY(cup3d_pressure_rhs(h, dt));
   if (second_order) {
     TRY(cup3d_div_pressure(h));
     ProfileScope ps("project_pointwise");
-    LAUNCH_VEC(k_sub_divp, s->lhs, s->tmpV, s->pres, N);
+    LAUNCH_VEC_S(k_sub_divp, s->lhs, s->tmpV, s->pres, N);
   } else {
     TRY(cup3d_sim_fill(h, CUP3D_FIELD_PRES, 0.0));  // 15102-15106
   }
@@ -610,7 +616,7 @@ int cup3d_pressure_project(cup3d_sim_t *h, double dt, int step, const cup3d_pois
   Reducer red{s, G};
   TRY(red.begin(2)); TRY(red.wait());                        // MPI_Allreduce(2), 15123
   const double avg = s->h_red[0] / s->h_red[1];              // 15126
-  { ProfileScope ps("project_pointwise"); LAUNCH_VEC(k_shift_mean, s->pres, second_order ? s->pold : (const double *)nullptr, N, avg); }
+  { ProfileScope ps("project_pointwise"); LAUNCH_VEC_S(k_shift_mean, s->pres, second_order ? s->pold : (const double *)nullptr, N, avg); }
   TRY(cup3d_grad_p_update(h, dt));                           // KernelGradP + vel += tmpV/h^3, 15146-15159
   CUP3D_HIP(hipGetLastError());
   return CUP3D_OK;
