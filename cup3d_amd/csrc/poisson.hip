@@ -40,8 +40,7 @@ __device__ __forceinline__ double mad(double a, double b, double c) {
 // first version half of all LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50, and the waves
 // spent 35 % of their cycles in SQ_WAIT_INST_LDS: profiles/r01/pmc_block_preconditioner_sq.txt): a 64-bit access is served 32
 // lanes at a time, and four 8-wide rows at pitch 10 overlap in banks, while at pitch 8 the four rows tile the 32 bank pairs
-// exactly.  The price is that the x-1 / x+1 reads of the lanes at x = 0 / 7 fetch a cell of the neighbouring row, which is
-// multiplied by 0 (one FP64 multiply per side and plane; exact for the others, which are multiplied by 1).
+// exactly.  The x-1 / x+1 reads of the lanes at x = 0 / 7, which would fetch a cell of the neighbouring row, go to the zero row.
 template <bool FMA>
 __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, double *out, double *__restrict__ block_sums) {
   // (86 VGPRs -> 5 waves/SIMD.  Forcing 6 with amdgpu_waves_per_eu spills five values that are reloaded every iteration: 0.476
@@ -52,7 +51,9 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
   const int l = threadIdx.x;
   const int base = ((l >> 3) + 1) * 8 + (l & 7);
   for (int i = l; i < 640; i += 64) P[i] = 0.0;
-  const double ml = (l & 7) == 0 ? 0.0 : 1.0, mr = (l & 7) == 7 ? 0.0 : 1.0;
+  // x-1 / x+1 reads of the edge lanes are redirected to the zero row of the same plane, at the one bank the other lanes of the
+  // half-wave leave free (address 7 for x = 0, address 0 for x = 7): still conflict-free, and no masking arithmetic
+  const int am = (l & 7) == 0 ? 7 : base - 1, ap = (l & 7) == 7 ? 0 : base + 1;
   const double invh = 1 / block_h(g, slot);  // main.cpp:14723
   double r[8], p[8], x[8], Ax[8];
   double rr = 0;
@@ -75,7 +76,7 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
       double a2 = 0;
 #pragma unroll
       for (int z = 0; z < 8; ++z) {                         // kernelPoissonGetZInner, 14662-14682
-        double t = mad<FMA>(-6.0, p[z], P[z * 80 + base - 1] * ml + P[z * 80 + base + 1] * mr);
+        double t = mad<FMA>(-6.0, p[z], P[z * 80 + am] + P[z * 80 + ap]);
         t += P[z * 80 + base - 8];
         t += P[z * 80 + base + 8];
         t += z > 0 ? p[z - 1] : 0.0;
