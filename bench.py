@@ -325,6 +325,9 @@ def report(a, sim, prof, sec, iters, world, alt=None):
             ach = ALGO_BYTES[name] * cells_local / (avg_ms * 1e-3) / 1e9
             e.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(f"{name}@{a.size}")})
+        if name == "poisson_block_cg":
+            e["note"] = ("one wavefront per block, <= 100 CG iterations in registers: bound by FP64 issue and dependent chains, not by HBM "
+                         "(SQ counters in profiles/r01/pmc_block_preconditioner_sq_after.txt); its HBM traffic equals the algorithmic 16 B/cell")
         kernels.append(e)
     with_roof = [k for k in kernels if "achieved" in k]
     dominant = with_roof[0] if with_roof else None
