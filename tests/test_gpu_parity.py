@@ -517,3 +517,53 @@ def test_rccl_plumbing_on_one_rank():
     finally:
         cu.lib().cup3d_comm_finalize()
         cu.capi.check(cu.lib().cup3d_debug_set_option(b"force_allreduce", 0))
+
+
+# ------------------------------------------------------------------ analytic known answers
+def _cell_coords(g):
+    ax = np.arange(8) + 0.5
+    X = (g.index[:, 0, None] * 8 + ax[None, :])[:, None, None, :] * g.h
+    Y = (g.index[:, 1, None] * 8 + ax[None, :])[:, None, :, None] * g.h
+    Z = (g.index[:, 2, None] * 8 + ax[None, :])[:, :, None, None] * g.h
+    return X, Y, Z
+
+
+def test_kat_discrete_laplacian_eigenmode():
+    """ComputeLHS of a trigonometric mode on a periodic grid = the discrete eigenvalue times the mode:
+    h * sum_d (2 cos(k_d h) - 2) * p   (KernelLHSPoisson 9205-9215 is h * (sum of 6 neighbours - 6 p))."""
+    ext = 2 * np.pi
+    sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=4, levelStart=3, extent=ext, BC_x="periodic", BC_y="periodic", BC_z="periodic",
+                            bMeanConstraint=0)
+    g = sim.grid
+    X, Y, Z = _cell_coords(g)
+    kx, ky, kz = 2, 3, 1
+    p = np.sin(kx * X) * np.cos(ky * Y) * np.sin(kz * Z + 0.3)
+    sim.upload("pres", np.ascontiguousarray(p))
+    cu.ComputeLHS(sim)(0)
+    lam = g.h * sum(2 * np.cos(k * g.h) - 2 for k in (kx, ky, kz))
+    assert np.abs(sim.download("lhs") - lam * p).max() <= 1e-13 * abs(lam)
+
+
+def test_kat_taylor_green_energy_decay():
+    """A small-amplitude Taylor-Green vortex on a periodic box is an eigenmode of the diffusion operator: the kinetic energy decays as
+    exp(-2 nu (a^2 + b^2 + c^2) t) up to the (tiny) nonlinear term and the O(h^2) error of the 7-point Laplacian."""
+    ext, nu, umax = 2 * np.pi, 0.05, 1e-3
+    sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=4, levelStart=3, extent=ext, nu=nu, CFL=0.3, rampup=0, BC_x="periodic",
+                            BC_y="periodic", BC_z="periodic", poissonTol=1e-12, poissonTolRel=1e-10)
+    o = O.OracleGrid((1, 1, 1), 4, 3, ext, ("periodic",) * 3)
+    vel = o.taylor_green([ext] * 3, umax)
+    sim.upload("vel", vel)
+    e0 = (vel ** 2).sum()
+    S = cu.Simulation(sim)
+    sim.step = 21
+    t = 0.0
+    for _ in range(20):
+        dt = S.calcMaxTimestep()
+        S.advance(dt)
+        t += dt
+    e1 = (sim.download("vel") ** 2).sum()
+    h = sim.grid.h
+    lam_h = 3 * (2 - 2 * np.cos(h)) / h ** 2          # discrete |k|^2 of the (1,1,1) mode
+    assert t > 0.1
+    assert abs(np.log(e1 / e0) + 2 * nu * lam_h * t) <= 1e-4 * 2 * nu * lam_h * t   # discrete decay rate (oracle: 5e-8)
+    assert abs(np.log(e1 / e0) + 2 * nu * 3 * t) <= 2e-3 * 2 * nu * 3 * t           # continuum rate, O(h^2) away
