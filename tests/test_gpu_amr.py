@@ -402,3 +402,45 @@ def test_random_meshes_everything_bitexact(seed):
         assert np.array_equal(S.sim.grid.tables, m2.tables)
         assert np.array_equal(S.sim.download("vel"), m.transfer(m2, velo))
         assert np.array_equal(S.sim.download("pres"), m.transfer(m2, preso))
+
+
+def test_flux_correction_is_conservative_on_a_large_periodic_mesh():
+    """Size-independent property of the multi-level operators: on a periodic mesh the flux-corrected operators are discrete
+    divergences, so their sum over all cells vanishes to round-off (it is O(1) per interface cell without the correction).
+    The mesh (several thousand blocks, three levels) is grown by the device's own adaptMesh."""
+    ext, lmax = 2 * np.pi, 5
+    sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=lmax, levelStart=3, extent=ext, BC_x="periodic", BC_y="periodic", BC_z="periodic",
+                            bMeanConstraint=0)
+    g = sim.grid
+    ax = np.arange(8) + 0.5
+    X = (g.index[:, 0, None] * 8 + ax[None, :])[:, None, None, :] * g.h
+    Y = (g.index[:, 1, None] * 8 + ax[None, :])[:, None, :, None] * g.h
+    Z = (g.index[:, 2, None] * 8 + ax[None, :])[:, :, None, None] * g.h
+    gss = np.exp(-((X - 2.6) ** 2 + (Y - 3.1) ** 2 + (Z - 3.4) ** 2) / 0.6)
+    sim.upload("vel", np.ascontiguousarray(np.stack([-(Y - 3.1) * gss, (X - 2.6) * gss, 0.3 * gss + 0 * X], axis=-1)))
+    S = cu.Simulation(sim)
+    for _ in range(2):
+        cu.ComputeVorticity(S.sim)(0)
+        w = S.sim.download("tmpV")
+        linf = np.sqrt((w ** 2).sum(axis=-1)).reshape(S.sim.nblocks, -1).max(axis=1)
+        S.adaptMesh(float(np.quantile(linf, 0.7)), -1.0)
+    sim = S.sim
+    t = sim.grid.tables
+    assert sim.nblocks > 3000 and len(set(t[:, 0].tolist())) == 3
+    rng = np.random.default_rng(4)
+    p = rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8))
+    v = rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8, 3))
+    sim.bMeanConstraint = 0
+    sim.upload("pres", p)
+    cu.ComputeLHS(sim)(0)
+    lhs = sim.download("lhs")
+    assert abs(lhs.sum()) <= 1e-11 * np.abs(lhs).sum()
+    sim.upload("vel", v); sim.fill("chi", 0.0); sim.fill("tmpV", 0.0)
+    check(lib().cup3d_pressure_rhs(sim.handle, 0.01))
+    rhs = sim.download("lhs")
+    assert abs(rhs.sum()) <= 1e-11 * np.abs(rhs).sum()
+    check(lib().cup3d_div_pressure(sim.handle))
+    dp = sim.download("tmpV")[..., 0]
+    assert abs(dp.sum()) <= 1e-11 * np.abs(dp).sum()
+    # momentum: the diffusive part of the advect-diffuse increment is conservative; switch advection off via a huge... (not separable:
+    # the upwind advection term is not in conservation form in the reference either), so only the three divergences above are asserted
