@@ -407,8 +407,8 @@ def test_random_meshes_everything_bitexact(seed):
 def test_flux_correction_is_conservative_on_a_large_periodic_mesh():
     """Size-independent property of the multi-level operators: on a periodic mesh the flux-corrected operators are discrete
     divergences, so their sum over all cells vanishes to round-off (it is O(1) per interface cell without the correction).
-    The mesh (1 590 blocks on three levels) is grown by the device's own adaptMesh."""
-    ext, lmax = 2 * np.pi, 5
+    The mesh (several thousand blocks on three levels) is grown by the device's own adaptMesh."""
+    ext, lmax = 2 * np.pi, 6
     sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=lmax, levelStart=3, extent=ext, BC_x="periodic", BC_y="periodic", BC_z="periodic",
                             bMeanConstraint=0)
     g = sim.grid
