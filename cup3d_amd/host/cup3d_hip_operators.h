@@ -45,6 +45,10 @@ public:
     ensure();
     return dsim;
   }
+  // resident mode (install(sim, true) / CUP3D_HIP_RESIDENT=1): between AdvectionDiffusionHIP and PressureProjectionHIP the
+  // velocity stays in HBM (no download / upload), see install()
+  bool resident = false;      // allowed at all: decided by install() from the pipeline
+  bool vel_on_device = false; // the device copy of vel is newer than the host's
   void upload(int field) {
     ensure();
     const std::vector<Info> &I = infos(field);
@@ -168,8 +172,27 @@ public:
     dev.upload(CUP3D_FIELD_VEL);
     const double uinf[3] = {sim.uinf[0], sim.uinf[1], sim.uinf[2]};
     CUP3D_HIP_CALL(cup3d_advect_diffuse(dev.handle(), sim.dt, sim.nu, uinf));
+    if (dev.resident && sim.obstacle_vector->nObstacles() == 0) {
+      dev.vel_on_device = true;  // nobody on the host reads vel / tmpV before the projection (install() checked the pipeline)
+      return;
+    }
     dev.download(CUP3D_FIELD_VEL);
     dev.download(CUP3D_FIELD_TMPV);
+  }
+};
+
+// ExternalForcing::operator()(dt), main.cpp:10581-10596: on the device while the velocity is resident there, else the
+// reference's own operator
+class ExternalForcingHIP : public Operator {
+  std::shared_ptr<DeviceMirror> devp;
+  std::shared_ptr<Operator> cpu;
+
+public:
+  ExternalForcingHIP(SimulationData &s, std::shared_ptr<DeviceMirror> d, std::shared_ptr<Operator> original) : Operator(s), devp(d), cpu(original) {}
+  void operator()(const Real dt) override {
+    if (!devp->vel_on_device) { (*cpu)(dt); return; }
+    const int dir = sim.BCy_flag == wall ? 1 : 2;  // 10582-10583
+    CUP3D_HIP_CALL(cup3d_external_forcing(devp->handle(), sim.uMax_forced, sim.nu, sim.extents[dir], dt));
   }
 };
 
@@ -211,7 +234,8 @@ public:
       fflush(0);
       MPI_Abort(sim.comm, 1);
     }
-    dev.upload(CUP3D_FIELD_VEL);
+    if (!dev.vel_on_device) dev.upload(CUP3D_FIELD_VEL);
+    dev.vel_on_device = false;
     dev.upload(CUP3D_FIELD_PRES);
     const cup3d_poisson_params p = poisson_params(sim);
     CUP3D_HIP_CALL(cup3d_pressure_project(dev.handle(), dt, sim.step, &p, &last));
@@ -224,17 +248,38 @@ public:
 struct Installed {
   std::shared_ptr<DeviceMirror> mirror;
   std::shared_ptr<AdvectionDiffusionHIP> advdiff;
+  std::shared_ptr<ExternalForcingHIP> forcing;
   std::shared_ptr<PressureProjectionHIP> projection;
 };
 
 // Swap the hot-path operators of an initialised Simulation for the HIP-backed ones.
-inline Installed install(SimulationData &sim) {
+// resident (default: environment CUP3D_HIP_RESIDENT=1): keep the velocity in HBM between AdvectionDiffusion and
+// PressureProjection.  Allowed only if every operator the reference put between the two (setupOperators 15229-15246) is
+// ExternalForcing (then run on the device too) or one of the obstacle operators, which return immediately without obstacles
+// (13813-13814, 14327-14328); with obstacles, or with FixMassFlux in between, every operator round-trips as before.
+inline Installed install(SimulationData &sim, int resident = -1) {
   Installed r;
   r.mirror = std::make_shared<DeviceMirror>(sim);
+  if (resident < 0) {
+    const char *e = getenv("CUP3D_HIP_RESIDENT");
+    resident = e ? atoi(e) : 0;
+  }
+  bool between = false, safe = true;
+  for (auto &op : sim.pipeline) {
+    if (std::dynamic_pointer_cast<AdvectionDiffusion>(op)) between = true;
+    else if (std::dynamic_pointer_cast<PressureProjection>(op)) between = false;
+    else if (between && !(std::dynamic_pointer_cast<ExternalForcing>(op) || std::dynamic_pointer_cast<UpdateObstacles>(op) ||
+                          std::dynamic_pointer_cast<Penalization>(op)))
+      safe = false;
+  }
+  r.mirror->resident = resident != 0 && safe;
   for (auto &op : sim.pipeline) {
     if (std::dynamic_pointer_cast<AdvectionDiffusion>(op)) {
       r.advdiff = std::make_shared<AdvectionDiffusionHIP>(sim, r.mirror);
       op = r.advdiff;
+    } else if (r.mirror->resident && std::dynamic_pointer_cast<ExternalForcing>(op)) {
+      r.forcing = std::make_shared<ExternalForcingHIP>(sim, r.mirror, op);
+      op = r.forcing;
     } else if (std::dynamic_pointer_cast<PressureProjection>(op)) {
       r.projection = std::make_shared<PressureProjectionHIP>(sim, r.mirror);
       op = r.projection;

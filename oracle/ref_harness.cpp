@@ -238,12 +238,12 @@ int main(int argc, char **argv) {
       else if (k == "mean") sd.bMeanConstraint = (int)v;
       else { fprintf(stderr, "ref_tool: unknown set key %s\n", k.c_str()); exit(2); }
     } else if (cmd == "hip") {
-      /* `hip on`: swap AdvectionDiffusion / PressureProjection in sim.pipeline for the HIP-backed
+      /* `hip on` | `hip resident`: swap AdvectionDiffusion / PressureProjection in sim.pipeline for the HIP-backed
          operators (cup3d_hip::install); every later op/steps command runs through them */
       std::string v; script >> v;
 #ifdef CUP3D_WITH_HIP
       static cup3d_hip::Installed inst;
-      inst = cup3d_hip::install(sd);
+      inst = cup3d_hip::install(sd, v == "resident" ? 1 : -1);  /* `hip resident`: vel stays in HBM between the two operators */
       hip_adv = inst.advdiff; hip_proj = inst.projection;
 #else
       fprintf(stderr, "ref_tool: built without CUP3D_WITH_HIP\n"); exit(2);

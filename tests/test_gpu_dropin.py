@@ -26,8 +26,9 @@ def run(tool, script, args, wd):
             for l in out.splitlines() if l.startswith("REF ")]
 
 
+@pytest.mark.parametrize("mode", ["hip on", "hip resident"])
 @pytest.mark.parametrize("bc", [("periodic", "periodic", "periodic"), ("wall", "wall", "wall"), ("freespace", "periodic", "wall")])
-def test_reference_time_loop_with_hip_operators(tmp_path, bc):
+def test_reference_time_loop_with_hip_operators(tmp_path, bc, mode):
     bpd, lmax, lstart, nsteps = (1, 1, 1), 3, 2, 5
     args = O.ref_args(bpd, lmax, lstart, 2 * np.pi, bc, nu=0.01, cfl=0.3, extra=["-rampup", "3"])
     tail = ["zero chi"] + sum([["op steps 1", f"dump vel v{n}.bin", f"dump pres p{n}.bin"] for n in range(nsteps)], [])
@@ -35,7 +36,7 @@ def test_reference_time_loop_with_hip_operators(tmp_path, bc):
     cpu_dir.mkdir()
     hip_dir.mkdir()
     rc = run(O.REF_TOOL, tail, args, str(cpu_dir))
-    rh = run(REF_HIP, ["hip on"] + tail, args, str(hip_dir))
+    rh = run(REF_HIP, [mode] + tail, args, str(hip_dir))  # "hip resident": vel stays in HBM between the two operators; ExternalForcing on device
     nb = 64
     for n in range(nsteps):
         assert abs(rc[n]["value"] - rh[n]["value"]) <= 1e-3 * rc[n]["value"]          # dt from findMaxU
