@@ -97,7 +97,7 @@ __device__ __forceinline__ void face_element(int f, int e, int &nb_cell, int &ow
 }
 
 // CPT = cells per thread (2 -> 256 threads, 1 -> 512 threads).  VAR: 0 production,
-// 1 IEEE division instead of div60 (A/B), 2/3 timing ablations with WRONG results
+// 1 IEEE division instead of div60 (A/B), 4 plain instead of nontemporal stores (A/B), 2/3 timing ablations with WRONG results
 // (2: no stencil arithmetic, 3: no ghost staging) -- cup3d_debug_set_option only.
 // AMR (multi-level meshes): spacing per block, face fluxes facD*(u_in - u_ghost) of the interface faces into g.flux
 // (main.cpp:9550-9637), and the stage is NOT fused with the Runge-Kutta update: tmpV receives the raw increment, which
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int k = 0; k < CPT; ++k) told[k][c] = tp[c * 512 + k * 256 + cell0];
+      for (int k = 0; k < CPT; ++k) told[k][c] = VAR != 4 ? __builtin_nontemporal_load(&tp[c * 512 + k * 256 + cell0]) : tp[c * 512 + k * 256 + cell0];
   }
   // ---- ghosts: 18 (face, component) units of 192 values.  Every global load of the tile
   // (centre, tmpV, ghosts: ~27 per thread) is issued before the first LDS write, so ONE memory
@@ -284,8 +284,13 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
     for (int c = 0; c < 3; ++c) {
       const double tn = (FIRST_STAGE ? 0.0 : told[k][c]) + res[c];  // o += ..., main.cpp:9546-9548
       if (AMR) { tout[c * 512 + k * 256 + cell0] = tn; continue; }
-      vout[c * 512 + k * 256 + cell0] = uc[k][c] + tn * a.alpha;          // V += tmpV*ih3, 9718-9720
-      tout[c * 512 + k * 256 + cell0] = tn * a.beta;                      // tmpV *= beta, 9721-9723
+      if (VAR != 4) {  // streaming stores (and tmpV load above): both arrays are next touched a full sweep later (2.73 vs 2.87 ms)
+        __builtin_nontemporal_store(uc[k][c] + tn * a.alpha, &vout[c * 512 + k * 256 + cell0]);  // V += tmpV*ih3, 9718-9720
+        __builtin_nontemporal_store(tn * a.beta, &tout[c * 512 + k * 256 + cell0]);              // tmpV *= beta, 9721-9723
+        continue;
+      }
+      vout[c * 512 + k * 256 + cell0] = uc[k][c] + tn * a.alpha;  // VAR 4: plain stores (A/B)
+      tout[c * 512 + k * 256 + cell0] = tn * a.beta;
     }
   }
 }
@@ -373,6 +378,7 @@ static int advdiff_stage(Sim *s, int rk, double dt, double nu, const double uinf
         case 1: ADV2(2, 1); break;
         case 2: ADV2(2, 2); break;
         case 3: ADV2(2, 3); break;
+        case 4: ADV2(2, 4); break;
         default: set_error("unknown advdiff_variant"); return CUP3D_EINVAL;
       }
 #undef ADV2
