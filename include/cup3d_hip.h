@@ -153,7 +153,7 @@ typedef struct {
   int max_iter;        /* 1000 (main.cpp:14449) */
   int max_restarts;    /* 100  (main.cpp:14374) */
   int block_solver;    /* how the block preconditioner M^-1 (getZImplParallel, 14704-14745) is evaluated:
-                          0 = the reference's block-local CG, restated iteration for iteration;
+                          0 = the reference's block-local CG, restated iteration for iteration (FMA-contracted on the device);
                           1 = direct block solve by fast diagonalisation (same operator, exact to rounding) */
 } cup3d_poisson_params;
 typedef struct {

@@ -37,7 +37,7 @@ def make(size, bc="periodic"):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["adv", "pre", "one", "loops"])
+    ap.add_argument("what", choices=["adv", "pre", "one", "loops", "pcie"])
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--variants", default="0,1,2,3")
     ap.add_argument("--kernel", default="adv")
@@ -62,6 +62,20 @@ def main():
             print(json.dumps({"probe": "advdiff", "size": a.size, "variant": v, "avg_ms": round(avg, 4),
                               "GBps_algorithmic": round(96 * cells / avg / 1e6, 1), "frac_8TBs": round(96 * cells / avg / 1e6 / 8000, 4)}))
         check(lib().cup3d_debug_set_option(b"advdiff_variant", 0))
+    elif a.what == "pcie":
+        # host <-> device rate of the boundary's block transfers (reference layout AoS on the host, SoA slab on the device)
+        import time
+        sim = make(a.size)
+        vel = sim.download("vel")
+        for name, fn in (("upload_vel", lambda: sim.upload("vel", vel)), ("download_vel", lambda: sim.download("vel"))):
+            fn()
+            lib().cup3d_device_synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.reps):
+                fn()
+            lib().cup3d_device_synchronize()
+            sec = (time.perf_counter() - t0) / a.reps
+            print(json.dumps({"probe": name, "size": a.size, "GB": round(vel.nbytes / 1e9, 3), "seconds": round(sec, 4), "GBps": round(vel.nbytes / sec / 1e9, 2)}))
     elif a.what == "loops":
         # grid size of the fused BiCGSTAB vector loops (cup3d_debug_set_option "vec_groups")
         sim = make(a.size, "wall")
