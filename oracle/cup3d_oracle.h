@@ -105,10 +105,18 @@ void orc_mesh_div_pressure(const orc_mesh *, const double *pres, double *tmpV);
 void orc_mesh_grad_p(const orc_mesh *, const double *pres, double *tmpV, double dt);
 void orc_mesh_project(const orc_mesh *, double *vel, double *pres, double *tmpV, double *lhs, const double *chi, double dt, int step,
                       orc_solve_info *);
+void orc_mesh_project_obst(const orc_mesh *, double *vel, double *pres, double *tmpV, double *lhs, const double *chi, double dt, int step,
+                           orc_solve_info *, long n, const long long *ids, const double *ochi, const double *oudef);
 double orc_mesh_max_u(const orc_mesh *, const double *vel, const double uinf[3]);
 void orc_mesh_vorticity(const orc_mesh *, const double *vel, double *tmpV); /* ComputeVorticity, main.cpp:8624-8746 */
 void orc_mesh_tag(const orc_mesh *, const double *field, int nc, double rtol, double ctol, signed char *states);
 void orc_mesh_states(const orc_mesh *, int *out27);
+/* obstacle operators for one obstacle given by its ObstacleBlocks (ids, chi[n][512], udef[n][512][3]) and rigid = cm[3], vel[3],
+ * omega[3]: KernelPenalization + kernelFinalizePenalizationForce (13841-13938), kernelUpdateTmpV (14948-14979) */
+void orc_mesh_penalize(const orc_mesh *, double *vel, const double *chi_field, long n, const long long *ids, const double *chi,
+                       const double *udef, const double rigid[9], double dt, double lambda, int implicit, double force6[6]);
+void orc_mesh_update_tmpv(const orc_mesh *, double *tmpV, const double *chi_field, long n, const long long *ids, const double *chi,
+                          const double *udef);
 /* mesh adaptation (one rank): ValidStates 5330-5492 (in/out states), the leaf set after Adapt 5086-5159, and the field data
  * on the adapted mesh (RefineBlocks 5493-5565 from the old mesh's tensorial tiles, compress 5272-5329, copies) */
 void orc_mesh_valid_states(const orc_mesh *, signed char *states);

@@ -825,13 +825,17 @@ void orc_mesh_grad_p(const orc_mesh *m, const double *pres, double *tmpV, double
   faces_free(&F);
 }
 
-/* PressureProjection::operator(), main.cpp:15061-15160, on a multi-level mesh (no obstacles: udef = 0) */
-void orc_mesh_project(const orc_mesh *m, double *vel, double *pres, double *tmpV, double *lhs, const double *chi, double dt, int step,
-                      orc_solve_info *info) {
+/* PressureProjection::operator(), main.cpp:15061-15160, on a multi-level mesh; with an obstacle (n > 0) tmpV receives its
+ * deformation velocity first (kernelUpdateTmpV, 15081-15082) and chi enters the right-hand side */
+void orc_mesh_update_tmpv(const orc_mesh *m, double *tmpV, const double *chi_field, long n, const long long *ids, const double *chi,
+                          const double *udef);
+void orc_mesh_project_obst(const orc_mesh *m, double *vel, double *pres, double *tmpV, double *lhs, const double *chi, double dt, int step,
+                           orc_solve_info *info, long n, const long long *ids, const double *ochi, const double *oudef) {
   const long N = m->nblocks * BS3;
   double *pOld = (double *)malloc(N * sizeof(double));
   memcpy(pOld, pres, N * sizeof(double));
   memset(tmpV, 0, 3 * N * sizeof(double));
+  if (n > 0) orc_mesh_update_tmpv(m, tmpV, chi, n, ids, ochi, oudef);
   orc_mesh_pressure_rhs(m, vel, tmpV, chi, lhs, dt);
   if (step > 2) {
     orc_mesh_div_pressure(m, pres, tmpV);
@@ -854,6 +858,10 @@ void orc_mesh_project(const orc_mesh *m, double *vel, double *pres, double *tmpV
     for (long i = b * BS3 * 3; i < (b + 1) * BS3 * 3; i++) vel[i] += fac * tmpV[i];
   }
   free(pOld);
+}
+void orc_mesh_project(const orc_mesh *m, double *vel, double *pres, double *tmpV, double *lhs, const double *chi, double dt, int step,
+                      orc_solve_info *info) {
+  orc_mesh_project_obst(m, vel, pres, tmpV, lhs, chi, dt, step, info, 0, NULL, NULL, NULL);
 }
 
 double orc_mesh_max_u(const orc_mesh *m, const double *vel, const double uinf[3]) { /* findMaxU, main.cpp:8603-8623 */
@@ -1103,4 +1111,63 @@ void orc_mesh_transfer(const orc_mesh *mo, const orc_mesh *mn, const double *fo,
   }
 #undef Lb
   tile_free(&t);
+}
+
+/* ======================= obstacle operators ======================= */
+/* One obstacle = the ObstacleBlocks it owns (7256-7263): block ids, chi[n][512], udef[n][512][3] (AoS), and its rigid motion.
+ * KernelPenalization::visit + kernelFinalizePenalizationForce, main.cpp:13853-13938: vel is penalised in place towards the
+ * obstacle velocity, force6 = force[3], torque[3] summed over the obstacle's blocks in block order. */
+void orc_mesh_penalize(const orc_mesh *m, double *vel, const double *chi_field, long n, const long long *ids, const double *chi,
+                       const double *udef, const double rigid[9], double dt, double lambda, int implicit, double force6[6]) {
+  const double invdt = 1.0 / dt, lambdaFac = implicit ? lambda : invdt;
+  const double *CM = rigid, *vt = rigid + 3, *om = rigid + 6;
+  double M[6] = {0, 0, 0, 0, 0, 0};
+  /* blocks are visited in m_vInfo order (the obstacleBlocks vector is indexed by blockID) */
+  long *order = (long *)malloc(n * sizeof(long));
+  for (long i = 0; i < n; i++) order[i] = i;
+  for (long i = 1; i < n; i++) { long k = order[i], j = i; while (j > 0 && ids[order[j - 1]] > ids[k]) { order[j] = order[j - 1]; j--; } order[j] = k; }
+  for (long oi = 0; oi < n; oi++) {
+    const long i = order[oi], b = (long)ids[i];
+    const double h = orc_mesh_h(m, b), dv = pow(h, 3);
+    const double org[3] = {m->index[3 * b] * BS * h, m->index[3 * b + 1] * BS * h, m->index[3 * b + 2] * BS * h};
+    double F[6] = {0, 0, 0, 0, 0, 0};
+    for (int iz = 0; iz < BS; iz++)
+      for (int iy = 0; iy < BS; iy++)
+        for (int ix = 0; ix < BS; ix++) {
+          const int c = (iz * BS + iy) * BS + ix;
+          const double CHI = chi[i * BS3 + c];
+          if (chi_field[b * BS3 + c] > CHI) continue;
+          if (CHI <= 0) continue;
+          double p[3] = {org[0] + h * (ix + 0.5), org[1] + h * (iy + 0.5), org[2] + h * (iz + 0.5)};
+          p[0] -= CM[0]; p[1] -= CM[1]; p[2] -= CM[2];
+          const double *U = udef + (i * BS3 + c) * 3;
+          const double UT[3] = {vt[0] + om[1] * p[2] - om[2] * p[1] + U[0], vt[1] + om[2] * p[0] - om[0] * p[2] + U[1],
+                                vt[2] + om[0] * p[1] - om[1] * p[0] + U[2]};
+          const double X = implicit ? (CHI > 0.5 ? 1.0 : 0.0) : CHI;
+          const double penalFac = implicit ? X * lambdaFac / (1 + X * lambdaFac * dt) : X * lambdaFac;
+          double *v = vel + (b * BS3 + c) * 3;
+          const double FPX = penalFac * (UT[0] - v[0]), FPY = penalFac * (UT[1] - v[1]), FPZ = penalFac * (UT[2] - v[2]);
+          v[0] = v[0] + dt * FPX; v[1] = v[1] + dt * FPY; v[2] = v[2] + dt * FPZ;
+          F[0] += dv * FPX; F[1] += dv * FPY; F[2] += dv * FPZ;
+          F[3] += dv * (p[1] * FPZ - p[2] * FPY);
+          F[4] += dv * (p[2] * FPX - p[0] * FPZ);
+          F[5] += dv * (p[0] * FPY - p[1] * FPX);
+        }
+    for (int k = 0; k < 6; k++) M[k] += F[k];
+  }
+  for (int k = 0; k < 6; k++) force6[k] = M[k];
+  free(order);
+}
+
+/* kernelUpdateTmpV, main.cpp:14948-14979: tmpV += udef where the block's chi does not exceed the obstacle's */
+void orc_mesh_update_tmpv(const orc_mesh *m, double *tmpV, const double *chi_field, long n, const long long *ids, const double *chi,
+                          const double *udef) {
+  (void)m;
+  for (long i = 0; i < n; i++) {
+    const long b = (long)ids[i];
+    for (int c = 0; c < BS3; c++) {
+      if (chi_field[b * BS3 + c] > chi[i * BS3 + c]) continue;
+      for (int k = 0; k < 3; k++) tmpV[(b * BS3 + c) * 3 + k] += udef[(i * BS3 + c) * 3 + k];
+    }
+  }
 }

@@ -236,6 +236,8 @@ int main(int argc, char **argv) {
       else if (k == "uinfy") sd.uinf[1] = v;
       else if (k == "uinfz") sd.uinf[2] = v;
       else if (k == "mean") sd.bMeanConstraint = (int)v;
+      else if (k == "lambda") sd.lambda = v;
+      else if (k == "implicit") sd.bImplicitPenalization = v != 0;
       else { fprintf(stderr, "ref_tool: unknown set key %s\n", k.c_str()); exit(2); }
     } else if (cmd == "hip") {
       /* `hip on` | `hip resident`: swap AdvectionDiffusion / PressureProjection in sim.pipeline for the HIP-backed
@@ -279,6 +281,39 @@ int main(int argc, char **argv) {
       const size_t per = 512 * F.ncomp;
       if (buf.size() != F.infos->size() * per * 8) { fprintf(stderr, "loadb %s: size mismatch\n", fname.c_str()); exit(2); }
       for (size_t i = 0; i < F.infos->size(); i++) memcpy((*F.infos)[i].block, buf.data() + i * per * 8, per * 8);
+    } else if (cmd == "obstacle") {
+      /* `obstacle <file>`: add ONE synthetic obstacle (the reference's own obstacles are fish whose geometry needs GSL): a
+         plain Obstacle whose ObstacleBlocks (7256-7263: chi[8][8][8], udef[8][8][8][3]) are read from the file together with its
+         rigid motion.  File: int64 n, int64 blockID[n], double chi[n][512], double udef[n][512][3], double cm[3], vel[3], omega[3].
+         Everything downstream (KernelPenalization 13841-13912, kernelUpdateTmpV 14948-14979, KernelPressureRHS) is the
+         reference's own code. */
+      std::string path; script >> path;
+      auto buf = read_file(path);
+      const char *q = buf.data();
+      long long n; memcpy(&n, q, 8); q += 8;
+      std::vector<long long> ids(n); memcpy(ids.data(), q, 8 * n); q += 8 * n;
+      auto ob = std::make_shared<Obstacle>(sd);
+      ob->obstacleBlocks.assign(sd.chiInfo().size(), nullptr);
+      for (long long i = 0; i < n; i++) {
+        ObstacleBlock *b = new ObstacleBlock();
+        memcpy(&b->chi[0][0][0], q + (size_t)i * 512 * 8, 512 * 8);
+        ob->obstacleBlocks[ids[i]] = b;
+      }
+      q += (size_t)n * 512 * 8;
+      for (long long i = 0; i < n; i++) memcpy(&ob->obstacleBlocks[ids[i]]->udef[0][0][0][0], q + (size_t)i * 1536 * 8, 1536 * 8);
+      q += (size_t)n * 1536 * 8;
+      double rm[9]; memcpy(rm, q, 72);
+      for (int d = 0; d < 3; d++) { ob->centerOfMass[d] = rm[d]; ob->transVel[d] = rm[3 + d]; ob->angVel[d] = rm[6 + d]; }
+      sd.obstacle_vector->addObstacle(ob);
+    } else if (cmd == "forces") {
+      /* `forces <file>`: force[3], torque[3] of every obstacle as kernelFinalizePenalizationForce left them (13913-13938) */
+      std::string path; script >> path;
+      std::vector<double> out;
+      for (const auto &o : sd.obstacle_vector->getObstacleVector()) {
+        for (int d = 0; d < 3; d++) out.push_back(o->force[d]);
+        for (int d = 0; d < 3; d++) out.push_back(o->torque[d]);
+      }
+      write_file(path, out.data(), out.size() * 8);
     } else if (cmd == "amrtol") {
       /* tolerance_for_refinement / tolerance_for_compression of the five MeshAdaptation objects
          (main.cpp:5037-5038); `amrtol -1 -2` makes every block refine, `amrtol 1e300 1e299` compress */
@@ -318,13 +353,19 @@ int main(int argc, char **argv) {
     } else if (cmd == "op") {
       std::string op; script >> op;
       double arg = 0;
-      if (op == "advdiff" || op == "project" || op == "steps" || op == "forcing") script >> arg;
+      if (op == "advdiff" || op == "project" || op == "steps" || op == "forcing" || op == "penalize") script >> arg;
       for (int r = 0; r < rep; r++) {
         cup3d_stub_iallreduce7 = 0;
         double value = 0;
         const double t0 = now();
         if (op == "advdiff") { sd.dt = arg; if (hip_adv) (*hip_adv)(arg); else advdiff(arg); }
         else if (op == "lhs") lhsop(0);
+        else if (op == "penalize") { /* Penalization::operator() without the collision model, main.cpp:14330-14340 */
+          const std::vector<Info> &ci = sd.chiInfo(), &vi = sd.velInfo();
+          KernelPenalization K(arg, sd.lambda, sd.bImplicitPenalization, sd.obstacle_vector);
+          for (size_t i = 0; i < ci.size(); ++i) K(vi[i], ci[i]);
+          kernelFinalizePenalizationForce(sd);
+        }
         else if (op == "vorticity") { ComputeVorticity w(sd); w(0); } /* first half of adaptMesh, main.cpp:15180-15181 */
         else if (op == "precond") {
 #pragma omp parallel

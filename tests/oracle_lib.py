@@ -100,6 +100,8 @@ def lib():
     L.orc_mesh_grad_p.argtypes = [vp, _dp, _dp, C.c_double]
     L.orc_mesh_project.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.POINTER(SolveInfo)]
     L.orc_mesh_states.argtypes = [vp, _ip]
+    L.orc_mesh_penalize.argtypes = [vp, _dp, _dp, C.c_long, _lp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_int, _dp]
+    L.orc_mesh_update_tmpv.argtypes = [vp, _dp, _dp, C.c_long, _lp, _dp, _dp]
     _bp = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
     L.orc_mesh_valid_states.argtypes = [vp, _bp]
     L.orc_mesh_adapted_leaves.restype = C.c_long
@@ -107,6 +109,7 @@ def lib():
     L.orc_mesh_transfer.argtypes = [vp, vp, _dp, _dp, C.c_int, C.c_int]
     L.orc_mesh_vorticity.argtypes = [vp, _dp, _dp]
     L.orc_mesh_tag.argtypes = [vp, _dp, C.c_int, C.c_double, C.c_double, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]
+    L.orc_mesh_project_obst.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.POINTER(SolveInfo), C.c_long, _lp, _dp, _dp]
     L.orc_mesh_max_u.restype = C.c_double
     L.orc_mesh_max_u.argtypes = [vp, _dp, _dp]
     _lib = L
@@ -278,6 +281,14 @@ class OracleMesh:
         lib().orc_mesh_project(self.m, vel, pres, tmpV, lhs, chi, dt, step, C.byref(info))
         return info, tmpV, lhs
 
+    def project_obst(self, vel, pres, dt, step, chi_field, obst, tol=1e-6, tol_rel=1e-4, mean_constraint=1):
+        """PressureProjection with one obstacle (chi in the RHS, udef through tmpV); vel and pres are updated in place."""
+        tmpV, lhs = np.zeros_like(vel), np.zeros_like(pres)
+        info = SolveInfo(tol, tol_rel, mean_constraint, 0, 0, 0.0, 0.0)
+        lib().orc_mesh_project_obst(self.m, vel, pres, tmpV, lhs, np.ascontiguousarray(chi_field), dt, step, C.byref(info), len(obst["ids"]),
+                                    np.ascontiguousarray(obst["ids"], dtype=np.int64), np.ascontiguousarray(obst["chi"]), np.ascontiguousarray(obst["udef"]))
+        return info
+
     def max_u(self, vel, uinf=(0, 0, 0)):
         return lib().orc_mesh_max_u(self.m, vel, np.asarray(uinf, dtype=np.float64))
 
@@ -310,6 +321,21 @@ class OracleMesh:
         out = np.zeros((new_mesh.nb, 8, 8, 8, 3) if nc == 3 else (new_mesh.nb, 8, 8, 8))
         lib().orc_mesh_transfer(self.m, new_mesh.m, np.ascontiguousarray(field), out, nc, 1 if nc == 3 else 0)
         return out
+
+    def penalize(self, vel, chi_field, obst, dt, lam, implicit):
+        """obst = dict(ids, chi[n,8,8,8], udef[n,8,8,8,3], rigid[9]); returns (vel', force6)."""
+        v = np.ascontiguousarray(vel).copy()
+        f6 = np.zeros(6)
+        lib().orc_mesh_penalize(self.m, v, np.ascontiguousarray(chi_field), len(obst["ids"]), np.ascontiguousarray(obst["ids"], dtype=np.int64),
+                                np.ascontiguousarray(obst["chi"]), np.ascontiguousarray(obst["udef"]), np.ascontiguousarray(obst["rigid"]),
+                                dt, lam, 1 if implicit else 0, f6)
+        return v, f6
+
+    def update_tmpv(self, tmpV, chi_field, obst):
+        t = np.ascontiguousarray(tmpV).copy()
+        lib().orc_mesh_update_tmpv(self.m, t, np.ascontiguousarray(chi_field), len(obst["ids"]), np.ascontiguousarray(obst["ids"], dtype=np.int64),
+                                   np.ascontiguousarray(obst["chi"]), np.ascontiguousarray(obst["udef"]))
+        return t
 
     def states(self):
         out = np.zeros((self.nb, 27), dtype=np.int32)
@@ -449,3 +475,29 @@ def build_balanced_mesh(bpd, level_max, bc, refine):
     Zs = np.array([lib().orc_sfc_forward(sfc, t[0], t[1], t[2], t[3]) for t in out], dtype=np.int64)
     lib().orc_sfc_destroy(sfc)
     return levels, Zs
+
+
+def synthetic_obstacle(tables_h, nb, seed, frac=0.4):
+    """A synthetic obstacle for the harness's `obstacle` command and the oracle: ObstacleBlocks on a random subset of the blocks
+    with a smooth-ish chi in [0,1] (zeros included) and a small deformation velocity, plus a rigid motion.
+    Returns (obst dict, chi_field [nb,8,8,8] = what CreateObstacles would leave in sim.chi for a single obstacle)."""
+    rng = np.random.default_rng(seed)
+    ids = np.sort(rng.choice(nb, size=max(1, int(frac * nb)), replace=False)).astype(np.int64)
+    chi = rng.uniform(-0.4, 1.2, (len(ids), 8, 8, 8)).clip(0.0, 1.0)
+    udef = 0.1 * rng.uniform(-1, 1, (len(ids), 8, 8, 8, 3))
+    rigid = np.concatenate([rng.uniform(1.0, 4.0, 3), rng.uniform(-0.3, 0.3, 3), rng.uniform(-0.2, 0.2, 3)])
+    chi_field = np.zeros((nb, 8, 8, 8))
+    chi_field[ids] = chi
+    # a few cells where the grid's chi exceeds the obstacle's (another obstacle would own them): exercised `continue` branch
+    mask = rng.uniform(size=chi_field.shape) < 0.05
+    chi_field[mask] = np.minimum(1.0, chi_field[mask] + 0.3)
+    return dict(ids=ids, chi=chi, udef=udef, rigid=rigid), chi_field
+
+
+def write_obstacle_file(path, obst):
+    with open(path, "wb") as f:
+        np.array([len(obst["ids"])], dtype=np.int64).tofile(f)
+        np.ascontiguousarray(obst["ids"], dtype=np.int64).tofile(f)
+        np.ascontiguousarray(obst["chi"], dtype=np.float64).tofile(f)
+        np.ascontiguousarray(obst["udef"], dtype=np.float64).tofile(f)
+        np.ascontiguousarray(obst["rigid"], dtype=np.float64).tofile(f)
