@@ -41,6 +41,13 @@ _lp = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _vp = C.c_void_p
 
+class Obstacle(C.Structure):
+    """cup3d_obstacle"""
+    _fields_ = [("nblocks", C.c_long), ("slots", C.c_void_p), ("chi", C.c_void_p), ("udef", C.c_void_p),
+                ("cm", C.c_double * 3), ("vel", C.c_double * 3), ("omega", C.c_double * 3),
+                ("force", C.c_double * 3), ("torque", C.c_double * 3)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/cup3d_hip.h
 SIGNATURES = {
     "cup3d_last_error": (C.c_char_p, []),
@@ -99,6 +106,8 @@ SIGNATURES = {
     "cup3d_prolong": (C.c_int, [_vp, _vp, C.c_int]),
     "cup3d_tag_blocks": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]),
     "cup3d_compute_vorticity": (C.c_int, [_vp]),
+    "cup3d_penalization": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(Obstacle)]),
+    "cup3d_update_tmpv": (C.c_int, [_vp, C.c_int, C.POINTER(Obstacle)]),
     "cup3d_profile_enable": (C.c_int, [C.c_int]),
     "cup3d_profile_reset": (C.c_int, []),
     "cup3d_profile_read": (C.c_int, [C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),

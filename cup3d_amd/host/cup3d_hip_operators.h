@@ -220,6 +220,7 @@ class PressureProjectionHIP : public Operator {
   std::shared_ptr<DeviceMirror> devp;
   DeviceMirror &dev;
   std::shared_ptr<PoissonSolverHIP> solver;
+  bool had_obstacles = false;
 
 public:
   cup3d_poisson_result last{};
@@ -228,11 +229,18 @@ public:
     sim.pressureSolver = solver;  // as at main.cpp:15058-15059
   }
   void operator()(const Real dt) override {
-    if (sim.obstacle_vector->nObstacles() > 0) {
-      // obstacles: chi and udef (kernelUpdateTmpV, 14948-14979) are produced on the host
-      fprintf(stderr, "cup3d_hip: PressureProjectionHIP with obstacles is not wired yet (next round)\n");
-      fflush(0);
-      MPI_Abort(sim.comm, 1);
+    const bool obstacles = sim.obstacle_vector->nObstacles() > 0;
+    if (obstacles) {
+      // tmpV = 0; kernelUpdateTmpV(sim) (15066-15082) with the reference's own host code -- the ObstacleBlocks live there -- then chi
+      // and tmpV (= udef) go up: the device right-hand side reads both (KernelPressureRHS 14849-14875)
+      for (auto &info : sim.tmpVInfo()) ((VectorBlock *)info.block)->clear();
+      kernelUpdateTmpV(sim);
+      dev.upload(CUP3D_FIELD_TMPV);
+      dev.upload(CUP3D_FIELD_CHI);
+      had_obstacles = true;
+    } else if (had_obstacles) {
+      CUP3D_HIP_CALL(cup3d_sim_fill(dev.handle(), CUP3D_FIELD_CHI, 0.0));
+      had_obstacles = false;
     }
     if (!dev.vel_on_device) dev.upload(CUP3D_FIELD_VEL);
     dev.vel_on_device = false;

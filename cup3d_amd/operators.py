@@ -143,6 +143,9 @@ class SimulationData:
         self.handle = h
         self.pressureSolver = None
         self.last_poisson = None
+        self.obstacles = []            # ObstacleData list (geometry and motion come from the host)
+        self.lambda_penal = 1e6        # sim.lambda (-lambda)
+        self.bImplicitPenalization = True
 
     def __del__(self):
         try:
@@ -226,6 +229,43 @@ class ComputeVorticity(Operator):
         check(lib().cup3d_compute_vorticity(self.sim.handle))
 
 
+class ObstacleData:
+    """Host-side description of one obstacle for the device operators: the non-null ObstacleBlocks (block slots, chi, udef in the
+    reference's layout, main.cpp:7256-7263) and the rigid motion (centre of mass, translation and angular velocity)."""
+
+    def __init__(self, slots, chi, udef, cm, vel, omega):
+        self.slots = np.ascontiguousarray(slots, dtype=np.int32)
+        self.chi = np.ascontiguousarray(chi, dtype=np.float64).reshape(len(self.slots), 8, 8, 8)
+        self.udef = np.ascontiguousarray(udef, dtype=np.float64).reshape(len(self.slots), 8, 8, 8, 3)
+        self.cm, self.vel, self.omega = (np.array(v, dtype=np.float64) for v in (cm, vel, omega))
+        self.force, self.torque = np.zeros(3), np.zeros(3)
+
+
+def _obstacle_array(obstacles):
+    from .capi import Obstacle
+    arr = (Obstacle * max(1, len(obstacles)))()
+    for o, a in zip(obstacles, arr):
+        a.nblocks = len(o.slots)
+        a.slots, a.chi, a.udef = o.slots.ctypes.data, o.chi.ctypes.data, o.udef.ctypes.data
+        for d in range(3):
+            a.cm[d], a.vel[d], a.omega[d] = o.cm[d], o.vel[d], o.omega[d]
+    return arr
+
+
+class Penalization(Operator):
+    """Penalization::operator()(dt) without the collision model (main.cpp:14326-14341) for sim.obstacles (ObstacleData list):
+    KernelPenalization on the resident vel / chi, then the obstacles' force and torque."""
+
+    def __call__(self, dt):
+        s = self.sim
+        if not s.obstacles:
+            return
+        arr = _obstacle_array(s.obstacles)
+        check(lib().cup3d_penalization(s.handle, dt, s.lambda_penal, 1 if s.bImplicitPenalization else 0, len(s.obstacles), arr))
+        for o, a in zip(s.obstacles, arr):
+            o.force, o.torque = np.array(a.force[:]), np.array(a.torque[:])
+
+
 class ExternalForcing(Operator):
     """ExternalForcing::operator()(dt), main.cpp:10581-10596."""
 
@@ -289,6 +329,9 @@ class PressureProjection(Operator):
     def __call__(self, dt):
         s = self.sim
         s.dt = dt
+        if s.obstacles:  # tmpV = 0; kernelUpdateTmpV (15066-15082): chi must be resident (sim.upload("chi", ...))
+            s.fill("tmpV", 0.0)
+            check(lib().cup3d_update_tmpv(s.handle, len(s.obstacles), _obstacle_array(s.obstacles)))
         p, r = s.poisson_params(), PoissonResult()
         check(lib().cup3d_pressure_project(s.handle, dt, s.step, C.byref(p), C.byref(r)))
         s.last_poisson = r

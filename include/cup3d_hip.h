@@ -200,6 +200,23 @@ int cup3d_tag_blocks(cup3d_sim_t *, int field, double rtol, double ctol, signed 
  * expansion from the parent's tensorial [-1,2) tile on the OLD mesh, coarse/fine ghosts included), the parent of a
  * compressed octet from compress (5272-5329).  Every block of dst must be a block, a child or the parent of blocks of src. */
 int cup3d_adapt_transfer(cup3d_sim_t *src, cup3d_sim_t *dst, int field);
+/* Obstacle operators (the obstacles themselves -- geometry, chi/udef rasterisation, rigid-body integration -- stay on the host).
+ * One cup3d_obstacle = the ObstacleBlocks of one Obstacle on this rank in the reference's own layout (struct ObstacleBlock,
+ * main.cpp:7256-7263) plus its rigid motion. */
+typedef struct {
+  long nblocks;          /* number of non-null entries of Obstacle::obstacleBlocks */
+  const int32_t *slots;  /* [nblocks] their block slots (= Info::blockID) */
+  const double *chi;     /* [nblocks][8][8][8]     ObstacleBlock::chi */
+  const double *udef;    /* [nblocks][8][8][8][3]  ObstacleBlock::udef */
+  double cm[3], vel[3], omega[3]; /* getCenterOfMass(), getTranslationVelocity(), getAngularVelocity() */
+  double force[3], torque[3];     /* out of cup3d_penalization: Obstacle::force / torque (13932-13937) */
+} cup3d_obstacle;
+/* Penalization::operator() without the collision model (14330-14340): KernelPenalization (13841-13912) on the resident vel with
+ * the resident chi, obstacle after obstacle, then kernelFinalizePenalizationForce (13913-13938) */
+int cup3d_penalization(cup3d_sim_t *, double dt, double lambda, int implicit_penalization, int nobstacles, cup3d_obstacle *obstacles);
+/* kernelUpdateTmpV (14948-14979): tmpV += udef where chi <= the obstacle's chi; call after clearing tmpV and before
+ * cup3d_pressure_rhs / cup3d_pressure_project (15066-15085) */
+int cup3d_update_tmpv(cup3d_sim_t *, int nobstacles, const cup3d_obstacle *obstacles);
 /* ComputeVorticity::operator() (8726-8746, KernelVorticity 8624-8645): tmpV <- curl(vel); any mesh */
 int cup3d_compute_vorticity(cup3d_sim_t *);
 

@@ -263,6 +263,45 @@ def amr_adapt_case(name, bpd, lmax, bc, passes, seed, qr=0.75, qc=0.4):
           "levels", sorted(set(t[:, 0].tolist())), "->", sorted(set(t2[:, 0].tolist())))
 
 
+def obstacle_cases():
+    """KernelPenalization (+ force / torque), kernelUpdateTmpV inside PressureProjection and the chi-weighted right-hand side of
+    the reference, driven by a synthetic obstacle (oracle_lib.synthetic_obstacle; the reference's own obstacles are fish whose
+    geometry needs GSL).  One uniform grid and one multi-level mesh; stores the obstacle, the inputs and the outputs."""
+    out = {}
+    for name, implicit, lam in (("f16_mixed", 1, 1e6), ("amr_periodic_l01", 0, 1e4)):
+        g = np.load(os.path.join(HERE, name + ".npz"))
+        bpd, lmax = tuple(int(b) for b in g["bpd"]), int(g["level_max"])
+        bc = tuple(O.BC_NAMES[int(b)] for b in g["bc"])
+        t = g["tables"]
+        nb = len(t)
+        wd = O.tempfile.mkdtemp(prefix="golden_")
+        if name.startswith("amr"):
+            passes = [c for c in AMR_CASES if c[0] == name][0][4]
+            pre, lstart = amr_mesh_script(wd, bpd, passes), 0
+        else:
+            pre, lstart = ["zero chi"], int(g["level"])
+        rng = np.random.default_rng(77)
+        vel, pres = rng.uniform(-1, 1, (nb, 8, 8, 8, 3)), rng.uniform(-1, 1, (nb, 8, 8, 8))
+        obst, chif = O.synthetic_obstacle(None, nb, 78)
+        O.write_obstacle_file(os.path.join(wd, "ob.bin"), obst)
+        for n, a in (("velb", vel), ("presb", pres), ("chib", chif)):
+            a.tofile(os.path.join(wd, n + ".bin"))
+        dt, step = 0.01, 5
+        script = pre + ["tables t.bin", "obstacle ob.bin", "loadb vel velb.bin", "loadb pres presb.bin", "loadb chi chib.bin", f"set lambda {lam}",
+                        f"set implicit {implicit}", f"op penalize {dt}", "dump vel pen.bin", "forces f.bin", "loadb vel velb.bin", f"set step {step}",
+                        f"op project {dt}", "dump vel pv.bin", "dump pres pp.bin"]
+        recs, wd = O.run_ref(script, O.ref_args(bpd, lmax, lstart, EXT, bc), threads=1, workdir=wd)
+        t2, _ = O.read_tables(os.path.join(wd, "t.bin"))
+        assert np.array_equal(t2, t), name
+        out.update({name + "_vel_in": vel, name + "_pres_in": pres, name + "_chi_field": chif, name + "_ids": obst["ids"], name + "_ochi": obst["chi"],
+                    name + "_oudef": obst["udef"], name + "_rigid": obst["rigid"], name + "_par": np.array([dt, lam, implicit, step]),
+                    name + "_pen_vel": O.read_blocks(os.path.join(wd, "pen.bin"), nb, 3), name + "_force6": np.fromfile(os.path.join(wd, "f.bin")),
+                    name + "_pr_vel": O.read_blocks(os.path.join(wd, "pv.bin"), nb, 3), name + "_pr_pres": O.read_blocks(os.path.join(wd, "pp.bin"), nb, 1),
+                    name + "_pr_iters": [int(r["iters"]) for r in recs if r["op"] == "project"][0]})
+        print(name, "obstacle blocks", len(obst["ids"]), "force", out[name + "_force6"][:3], "project iters", out[name + "_pr_iters"])
+    np.savez_compressed(os.path.join(HERE, "obstacle_ops.npz"), **out)
+
+
 def sfc_cases():
     out = {}
     for bpd, lmax in SFC_CASES:
@@ -285,3 +324,4 @@ if __name__ == "__main__":
         field_case(*c)
     traj_case()
     vorticity_cases()
+    obstacle_cases()

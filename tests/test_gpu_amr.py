@@ -444,3 +444,42 @@ def test_flux_correction_is_conservative_on_a_large_periodic_mesh():
     assert abs(dp.sum()) <= 1e-11 * np.abs(dp).sum()
     # momentum: the diffusive part of the advect-diffuse increment is conservative; switch advection off via a huge... (not separable:
     # the upwind advection term is not in conservation form in the reference either), so only the three divergences above are asserted
+
+
+# ------------------------------------------------------------------ obstacle operators
+@pytest.mark.parametrize("name", ["f16_mixed", "amr_periodic_l01"])
+def test_obstacle_operators(golden_dir, name):
+    """cup3d_penalization / cup3d_update_tmpv / projection with chi and udef against the reference's golden (synthetic obstacle):
+    velocities and tmpV bit-exact, force and torque to summation order, projection to solver tolerance."""
+    z = np.load(os.path.join(golden_dir, "obstacle_ops.npz"))
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    t = g["tables"]
+    bpd, lmax, bc = tuple(int(b) for b in g["bpd"]), int(g["level_max"]), tuple(BCN[int(b)] for b in g["bc"])
+    m = O.OracleMesh(bpd, lmax, float(g["extent"]), bc, t[:, 0], t[:, 1])
+    sim = cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=0, extent=float(g["extent"]), BC_x=bc[0], BC_y=bc[1],
+                            BC_z=bc[2], leaves=(t[:, 0], t[:, 1]), poissonTol=1e-12, poissonTolRel=1e-10)
+    assert np.array_equal(sim.grid.tables, t)
+    dt, lam, implicit, step = z[name + "_par"]
+    vel, pres, chif = z[name + "_vel_in"], z[name + "_pres_in"], z[name + "_chi_field"]
+    rigid = z[name + "_rigid"]
+    ob = cu.ObstacleData(z[name + "_ids"], z[name + "_ochi"], z[name + "_oudef"], rigid[0:3], rigid[3:6], rigid[6:9])
+    sim.obstacles, sim.lambda_penal, sim.bImplicitPenalization = [ob], float(lam), bool(implicit)
+    sim.upload("vel", vel); sim.upload("chi", chif)
+    cu.Penalization(sim)(float(dt))
+    assert np.array_equal(sim.download("vel"), z[name + "_pen_vel"])
+    f6 = z[name + "_force6"]
+    assert np.abs(np.concatenate([ob.force, ob.torque]) - f6).max() <= 1e-12 * np.abs(f6).max()
+    # kernelUpdateTmpV
+    obst = dict(ids=z[name + "_ids"], chi=z[name + "_ochi"], udef=z[name + "_oudef"], rigid=rigid)
+    sim.fill("tmpV", 0.0)
+    check(lib().cup3d_update_tmpv(sim.handle, 1, cu.operators._obstacle_array([ob])))
+    assert np.array_equal(sim.download("tmpV"), m.update_tmpv(np.zeros_like(vel), chif, obst))
+    # projection with the obstacle, both sides solved tightly
+    sim.upload("vel", vel); sim.upload("pres", pres)
+    sim.step = int(step)
+    cu.PressureProjection(sim)(float(dt))
+    v, p = vel.copy(), pres.copy()
+    m.project_obst(v, p, float(dt), int(step), chif, obst, tol=1e-12, tol_rel=1e-10)
+    corr = np.abs(v - vel).max()
+    assert np.abs(sim.download("pres") - p).max() <= 1e-6 * np.abs(p).max()
+    assert np.abs(sim.download("vel") - v).max() <= 1e-6 * corr

@@ -101,3 +101,26 @@ def test_multilevel_mesh_through_the_shim(tmp_path):
     assert np.abs(c["prp"] - h["prp"]).max() <= 1e-6 * np.abs(c["prp"]).max()
     assert np.abs(c["st"] - h["st"]).max() <= 1e-6 * np.abs(c["st"]).max()    # three steps of the reference's own loop
     assert np.abs(c["stp"] - h["stp"]).max() <= 1e-5 * np.abs(c["stp"]).max()
+
+
+def test_projection_with_an_obstacle_through_the_shim(tmp_path):
+    """PressureProjectionHIP with obstacles: the shim runs the reference's own kernelUpdateTmpV on the host, uploads chi and tmpV
+    (= udef) and the device right-hand side reads both.  Synthetic obstacle; both sides at 1e-12 / 1e-10."""
+    bpd, lmax, bc = (2, 2, 2), 2, ("periodic", "wall", "freespace")
+    args = O.ref_args(bpd, lmax, 1, 2 * np.pi, bc, extra=["-poissonTol", "1e-12", "-poissonTolRel", "1e-10"])
+    nb = 64
+    rng = np.random.default_rng(8)
+    vel, pres = rng.uniform(-1, 1, (nb, 8, 8, 8, 3)), rng.uniform(-1, 1, (nb, 8, 8, 8))
+    obst, chif = O.synthetic_obstacle(None, nb, 9)
+    res = {}
+    for tag, tool, pre in (("cpu", O.REF_TOOL, []), ("hip", REF_HIP, ["hip on"])):
+        d = tmp_path / tag
+        d.mkdir()
+        O.write_obstacle_file(str(d / "ob.bin"), obst)
+        vel.tofile(str(d / "velb.bin")); pres.tofile(str(d / "presb.bin")); chif.tofile(str(d / "chib.bin"))
+        run(tool, pre + ["obstacle ob.bin", "loadb vel velb.bin", "loadb pres presb.bin", "loadb chi chib.bin", "set step 4", "op project 0.01",
+                         "dump vel pv.bin", "dump pres pp.bin"], args, str(d))
+        res[tag] = (O.read_blocks(str(d / "pv.bin"), nb, 3), O.read_blocks(str(d / "pp.bin"), nb, 1))
+    corr = np.abs(res["cpu"][0] - vel).max()
+    assert np.abs(res["cpu"][0] - res["hip"][0]).max() <= 1e-6 * corr
+    assert np.abs(res["cpu"][1] - res["hip"][1]).max() <= 1e-6 * np.abs(res["cpu"][1]).max()
