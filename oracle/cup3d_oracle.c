@@ -451,12 +451,14 @@ void orc_lhs(const orc_grid *g, const double *pres, double *lhs, int mc) { /* Co
 
 /* poisson_kernels, main.cpp:14617-14745 */
 static double precond_inner(double p[BS + 2][BS + 2][BS + 2], double Ax[BS][BS][BS], double r[BS][BS][BS],
-                            double blk[BS][BS][BS], double sqrNorm0, double rr) { /* kernelPoissonGetZInner 14651-14703 */
+                            double blk[BS][BS][BS], double sqrNorm0, double rr, double coefficient) {
+  /* kernelPoissonGetZInner 14651-14703 (coefficient = -6: `- 6 * p` and `+ (-6) * p` round identically) and
+   * kernelDiffusionGetZInner 10482-10533 (coefficient = -6 - h^2/(nu dt)): the same routine otherwise */
   double a2Partial[BS] = {0};
   for (int iz = 0; iz < BS; iz++)
     for (int iy = 0; iy < BS; iy++) {
       double t[BS];
-      for (int ix = 0; ix < BS; ix++) t[ix] = p[iz + 1][iy + 1][ix] + p[iz + 1][iy + 1][ix + 2] - 6 * p[iz + 1][iy + 1][ix + 1];
+      for (int ix = 0; ix < BS; ix++) t[ix] = p[iz + 1][iy + 1][ix] + p[iz + 1][iy + 1][ix + 2] + coefficient * p[iz + 1][iy + 1][ix + 1];
       for (int ix = 0; ix < BS; ix++) t[ix] += p[iz + 1][iy][ix + 1];
       for (int ix = 0; ix < BS; ix++) t[ix] += p[iz + 1][iy + 2][ix + 1];
       for (int ix = 0; ix < BS; ix++) t[ix] += p[iz][iy + 1][ix + 1];
@@ -490,7 +492,11 @@ static double precond_inner(double p[BS + 2][BS + 2][BS + 2], double Ax[BS][BS][
 
 long orc_precond_total_iters = 0; /* diagnostic: block-CG iterations summed over blocks by the last orc_precond call */
 /* one block of getZImplParallel (main.cpp:14704-14745): blk <- approximate solve of the 8^3 Dirichlet problem; returns CG iterations */
-long orc_precond_block(double *pblk, double h) {
+long orc_precond_block_coef(double *pblk, double h, double coefficient);
+long orc_precond_block(double *pblk, double h) { return orc_precond_block_coef(pblk, h, -6.0); }
+/* the same with the centre coefficient of the block operator as a parameter: diffusion_kernels::getZImplParallel,
+ * main.cpp:10534-10579, passes -6 - h^2/nu/dt (10570) */
+long orc_precond_block_coef(double *pblk, double h, double coefficient) {
   long total = 0;
   double p[BS + 2][BS + 2][BS + 2], Ax[BS][BS][BS], r[BS][BS][BS];
   memset(p, 0, sizeof p);
@@ -510,7 +516,7 @@ long orc_precond_block(double *pblk, double h) {
   const double sqrNorm0 = (double)1 / (BS3 * BS3) * rr;
   if (sqrNorm0 < 1e-32) return 0;
   for (int k = 0; k < 100; k++) {
-    rr = precond_inner(p, Ax, r, blk, sqrNorm0, rr);
+    rr = precond_inner(p, Ax, r, blk, sqrNorm0, rr, coefficient);
     total++;
     if (rr <= 0) break;
   }
@@ -527,11 +533,16 @@ void orc_precond(const orc_grid *g, double *pres) { /* getZImplParallel, main.cp
  * _preconditioner (9334-9364, in place), `corner` the first cell of the block whose index is (0,0,0) */
 void orc_solve_generic(void *g, long N, long corner, void (*op_lhs)(void *, const double *, double *, int),
                        void (*op_precond)(void *, double *), double *lhs, double *pres, orc_solve_info *info) {
+  orc_solve_generic2(g, N, corner, op_lhs, op_precond, lhs, pres, info, 100);
+}
+/* max_restarts: 100 in PoissonSolverAMR::solve (14567); DiffusionSolver::solve (6896-7146) is the same routine without a
+ * restart cap and without mean constraint (pass mean_constraint 0 and INT_MAX) */
+void orc_solve_generic2(void *g, long N, long corner, void (*op_lhs)(void *, const double *, double *, int),
+                        void (*op_precond)(void *, double *), double *lhs, double *pres, orc_solve_info *info, int max_restarts) {
 #define solver_lhs(g, in, out, mc) op_lhs(g, in, out, mc)
 #define solver_precond(g, in, out, N) (memcpy(out, in, (N) * sizeof(double)), op_precond(g, out))
   const int mc = info->mean_constraint;
   const double eps = 1e-100, max_error = info->tol, max_rel_error = info->tol_rel;
-  const int max_restarts = 100;
   int serious_breakdown = 0, useXopt = 0, restarts = 0;
   double min_norm = 1e50, norm_1 = 0.0, norm_2 = 0.0;
   double *buf = (double *)calloc((size_t)18 * N, sizeof(double));

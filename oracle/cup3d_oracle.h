@@ -66,6 +66,9 @@ void orc_precond(const orc_grid *, double *pres);
 typedef struct { double tol, tol_rel; int mean_constraint; int iters; int restarts; double norm0, norm; } orc_solve_info;
 void orc_solve(const orc_grid *, double *lhs, double *pres, orc_solve_info *);
 long orc_precond_block(double *blk, double h); /* one 8^3 block of getZImplParallel; returns its CG iterations */
+long orc_precond_block_coef(double *blk, double h, double coefficient); /* diffusion_kernels::getZImplParallel, 10534-10579 */
+void orc_solve_generic2(void *mesh, long N, long corner, void (*op_lhs)(void *, const double *, double *, int),
+                        void (*op_precond)(void *, double *), double *lhs, double *pres, orc_solve_info *, int max_restarts);
 void orc_solve_generic(void *mesh, long N, long corner, void (*op_lhs)(void *, const double *, double *, int),
                        void (*op_precond)(void *, double *), double *lhs, double *pres, orc_solve_info *);
 void orc_pressure_rhs(const orc_grid *, const double *vel, const double *udef, const double *chi, double *lhs, double dt); /* 14849-14875 */
@@ -108,6 +111,14 @@ void orc_mesh_project(const orc_mesh *, double *vel, double *pres, double *tmpV,
 void orc_mesh_project_obst(const orc_mesh *, double *vel, double *pres, double *tmpV, double *lhs, const double *chi, double dt, int step,
                            orc_solve_info *, long n, const long long *ids, const double *ochi, const double *oudef);
 double orc_mesh_max_u(const orc_mesh *, const double *vel, const double uinf[3]);
+/* implicit diffusion (AdvectionDiffusionImplicit, main.cpp:10030-10118); `sequential`: see cup3d_oracle_amr.c */
+void orc_mesh_advect_implicit(const orc_mesh *, double *vel, double *tmpV, double dt, double nu, const double uinf[3], int sequential);
+void orc_mesh_diffusion_rhs(const orc_mesh *, const double *vel, double *tmpV);
+void orc_mesh_diff_lhs(const orc_mesh *, const double *pres, double *lhs, int direction, double dt, double nu);
+void orc_mesh_diff_precond(const orc_mesh *, double *pres, double dt, double nu);
+void orc_mesh_diff_solve(const orc_mesh *, double *lhs, double *pres, int direction, double dt, double nu, orc_solve_info *);
+void orc_mesh_advdiff_implicit(const orc_mesh *, double *vel, double *pres, double *tmpV, double *lhs, double dt, double nu,
+                               const double uinf[3], double tol, double tol_rel, int sequential, int iters[3]);
 void orc_mesh_vorticity(const orc_mesh *, const double *vel, double *tmpV); /* ComputeVorticity, main.cpp:8624-8746 */
 void orc_mesh_tag(const orc_mesh *, const double *field, int nc, double rtol, double ctol, signed char *states);
 void orc_mesh_states(const orc_mesh *, int *out27);

@@ -177,9 +177,10 @@ static void apply_bc(const orc_mesh *m, long b, tile_t *t, int coarse) {
             p[d] = gg; q[d] = face; p[d1] = q[d1] = a1; p[d2] = q[d2] = a2;
             for (int c = 0; c < t->nc; c++) {
               double v = coarse ? CT(t, q[0], q[1], q[2], c) : FT(t, q[0], q[1], q[2], c);
-              if (t->is_vector) {
+              if (t->is_vector) { /* 1: vector element; 2 + k: scalar element of BlockLabBC<.., direction = k> (6120, 6384-6394) */
+                const int ceff = t->is_vector == 1 ? c : t->is_vector - 2;
                 if (m->bc[d] == ORC_BC_WALL) v = (-1.0) * v;
-                else if (c == d) v = (-1.) * v;
+                else if (ceff == d) v = (-1.) * v;
               }
               if (coarse) CT(t, p[0], p[1], p[2], c) = v; else FT(t, p[0], p[1], p[2], c) = v;
             }
@@ -862,6 +863,213 @@ void orc_mesh_project_obst(const orc_mesh *m, double *vel, double *pres, double 
 void orc_mesh_project(const orc_mesh *m, double *vel, double *pres, double *tmpV, double *lhs, const double *chi, double dt, int step,
                       orc_solve_info *info) {
   orc_mesh_project_obst(m, vel, pres, tmpV, lhs, chi, dt, step, info, 0, NULL, NULL, NULL);
+}
+
+
+/* ------------------------------------------------------------------ implicit diffusion (AdvectionDiffusionImplicit)
+ * KernelAdvect (main.cpp:9849-10029): tmpV = facD*lap(u) (+ face fluxes, flux-corrected), vel += facA*(u.grad)u/h^3 IN PLACE.
+ * The reference updates vel while later blocks still build their ghosted tiles from it (the lab is loaded per block inside
+ * the same loop, 5598-5602), so its result depends on the block order and, with more than one thread, on timing.
+ *   sequential = 1: the reference's behaviour with ONE thread (blocks in m_vInfo order, each tile loaded from the partially
+ *                   updated field) -- what oracle/_ref reproduces bit for bit with OMP_NUM_THREADS=1;
+ *   sequential = 0: every tile is loaded from the field as it was on entry (what the operator means, and the only
+ *                   order-independent reading): the device path implements this one. */
+void orc_mesh_advect_implicit(const orc_mesh *m, double *vel, double *tmpV, double dt, double nu, const double uinf[3], int sequential) {
+  faces_t F;
+  faces_init(m, &F, 3);
+  double *copy = NULL;
+  const double *src = vel;
+  if (!sequential) {
+    copy = (double *)malloc((size_t)m->nblocks * BS3 * 3 * sizeof(double));
+    memcpy(copy, vel, (size_t)m->nblocks * BS3 * 3 * sizeof(double));
+    src = copy;
+  }
+#define V(x, y, z, c) FT(&t, x, y, z, c)
+  tile_t t;
+  tile_init(&t, 3, 1, -3, 4, 0);
+  for (long b = 0; b < m->nblocks; b++) {
+    orc_mesh_lab(m, src, b, &t);
+    const double h = orc_mesh_h(m, b), h3 = h * h * h;
+    const double facA = -dt / h * h3, facD = (nu / h) * (dt / h) * h3;
+    double *o = tmpV + b * BS3 * 3, *v = vel + b * BS3 * 3;
+    for (int z = 0; z < BS; z++)
+      for (int y = 0; y < BS; y++)
+        for (int x = 0; x < BS; x++) {
+          const double uAbs[3] = {V(x, y, z, 0) + uinf[0], V(x, y, z, 1) + uinf[1], V(x, y, z, 2) + uinf[2]};
+          double dx[3], dy[3], dz[3], lap[3];
+          for (int c = 0; c < 3; c++) {
+            dx[c] = upwind5m(uAbs[0], V(x - 3, y, z, c), V(x - 2, y, z, c), V(x - 1, y, z, c), V(x, y, z, c), V(x + 1, y, z, c), V(x + 2, y, z, c), V(x + 3, y, z, c));
+            dy[c] = upwind5m(uAbs[1], V(x, y - 3, z, c), V(x, y - 2, z, c), V(x, y - 1, z, c), V(x, y, z, c), V(x, y + 1, z, c), V(x, y + 2, z, c), V(x, y + 3, z, c));
+            dz[c] = upwind5m(uAbs[2], V(x, y, z - 3, c), V(x, y, z - 2, c), V(x, y, z - 1, c), V(x, y, z, c), V(x, y, z + 1, c), V(x, y, z + 2, c), V(x, y, z + 3, c));
+          }
+          lap[0] = ((V(x + 1, y, z, 0) + V(x - 1, y, z, 0)) + ((V(x, y + 1, z, 0) + V(x, y - 1, z, 0)) + (V(x, y, z + 1, 0) + V(x, y, z - 1, 0)))) - 6 * V(x, y, z, 0);
+          lap[1] = ((V(x, y + 1, z, 1) + V(x, y - 1, z, 1)) + ((V(x, y, z + 1, 1) + V(x, y, z - 1, 1)) + (V(x + 1, y, z, 1) + V(x - 1, y, z, 1)))) - 6 * V(x, y, z, 1);
+          lap[2] = ((V(x, y, z + 1, 2) + V(x, y, z - 1, 2)) + ((V(x + 1, y, z, 2) + V(x - 1, y, z, 2)) + (V(x, y + 1, z, 2) + V(x, y - 1, z, 2)))) - 6 * V(x, y, z, 2);
+          const double duA = uAbs[0] * dx[0] + (uAbs[1] * dy[0] + uAbs[2] * dz[0]);
+          const double dvA = uAbs[1] * dy[1] + (uAbs[2] * dz[1] + uAbs[0] * dx[1]);
+          const double dwA = uAbs[2] * dz[2] + (uAbs[0] * dx[2] + uAbs[1] * dy[2]);
+          const long i = ((z * BS + y) * BS + x) * 3;
+          o[i + 0] = facD * lap[0];
+          o[i + 1] = facD * lap[1];
+          o[i + 2] = facD * lap[2];
+          v[i + 0] += facA * duA / h3; /* 9939-9941 */
+          v[i + 1] += facA * dvA / h3;
+          v[i + 2] += facA * dwA / h3;
+        }
+    for (int f = 0; f < 6; f++) {
+      if (!F.stored[b * 6 + f]) continue;
+      for (int i1 = 0; i1 < 8; i1++)
+        for (int i2 = 0; i2 < 8; i2++) {
+          FACE_CELLS(f, i2, i1, p, q)
+          for (int c = 0; c < 3; c++) FACE(&F, b, f, i2 + i1 * 8, c) = facD * (V(p[0], p[1], p[2], c) - V(q[0], q[1], q[2], c));
+        }
+    }
+  }
+  tile_free(&t);
+#undef V
+  free(copy);
+  fix_fluxes(m, &F, tmpV, 3);
+  faces_free(&F);
+}
+
+/* KernelDiffusionRHS (main.cpp:9729-9848): tmpV = h*lap(vel) with the component-wise associations, flux-corrected */
+void orc_mesh_diffusion_rhs(const orc_mesh *m, const double *vel, double *tmpV) {
+  faces_t F;
+  faces_init(m, &F, 3);
+#define V(x, y, z, c) FT(&t, x, y, z, c)
+#pragma omp parallel num_threads(mesh_threads(m))
+  {
+  tile_t t;
+  tile_init(&t, 3, 1, -1, 2, 0);
+#pragma omp for schedule(dynamic, 1)
+  for (long b = 0; b < m->nblocks; b++) {
+    orc_mesh_lab(m, vel, b, &t);
+    const double facD = orc_mesh_h(m, b);
+    double *o = tmpV + b * BS3 * 3;
+    for (int z = 0; z < BS; z++)
+      for (int y = 0; y < BS; y++)
+        for (int x = 0; x < BS; x++) {
+          const double duD = ((V(x + 1, y, z, 0) + V(x - 1, y, z, 0)) + ((V(x, y + 1, z, 0) + V(x, y - 1, z, 0)) + (V(x, y, z + 1, 0) + V(x, y, z - 1, 0)))) - 6 * V(x, y, z, 0);
+          const double dvD = ((V(x, y + 1, z, 1) + V(x, y - 1, z, 1)) + ((V(x, y, z + 1, 1) + V(x, y, z - 1, 1)) + (V(x + 1, y, z, 1) + V(x - 1, y, z, 1)))) - 6 * V(x, y, z, 1);
+          const double dwD = ((V(x, y, z + 1, 2) + V(x, y, z - 1, 2)) + ((V(x + 1, y, z, 2) + V(x - 1, y, z, 2)) + (V(x, y + 1, z, 2) + V(x, y - 1, z, 2)))) - 6 * V(x, y, z, 2);
+          const long i = ((z * BS + y) * BS + x) * 3;
+          o[i + 0] = facD * duD;
+          o[i + 1] = facD * dvD;
+          o[i + 2] = facD * dwD;
+        }
+    for (int f = 0; f < 6; f++) {
+      if (!F.stored[b * 6 + f]) continue;
+      for (int i1 = 0; i1 < 8; i1++)
+        for (int i2 = 0; i2 < 8; i2++) {
+          FACE_CELLS(f, i2, i1, p, q)
+          for (int c = 0; c < 3; c++) FACE(&F, b, f, i2 + i1 * 8, c) = facD * (V(p[0], p[1], p[2], c) - V(q[0], q[1], q[2], c));
+        }
+    }
+  }
+  tile_free(&t);
+  }
+#undef V
+  fix_fluxes(m, &F, tmpV, 3);
+  faces_free(&F);
+}
+
+/* DiffusionSolver::_lhs -> KernelLHSDiffusion (main.cpp:6726-6803) on the BlockLabBC<ScalarGrid, .., direction> tile:
+ * lhs = h*(sum6 - 6p) + coef*p, coef = -h^3/(dt nu); face fluxes h*(p_in - p_ghost); flux-corrected */
+void orc_mesh_diff_lhs(const orc_mesh *m, const double *pres, double *lhs, int direction, double dt, double nu) {
+  faces_t F;
+  faces_init(m, &F, 1);
+#define P(x, y, z) FT(&t, x, y, z, 0)
+#pragma omp parallel num_threads(mesh_threads(m))
+  {
+  tile_t t;
+  tile_init(&t, 1, 2 + direction, -1, 2, 0);
+#pragma omp for schedule(dynamic, 1)
+  for (long b = 0; b < m->nblocks; b++) {
+    orc_mesh_lab(m, pres, b, &t);
+    const double h = orc_mesh_h(m, b), coef = -1.0 / (dt * nu) * h * h * h;
+    double *o = lhs + b * BS3;
+    for (int z = 0; z < BS; z++)
+      for (int y = 0; y < BS; y++)
+        for (int x = 0; x < BS; x++)
+          o[(z * BS + y) * BS + x] =
+              h * (P(x - 1, y, z) + P(x + 1, y, z) + P(x, y - 1, z) + P(x, y + 1, z) + P(x, y, z - 1) + P(x, y, z + 1) - 6.0 * P(x, y, z)) + coef * P(x, y, z);
+    for (int f = 0; f < 6; f++) {
+      if (!F.stored[b * 6 + f]) continue;
+      for (int i1 = 0; i1 < 8; i1++)
+        for (int i2 = 0; i2 < 8; i2++) {
+          FACE_CELLS(f, i2, i1, p, q)
+          FACE(&F, b, f, i2 + i1 * 8, 0) = h * (P(p[0], p[1], p[2]) - P(q[0], q[1], q[2]));
+        }
+    }
+  }
+  tile_free(&t);
+  }
+#undef P
+  fix_fluxes(m, &F, lhs, 1);
+  faces_free(&F);
+}
+
+/* DiffusionSolver::_preconditioner -> diffusion_kernels::getZImplParallel (main.cpp:10534-10579), in place */
+void orc_mesh_diff_precond(const orc_mesh *m, double *pres, double dt, double nu) {
+#pragma omp parallel for num_threads(mesh_threads(m))
+  for (long b = 0; b < m->nblocks; b++) {
+    const double h = orc_mesh_h(m, b);
+    orc_precond_block_coef(pres + b * BS3, h, -6.0 - h * h / nu / dt); /* 10570 */
+  }
+}
+
+typedef struct { const orc_mesh *m; int direction; double dt, nu; } diff_ctx;
+static void diff_lhs_cb(void *c, const double *in, double *out, int mc) {
+  (void)mc;
+  const diff_ctx *d = (const diff_ctx *)c;
+  orc_mesh_diff_lhs(d->m, in, out, d->direction, d->dt, d->nu);
+}
+static void diff_precond_cb(void *c, double *io) {
+  const diff_ctx *d = (const diff_ctx *)c;
+  orc_mesh_diff_precond(d->m, io, d->dt, d->nu);
+}
+/* DiffusionSolver::solve (main.cpp:6896-7146): rhs in lhs, initial guess and result in pres */
+void orc_mesh_diff_solve(const orc_mesh *m, double *lhs, double *pres, int direction, double dt, double nu, orc_solve_info *info) {
+  diff_ctx c = {m, direction, dt, nu};
+  info->mean_constraint = 0;
+  orc_solve_generic2(&c, m->nblocks * BS3, 0, diff_lhs_cb, diff_precond_cb, lhs, pres, info, 0x7fffffff);
+}
+
+/* AdvectionDiffusionImplicit::euler (main.cpp:10030-10118).  On return: vel advanced, pres unchanged, tmpV = the right-hand
+ * side vector of the three Helmholtz solves, lhs = scratch of the last solve; iters[3] = iterations per component */
+void orc_mesh_advdiff_implicit(const orc_mesh *m, double *vel, double *pres, double *tmpV, double *lhs, double dt, double nu,
+                               const double uinf[3], double tol, double tol_rel, int sequential, int iters[3]) {
+  const long N = m->nblocks * BS3;
+  double *pressure = (double *)malloc(N * sizeof(double)), *velocity = (double *)malloc(3 * N * sizeof(double));
+  orc_mesh_advect_implicit(m, vel, tmpV, dt, nu, uinf, sequential);
+  for (long b = 0; b < m->nblocks; b++) {
+    const double h = orc_mesh_h(m, b), ih3 = 1.0 / (h * h * h);
+    for (long i = b * BS3; i < (b + 1) * BS3; i++) {
+      pressure[i] = pres[i];
+      for (int c = 0; c < 3; c++) {
+        velocity[3 * i + c] = vel[3 * i + c];
+        vel[3 * i + c] = tmpV[3 * i + c] * ih3 + vel[3 * i + c]; /* 10051-10053 */
+      }
+    }
+  }
+  orc_mesh_diffusion_rhs(m, vel, tmpV);
+  for (long b = 0; b < m->nblocks; b++) {
+    const double h = orc_mesh_h(m, b), ih3 = 1.0 / (h * h * h);
+    for (long i = b * BS3 * 3; i < (b + 1) * BS3 * 3; i++)
+      tmpV[i] = -tmpV[i] * ih3 + (vel[i] - velocity[i]) / (dt * nu); /* 10066-10074 */
+  }
+  for (int index = 0; index < 3; index++) {
+    for (long b = 0; b < m->nblocks; b++) {
+      const double h = orc_mesh_h(m, b), h3 = h * h * h;
+      for (long i = b * BS3; i < (b + 1) * BS3; i++) { pres[i] = 0; lhs[i] = h3 * tmpV[3 * i + index]; }
+    }
+    orc_solve_info info = {tol, tol_rel, 0, 0, 0, 0, 0};
+    orc_mesh_diff_solve(m, lhs, pres, index, dt, nu, &info);
+    if (iters) iters[index] = info.iters;
+    for (long i = 0; i < N; i++) vel[3 * i + index] += pres[i];
+  }
+  memcpy(pres, pressure, N * sizeof(double));
+  free(pressure); free(velocity);
 }
 
 double orc_mesh_max_u(const orc_mesh *m, const double *vel, const double uinf[3]) { /* findMaxU, main.cpp:8603-8623 */

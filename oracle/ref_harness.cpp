@@ -24,6 +24,8 @@
  *   set step|dt|time|nu|uinfx|uinfy|uinfz|mean <value>
  *   op advdiff <dt> | lhs | precond | solve | project <dt> | maxu |
  *      steps <n> | forcing <dt> | rhs | divp | gradp   (the last three use `set dt`)
+ *      advdiff_implicit <dt> | advect | diffrhs | diffprecond | difflhs <dir> | diffsolve <dir>   (implicit diffusion;
+ *      `set dt`, `set nu`, `set difftol`, `set difftolrel`; value = number of 6-double reductions = solver iterations)
  *   hip on                 (ref_tool_hip only) route advdiff/project/steps through the HIP drop-in
  *   lab <field> <s> <e> <tensorial> <file>   ghosted tiles of every block (BlockLab::load)
  *   loadb <field> <file>   block-order load (multi-level meshes)
@@ -75,10 +77,12 @@
 #include <unordered_map>
 #include <utility>
 #include <vector>
+static long cup3d_stub_iallreduce6 = 0;
 static long cup3d_stub_iallreduce7 = 0; /* one 7-double Iallreduce per BiCGSTAB iteration (main.cpp:14546) */
 #define CUP3D_STUB_COUNT_IALLREDUCE(n)                                         \
   do {                                                                         \
     if ((n) == 7) cup3d_stub_iallreduce7++;                                    \
+    if ((n) == 6) cup3d_stub_iallreduce6++; /* DiffusionSolver, main.cpp:7083 */ \
   } while (0)
 #include <mpi.h>
 #define main cup3d_reference_main
@@ -238,6 +242,8 @@ int main(int argc, char **argv) {
       else if (k == "mean") sd.bMeanConstraint = (int)v;
       else if (k == "lambda") sd.lambda = v;
       else if (k == "implicit") sd.bImplicitPenalization = v != 0;
+      else if (k == "difftol") sd.DiffusionErrorTol = v;
+      else if (k == "difftolrel") sd.DiffusionErrorTolRel = v;
       else { fprintf(stderr, "ref_tool: unknown set key %s\n", k.c_str()); exit(2); }
     } else if (cmd == "hip") {
       /* `hip on` | `hip resident`: swap AdvectionDiffusion / PressureProjection in sim.pipeline for the HIP-backed
@@ -353,9 +359,11 @@ int main(int argc, char **argv) {
     } else if (cmd == "op") {
       std::string op; script >> op;
       double arg = 0;
-      if (op == "advdiff" || op == "project" || op == "steps" || op == "forcing" || op == "penalize") script >> arg;
+      if (op == "advdiff" || op == "project" || op == "steps" || op == "forcing" || op == "penalize" || op == "advdiff_implicit" ||
+          op == "difflhs" || op == "diffsolve") script >> arg;
       for (int r = 0; r < rep; r++) {
         cup3d_stub_iallreduce7 = 0;
+        cup3d_stub_iallreduce6 = 0;
         double value = 0;
         const double t0 = now();
         if (op == "advdiff") { sd.dt = arg; if (hip_adv) (*hip_adv)(arg); else advdiff(arg); }
@@ -379,6 +387,27 @@ int main(int argc, char **argv) {
         }
         else if (op == "divp") compute<ScalarLab>(KernelDivPressure(sd), sd.pres, sd.tmpV);   /* main.cpp:15088 */
         else if (op == "gradp") compute<ScalarLab>(KernelGradP(sd, sd.dt), sd.pres, sd.tmpV); /* main.cpp:15146 */
+        /* implicit diffusion (AdvectionDiffusionImplicit::euler, main.cpp:10030-10118) and its parts; all use `set dt`, `set nu` */
+        else if (op == "advdiff_implicit") { sd.dt = arg; AdvectionDiffusionImplicit a(sd); a(arg); }
+        else if (op == "advect") compute<VectorLab>(KernelAdvect(sd, sd.dt), sd.vel, sd.tmpV);       /* 10038 */
+        else if (op == "diffrhs") compute<VectorLab>(KernelDiffusionRHS(sd), sd.vel, sd.tmpV);        /* 10057 */
+        else if (op == "diffprecond") {                                                               /* 6823-6824 */
+#pragma omp parallel
+          { diffusion_kernels::getZImplParallel(sd.presInfo(), sd.nu, sd.dt); }
+        }
+        else if (op == "difflhs" || op == "diffsolve") { /* <direction>: DiffusionSolver::_lhs (pres -> lhs) / ::solve */
+          DiffusionSolver ds(sd);
+          ds.mydirection = (int)arg;
+          ds.dt = sd.dt;
+          if (op == "diffsolve") ds.solve();
+          else {
+            const size_t nb = sd.presInfo().size();
+            std::vector<Real> in(nb * 512), out(nb * 512);
+            for (size_t i = 0; i < nb; i++) memcpy(&in[i * 512], sd.presInfo()[i].block, 4096);
+            ds._lhs(in, out);
+          }
+          value = (double)cup3d_stub_iallreduce6;
+        }
         else if (op == "maxu") value = findMaxU(sd);
         else if (op == "forcing") { ExternalForcing f(sd); f(arg); }
         else if (op == "steps") {

@@ -302,6 +302,52 @@ def obstacle_cases():
     np.savez_compressed(os.path.join(HERE, "obstacle_ops.npz"), **out)
 
 
+def implicit_cases():
+    """AdvectionDiffusionImplicit (main.cpp:10030-10118) and its parts -- KernelAdvect, KernelDiffusionRHS, DiffusionSolver::_lhs for
+    the three directions, diffusion_kernels::getZImplParallel, DiffusionSolver::solve -- on a uniform mixed-BC grid and on a
+    multi-level mesh, ONE thread (KernelAdvect updates vel in place while later blocks still read it: the reference's result is
+    only defined for a fixed block order)."""
+    out = {}
+    for name in ("f16_mixed", "amr_mixed_l12"):
+        g = np.load(os.path.join(HERE, name + ".npz"))
+        bpd, lmax = tuple(int(b) for b in g["bpd"]), int(g["level_max"])
+        bc = tuple(O.BC_NAMES[int(b)] for b in g["bc"])
+        t = g["tables"]
+        nb = len(t)
+        wd = O.tempfile.mkdtemp(prefix="golden_")
+        if name.startswith("amr"):
+            passes = [c for c in AMR_CASES if c[0] == name][0][4]
+            pre, lstart = amr_mesh_script(wd, bpd, passes), 0
+        else:
+            pre, lstart = ["zero chi"], int(g["level"])
+        rng = np.random.default_rng(91)
+        vel, pres, rhs = 0.5 * rng.uniform(-1, 1, (nb, 8, 8, 8, 3)), rng.uniform(-1, 1, (nb, 8, 8, 8)), rng.uniform(-1, 1, (nb, 8, 8, 8))
+        for n, a in (("velb", vel), ("presb", pres), ("rhsb", rhs)):
+            a.tofile(os.path.join(wd, n + ".bin"))
+        dt, nu, uinf = 0.05, 2.0, (0.1, -0.2, 0.3)  # nu*dt/h^2 = O(1): the Helmholtz solves need O(10) iterations
+        script = pre + ["tables t.bin", f"set nu {nu}", f"set dt {dt}", f"set uinfx {uinf[0]}", f"set uinfy {uinf[1]}", f"set uinfz {uinf[2]}",
+                        "loadb vel velb.bin", "op advect", "dump vel adv_vel.bin", "dump tmpV adv_tmp.bin",
+                        "loadb vel velb.bin", "op diffrhs", "dump tmpV drhs.bin"]
+        for d in range(3):
+            script += ["loadb pres presb.bin", f"op difflhs {d}", f"dump lhs dlhs{d}.bin"]
+        script += ["loadb pres presb.bin", "op diffprecond", "dump pres dpre.bin",
+                   "set difftol 1e-9", "set difftolrel 1e-9", "loadb lhs rhsb.bin", "loadb pres presb.bin", "op diffsolve 1", "dump pres dsol.bin",
+                   "set difftol 1e-6", "set difftolrel 1e-4",
+                   "loadb vel velb.bin", "loadb pres presb.bin", f"op advdiff_implicit {dt}", "dump vel imp_vel.bin", "dump pres imp_pres.bin"]
+        recs, wd = O.run_ref(script, O.ref_args(bpd, lmax, lstart, EXT, bc), threads=1, workdir=wd)
+        t2, _ = O.read_tables(os.path.join(wd, "t.bin"))
+        assert np.array_equal(t2, t), name
+        rb = lambda f, nc: O.read_blocks(os.path.join(wd, f), nb, nc)  # noqa: E731
+        assert np.array_equal(rb("imp_pres.bin", 1), pres)
+        out.update({name + "_vel_in": vel, name + "_pres_in": pres, name + "_rhs_in": rhs, name + "_par": np.array([dt, nu, *uinf]),
+                    name + "_adv_vel": rb("adv_vel.bin", 3), name + "_adv_tmp": rb("adv_tmp.bin", 3), name + "_drhs": rb("drhs.bin", 3),
+                    name + "_dlhs": np.stack([rb(f"dlhs{d}.bin", 1) for d in range(3)]), name + "_dpre": rb("dpre.bin", 1),
+                    name + "_dsol": rb("dsol.bin", 1), name + "_imp_vel": rb("imp_vel.bin", 3),
+                    name + "_dsol_iters": [int(float(r["value"])) for r in recs if r["op"] == "diffsolve"][0]})
+        print(name, "blocks", nb, "diffsolve iters", out[name + "_dsol_iters"])
+    np.savez_compressed(os.path.join(HERE, "implicit_diffusion.npz"), **out)
+
+
 def sfc_cases():
     out = {}
     for bpd, lmax in SFC_CASES:
@@ -325,3 +371,4 @@ if __name__ == "__main__":
     traj_case()
     vorticity_cases()
     obstacle_cases()
+    implicit_cases()

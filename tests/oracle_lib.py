@@ -112,6 +112,12 @@ def lib():
     L.orc_mesh_project_obst.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.POINTER(SolveInfo), C.c_long, _lp, _dp, _dp]
     L.orc_mesh_max_u.restype = C.c_double
     L.orc_mesh_max_u.argtypes = [vp, _dp, _dp]
+    L.orc_mesh_advect_implicit.argtypes = [vp, _dp, _dp, C.c_double, C.c_double, _dp, C.c_int]
+    L.orc_mesh_diffusion_rhs.argtypes = [vp, _dp, _dp]
+    L.orc_mesh_diff_lhs.argtypes = [vp, _dp, _dp, C.c_int, C.c_double, C.c_double]
+    L.orc_mesh_diff_precond.argtypes = [vp, _dp, C.c_double, C.c_double]
+    L.orc_mesh_diff_solve.argtypes = [vp, _dp, _dp, C.c_int, C.c_double, C.c_double, C.POINTER(SolveInfo)]
+    L.orc_mesh_advdiff_implicit.argtypes = [vp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, _dp, C.c_double, C.c_double, C.c_int, _ip]
     _lib = L
     return L
 
@@ -336,6 +342,45 @@ class OracleMesh:
         lib().orc_mesh_update_tmpv(self.m, t, np.ascontiguousarray(chi_field), len(obst["ids"]), np.ascontiguousarray(obst["ids"], dtype=np.int64),
                                    np.ascontiguousarray(obst["chi"]), np.ascontiguousarray(obst["udef"]))
         return t
+
+    # ---- implicit diffusion (AdvectionDiffusionImplicit, main.cpp:10030-10118)
+    def advect_implicit(self, vel, dt, nu, uinf, sequential):
+        """KernelAdvect: returns (vel', tmpV).  sequential=True is the reference with one thread (in-place update seen by
+        later blocks), False the order-independent reading the device implements."""
+        v = np.ascontiguousarray(vel).copy()
+        t = np.zeros_like(v)
+        lib().orc_mesh_advect_implicit(self.m, v, t, dt, nu, np.asarray(uinf, dtype=np.float64), 1 if sequential else 0)
+        return v, t
+
+    def diffusion_rhs(self, vel):
+        out = np.zeros_like(vel)
+        lib().orc_mesh_diffusion_rhs(self.m, np.ascontiguousarray(vel), out)
+        return out
+
+    def diff_lhs(self, pres, direction, dt, nu):
+        out = np.zeros_like(pres)
+        lib().orc_mesh_diff_lhs(self.m, np.ascontiguousarray(pres), out, direction, dt, nu)
+        return out
+
+    def diff_precond(self, pres, dt, nu):
+        p = np.ascontiguousarray(pres).copy()
+        lib().orc_mesh_diff_precond(self.m, p, dt, nu)
+        return p
+
+    def diff_solve(self, rhs, x0, direction, dt, nu, tol=1e-6, tol_rel=1e-4):
+        lhs, p = np.ascontiguousarray(rhs).copy(), np.ascontiguousarray(x0).copy()
+        info = SolveInfo(tol, tol_rel, 0, 0, 0, 0.0, 0.0)
+        lib().orc_mesh_diff_solve(self.m, lhs, p, direction, dt, nu, C.byref(info))
+        return p, info
+
+    def advdiff_implicit(self, vel, pres, dt, nu, uinf, sequential, tol=1e-6, tol_rel=1e-4):
+        """AdvectionDiffusionImplicit::euler: returns (vel', iterations[3]); pres is scratch and comes back unchanged."""
+        v, p = np.ascontiguousarray(vel).copy(), np.ascontiguousarray(pres).copy()
+        t, l = np.zeros_like(v), np.zeros_like(p)
+        it = np.zeros(3, dtype=np.int32)
+        lib().orc_mesh_advdiff_implicit(self.m, v, p, t, l, dt, nu, np.asarray(uinf, dtype=np.float64), tol, tol_rel, 1 if sequential else 0, it)
+        assert np.array_equal(p, pres)
+        return v, it
 
     def states(self):
         out = np.zeros((self.nb, 27), dtype=np.int32)
