@@ -75,6 +75,7 @@ SIGNATURES = {
     "cup3d_grid_neighbours": (C.c_int, [_vp, _ip]),
     "cup3d_grid_halo_plan": (C.c_int, [_vp, _lp, _lp, _vp]),
     "cup3d_calc_max_timestep": (C.c_double, [C.c_double] * 4 + [C.c_int, C.c_int, C.c_double, _dp]),
+    "cup3d_calc_max_timestep2": (C.c_double, [C.c_double] * 4 + [C.c_int, C.c_int, C.c_double, _dp, C.c_int]),
     "cup3d_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "cup3d_device_init": (C.c_int, [C.c_int]),
     "cup3d_set_stream": (C.c_int, [_vp]),
@@ -106,6 +107,12 @@ SIGNATURES = {
     "cup3d_prolong": (C.c_int, [_vp, _vp, C.c_int]),
     "cup3d_tag_blocks": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]),
     "cup3d_compute_vorticity": (C.c_int, [_vp]),
+    "cup3d_advect_diffuse_implicit": (C.c_int, [_vp, C.c_double, C.c_double, _dp, C.POINTER(PoissonParams), C.POINTER(PoissonResult)]),
+    "cup3d_advect_implicit": (C.c_int, [_vp, C.c_double, C.c_double, _dp]),
+    "cup3d_diffusion_rhs": (C.c_int, [_vp]),
+    "cup3d_diffusion_lhs": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double]),
+    "cup3d_diffusion_preconditioner": (C.c_int, [_vp, C.c_double, C.c_double]),
+    "cup3d_diffusion_solve": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.POINTER(PoissonParams), C.POINTER(PoissonResult)]),
     "cup3d_penalization": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(Obstacle)]),
     "cup3d_update_tmpv": (C.c_int, [_vp, C.c_int, C.POINTER(Obstacle)]),
     "cup3d_profile_enable": (C.c_int, [C.c_int]),

@@ -102,7 +102,11 @@ __device__ __forceinline__ void face_element(int f, int e, int &nb_cell, int &ow
 // AMR (multi-level meshes): spacing per block, face fluxes facD*(u_in - u_ghost) of the interface faces into g.flux
 // (main.cpp:9550-9637), and the stage is NOT fused with the Runge-Kutta update: tmpV receives the raw increment, which
 // k_flux_fix corrects before k_rk_update applies it (a.alpha is then the bare Williamson coefficient).
-template <bool FIRST_STAGE, int CPT, int VAR, bool AMR = false>
+// IMPLICIT: KernelAdvect of the implicit-diffusion integrator (main.cpp:9849-10029) on the same tile: tmpV = facD*lap(u) (+ the
+// same face fluxes), vel' = vel + facA*(u.grad)u/h^3.  The reference updates vel in place while other blocks still load their
+// tiles from it (its result depends on block order / thread timing); here every tile comes from the field on entry and the
+// result goes to the second buffer.
+template <bool FIRST_STAGE, int CPT, int VAR, bool AMR = false, bool IMPLICIT = false>
 __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
   constexpr int NT = 512 / CPT, NW = NT / 64;
   __shared__ double tile[3 * kCompStride];  // 48,768 B -> 3 workgroups per CU
@@ -218,10 +222,10 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
   __syncthreads();
 
   // ---- compute
-  const double h = AMR ? g.hb[slot] : g.h, h3 = h * h * h;
+  const double h = (AMR || IMPLICIT) ? block_h(g, slot) : g.h, h3 = h * h * h;
   const double facA = -a.dt / h * h3 * 1.0;                 // main.cpp:9487 (coef = 1)
   const double facD = (a.nu / h) * (a.dt / h) * h3 * 1.0;   // main.cpp:9488
-  if (AMR && t < 192) {
+  if ((AMR || IMPLICIT) && g.flux && t < 192) {
     const int c = t >> 6, a1 = lane & 7, a2 = lane >> 3;
     const double *L = tile + c * kCompStride;
     for (int f = 0; f < 6; ++f) {
@@ -278,8 +282,13 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
         lap = (sz + (sx + sy)) - 6 * cc;
         adv = ua2 * dz + (ua0 * dx + ua1 * dy);
       }
+      if (IMPLICIT) {  // 9936-9941
+        tout[c * 512 + k * 256 + cell0] = facD * lap;
+        vout[c * 512 + k * 256 + cell0] = cc + facA * adv / h3;
+      }
       res[c] = facA * adv + facD * lap;
     }
+    if (IMPLICIT) continue;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double tn = (FIRST_STAGE ? 0.0 : told[k][c]) + res[c];  // o += ..., main.cpp:9546-9548
@@ -329,6 +338,27 @@ int launch_pack(Sim *src, const double *field, int nc, int w, hipStream_t st) {
   if (!nsend) return CUP3D_OK;
   hipLaunchKernelGGL(k_pack_faces, dim3(nsend), dim3(64), 0, st, field, src->d_send_faces, nc, w, src->halo_send);
   CUP3D_HIP(hipGetLastError());
+  return CUP3D_OK;
+}
+
+int launch_advect_implicit(Sim *s, double dt, double nu, const double uinf[3]) {
+  int rc = halo_begin(s, s->vel, 3, 3);
+  if (rc) return rc;
+  AdvArgs a;
+  a.vel = s->vel; a.vel_out = s->vel2; a.tmp = s->tmpV; a.halo = s->halo_recv;
+  a.dt = dt; a.nu = nu; a.u0 = uinf[0]; a.u1 = uinf[1]; a.u2 = uinf[2];
+  a.alpha = a.beta = 0;
+  const bool split = s->grid->nranks > 1;
+  for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
+    GridDev g = split ? s->gdev(pass == 1, pass == 0) : s->gdev();
+    if (pass == 1 && (rc = halo_finish(s))) return rc;
+    if (g.nblocks == 0) continue;
+    ProfileScope ps("advect_implicit");
+    hipLaunchKernelGGL((k_advdiff<true, 2, 0, false, true>), dim3(launch_groups(g)), dim3(256), 0, stream(), g, a);
+  }
+  CUP3D_HIP(hipGetLastError());
+  if (s->grid->multilevel && (rc = amr_flux_fix(s, 3, s->tmpV, 3))) return rc;  // compute<VectorLab>(.., vel, tmpV), 10038
+  std::swap(s->vel, s->vel2);
   return CUP3D_OK;
 }
 

@@ -29,6 +29,7 @@ struct AmrDev {
   const int32_t *nbr27;  // [nb][27]
   const int32_t *nbr;    // [nb][6]
   const int32_t *index;  // [nb][3]
+  int bc_comp;           // scalar fields: -1 = zero-gradient domain faces (BlockLabNeumann3D); k = element of BlockLabBC<.., direction k>
 };
 
 __device__ __forceinline__ double avg_down8(const double v[8]) {  // AverageDown, main.cpp:3877-3882
@@ -111,7 +112,10 @@ __global__ void __launch_bounds__(64) k_ghost_prolong(AmrDev a, const int32_t *_
           if (n < 0) {  // domain face: _apply_bc on the coarse tile copies the face cell with the same transverse coordinates
             P[t] = rg < 0 ? 0 : 3;
             rg = 0;
-            if (is_vector && (n == -3 || c == t)) flip = !flip;  // wall: all components; freespace: the normal one
+            // wall: all components; freespace: the normal one.  A scalar of BlockLabBC<ScalarGrid, .., direction> (the Helmholtz
+            // solves of the implicit diffusion, main.cpp:6853-6862) behaves as component `direction` of a vector
+            const int cc = is_vector ? c : a.bc_comp;
+            if ((is_vector || a.bc_comp >= 0) && (n == -3 || cc == t)) flip = !flip;
           }
         }
         code[t] = rg;
@@ -420,7 +424,7 @@ __global__ void __launch_bounds__(256) k_compress_blocks(const int32_t *__restri
 // ---- host side
 int amr_fill_ghosts(Sim *s, const double *field, int nc, int w, double *slabs) {
   const Grid *g = s->grid;
-  AmrDev a{s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_nbr, s->d_index};
+  AmrDev a{s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_nbr, s->d_index, nc == 1 ? s->scalar_bc_dir : -1};
   ProfileScope ps("amr_ghosts");
   if (s->n_restrict) {
     if (w == 3) hipLaunchKernelGGL(k_ghost_restrict<3>, dim3(s->n_restrict), dim3(64), 0, stream(), a, s->d_restrict_list, field, nc, slabs);
@@ -436,7 +440,7 @@ int amr_fill_ghosts(Sim *s, const double *field, int nc, int w, double *slabs) {
 }
 
 int amr_flux_fix(Sim *s, int nfc, double *out, int out_nc) {
-  AmrDev a{s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_nbr, s->d_index};
+  AmrDev a{s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_nbr, s->d_index, -1};
   ProfileScope ps("amr_flux_fix");
   for (int d = 0; d < 3; ++d) {
     const unsigned n = (unsigned)s->grid->fix_faces[d].size();
@@ -537,7 +541,7 @@ extern "C" int cup3d_adapt_transfer(cup3d_sim_t *src_h, cup3d_sim_t *dst_h, int 
   if (!octets.empty()) hipLaunchKernelGGL(k_compress_blocks, dim3((unsigned)(octets.size() / 9)), dim3(256), 0, stream(), d_octets.p, fs, fd, nc);
   if (!items.empty()) {
     if ((rc = d_n27.upload(mo->nbr27)) || (rc = d_nbr.upload(mo->nbr)) || (rc = d_index.upload(mo->index))) return rc;
-    AmrDev a{nullptr, nullptr, d_n27.p, d_nbr.p, d_index.p};
+    AmrDev a{nullptr, nullptr, d_n27.p, d_nbr.p, d_index.p, -1};
     RefineTab tab{d_items.p, d_finer.p};
     const unsigned n = (unsigned)(items.size() / 9);
     if (nc == 3) hipLaunchKernelGGL(k_refine<3>, dim3(n), dim3(256), 0, stream(), a, tab, fs, fd);

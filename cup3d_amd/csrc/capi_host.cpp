@@ -152,8 +152,13 @@ int cup3d_grid_halo_plan(const cup3d_grid_t *gh, long *send_count, long *recv_co
 }
 
 double cup3d_calc_max_timestep(double hmin, double umax, double nu, double cfl, int step, int rampup, double dt_old, double coefU[3]) {
-  // Simulation::calcMaxTimestep, main.cpp:15268-15303 (explicit diffusion, CFL > 0)
-  const double dt_diffusion = (1.0 / 6.0) * hmin * hmin / (nu + (1.0 / 6.0) * hmin * umax);
+  return cup3d_calc_max_timestep2(hmin, umax, nu, cfl, step, rampup, dt_old, coefU, 0);
+}
+
+double cup3d_calc_max_timestep2(double hmin, double umax, double nu, double cfl, int step, int rampup, double dt_old, double coefU[3],
+                                int implicit_diffusion) {
+  // Simulation::calcMaxTimestep, main.cpp:15268-15303 (CFL > 0); with -implicitDiffusion the diffusive limit is 0.1 after step 10
+  const double dt_diffusion = (implicit_diffusion && step > 10) ? 0.1 : (1.0 / 6.0) * hmin * hmin / (nu + (1.0 / 6.0) * hmin * umax);
   const double dt_advection = hmin / (umax + 1e-8);
   double dt;
   if (step < rampup) {

@@ -41,8 +41,10 @@ __device__ __forceinline__ double mad(double a, double b, double c) {
 // spent 35 % of their cycles in SQ_WAIT_INST_LDS: profiles/r01/pmc_block_preconditioner_sq.txt): a 64-bit access is served 32
 // lanes at a time, and four 8-wide rows at pitch 10 overlap in banks, while at pitch 8 the four rows tile the 32 bank pairs
 // exactly.  The x-1 / x+1 reads of the lanes at x = 0 / 7, which would fetch a cell of the neighbouring row, go to the zero row.
-template <bool FMA>
-__global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, double *out, double *__restrict__ block_sums) {
+// HELM: diffusion_kernels::getZImplParallel (main.cpp:10534-10579) -- the same block CG with centre coefficient
+// -6 - h^2/nu/dt (10570) instead of -6, for the Helmholtz solves of the implicit diffusion.
+template <bool FMA, bool HELM = false>
+__global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, double *out, double *__restrict__ block_sums, double nu, double dt) {
   // (86 VGPRs -> 5 waves/SIMD.  Forcing 6 with amdgpu_waves_per_eu spills five values that are reloaded every iteration: 0.476
   //  vs 0.431 ms at 256^3, so the natural allocation stays.)
   __shared__ double P[8 * 80];
@@ -55,6 +57,8 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
   // half-wave leave free (address 7 for x = 0, address 0 for x = 7): still conflict-free, and no masking arithmetic
   const int am = (l & 7) == 0 ? 7 : base - 1, ap = (l & 7) == 7 ? 0 : base + 1;
   const double invh = 1 / block_h(g, slot);  // main.cpp:14723
+  double centre = -6.0;
+  if constexpr (HELM) { const double hq = block_h(g, slot); centre = -6.0 - hq * hq / nu / dt; }
   double r[8], p[8], x[8], Ax[8];
   double rr = 0;
 #pragma unroll
@@ -76,7 +80,7 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
       double a2 = 0;
 #pragma unroll
       for (int z = 0; z < 8; ++z) {                         // kernelPoissonGetZInner, 14662-14682
-        double t = mad<FMA>(-6.0, p[z], P[z * 80 + am] + P[z * 80 + ap]);
+        double t = mad<FMA>(centre, p[z], P[z * 80 + am] + P[z * 80 + ap]);
         t += P[z * 80 + base - 8];
         t += P[z * 80 + base + 8];
         t += z > 0 ? p[z - 1] : 0.0;
@@ -240,10 +244,20 @@ int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
   // iteration whose summation order already differs from the CPU's, FMA moves it by ~1e-15 relative (the CG's own truncation
   // is 1e-7), and with the conflict-free LDS layout the kernel is VALU-issue/dependency bound, where the contraction is worth
   // 10 % (0.571 vs 0.634 ms at 256^3).  cup3d_debug_set_option("precond_no_fma", 1) selects the uncontracted association.
-  if (!debug_option("precond_no_fma")) hipLaunchKernelGGL(k_precond<true>, dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, sums);
-  else hipLaunchKernelGGL(k_precond<false>, dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, sums);
+  if (!debug_option("precond_no_fma")) hipLaunchKernelGGL((k_precond<true, false>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, sums, 0.0, 0.0);
+  else hipLaunchKernelGGL((k_precond<false, false>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, sums, 0.0, 0.0);
   CUP3D_HIP(hipGetLastError());
   s->sums_of = want_sums ? out : nullptr;  // block sums of `out` are fresh: the next LHS of `out` reuses them
+  return CUP3D_OK;
+}
+
+int launch_precond_diffusion(Sim *s, const double *in, double *out, const HelmholtzOp &op) {
+  GridDev g = s->gdev();
+  ProfileScope ps("diffusion_block_cg");
+  if (!debug_option("precond_no_fma")) hipLaunchKernelGGL((k_precond<true, true>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, (double *)nullptr, op.nu, op.dt);
+  else hipLaunchKernelGGL((k_precond<false, true>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, (double *)nullptr, op.nu, op.dt);
+  CUP3D_HIP(hipGetLastError());
+  s->sums_of = nullptr;
   return CUP3D_OK;
 }
 
@@ -459,7 +473,9 @@ static int ensure_vectors(Sim *s) {
 #define LAUNCH_VEC_S(kern, ...) hipLaunchKernelGGL(kern, dim3(Gs), dim3(256), 0, stream(), __VA_ARGS__)
 #define TRY(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
-static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *res) {
+// helm != nullptr: DiffusionSolver::solve (main.cpp:6896-7146) -- the same routine on the Helmholtz operator of one velocity
+// component, with no mean constraint and no cap on the breakdown restarts
+static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *res, const HelmholtzOp *helm = nullptr) {
   TRY(ensure_vectors(s));
   s->block_solver = P.block_solver;
   Vecs V;
@@ -467,11 +483,16 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   V.xin = V.v[X_];
   const long N = s->nb * 512L;
   const unsigned G = vec_groups(N), Gs = vec_groups_simple(N);
-  const int mc = P.mean_constraint;
+  const int mc = helm ? 0 : P.mean_constraint;
+  const int max_restarts = helm ? 0x7fffffff : P.max_restarts;
   const double eps = 1e-100;
   Reducer red{s, G};
-  auto LHS = [&](int in, int out) { return launch_lhs(s, V.v[in], V.v[out], mc); };       // _lhs, 9365-9393
-  auto PRE = [&](int in, int out) { return launch_precond(s, V.v[in], V.v[out], mc > 0 && mc <= 2); };       // _preconditioner, 9334-9364
+  auto LHS = [&](int in, int out) {  // _lhs, 9365-9393 / 6836-6875
+    return helm ? launch_lhs_diffusion(s, V.v[in], V.v[out], *helm) : launch_lhs(s, V.v[in], V.v[out], mc);
+  };
+  auto PRE = [&](int in, int out) {  // _preconditioner, 9334-9364 / 6804-6835
+    return helm ? launch_precond_diffusion(s, V.v[in], V.v[out], *helm) : launch_precond(s, V.v[in], V.v[out], mc > 0 && mc <= 2);
+  };
 
   if ((mc == 1 || mc > 2) && s->grid->corner_slot >= 0)  // rhs(0,0,0) = 0, 14404-14407
     hipLaunchKernelGGL(k_set_one, dim3(1), dim3(1), 0, stream(), s->lhs, (size_t)s->grid->corner_slot * 512, 0.0);
@@ -529,7 +550,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     if (std::fabs(alphat) < 10 * std::fabs(alpha)) alpha = alphat;      // 14563-14564
     r0r_prev = r0r;
     const bool serious_breakdown = r0r * r0r < 1e-16 * norm_1 * norm_2;  // 14566
-    if (serious_breakdown && restarts < P.max_restarts) {               // 14567-14593
+    if (serious_breakdown && restarts < max_restarts) {                 // 14567-14593 / 7096-7120
       restarts++;
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_copy, V.v[R_], V.v[R0], N); }
       TRY(PRE(R0, RHAT)); TRY(LHS(RHAT, W_));
@@ -563,6 +584,8 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   }
   return CUP3D_OK;
 }
+
+int solve_helmholtz(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *res, const HelmholtzOp &op) { return solve(s, P, res, &op); }
 
 }  // namespace cup3d
 

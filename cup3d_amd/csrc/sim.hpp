@@ -67,6 +67,7 @@ struct Sim {
   double *pold = nullptr;
   bool chi_nonzero = false, udef_nonzero = false;
   int block_solver = 0;  // cup3d_poisson_params.block_solver of the running solve
+  int scalar_bc_dir = -1;  // >= 0 while a Helmholtz solve of the implicit diffusion runs: domain-face rule of the scalar tiles
   // solver vectors (allocated on first solve), each [nb][512]
   double *sv[18] = {nullptr};
   // reductions
@@ -112,5 +113,12 @@ int amr_flux_fix(Sim *s, int nfc, double *out, int out_nc);
 // kernels' launchers shared across translation units
 int launch_lhs(Sim *s, const double *p, double *out, int mean_constraint);
 int launch_precond(Sim *s, const double *in, double *out, bool want_sums);
+// implicit diffusion (DiffusionSolver, main.cpp:6719-7147): Helmholtz operator of velocity component `direction`
+struct HelmholtzOp { int direction; double dt, nu; };
+int launch_lhs_diffusion(Sim *s, const double *p, double *out, const HelmholtzOp &op);
+int launch_precond_diffusion(Sim *s, const double *in, double *out, const HelmholtzOp &op);
+int solve_helmholtz(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *res, const HelmholtzOp &op);
+int launch_diffusion_rhs(Sim *s);
+int launch_advect_implicit(Sim *s, double dt, double nu, const double uinf[3]);
 
 }  // namespace cup3d

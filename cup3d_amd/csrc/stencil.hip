@@ -51,9 +51,11 @@ __device__ __forceinline__ void write_face_fluxes(const GridDev &g, int slot, Fn
   }
 }
 
-// scalar tile with zero-gradient domain faces (BlockLabNeumann3D, main.cpp:6561-6581)
+// scalar tile with zero-gradient domain faces (BlockLabNeumann3D, main.cpp:6561-6581); bc_comp >= 0: the scalar element of
+// BlockLabBC<ScalarGrid, .., direction = bc_comp> instead (wall: negated; freespace: negated behind the faces normal to
+// bc_comp, main.cpp:6120, 6384-6394) -- the tiles of DiffusionSolver::_lhs (6853-6862)
 __device__ __forceinline__ void load_scalar_tile(const GridDev &g, int slot, const double *__restrict__ f, const double *__restrict__ halo,
-                                                 double *tile, double c[2]) {
+                                                 double *tile, double c[2], int bc_comp = -1) {
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const double *own = f + (size_t)slot * 512;
@@ -75,6 +77,7 @@ __device__ __forceinline__ void load_scalar_tile(const GridDev &g, int slot, con
       face1(face, lane, nb_cell, own_cell, lds);
       const double *__restrict__ base = n >= kNbrHalo ? halo + (size_t)(n - kNbrHalo) * 64 : (n >= 0 ? f + (size_t)n * 512 : own);
       gv[i] = base[n >= kNbrHalo ? lane : (n >= 0 ? nb_cell : own_cell)];
+      if (n < 0 && bc_comp >= 0 && (n == -3 || bc_comp == (face >> 1))) gv[i] = -gv[i];
       gl[i] = lds;
     }
   }
@@ -315,6 +318,89 @@ __global__ void __launch_bounds__(256) k_add_scaled(const double *__restrict__ h
     const double h = hb[i / 1536];
     vel[i] += (1.0 / (h * h * h)) * tmpV[i];
   }
+}
+
+// ---- KernelLHSDiffusion (main.cpp:6726-6803): out = h*(sum6 - 6p) + coef*p, coef = -h^3/(dt nu), on the BlockLabBC tile of
+// velocity component `dir`
+__global__ void __launch_bounds__(256) k_lhs_diffusion(GridDev g, const double *__restrict__ p, const double *__restrict__ halo, double *__restrict__ out,
+                                                       int dir, double dt, double nu) {
+  __shared__ double tile[kT];
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  double c[2];
+  load_scalar_tile(g, slot, p, halo, tile, c, dir);
+  __syncthreads();
+  const int t = threadIdx.x;
+  int x, y, z0, cell0;
+  thread_cells(t, x, y, z0, cell0);
+  const double h = block_h(g, slot), coef = -1.0 / (dt * nu) * h * h * h;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int z = z0 + 4 * k, b = tix(x, y, z);
+    out[(size_t)slot * 512 + k * 256 + cell0] =
+        h * (tile[b - 1] + tile[b + 1] + tile[b - 10] + tile[b + 10] + tile[b - kTP] + tile[b + kTP] - 6.0 * c[k]) + coef * c[k];
+  }
+  if (g.flux) write_face_fluxes<1>(g, slot, [&](int, int in, int gh, int, int) { return h * (tile[in] - tile[gh]); });
+}
+
+// ---- KernelDiffusionRHS (main.cpp:9729-9848): tmpV = h*lap(vel), each component with its own association
+__global__ void __launch_bounds__(256) k_diffusion_rhs(GridDev g, const double *__restrict__ vel, const double *__restrict__ halo, double *__restrict__ tmpV) {
+  __shared__ double tv[3 * kT];
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  load_vector_tile(g, slot, vel, halo, tv);
+  __syncthreads();
+  const int t = threadIdx.x;
+  int x, y, z0, cell0;
+  thread_cells(t, x, y, z0, cell0);
+  const double facD = block_h(g, slot);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int b = tix(x, y, z0 + 4 * k);
+    const size_t o = (size_t)slot * 1536 + k * 256 + cell0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double *L = tv + c * kT;
+      const double sx = L[b + 1] + L[b - 1], sy = L[b + 10] + L[b - 10], sz = L[b + kTP] + L[b - kTP];
+      const double lap = (c == 0 ? (sx + (sy + sz)) : (c == 1 ? (sy + (sz + sx)) : (sz + (sx + sy)))) - 6 * L[b];
+      tmpV[o + c * 512] = facD * lap;
+    }
+  }
+  if (g.flux) write_face_fluxes<3>(g, slot, [&](int c, int in, int gh, int, int) { return facD * (tv[c * kT + in] - tv[c * kT + gh]); });
+}
+
+int launch_lhs_diffusion(Sim *s, const double *p, double *out, const HelmholtzOp &op) {
+  s->scalar_bc_dir = op.direction;  // the coarse shadow tiles behind coarse/fine faces follow the same domain-face rule
+  int rc = halo_begin(s, p, 1, 1);
+  s->scalar_bc_dir = -1;
+  if (rc) return rc;
+  const bool split = s->grid->nranks > 1;
+  for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
+    GridDev g = split ? s->gdev(pass == 1, pass == 0) : s->gdev();
+    if (pass == 1 && (rc = halo_finish(s))) return rc;
+    if (g.nblocks == 0) continue;
+    ProfileScope ps("diffusion_lhs");
+    hipLaunchKernelGGL(k_lhs_diffusion, dim3(launch_groups(g)), dim3(256), 0, stream(), g, p, s->halo_recv, out, op.direction, op.dt, op.nu);
+  }
+  CUP3D_HIP(hipGetLastError());
+  if (s->grid->multilevel && (rc = amr_flux_fix(s, 1, out, 1))) return rc;  // compute<Lab>(.., pres, lhs) corrector, 6857-6862
+  return CUP3D_OK;
+}
+
+int launch_diffusion_rhs(Sim *s) {
+  int rc = halo_begin(s, s->vel, 3, 1);
+  if (rc) return rc;
+  const bool split = s->grid->nranks > 1;
+  for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
+    GridDev g = split ? s->gdev(pass == 1, pass == 0) : s->gdev();
+    if (pass == 1 && (rc = halo_finish(s))) return rc;
+    if (g.nblocks == 0) continue;
+    ProfileScope ps("diffusion_rhs");
+    hipLaunchKernelGGL(k_diffusion_rhs, dim3(launch_groups(g)), dim3(256), 0, stream(), g, s->vel, s->halo_recv, s->tmpV);
+  }
+  CUP3D_HIP(hipGetLastError());
+  if (s->grid->multilevel && (rc = amr_flux_fix(s, 3, s->tmpV, 3))) return rc;  // compute<VectorLab>(.., vel, tmpV), 10057
+  return CUP3D_OK;
 }
 
 int launch_lhs(Sim *s, const double *p, double *out, int mc) {

@@ -181,6 +181,36 @@ public:
   }
 };
 
+// AdvectionDiffusionImplicit::operator()(dt), main.cpp:10030-10119 (-implicitDiffusion 1): one upwind-advection kernel, one
+// 7-point kernel and three Helmholtz solves (DiffusionSolver) on the device.  sim.pres is only scratch there and is restored
+// (10108-10117), so the host copy is simply left alone.  The reference's KernelAdvect updates vel in place while other blocks
+// still read it; the device reads every tile from the velocity on entry (include/cup3d_hip.h), so on more than one block the two
+// agree to O(dt) of the advective increment, not to round-off.
+class AdvectionDiffusionImplicitHIP : public Operator {
+  std::shared_ptr<DeviceMirror> devp;
+  DeviceMirror &dev;
+
+public:
+  cup3d_poisson_result last[3];
+  AdvectionDiffusionImplicitHIP(SimulationData &s, std::shared_ptr<DeviceMirror> d) : Operator(s), devp(d), dev(*d) {}
+  void operator()(const Real dt) override {
+    (void)dt;  // euler(sim.dt), 10119
+    dev.upload(CUP3D_FIELD_VEL);
+    const double uinf[3] = {sim.uinf[0], sim.uinf[1], sim.uinf[2]};
+    cup3d_poisson_params p;
+    cup3d_poisson_default_params(&p);
+    p.tol = sim.DiffusionErrorTol;
+    p.tol_rel = sim.DiffusionErrorTolRel;
+    CUP3D_HIP_CALL(cup3d_advect_diffuse_implicit(dev.handle(), sim.dt, sim.nu, uinf, &p, last));
+    if (dev.resident && sim.obstacle_vector->nObstacles() == 0) {
+      dev.vel_on_device = true;
+      return;
+    }
+    dev.download(CUP3D_FIELD_VEL);
+    dev.download(CUP3D_FIELD_TMPV);
+  }
+};
+
 // ExternalForcing::operator()(dt), main.cpp:10581-10596: on the device while the velocity is resident there, else the
 // reference's own operator
 class ExternalForcingHIP : public Operator {
@@ -255,7 +285,7 @@ public:
 
 struct Installed {
   std::shared_ptr<DeviceMirror> mirror;
-  std::shared_ptr<AdvectionDiffusionHIP> advdiff;
+  std::shared_ptr<Operator> advdiff;  // AdvectionDiffusionHIP, or AdvectionDiffusionImplicitHIP with -implicitDiffusion 1
   std::shared_ptr<ExternalForcingHIP> forcing;
   std::shared_ptr<PressureProjectionHIP> projection;
 };
@@ -274,7 +304,7 @@ inline Installed install(SimulationData &sim, int resident = -1) {
   }
   bool between = false, safe = true;
   for (auto &op : sim.pipeline) {
-    if (std::dynamic_pointer_cast<AdvectionDiffusion>(op)) between = true;
+    if (std::dynamic_pointer_cast<AdvectionDiffusion>(op) || std::dynamic_pointer_cast<AdvectionDiffusionImplicit>(op)) between = true;
     else if (std::dynamic_pointer_cast<PressureProjection>(op)) between = false;
     else if (between && !(std::dynamic_pointer_cast<ExternalForcing>(op) || std::dynamic_pointer_cast<UpdateObstacles>(op) ||
                           std::dynamic_pointer_cast<Penalization>(op)))
@@ -284,6 +314,9 @@ inline Installed install(SimulationData &sim, int resident = -1) {
   for (auto &op : sim.pipeline) {
     if (std::dynamic_pointer_cast<AdvectionDiffusion>(op)) {
       r.advdiff = std::make_shared<AdvectionDiffusionHIP>(sim, r.mirror);
+      op = r.advdiff;
+    } else if (std::dynamic_pointer_cast<AdvectionDiffusionImplicit>(op)) {  // setupOperators 15231-15232
+      r.advdiff = std::make_shared<AdvectionDiffusionImplicitHIP>(sim, r.mirror);
       op = r.advdiff;
     } else if (r.mirror->resident && std::dynamic_pointer_cast<ExternalForcing>(op)) {
       r.forcing = std::make_shared<ExternalForcingHIP>(sim, r.mirror, op);

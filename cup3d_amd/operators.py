@@ -114,7 +114,7 @@ class SimulationData:
     def __init__(self, bpdx=1, bpdy=1, bpdz=1, levelMax=1, levelStart=None, extent=1.0, nu=0.0, CFL=0.1,
                  BC_x="freespace", BC_y="freespace", BC_z="freespace", uinf=(0.0, 0.0, 0.0), uMax_forced=0.0,
                  poissonTol=1e-6, poissonTolRel=1e-4, bMeanConstraint=1, poissonSolver="hip_iterative", rampup=100,
-                 blockSolver=0, leaves=None,
+                 blockSolver=0, leaves=None, implicitDiffusion=False, diffusionTol=1e-6, diffusionTolRel=1e-4,
                  rank=0, nranks=1, device=None):
         if device is not None or not capi._device_ready:
             capi.device_init(0 if device is None else device)
@@ -134,6 +134,8 @@ class SimulationData:
         self.uMax_forced, self.rampup = float(uMax_forced), int(rampup)
         self.PoissonErrorTol, self.PoissonErrorTolRel, self.bMeanConstraint = poissonTol, poissonTolRel, bMeanConstraint
         self.poissonSolver = poissonSolver
+        # -implicitDiffusion / -diffusionTol / diffusionTolRel (main.cpp:15368-15370)
+        self.implicitDiffusion, self.DiffusionErrorTol, self.DiffusionErrorTolRel = bool(implicitDiffusion), diffusionTol, diffusionTolRel
         self.blockSolver = int(blockSolver)  # 0: block CG as in the reference, 1: direct block solve (fast diagonalisation)
         self.dt, self.dt_old, self.time, self.step, self.step_2nd_start = 0.0, 0.0, 0.0, 0, 2
         self.coefU = np.array([1.5, -2.0, 0.5])
@@ -185,7 +187,8 @@ class SimulationData:
                              extent=self.maxextent, nu=self.nu, CFL=self.CFL, BC_x=self.BCx_flag, BC_y=self.BCy_flag, BC_z=self.BCz_flag,
                              uinf=self.uinf, uMax_forced=self.uMax_forced, poissonTol=self.PoissonErrorTol, poissonTolRel=self.PoissonErrorTolRel,
                              bMeanConstraint=self.bMeanConstraint, poissonSolver=self.poissonSolver, rampup=self.rampup,
-                             blockSolver=self.blockSolver, leaves=(lv, zs))
+                             blockSolver=self.blockSolver, leaves=(lv, zs), implicitDiffusion=self.implicitDiffusion,
+                             diffusionTol=self.DiffusionErrorTol, diffusionTolRel=self.DiffusionErrorTolRel)
         for f in ("vel", "pres"):
             check(lib().cup3d_adapt_transfer(self.handle, new.handle, FIELDS[f]))
         new.dt, new.dt_old, new.time, new.step, new.coefU = self.dt, self.dt_old, self.time, self.step, self.coefU.copy()
@@ -220,6 +223,53 @@ class AdvectionDiffusion(Operator):
         s = self.sim
         s.dt = dt
         check(lib().cup3d_advect_diffuse(s.handle, dt, s.nu, s.uinf))
+
+
+class AdvectionDiffusionImplicit(Operator):
+    """AdvectionDiffusionImplicit::operator()(dt), main.cpp:10030-10119 (calls euler(sim.dt)): upwind advection + one Helmholtz
+    solve per velocity component (DiffusionSolver, 6719-7147).  `last_diffusion` holds the three solver results."""
+
+    def diffusion_params(self):
+        s = self.sim
+        p = PoissonParams()
+        lib().cup3d_poisson_default_params(C.byref(p))
+        p.tol, p.tol_rel = s.DiffusionErrorTol, s.DiffusionErrorTolRel
+        return p
+
+    def __call__(self, dt):
+        s = self.sim
+        s.dt = dt
+        res = (PoissonResult * 3)()
+        check(lib().cup3d_advect_diffuse_implicit(s.handle, dt, s.nu, s.uinf, C.byref(self.diffusion_params()), res))
+        self.last_diffusion = [res[0], res[1], res[2]]
+        return self.last_diffusion
+
+
+class DiffusionSolver:
+    """class DiffusionSolver (main.cpp:6719-7147) on the device: right-hand side in sim.lhs, initial guess and result in sim.pres;
+    `mydirection` selects the velocity component whose boundary rule the ghosts follow, `dt` the Helmholtz coefficient."""
+
+    def __init__(self, sim):
+        self.sim, self.mydirection, self.dt = sim, 0, sim.dt
+
+    def _params(self):
+        p = PoissonParams()
+        lib().cup3d_poisson_default_params(C.byref(p))
+        p.tol, p.tol_rel = self.sim.DiffusionErrorTol, self.sim.DiffusionErrorTolRel
+        return p
+
+    def solve(self):
+        r = PoissonResult()
+        check(lib().cup3d_diffusion_solve(self.sim.handle, self.mydirection, self.dt, self.sim.nu, C.byref(self._params()), C.byref(r)))
+        return r
+
+    def lhs(self):
+        """_lhs: sim.lhs <- A sim.pres."""
+        check(lib().cup3d_diffusion_lhs(self.sim.handle, self.mydirection, self.dt, self.sim.nu))
+
+    def preconditioner(self):
+        """_preconditioner on sim.pres in place."""
+        check(lib().cup3d_diffusion_preconditioner(self.sim.handle, self.dt, self.sim.nu))
 
 
 class ComputeVorticity(Operator):
@@ -375,7 +425,7 @@ class Simulation:
 
     def __init__(self, sim):
         self.sim = sim
-        self.pipeline = [AdvectionDiffusion(sim)]
+        self.pipeline = [AdvectionDiffusionImplicit(sim) if sim.implicitDiffusion else AdvectionDiffusion(sim)]  # 15231-15234
         if sim.uMax_forced > 0:
             self.pipeline.append(ExternalForcing(sim))
         self.pipeline.append(PressureProjection(sim))
@@ -394,7 +444,7 @@ class Simulation:
         s = self.sim
         s.dt_old = s.dt
         s.uMax_measured = findMaxU(s)
-        s.dt = lib().cup3d_calc_max_timestep(s.hmin, s.uMax_measured, s.nu, s.CFL, s.step, s.rampup, s.dt_old, s.coefU)
+        s.dt = lib().cup3d_calc_max_timestep2(s.hmin, s.uMax_measured, s.nu, s.CFL, s.step, s.rampup, s.dt_old, s.coefU, int(s.implicitDiffusion))
         if s.dt <= 0:
             raise Cup3dError(f"dt <= 0. CFL={s.CFL}, hMin={s.hmin}, sim.uMax_measured={s.uMax_measured}")
         return s.dt

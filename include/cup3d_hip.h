@@ -108,6 +108,9 @@ long cup3d_grid_nsend_faces(const cup3d_grid_t *);
  * updates coefU when step > step_2nd_start. */
 double cup3d_calc_max_timestep(double hmin, double umax, double nu, double cfl, int step, int rampup, double dt_old,
                                double coefU[3]);
+/* the same with sim.implicitDiffusion: the diffusive limit becomes 0.1 once step > 10 (15269-15273) */
+double cup3d_calc_max_timestep2(double hmin, double umax, double nu, double cfl, int step, int rampup, double dt_old,
+                                double coefU[3], int implicit_diffusion);
 
 /* ---------------------------------------------------------------------------
  * Device side.
@@ -217,6 +220,28 @@ int cup3d_penalization(cup3d_sim_t *, double dt, double lambda, int implicit_pen
 /* kernelUpdateTmpV (14948-14979): tmpV += udef where chi <= the obstacle's chi; call after clearing tmpV and before
  * cup3d_pressure_rhs / cup3d_pressure_project (15066-15085) */
 int cup3d_update_tmpv(cup3d_sim_t *, int nobstacles, const cup3d_obstacle *obstacles);
+/* Implicit diffusion: AdvectionDiffusionImplicit (main.cpp:7148-7157, 10030-10119), selected by -implicitDiffusion (15231-15232).
+ * One call = euler(dt): KernelAdvect, the explicit-diffusion guess, KernelDiffusionRHS and one DiffusionSolver::solve per velocity
+ * component.  `params`: tol / tol_rel = sim.DiffusionErrorTol / DiffusionErrorTolRel (15369-15370), max_iter; mean_constraint,
+ * max_restarts and block_solver are ignored (DiffusionSolver has no mean constraint, no restart cap and its own block CG).
+ * results[3] (may be NULL): per-component solver statistics.  pres is used as scratch and restored; tmpV and lhs are clobbered.
+ * KernelAdvect (9849-10029) updates vel IN PLACE in the reference while other blocks still build their ghosted tiles from it, so
+ * the reference's own result depends on block order and thread timing; this implementation reads every tile from the velocity
+ * on entry (the order-independent reading).  Everything else is the reference's arithmetic. */
+int cup3d_advect_diffuse_implicit(cup3d_sim_t *, double dt, double nu, const double uinf[3], const cup3d_poisson_params *params,
+                                  cup3d_poisson_result results[3]);
+/* its parts, for tests and for callers that interleave their own operators:
+ * compute<VectorLab>(KernelAdvect(sim, dt), vel, tmpV) (10038): tmpV <- facD*lap(vel), vel <- vel + facA*(u.grad)u/h^3 */
+int cup3d_advect_implicit(cup3d_sim_t *, double dt, double nu, const double uinf[3]);
+/* compute<VectorLab>(KernelDiffusionRHS(sim), vel, tmpV) (10057, 9729-9848): tmpV <- h*lap(vel) */
+int cup3d_diffusion_rhs(cup3d_sim_t *);
+/* DiffusionSolver::_lhs (6836-6875) with mydirection = direction: lhs <- h*(sum6 - 6 pres) - h^3/(dt nu)*pres on the
+ * BlockLabBC<ScalarGrid, .., direction> tile (wall: ghost = -face cell; freespace: negated behind the faces normal to direction) */
+int cup3d_diffusion_lhs(cup3d_sim_t *, int direction, double dt, double nu);
+/* diffusion_kernels::getZImplParallel (10534-10579): pres <- block-local CG solve with centre coefficient -6 - h^2/nu/dt, in place */
+int cup3d_diffusion_preconditioner(cup3d_sim_t *, double dt, double nu);
+/* DiffusionSolver::solve (6896-7146): right-hand side in lhs (clobbered), initial guess and result in pres */
+int cup3d_diffusion_solve(cup3d_sim_t *, int direction, double dt, double nu, const cup3d_poisson_params *params, cup3d_poisson_result *result);
 /* ComputeVorticity::operator() (8726-8746, KernelVorticity 8624-8645): tmpV <- curl(vel); any mesh */
 int cup3d_compute_vorticity(cup3d_sim_t *);
 

@@ -313,9 +313,12 @@ double orc_max_u(const orc_grid *g, const double *vel, const double uinf[3]) { /
 }
 
 double orc_calc_dt(double hmin, double umax, double nu, double cfl, int step, int rampup, double dt_old, double coefU[3]) {
-  /* main.cpp:15254-15305, explicit-diffusion branch, CFL > 0 */
+  return orc_calc_dt2(hmin, umax, nu, cfl, step, rampup, dt_old, coefU, 0);
+}
+double orc_calc_dt2(double hmin, double umax, double nu, double cfl, int step, int rampup, double dt_old, double coefU[3], int implicitDiffusion) {
+  /* main.cpp:15254-15305, CFL > 0 */
   double dt;
-  const double dtDiffusion = (1.0 / 6.0) * hmin * hmin / (nu + (1.0 / 6.0) * hmin * umax);
+  const double dtDiffusion = (implicitDiffusion && step > 10) ? 0.1 : (1.0 / 6.0) * hmin * hmin / (nu + (1.0 / 6.0) * hmin * umax);
   const double dtAdvection = hmin / (umax + 1e-8);
   if (step < rampup) {
     const double x = step / (double)rampup;

@@ -53,6 +53,7 @@ double orc_max_u(const orc_grid *, const double *vel, const double uinf[3]);    
 /* Simulation::calcMaxTimestep, main.cpp:15254-15305; returns dt, updates coefU when step>2 */
 double orc_calc_dt(double hmin, double umax, double nu, double cfl, int step, int rampup,
                    double dt_old, double coefU[3]);
+double orc_calc_dt2(double hmin, double umax, double nu, double cfl, int step, int rampup, double dt_old, double coefU[3], int implicitDiffusion);
 void orc_external_forcing(const orc_grid *, double *vel, double umax_forced, double nu, double H, double dt); /* 10581-10596 */
 /* AdvectionDiffusion::operator(), main.cpp:9640-9728 (RK3, KernelAdvectDiffuse 9461-9549) */
 void orc_advect_diffuse(const orc_grid *, double *vel, double *tmpV, double dt, double nu, const double uinf[3]);

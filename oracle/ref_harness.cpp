@@ -366,7 +366,7 @@ int main(int argc, char **argv) {
         cup3d_stub_iallreduce6 = 0;
         double value = 0;
         const double t0 = now();
-        if (op == "advdiff") { sd.dt = arg; if (hip_adv) (*hip_adv)(arg); else advdiff(arg); }
+        if (op == "advdiff") { sd.dt = arg; if (hip_adv && !sd.implicitDiffusion) (*hip_adv)(arg); else advdiff(arg); }
         else if (op == "lhs") lhsop(0);
         else if (op == "penalize") { /* Penalization::operator() without the collision model, main.cpp:14330-14340 */
           const std::vector<Info> &ci = sd.chiInfo(), &vi = sd.velInfo();
@@ -388,7 +388,11 @@ int main(int argc, char **argv) {
         else if (op == "divp") compute<ScalarLab>(KernelDivPressure(sd), sd.pres, sd.tmpV);   /* main.cpp:15088 */
         else if (op == "gradp") compute<ScalarLab>(KernelGradP(sd, sd.dt), sd.pres, sd.tmpV); /* main.cpp:15146 */
         /* implicit diffusion (AdvectionDiffusionImplicit::euler, main.cpp:10030-10118) and its parts; all use `set dt`, `set nu` */
-        else if (op == "advdiff_implicit") { sd.dt = arg; AdvectionDiffusionImplicit a(sd); a(arg); }
+        else if (op == "advdiff_implicit") { /* with `hip on` and -implicitDiffusion 1 on the command line: the drop-in */
+          sd.dt = arg;
+          if (hip_adv && sd.implicitDiffusion) (*hip_adv)(arg);
+          else { AdvectionDiffusionImplicit a(sd); a(arg); }
+        }
         else if (op == "advect") compute<VectorLab>(KernelAdvect(sd, sd.dt), sd.vel, sd.tmpV);       /* 10038 */
         else if (op == "diffrhs") compute<VectorLab>(KernelDiffusionRHS(sd), sd.vel, sd.tmpV);        /* 10057 */
         else if (op == "diffprecond") {                                                               /* 6823-6824 */

@@ -68,6 +68,8 @@ def lib():
     L.orc_max_u.argtypes = [vp, _dp, _dp]
     L.orc_calc_dt.restype = C.c_double
     L.orc_calc_dt.argtypes = [C.c_double] * 4 + [C.c_int, C.c_int, C.c_double, _dp]
+    L.orc_calc_dt2.restype = C.c_double
+    L.orc_calc_dt2.argtypes = [C.c_double] * 4 + [C.c_int, C.c_int, C.c_double, _dp, C.c_int]
     L.orc_external_forcing.argtypes = [vp, _dp] + [C.c_double] * 4
     L.orc_advect_diffuse.argtypes = [vp, _dp, _dp, C.c_double, C.c_double, _dp]
     L.orc_advdiff_stage_rhs.argtypes = [vp, _dp, _dp, C.c_double, C.c_double, _dp]

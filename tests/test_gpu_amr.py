@@ -483,3 +483,130 @@ def test_obstacle_operators(golden_dir, name):
     corr = np.abs(v - vel).max()
     assert np.abs(sim.download("pres") - p).max() <= 1e-6 * np.abs(p).max()
     assert np.abs(sim.download("vel") - v).max() <= 1e-6 * corr
+
+
+# ------------------------------------------------------------------ implicit diffusion (AdvectionDiffusionImplicit, main.cpp:10030-10119)
+IMPLICIT = ["uniform_mixed", "uniform_periodic", "amr_periodic_l01", "amr_mixed_l12", "synthetic_l012"]
+
+
+def make_implicit(golden_dir, name, **kw):
+    if name.startswith("uniform"):
+        bpd, lmax = (2, 1, 2), 3
+        bc = ("freespace", "wall", "periodic") if name == "uniform_mixed" else ("periodic",) * 3
+        sim = cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=1, extent=EXT, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], **kw)
+        t = sim.grid.tables
+        m = O.OracleMesh(bpd, lmax, EXT, bc, t[:, 0], t[:, 1])
+        rng = np.random.default_rng(6)
+        f = dict(vel=rng.uniform(-1, 1, (m.nb, 8, 8, 8, 3)), pres=rng.uniform(-1, 1, (m.nb, 8, 8, 8)), rhs=rng.uniform(-1, 1, (m.nb, 8, 8, 8)))
+    else:
+        m, sim, f = make(golden_dir, name, **kw)
+    f["vel"] = 0.5 * f["vel"]
+    return m, sim, f
+
+
+@pytest.mark.parametrize("name", IMPLICIT)
+def test_implicit_diffusion_stencils_bitexact(golden_dir, name):
+    """KernelAdvect (order-independent reading: every tile from the velocity on entry -- the oracle's sequential=False; its
+    sequential=True mode is pinned against the reference), KernelDiffusionRHS and KernelLHSDiffusion for the three boundary
+    directions: bit-exact, flux correction at coarse/fine faces included."""
+    m, sim, f = make_implicit(golden_dir, name)
+    dt, nu, uinf = 0.05, 2.0, (0.1, -0.2, 0.3)
+    sim.nu, sim.uinf = nu, np.array(uinf)
+    sim.upload("vel", f["vel"])
+    check(lib().cup3d_advect_implicit(sim.handle, dt, nu, sim.uinf))
+    v, t = m.advect_implicit(f["vel"], dt, nu, uinf, False)
+    assert np.array_equal(sim.download("tmpV"), t)
+    assert np.array_equal(sim.download("vel"), v)
+    sim.upload("vel", f["vel"])
+    check(lib().cup3d_diffusion_rhs(sim.handle))
+    assert np.array_equal(sim.download("tmpV"), m.diffusion_rhs(f["vel"]))
+    ds = cu.DiffusionSolver(sim)
+    ds.dt = dt
+    out = []
+    for d in range(3):
+        ds.mydirection = d
+        sim.upload("pres", f["pres"])
+        ds.lhs()
+        out.append(sim.download("lhs"))
+        assert np.array_equal(out[-1], m.diff_lhs(f["pres"], d, dt, nu)), d
+    if name != "uniform_periodic" and name != "amr_periodic_l01":
+        assert not np.array_equal(out[0], out[1])  # the boundary rule of the component matters
+
+
+@pytest.mark.parametrize("name", IMPLICIT)
+def test_implicit_diffusion_solver(golden_dir, name):
+    """Helmholtz block CG, DiffusionSolver::solve and the whole AdvectionDiffusionImplicit step against the oracle: dot products and
+    the block-CG inner products are summed in another order on the device, so solver tolerance (both sides solved tightly)."""
+    m, sim, f = make_implicit(golden_dir, name, diffusionTol=1e-12, diffusionTolRel=1e-11)
+    dt, nu, uinf = 0.05, 2.0, (0.1, -0.2, 0.3)
+    sim.nu, sim.uinf = nu, np.array(uinf)
+    ds = cu.DiffusionSolver(sim)
+    ds.dt, ds.mydirection = dt, 1
+    sim.upload("pres", f["pres"])
+    ds.preconditioner()
+    z = m.diff_precond(f["pres"], dt, nu)
+    assert np.abs(sim.download("pres") - z).max() <= 2e-5 * np.abs(z).max()
+    sim.upload("lhs", f["rhs"]); sim.upload("pres", f["pres"])
+    r = ds.solve()
+    x, info = m.diff_solve(f["rhs"], f["pres"], 1, dt, nu, 1e-12, 1e-11)
+    assert r.iterations > 5 and info.iters > 5
+    assert np.abs(sim.download("pres") - x).max() <= 1e-7 * np.abs(x).max()
+    res = np.linalg.norm((f["rhs"] - m.diff_lhs(sim.download("pres"), 1, dt, nu)).ravel())
+    res0 = np.linalg.norm((f["rhs"] - m.diff_lhs(f["pres"], 1, dt, nu)).ravel())
+    assert res <= 1e-7 * res0   # true residual of the pipelined recurrences (refreshed every 50 iterations only)
+    # default tolerances: the returned iterate satisfies the reference's stopping rule under the ORACLE's operator
+    sim.DiffusionErrorTol, sim.DiffusionErrorTolRel = 1e-6, 1e-4
+    sim.upload("lhs", f["rhs"]); sim.upload("pres", f["pres"])
+    r = ds.solve()
+    res = np.linalg.norm((f["rhs"] - m.diff_lhs(sim.download("pres"), 1, dt, nu)).ravel())
+    assert res <= 1.05 * max(1e-6, 1e-4 * res0) and r.iterations >= 2
+    # the whole step
+    sim.DiffusionErrorTol, sim.DiffusionErrorTolRel = 1e-12, 1e-11
+    sim.upload("vel", f["vel"]); sim.upload("pres", f["pres"])
+    op = cu.AdvectionDiffusionImplicit(sim)
+    res3 = op(dt)
+    v, it = m.advdiff_implicit(f["vel"], f["pres"], dt, nu, uinf, False, 1e-12, 1e-11)
+    assert np.array_equal(sim.download("pres"), f["pres"])          # pres is scratch and comes back
+    change = np.abs(v - f["vel"]).max()
+    assert change > 1e-3
+    assert np.abs(sim.download("vel") - v).max() <= 1e-6 * change
+    assert all(r.iterations > 3 for r in res3)
+
+
+def test_implicit_diffusion_single_block_equals_reference_order():
+    """On one periodic block the reference's in-place KernelAdvect cannot be seen by any other tile: the device result must then
+    equal the oracle's sequential (= reference, one thread) mode as well."""
+    bc = ("periodic",) * 3
+    sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=1, levelStart=0, extent=EXT, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2])
+    assert sim.nblocks == 1
+    m = O.OracleMesh((1, 1, 1), 1, EXT, bc, [0], [0])
+    rng = np.random.default_rng(3)
+    vel = rng.uniform(-1, 1, (1, 8, 8, 8, 3))
+    sim.upload("vel", vel)
+    check(lib().cup3d_advect_implicit(sim.handle, 0.05, 2.0, np.array([0.1, 0.2, -0.3])))
+    v, t = m.advect_implicit(vel, 0.05, 2.0, (0.1, 0.2, -0.3), True)
+    assert np.array_equal(sim.download("vel"), v) and np.array_equal(sim.download("tmpV"), t)
+
+
+def test_implicit_time_loop(golden_dir):
+    """Simulation with -implicitDiffusion: the pipeline picks AdvectionDiffusionImplicit (15231-15234), calcMaxTimestep uses the
+    0.1 diffusive limit after step 10 (15269-15273); three steps on a multi-level mesh against the oracle's operators."""
+    m, sim, f = make_implicit(golden_dir, "amr_mixed_l12", implicitDiffusion=True, nu=0.5, CFL=0.3, diffusionTol=1e-12, diffusionTolRel=1e-11,
+                              poissonTol=1e-12, poissonTolRel=1e-10, rampup=0)
+    S = cu.Simulation(sim)
+    assert isinstance(S.pipeline[0], cu.AdvectionDiffusionImplicit)
+    sim.upload("vel", f["vel"]); sim.fill("pres", 0.0)
+    v, p = f["vel"].copy(), np.zeros_like(f["pres"])
+    coefU = np.zeros(3)
+    dt_old = 0.0
+    for step in range(3):
+        dt = S.calcMaxTimestep()
+        ref_dt = O.lib().orc_calc_dt2(sim.hmin, m.max_u(v, sim.uinf), sim.nu, sim.CFL, step, 0, dt_old, coefU, 1)
+        assert abs(dt - ref_dt) <= 1e-6 * ref_dt   # from findMaxU of trajectories that agree to solver round-off
+        S.advance(dt)
+        v, _ = m.advdiff_implicit(v, p, dt, sim.nu, sim.uinf, False, 1e-12, 1e-11)
+        m.project(v, p, dt, step, tol=1e-12, tol_rel=1e-10)
+        dt_old = dt
+        assert np.abs(sim.download("vel") - v).max() <= 1e-6 * np.abs(v).max(), step
+    sim.step = 11
+    assert S.calcMaxTimestep() <= 0.1

@@ -124,3 +124,34 @@ def test_projection_with_an_obstacle_through_the_shim(tmp_path):
     corr = np.abs(res["cpu"][0] - vel).max()
     assert np.abs(res["cpu"][0] - res["hip"][0]).max() <= 1e-6 * corr
     assert np.abs(res["cpu"][1] - res["hip"][1]).max() <= 1e-6 * np.abs(res["cpu"][1]).max()
+
+
+def test_implicit_diffusion_through_the_shim(tmp_path):
+    """-implicitDiffusion 1: install() swaps AdvectionDiffusionImplicit for AdvectionDiffusionImplicitHIP (KernelAdvect +
+    KernelDiffusionRHS + three DiffusionSolver solves on the device).
+    (a) One periodic block: the reference's in-place KernelAdvect is invisible to every tile, so reference and device compute
+        the same thing: agreement to solver round-off at tight tolerances.
+    (b) 64 blocks, Taylor-Green: the reference (one thread) lets later blocks see the already advected velocity of earlier
+        ones -- its own result depends on block order and thread timing -- while the device reads the velocity on entry; the
+        two differ by O(dt) of the advective increment (1 % here, measured with the oracle's two modes), which bounds what can
+        be asserted: 5 % of the step's change.  pres must come back untouched on both sides."""
+    rng = np.random.default_rng(8)
+    for tag, bpd, lmax, lstart, nb, dt, nu, tol in (("one", (1, 1, 1), 1, 0, 1, 0.05, 2.0, 1e-7), ("tgv", (1, 1, 1), 3, 2, 64, 0.003, 0.01, 0.05)):
+        args = O.ref_args(bpd, lmax, lstart, 2 * np.pi, ("periodic",) * 3, extra=["-implicitDiffusion", "1"])
+        pres = rng.uniform(-1, 1, (nb, 8, 8, 8))
+        script = ["zero chi", "loadb pres p_in.bin", f"set nu {nu}", "set difftol 1e-12", "set difftolrel 1e-11", "dump vel v0.bin"]
+        if tag == "one":
+            script.insert(1, "loadb vel v_in.bin")
+        script += [f"op advdiff_implicit {dt}", "dump vel v1.bin", "dump pres p1.bin"]
+        out = {}
+        for side, tool, pre in (("cpu", O.REF_TOOL, []), ("hip", REF_HIP, ["hip on"])):
+            d = tmp_path / (tag + side)
+            d.mkdir()
+            pres.tofile(str(d / "p_in.bin"))
+            (0.5 * np.random.default_rng(9).uniform(-1, 1, (1, 8, 8, 8, 3))).tofile(str(d / "v_in.bin"))
+            run(tool, pre + script, args, str(d))
+            out[side] = [O.read_blocks(str(d / f), nb, nc) for f, nc in (("v0.bin", 3), ("v1.bin", 3), ("p1.bin", 1))]
+            assert np.array_equal(out[side][2], pres)
+        change = np.abs(out["cpu"][1] - out["cpu"][0]).max()
+        assert change > 1e-3
+        assert np.abs(out["cpu"][1] - out["hip"][1]).max() <= tol * change, tag
