@@ -40,6 +40,11 @@ ALGO_BYTES = {
     "poisson_lhs": 16.0,       # p in, Ap out
     "poisson_block_cg": 16.0,  # r in, z out (FP64-VALU bound, shown against HBM for reference)
     "poisson_block_fdm": 16.0,  # r in, z out (direct block solve)
+    # --implicit-diffusion (AdvectionDiffusionImplicit, main.cpp:10030-10119)
+    "advect_implicit": 72.0,   # vel 24 in + vel' 24 out + tmpV 24 out
+    "diffusion_rhs": 48.0,     # vel 24 in + tmpV 24 out
+    "diffusion_lhs": 16.0,
+    "diffusion_block_cg": 16.0,
 }
 
 
@@ -189,6 +194,9 @@ def main():
     ap.add_argument("--stencil-only", action="store_true", help="BASELINE configs[1]: periodic, advect-diffuse only")
     ap.add_argument("--block-solver", type=int, default=0, help="0: block CG as in the reference, 1: direct block solve")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed region with the other block solver")
+    ap.add_argument("--implicit-diffusion", action="store_true",
+                    help="-implicitDiffusion 1: AdvectionDiffusionImplicit (upwind advection + three Helmholtz solves) instead of the explicit RK3")
+    ap.add_argument("--nu", type=float, default=0.01)
     ap.add_argument("--amr", action="store_true", help="time the step on a multi-level mesh built on the device (see run_amr)")
     ap.add_argument("--amr-base", type=int, default=4, help="--amr: uniform starting level (16^3 blocks at 4)")
     ap.add_argument("--amr-levels", type=int, default=3, help="--amr: number of levels of the final mesh")
@@ -233,13 +241,14 @@ def main():
     assert 8 << level == a.size, "--size must be 8 * 2^k"
     ext = 2 * np.pi
     bc = "periodic" if a.stencil_only else "wall"
-    sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=level + 1, levelStart=level, extent=ext, nu=0.01, CFL=0.3,
-                            BC_x=bc, BC_y=bc, BC_z=bc, uMax_forced=1.0, rampup=0, rank=rank, nranks=world, blockSolver=a.block_solver)
+    sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=level + 1, levelStart=level, extent=ext, nu=a.nu, CFL=0.3,
+                            BC_x=bc, BC_y=bc, BC_z=bc, uMax_forced=1.0, rampup=0, rank=rank, nranks=world, blockSolver=a.block_solver,
+                            implicitDiffusion=a.implicit_diffusion)
     sim.upload("vel", taylor_green_blocks(sim.grid, [ext] * 3, 1.0))
     sim.step = 21
     S = cu.Simulation(sim)
-    adv = cu.AdvectionDiffusion(sim)
-    iters = []
+    adv = S.pipeline[0]  # AdvectionDiffusion, or AdvectionDiffusionImplicit with --implicit-diffusion
+    iters, diff_iters = [], []
 
     def one_step():
         dt = S.calcMaxTimestep()
@@ -249,6 +258,8 @@ def main():
         else:
             S.advance(dt)
             iters.append(sim.last_poisson.iterations)
+        if a.implicit_diffusion:
+            diff_iters.append(sum(r.iterations for r in adv.last_diffusion))
 
     def fence():
         if dist is not None:
@@ -267,6 +278,7 @@ def main():
     fence()
     sec = time.perf_counter() - t0
     main_iters = list(iters)
+    a.diffusion_iters = round(float(np.mean(diff_iters[-a.steps:])), 2) if diff_iters else None
     if dist is not None:
         t = torch.tensor([sec], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -278,7 +290,7 @@ def main():
     prof = {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n.value)}
 
     alt = None
-    if not a.stencil_only and not a.no_alt:
+    if not a.stencil_only and not a.no_alt and not a.implicit_diffusion:
         # same workload once more with the block preconditioner evaluated by the other method
         # (cup3d_poisson_params.block_solver), reported next to the main number
         sim.blockSolver = 1 - a.block_solver
@@ -342,6 +354,8 @@ def report(a, sim, prof, sec, iters, world, alt=None):
                    else f"taylor-green {a.size}^3 uniform periodic, advect-diffuse RK3 only",
                    "cells": int(cells), "blocks": int(cells // 512), "block": "8^3", "partition": f"hilbert-range x{world}",
                    "bicgstab_iters_per_step": round(float(np.mean(iters)), 2) if iters else None,
+                   "nu": a.nu, "implicit_diffusion": bool(a.implicit_diffusion),
+                   "helmholtz_iters_per_step (3 solves)": getattr(a, "diffusion_iters", None),
                    "block_preconditioner": ("block CG (reference algorithm)", "direct block solve (fast diagonalisation)")[a.block_solver]},
         "roofline": ({k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]})
         if dominant else None,
