@@ -344,7 +344,8 @@ def report(a, sim, prof, sec, iters, world, alt=None):
     with_roof = [k for k in kernels if "achieved" in k]
     dominant = with_roof[0] if with_roof else None
     out = {
-        "metric": "Mcell-updates/s (advect+diffuse+Poisson), 512^3 uniform, 1/2/4/8 GPUs" if not a.stencil_only
+        "metric": ("Mcell-updates/s (advect+diffuse+Poisson), 512^3 uniform, 1/2/4/8 GPUs" if not a.implicit_diffusion
+                   else "Mcell-updates/s (implicit-diffusion advect+diffuse + Poisson), uniform") if not a.stencil_only
         else "Mcell-updates/s (advect+diffuse only), uniform periodic",
         "value": round(value, 2), "unit": "Mcell-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(sec / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
