@@ -136,6 +136,16 @@ def test_calc_max_timestep_matches_oracle():
         dt_a = L.cup3d_calc_max_timestep(0.05, 0.9 + 0.01 * step, 0.01, 0.3, step, 4, dt_a, coef_a)
         dt_b = O.lib().orc_calc_dt(0.05, 0.9 + 0.01 * step, 0.01, 0.3, step, 4, dt_b, coef_b)
         assert dt_a == dt_b and np.array_equal(coef_a, coef_b)
+    # -implicitDiffusion: the diffusive limit is 0.1 once step > 10 (main.cpp:15269-15273); nu large enough that it matters
+    dt_a = dt_b = 1e-4
+    seen = set()
+    for step in range(8, 15):
+        dt_a = L.cup3d_calc_max_timestep2(0.05, 0.2, 5.0, 0.3, step, 4, dt_a, coef_a, 1)
+        dt_b = O.lib().orc_calc_dt2(0.05, 0.2, 5.0, 0.3, step, 4, dt_b, coef_b, 1)
+        assert dt_a == dt_b and np.array_equal(coef_a, coef_b)
+        seen.add(dt_a)
+        assert L.cup3d_calc_max_timestep2(0.05, 0.2, 5.0, 0.3, step, 4, 0.0, np.zeros(3), 0) == L.cup3d_calc_max_timestep(0.05, 0.2, 5.0, 0.3, step, 4, 0.0, np.zeros(3))
+    assert len(seen) == 2 and abs(max(seen) - 0.075) < 1e-6   # min(0.1, CFL*h/u) after step 10, h^2/6/(nu + ..) before
 
 
 def test_bad_arguments_are_reported():
