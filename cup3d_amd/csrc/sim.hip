@@ -128,6 +128,25 @@ __global__ void __launch_bounds__(256) k_soa_to_aos(const double *__restrict__ s
   const int cell = r / nc, c = r - cell * nc;
   aos[i] = soa[(blk * nc + c) * 512 + cell];
 }
+// the same for a list of block slots (partial transfers): staged block b <-> field slot slots[b]
+__global__ void __launch_bounds__(256) k_aos_to_soa_list(const double *__restrict__ aos, double *__restrict__ field, const int32_t *__restrict__ slots,
+                                                         long ncell_total, int nc) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ncell_total * nc) return;
+  const long blk = i / (512L * nc);
+  const int r = (int)(i - blk * 512L * nc);
+  const int c = r / 512, cell = r - c * 512;
+  field[((size_t)slots[blk] * nc + c) * 512 + cell] = aos[(blk * 512 + cell) * nc + c];
+}
+__global__ void __launch_bounds__(256) k_soa_to_aos_list(const double *__restrict__ field, double *__restrict__ aos, const int32_t *__restrict__ slots,
+                                                         long ncell_total, int nc) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ncell_total * nc) return;
+  const long blk = i / (512L * nc);
+  const int r = (int)(i - blk * 512L * nc);
+  const int cell = r / nc, c = r - cell * nc;
+  aos[i] = field[((size_t)slots[blk] * nc + c) * 512 + cell];
+}
 __global__ void __launch_bounds__(256) k_fill(double *__restrict__ p, long n, double v) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
 }
@@ -311,6 +330,8 @@ void cup3d_sim_destroy(cup3d_sim_t *h) {
   for (double *p : s->sv) if (p) hipFree(p);
   if (s->h_red) hipHostFree(s->h_red);
   if (s->h_stage) hipHostFree(s->h_stage);
+  if (s->h_stage_slots) hipHostFree(s->h_stage_slots);
+  if (s->d_stage_slots) hipFree(s->d_stage_slots);
   int32_t *ip[] = {s->d_nbr, s->d_inner, s->d_boundary, s->d_send_faces, s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_index,
                    s->d_restrict_list, s->d_prolong_list, s->d_fix_list[0], s->d_fix_list[1], s->d_fix_list[2]};
   for (int32_t *p : ip) if (p) hipFree(p);
@@ -388,6 +409,8 @@ static int ensure_stage(Sim *s) {
   s->stage_blocks = 4096;
   CUP3D_HIP(hipHostMalloc((void **)&s->h_stage, s->stage_blocks * 1536 * sizeof(double), hipHostMallocDefault));
   CUP3D_HIP(hipMalloc((void **)&s->d_stage, s->stage_blocks * 1536 * sizeof(double)));
+  CUP3D_HIP(hipHostMalloc((void **)&s->h_stage_slots, s->stage_blocks * sizeof(int32_t), hipHostMallocDefault));
+  CUP3D_HIP(hipMalloc((void **)&s->d_stage_slots, s->stage_blocks * sizeof(int32_t)));
   return CUP3D_OK;
 }
 int cup3d_sim_upload_blocks(cup3d_sim_t *h, int field, const void *const *ptrs) {
@@ -419,6 +442,56 @@ int cup3d_sim_download_blocks(cup3d_sim_t *h, int field, void *const *ptrs) {
   for (size_t b0 = 0; b0 < (size_t)s->nb; b0 += s->stage_blocks) {
     const size_t n = std::min(s->stage_blocks, (size_t)s->nb - b0);
     hipLaunchKernelGGL(k_soa_to_aos, dim3((unsigned)((n * per + 255) / 256)), dim3(256), 0, g_stream, src + b0 * per, s->d_stage, (long)n * 512, nc);
+    CUP3D_HIP(hipGetLastError());
+    CUP3D_HIP(hipMemcpyAsync(s->h_stage, s->d_stage, n * per * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    CUP3D_HIP(hipStreamSynchronize(g_stream));
+    for (size_t i = 0; i < n; ++i) memcpy(ptrs[b0 + i], s->h_stage + i * per, per * sizeof(double));
+  }
+  return CUP3D_OK;
+}
+
+// Partial transfers: only the listed block slots move (e.g. the blocks an obstacle touches, so that the host-side obstacle
+// operators can run between two device operators without a full-field round trip).
+static int check_list(Sim *s, long n, const int32_t *slots) {
+  for (long i = 0; i < n; ++i)
+    if (slots[i] < 0 || slots[i] >= s->nb) { set_error("block slot %d out of range", (int)slots[i]); return CUP3D_EINVAL; }
+  return CUP3D_OK;
+}
+int cup3d_sim_upload_block_list(cup3d_sim_t *h, int field, long nlist, const int32_t *slots, const void *const *ptrs) {
+  if (!h || nlist < 0 || (nlist > 0 && (!slots || !ptrs))) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  int nc, rc;
+  double *dst = s->field(field, &nc);
+  if (!dst) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+  if ((rc = check_list(s, nlist, slots)) || (rc = ensure_stage(s))) return rc;
+  const size_t per = 512 * (size_t)nc;
+  for (size_t b0 = 0; b0 < (size_t)nlist; b0 += s->stage_blocks) {
+    const size_t n = std::min(s->stage_blocks, (size_t)nlist - b0);
+    for (size_t i = 0; i < n; ++i) {
+      memcpy(s->h_stage + i * per, ptrs[b0 + i], per * sizeof(double));
+      s->h_stage_slots[i] = slots[b0 + i];
+    }
+    CUP3D_HIP(hipMemcpyAsync(s->d_stage, s->h_stage, n * per * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    CUP3D_HIP(hipMemcpyAsync(s->d_stage_slots, s->h_stage_slots, n * sizeof(int32_t), hipMemcpyHostToDevice, g_stream));
+    hipLaunchKernelGGL(k_aos_to_soa_list, dim3((unsigned)((n * per + 255) / 256)), dim3(256), 0, g_stream, s->d_stage, dst, s->d_stage_slots, (long)n * 512, nc);
+    CUP3D_HIP(hipGetLastError());
+    CUP3D_HIP(hipStreamSynchronize(g_stream));
+  }
+  return nlist > 0 ? mark_written(s, field) : CUP3D_OK;
+}
+int cup3d_sim_download_block_list(cup3d_sim_t *h, int field, long nlist, const int32_t *slots, void *const *ptrs) {
+  if (!h || nlist < 0 || (nlist > 0 && (!slots || !ptrs))) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  int nc, rc;
+  double *src = s->field(field, &nc);
+  if (!src) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+  if ((rc = check_list(s, nlist, slots)) || (rc = ensure_stage(s))) return rc;
+  const size_t per = 512 * (size_t)nc;
+  for (size_t b0 = 0; b0 < (size_t)nlist; b0 += s->stage_blocks) {
+    const size_t n = std::min(s->stage_blocks, (size_t)nlist - b0);
+    for (size_t i = 0; i < n; ++i) s->h_stage_slots[i] = slots[b0 + i];
+    CUP3D_HIP(hipMemcpyAsync(s->d_stage_slots, s->h_stage_slots, n * sizeof(int32_t), hipMemcpyHostToDevice, g_stream));
+    hipLaunchKernelGGL(k_soa_to_aos_list, dim3((unsigned)((n * per + 255) / 256)), dim3(256), 0, g_stream, src, s->d_stage, s->d_stage_slots, (long)n * 512, nc);
     CUP3D_HIP(hipGetLastError());
     CUP3D_HIP(hipMemcpyAsync(s->h_stage, s->d_stage, n * per * sizeof(double), hipMemcpyDeviceToHost, g_stream));
     CUP3D_HIP(hipStreamSynchronize(g_stream));

@@ -80,6 +80,7 @@ struct Sim {
   double *d_stage = nullptr;
   double *h_stage = nullptr;  // pinned
   size_t stage_blocks = 0;
+  int32_t *d_stage_slots = nullptr, *h_stage_slots = nullptr;  // block lists of the partial transfers (cup3d_sim_*_block_list)
   // multi-level mesh tables (amr.hip); all nullptr / 0 on uniform grids
   int32_t *d_amr_faces = nullptr, *d_amr_fine = nullptr, *d_nbr27 = nullptr, *d_index = nullptr;
   int32_t *d_restrict_list = nullptr, *d_prolong_list = nullptr, *d_fix_list[3] = {nullptr, nullptr, nullptr};

@@ -62,6 +62,17 @@ public:
     for (size_t i = 0; i < I.size(); ++i) ptrs[i] = I[i].block;
     CUP3D_HIP_CALL(cup3d_sim_download_blocks(dsim, field, (void *const *)ptrs.data()));
   }
+  // Partial transfers of the blocks an obstacle covers (non-null ObstacleBlock of any obstacle): the host-side obstacle operators
+  // between AdvectionDiffusion and PressureProjection read and write the velocity in exactly those blocks
+  // (KernelIntegrateFluidMomenta 13637-13641, KernelPenalization 13853-13861), so in resident mode only they cross PCIe.
+  void download_obstacle_blocks(int field) {
+    obstacle_blocks(field);
+    CUP3D_HIP_CALL(cup3d_sim_download_block_list(dsim, field, (long)oslots.size(), oslots.data(), (void *const *)ptrs.data()));
+  }
+  void upload_obstacle_blocks(int field) {
+    obstacle_blocks(field);
+    CUP3D_HIP_CALL(cup3d_sim_upload_block_list(dsim, field, (long)oslots.size(), oslots.data(), (const void *const *)ptrs.data()));
+  }
 
 private:
   SimulationData &sim;
@@ -69,7 +80,22 @@ private:
   cup3d_sim_t *dsim = nullptr;
   std::vector<long long> signature;  // (level, Z) of every local block the mirror was built for
   std::vector<void *> ptrs;
+  std::vector<int32_t> oslots;
   bool device_ready = false;
+
+  void obstacle_blocks(int field) {
+    ensure();
+    const std::vector<Info> &I = infos(field);
+    oslots.clear();
+    ptrs.clear();
+    for (size_t i = 0; i < I.size(); ++i)
+      for (const auto &ob : sim.obstacle_vector->getObstacleVector())
+        if (ob->getObstacleBlocks()[I[i].blockID] != nullptr) {
+          oslots.push_back((int32_t)i);
+          ptrs.push_back(I[i].block);
+          break;
+        }
+  }
 
   const std::vector<Info> &infos(int field) {
     switch (field) {
@@ -172,8 +198,10 @@ public:
     dev.upload(CUP3D_FIELD_VEL);
     const double uinf[3] = {sim.uinf[0], sim.uinf[1], sim.uinf[2]};
     CUP3D_HIP_CALL(cup3d_advect_diffuse(dev.handle(), sim.dt, sim.nu, uinf));
-    if (dev.resident && sim.obstacle_vector->nObstacles() == 0) {
-      dev.vel_on_device = true;  // nobody on the host reads vel / tmpV before the projection (install() checked the pipeline)
+    if (dev.resident) {
+      // nobody on the host reads vel / tmpV before the projection except the obstacle operators, which get the blocks they touch
+      // from UpdateObstaclesHIP (install() checked the pipeline)
+      dev.vel_on_device = true;
       return;
     }
     dev.download(CUP3D_FIELD_VEL);
@@ -202,7 +230,7 @@ public:
     p.tol = sim.DiffusionErrorTol;
     p.tol_rel = sim.DiffusionErrorTolRel;
     CUP3D_HIP_CALL(cup3d_advect_diffuse_implicit(dev.handle(), sim.dt, sim.nu, uinf, &p, last));
-    if (dev.resident && sim.obstacle_vector->nObstacles() == 0) {
+    if (dev.resident) {
       dev.vel_on_device = true;
       return;
     }
@@ -223,6 +251,22 @@ public:
     if (!devp->vel_on_device) { (*cpu)(dt); return; }
     const int dir = sim.BCy_flag == wall ? 1 : 2;  // 10582-10583
     CUP3D_HIP_CALL(cup3d_external_forcing(devp->handle(), sim.uMax_forced, sim.nu, sim.extents[dir], dt));
+  }
+};
+
+// UpdateObstacles::operator()(dt), main.cpp:13812-13837, is the first host operator after the advection step that reads the
+// velocity -- in the blocks an obstacle covers only.  While the velocity is resident on the device this wrapper fetches exactly
+// those blocks, then runs the reference's own operator; Penalization (next in the pipeline) updates the same blocks on the host and
+// PressureProjectionHIP sends them back.
+class UpdateObstaclesHIP : public Operator {
+  std::shared_ptr<DeviceMirror> devp;
+  std::shared_ptr<Operator> cpu;
+
+public:
+  UpdateObstaclesHIP(SimulationData &s, std::shared_ptr<DeviceMirror> d, std::shared_ptr<Operator> original) : Operator(s), devp(d), cpu(original) {}
+  void operator()(const Real dt) override {
+    if (devp->vel_on_device && sim.obstacle_vector->nObstacles() > 0) devp->download_obstacle_blocks(CUP3D_FIELD_VEL);
+    (*cpu)(dt);
   }
 };
 
@@ -273,6 +317,7 @@ public:
       had_obstacles = false;
     }
     if (!dev.vel_on_device) dev.upload(CUP3D_FIELD_VEL);
+    else if (obstacles) dev.upload_obstacle_blocks(CUP3D_FIELD_VEL);  // what UpdateObstacles / Penalization changed on the host
     dev.vel_on_device = false;
     dev.upload(CUP3D_FIELD_PRES);
     const cup3d_poisson_params p = poisson_params(sim);
@@ -287,14 +332,17 @@ struct Installed {
   std::shared_ptr<DeviceMirror> mirror;
   std::shared_ptr<Operator> advdiff;  // AdvectionDiffusionHIP, or AdvectionDiffusionImplicitHIP with -implicitDiffusion 1
   std::shared_ptr<ExternalForcingHIP> forcing;
+  std::shared_ptr<UpdateObstaclesHIP> update_obstacles;
   std::shared_ptr<PressureProjectionHIP> projection;
 };
 
 // Swap the hot-path operators of an initialised Simulation for the HIP-backed ones.
 // resident (default: environment CUP3D_HIP_RESIDENT=1): keep the velocity in HBM between AdvectionDiffusion and
 // PressureProjection.  Allowed only if every operator the reference put between the two (setupOperators 15229-15246) is
-// ExternalForcing (then run on the device too) or one of the obstacle operators, which return immediately without obstacles
-// (13813-13814, 14327-14328); with obstacles, or with FixMassFlux in between, every operator round-trips as before.
+// ExternalForcing (then run on the device too) or one of the obstacle operators: UpdateObstacles and Penalization touch the
+// velocity only in the blocks an obstacle covers, so those blocks alone make the round trip (UpdateObstaclesHIP fetches them,
+// PressureProjectionHIP sends them back); without obstacles both return immediately (13813-13814, 14327-14328).  With
+// FixMassFlux in between, every operator round-trips in full as before.
 inline Installed install(SimulationData &sim, int resident = -1) {
   Installed r;
   r.mirror = std::make_shared<DeviceMirror>(sim);
@@ -321,6 +369,9 @@ inline Installed install(SimulationData &sim, int resident = -1) {
     } else if (r.mirror->resident && std::dynamic_pointer_cast<ExternalForcing>(op)) {
       r.forcing = std::make_shared<ExternalForcingHIP>(sim, r.mirror, op);
       op = r.forcing;
+    } else if (r.mirror->resident && std::dynamic_pointer_cast<UpdateObstacles>(op)) {
+      r.update_obstacles = std::make_shared<UpdateObstaclesHIP>(sim, r.mirror, op);
+      op = r.update_obstacles;
     } else if (std::dynamic_pointer_cast<PressureProjection>(op)) {
       r.projection = std::make_shared<PressureProjectionHIP>(sim, r.mirror);
       op = r.projection;

@@ -178,6 +178,25 @@ class SimulationData:
     def fill(self, field, value):
         check(lib().cup3d_sim_fill(self.handle, FIELDS[field], float(value)))
 
+    def _block_ptrs(self, a):
+        return (C.c_void_p * len(a))(*[a[i].ctypes.data for i in range(len(a))])
+
+    def upload_block_list(self, field, slots, blocks):
+        """Partial upload: blocks[i] ([8][8][8][(3)], the reference's block layout) -> block slot slots[i]."""
+        fid = FIELDS[field]
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        a = np.ascontiguousarray(blocks, dtype=np.float64)
+        if a.shape != ((len(sl), 8, 8, 8, 3) if FIELD_NCOMP[fid] == 3 else (len(sl), 8, 8, 8)):
+            raise ValueError(f"{field}: block list of shape {a.shape} for {len(sl)} slots")
+        check(lib().cup3d_sim_upload_block_list(self.handle, fid, len(sl), sl.ctypes.data_as(C.c_void_p), self._block_ptrs(a)))
+
+    def download_block_list(self, field, slots):
+        fid = FIELDS[field]
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        out = np.empty((len(sl), 8, 8, 8, 3) if FIELD_NCOMP[fid] == 3 else (len(sl), 8, 8, 8))
+        check(lib().cup3d_sim_download_block_list(self.handle, fid, len(sl), sl.ctypes.data_as(C.c_void_p), self._block_ptrs(out)))
+        return out
+
     def adapted(self, states):
         """A new SimulationData on the mesh that MeshAdaptation::Adapt produces from (valid) `states`, with vel and pres
         moved over on the device (refine / compress / copy; chi, lhs and tmpV are adapted without data in the reference

@@ -135,6 +135,11 @@ size_t cup3d_sim_device_bytes(const cup3d_sim_t *);
  * block (Info::block, main.cpp:343, 877-884) or one contiguous array [nb][8][8][8][nc] */
 int cup3d_sim_upload_blocks(cup3d_sim_t *, int field, const void *const *block_ptrs);
 int cup3d_sim_download_blocks(cup3d_sim_t *, int field, void *const *block_ptrs);
+/* the same for a subset: only the n listed block slots move (slots[i] <-> block_ptrs[i]).  Lets the host-side obstacle operators
+ * (UpdateObstacles / Penalization, which touch only the blocks an obstacle covers, 13841-13912) run between two device operators
+ * without a full-field round trip */
+int cup3d_sim_upload_block_list(cup3d_sim_t *, int field, long n, const int32_t *slots, const void *const *block_ptrs);
+int cup3d_sim_download_block_list(cup3d_sim_t *, int field, long n, const int32_t *slots, void *const *block_ptrs);
 int cup3d_sim_upload(cup3d_sim_t *, int field, const double *blocks);
 int cup3d_sim_download(cup3d_sim_t *, int field, double *blocks);
 int cup3d_sim_fill(cup3d_sim_t *, int field, double value);

@@ -24,6 +24,7 @@
  *   set step|dt|time|nu|uinfx|uinfy|uinfz|mean <value>
  *   op advdiff <dt> | lhs | precond | solve | project <dt> | maxu |
  *      steps <n> | forcing <dt> | rhs | divp | gradp   (the last three use `set dt`)
+ *      midstep <dt>        pipeline entries from AdvectionDiffusion through PressureProjection (works with `obstacle`)
  *      advdiff_implicit <dt> | advect | diffrhs | diffprecond | difflhs <dir> | diffsolve <dir>   (implicit diffusion;
  *      `set dt`, `set nu`, `set difftol`, `set difftolrel`; value = number of 6-double reductions = solver iterations)
  *   hip on                 (ref_tool_hip only) route advdiff/project/steps through the HIP drop-in
@@ -359,7 +360,7 @@ int main(int argc, char **argv) {
     } else if (cmd == "op") {
       std::string op; script >> op;
       double arg = 0;
-      if (op == "advdiff" || op == "project" || op == "steps" || op == "forcing" || op == "penalize" || op == "advdiff_implicit" ||
+      if (op == "advdiff" || op == "project" || op == "steps" || op == "forcing" || op == "penalize" || op == "advdiff_implicit" || op == "midstep" ||
           op == "difflhs" || op == "diffsolve") script >> arg;
       for (int r = 0; r < rep; r++) {
         cup3d_stub_iallreduce7 = 0;
@@ -411,6 +412,16 @@ int main(int argc, char **argv) {
             ds._lhs(in, out);
           }
           value = (double)cup3d_stub_iallreduce6;
+        }
+        else if (op == "midstep") {
+          /* the operators of Simulation::advance (15316-15318) from the advection-diffusion step through PressureProjection, as
+             they stand in sim.pipeline (setupOperators 15229-15246: [1] = AdvectionDiffusion(Implicit), then forcing, UpdateObstacles,
+             Penalization, PressureProjection) -- CreateObstacles before and the force diagnostics after need real obstacles */
+          sd.dt = arg;
+          for (size_t c = 1; c < sd.pipeline.size(); c++) {
+            (*sd.pipeline[c])(arg);
+            if (sd.pipeline[c] == std::shared_ptr<Operator>(proj) || (hip_proj && sd.pipeline[c] == hip_proj)) break;
+          }
         }
         else if (op == "maxu") value = findMaxU(sd);
         else if (op == "forcing") { ExternalForcing f(sd); f(arg); }

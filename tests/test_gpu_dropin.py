@@ -155,3 +155,33 @@ def test_implicit_diffusion_through_the_shim(tmp_path):
         change = np.abs(out["cpu"][1] - out["cpu"][0]).max()
         assert change > 1e-3
         assert np.abs(out["cpu"][1] - out["hip"][1]).max() <= tol * change, tag
+
+
+@pytest.mark.parametrize("implicit", [0, 1])
+def test_resident_mode_with_an_obstacle(tmp_path, implicit):
+    """AdvectionDiffusion -> ExternalForcing -> UpdateObstacles -> Penalization -> PressureProjection of the reference's pipeline
+    (`op midstep`) with a synthetic obstacle.  `hip on`: every operator round-trips its fields.  `hip resident`: the velocity stays in
+    HBM from AdvectionDiffusionHIP to PressureProjectionHIP (ExternalForcing on the device) and only the blocks the obstacle covers
+    travel: UpdateObstaclesHIP fetches them for the reference's own UpdateObstacles / Penalization, PressureProjectionHIP sends them
+    back.  Both must reproduce the CPU run: a stale host block would change the obstacle's computed velocity and the penalised cells."""
+    bpd, lmax, bc = (2, 2, 2), 2, ("periodic", "wall", "freespace")
+    args = O.ref_args(bpd, lmax, 1, 2 * np.pi, bc, extra=["-poissonTol", "1e-12", "-poissonTolRel", "1e-10"])
+    nb = 64
+    rng = np.random.default_rng(8)
+    vel, pres = rng.uniform(-1, 1, (nb, 8, 8, 8, 3)), rng.uniform(-1, 1, (nb, 8, 8, 8))
+    obst, chif = O.synthetic_obstacle(None, nb, 9)
+    res = {}
+    for tag, tool, pre in (("cpu", O.REF_TOOL, []), ("hip", REF_HIP, ["hip on"]), ("res", REF_HIP, ["hip resident"])):
+        d = tmp_path / tag
+        d.mkdir()
+        O.write_obstacle_file(str(d / "ob.bin"), obst)
+        vel.tofile(str(d / "velb.bin")); pres.tofile(str(d / "presb.bin")); chif.tofile(str(d / "chib.bin"))
+        run(tool, pre + ["obstacle ob.bin", "loadb vel velb.bin", "loadb pres presb.bin", "loadb chi chib.bin", "set lambda 1e4", f"set implicit {implicit}",
+                         "set step 4", "op midstep 0.01", "dump vel pv.bin", "dump pres pp.bin", "forces f.bin"], args, str(d))
+        res[tag] = (O.read_blocks(str(d / "pv.bin"), nb, 3), O.read_blocks(str(d / "pp.bin"), nb, 1), np.fromfile(str(d / "f.bin")))
+    change = np.abs(res["cpu"][0] - vel).max()
+    assert change > 0.5 and len(obst["ids"]) < nb        # the obstacle acted, and on a subset of the blocks
+    for tag in ("hip", "res"):
+        assert np.abs(res["cpu"][0] - res[tag][0]).max() <= 1e-6 * change, tag
+        assert np.abs(res["cpu"][1] - res[tag][1]).max() <= 1e-6 * np.abs(res["cpu"][1]).max(), tag
+        assert np.array_equal(res["cpu"][2], res[tag][2]), tag    # penalisation force / torque: host operator on identical inputs

@@ -567,3 +567,28 @@ def test_kat_taylor_green_energy_decay():
     assert t > 0.1
     assert abs(np.log(e1 / e0) + 2 * nu * lam_h * t) <= 1e-4 * 2 * nu * lam_h * t   # discrete decay rate (oracle: 5e-8)
     assert abs(np.log(e1 / e0) + 2 * nu * 3 * t) <= 2e-3 * 2 * nu * 3 * t           # continuum rate, O(h^2) away
+
+
+def test_partial_block_transfers():
+    """cup3d_sim_upload_block_list / cup3d_sim_download_block_list: only the listed slots move (the blocks an obstacle covers, in
+    the resident mode of the C++ shim), any order, lists longer than one staging chunk."""
+    sim = cu.SimulationData(bpdx=2, bpdy=2, bpdz=2, levelMax=4, levelStart=3, extent=1.0)   # 4096 blocks; staging chunk = 4096
+    nb = sim.nblocks
+    rng = np.random.default_rng(21)
+    for field, shape in (("vel", (nb, 8, 8, 8, 3)), ("pres", (nb, 8, 8, 8))):
+        a = rng.uniform(-1, 1, shape)
+        sim.upload(field, a)
+        slots = rng.permutation(nb)[:777].astype(np.int32)
+        assert np.array_equal(sim.download_block_list(field, slots), a[slots])
+        new = rng.uniform(-1, 1, (len(slots),) + shape[1:])
+        sim.upload_block_list(field, slots, new)
+        b = a.copy()
+        b[slots] = new
+        assert np.array_equal(sim.download(field), b)
+        assert np.array_equal(sim.download_block_list(field, np.arange(nb, dtype=np.int32)), b)   # the full list, one chunk
+        assert np.array_equal(sim.download_block_list(field, np.zeros(0, dtype=np.int32)), b[:0])
+        big = rng.integers(0, nb, 5000).astype(np.int32)                                            # two chunks, repeated slots
+        assert np.array_equal(sim.download_block_list(field, big), b[big])
+    from cup3d_amd.capi import Cup3dError
+    with pytest.raises(Cup3dError):
+        sim.download_block_list("pres", np.array([nb], dtype=np.int32))
