@@ -11,6 +11,10 @@
  *   (3) bench.py can time the reference's CPU operators ("cpu_baseline",
  *       kind "reference") on the GPU box's host cores.
  *
+ * _ref/ref_tool_mpi is the same file linked against a real MPI (conda MPICH in the build container) instead of the single-rank
+ * stub, for pinning what only exists on several ranks: block ownership (GridMPI partition 2970-2986) and, after adaptMesh,
+ * the LoadBalancer's block moves (4660-5022).  Run under mpiexec -n N; every output file gets the suffix .r<rank>.
+ *
  * Usage:  ref_tool <script> -- <reference command line>
  * Script lines (whitespace separated):
  *   tables <file>          int64[nb][6] = level,Z,ix,iy,iz,blockID_2 then
@@ -115,7 +119,9 @@ Field field_of(SimulationData &s, const std::string &name) {
 double now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-void write_file(const std::string &path, const void *p, size_t bytes) {
+void write_file(const std::string &path0, const void *p, size_t bytes) {
+  /* several ranks (ref_tool_mpi, linked against a real MPI): one file per rank, <path>.r<rank> */
+  const std::string path = ::sim.size > 1 ? path0 + ".r" + std::to_string(::sim.rank) : path0;
   FILE *f = fopen(path.c_str(), "wb");
   if (!f || fwrite(p, 1, bytes, f) != bytes) { perror(path.c_str()); exit(2); }
   fclose(f);
@@ -442,5 +448,7 @@ int main(int argc, char **argv) {
     }
   }
   fflush(0);
+  MPI_Barrier(MPI_COMM_WORLD); /* real MPI: a rank that leaves early makes mpiexec kill the others before they have written */
+  MPI_Finalize();
   _exit(0); /* skip the reference's destructors: nothing left to verify */
 }

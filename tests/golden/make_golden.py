@@ -348,6 +348,24 @@ def implicit_cases():
     np.savez_compressed(os.path.join(HERE, "implicit_diffusion.npz"), **out)
 
 
+PARTITION_CASES = [((2, 2, 2), 3, 2, 3), ((1, 2, 3), 2, 1, 2), ((2, 2, 2), 3, 2, 7), ((3, 1, 2), 3, 2, 5), ((1, 1, 1), 3, 2, 8)]
+
+
+def partition_cases():
+    """Block ownership on several ranks (GridMPI 2970-2986: contiguous ranges of the Hilbert order, the first ranks one block
+    longer) from the reference run under a REAL MPI (oracle/_ref/ref_tool_mpi, conda MPICH of the build container): per case and
+    rank the block table (level, Z, index, blockID_2) of that rank."""
+    out = {}
+    for k, (bpd, lmax, lstart, nranks) in enumerate(PARTITION_CASES):
+        wd = O.run_ref_mpi(["tables t.bin"], O.ref_args(bpd, lmax, lstart, EXT, ("periodic",) * 3), nranks)
+        out[f"case{k}"] = np.array(list(bpd) + [lmax, lstart, nranks])
+        for r in range(nranks):
+            t, _ = O.read_tables(os.path.join(wd, f"t.bin.r{r}"))
+            out[f"case{k}_r{r}"] = t
+        print("partition", bpd, lmax, lstart, nranks, [len(out[f"case{k}_r{r}"]) for r in range(nranks)])
+    np.savez_compressed(os.path.join(HERE, "partition_mpi.npz"), **out)
+
+
 def sfc_cases():
     out = {}
     for bpd, lmax in SFC_CASES:
@@ -372,3 +390,5 @@ if __name__ == "__main__":
     vorticity_cases()
     obstacle_cases()
     implicit_cases()
+    if O.have_ref_tool_mpi():
+        partition_cases()

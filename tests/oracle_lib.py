@@ -449,6 +449,25 @@ def run_ref(script_lines, args, threads=1, workdir=None, timeout=3600):
     return recs, wd
 
 
+REF_TOOL_MPI = os.path.join(ORACLE_DIR, "_ref", "ref_tool_mpi")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+def have_ref_tool_mpi():
+    return os.path.exists(REF_TOOL_MPI) and os.path.exists(MPIEXEC)
+
+
+def run_ref_mpi(script_lines, args, nranks, workdir=None, timeout=3600):
+    """Run oracle/_ref/ref_tool_mpi (the reference TU against a real MPI) on `nranks` ranks; output files get `.r<rank>`."""
+    wd = workdir or tempfile.mkdtemp(prefix="cup3d_refmpi_")
+    with open(os.path.join(wd, "script.txt"), "w") as f:
+        f.write("\n".join(script_lines) + "\n")
+    env = dict(os.environ, OMP_NUM_THREADS="1", LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:/opt/conda/lib")
+    subprocess.run([MPIEXEC, "-n", str(nranks), REF_TOOL_MPI, "script.txt", "--"] + list(args), cwd=wd, env=env, check=True,
+                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    return wd
+
+
 def read_blocks(path, nb, ncomp):
     a = np.fromfile(path, dtype=np.float64)
     shape = (nb, 8, 8, 8, 3) if ncomp == 3 else (nb, 8, 8, 8)

@@ -76,6 +76,27 @@ def expected_neighbour_index(idx, f, nbd, bc):
     return tuple(c)
 
 
+def test_block_ownership_equals_the_reference_under_real_mpi(golden_dir):
+    """tests/golden/partition_mpi.npz: the reference run on 2-8 ranks of a real MPI (oracle/_ref/ref_tool_mpi); the block table of
+    every rank must be what cup3d_grid_create_uniform(rank, nranks) and the oracle's partition rule give."""
+    z = np.load(os.path.join(golden_dir, "partition_mpi.npz"))
+    k = 0
+    while f"case{k}" in z:
+        bx, by, bz, lmax, lstart, nranks = (int(v) for v in z[f"case{k}"])
+        level = int(z[f"case{k}_r0"][0, 0])
+        total = (bx << level) * (by << level) * (bz << level)
+        assert sum(len(z[f"case{k}_r{r}"]) for r in range(nranks)) == total
+        for r in range(nranks):
+            ref = z[f"case{k}_r{r}"]
+            g = cu.Grid((bx, by, bz), lmax, level, 1.0, (1, 1, 1), r, nranks)
+            assert np.array_equal(g.tables, ref), (k, r)
+            a, n = C.c_longlong(), C.c_longlong()
+            O.lib().orc_partition(total, r, nranks, C.byref(a), C.byref(n))
+            assert sorted(ref[:, 1].tolist()) == list(range(a.value, a.value + n.value)), (k, r)
+        k += 1
+    assert k >= 5
+
+
 @pytest.mark.parametrize("nranks", [1, 2, 3, 8])
 @pytest.mark.parametrize("bc", [(1, 1, 1), (2, 0, 1)])
 def test_neighbours_partition_and_plan(nranks, bc):
