@@ -113,6 +113,21 @@ int cup3d_grid_adapted(const cup3d_grid_t *gh, const signed char *states, cup3d_
   }
   return CUP3D_OK;
 }
+int cup3d_grid_adapted_owners(const cup3d_grid_t *gh, const int32_t *owner, const signed char *states, int nranks, const cup3d_grid_t *ah,
+                              int32_t *new_owner) {
+  if (!gh || !owner || !states || !ah || !new_owner) return CUP3D_EINVAL;
+  const Grid *g = reinterpret_cast<const Grid *>(gh), *a = reinterpret_cast<const Grid *>(ah);
+  try {
+    std::unique_ptr<Grid> tmp;
+    const Grid *m = g;
+    if (!g->multilevel) { tmp = g->as_mesh(); m = tmp.get(); }
+    m->adapted_owners(owner, reinterpret_cast<const int8_t *>(states), nranks, *a, new_owner);
+  } catch (const std::exception &e) {
+    set_error("cup3d_grid_adapted_owners: %s", e.what());
+    return CUP3D_EINVAL;
+  }
+  return CUP3D_OK;
+}
 void cup3d_grid_destroy(cup3d_grid_t *g) { delete reinterpret_cast<Grid *>(g); }
 long cup3d_grid_nblocks(const cup3d_grid_t *g) { return (long)reinterpret_cast<const Grid *>(g)->nblocks(); }
 long cup3d_grid_nblocks_global(const cup3d_grid_t *g) { return (long)reinterpret_cast<const Grid *>(g)->total_blocks; }

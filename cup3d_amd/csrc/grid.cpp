@@ -332,6 +332,63 @@ void Grid::adapted_leaves(const int8_t *st, std::vector<int32_t> &levels, std::v
   }
 }
 
+void Grid::adapted_owners(const int32_t *owner, const int8_t *st, int nranks_, const Grid &adapted, int32_t *new_owner) const {
+  if (!multilevel || !adapted.multilevel) throw std::invalid_argument("adapted_owners needs multi-level mesh objects");
+  if (nranks_ < 1) throw std::invalid_argument("bad number of ranks");
+  std::vector<std::vector<int32_t>> list(nranks_);
+  auto put = [&](int r, int l, const int c[3]) {
+    const int32_t s = adapted.leaf(l, c);
+    if (s < 0) throw std::invalid_argument("the adapted mesh does not match the states");
+    list[r].push_back(s);
+  };
+  for (int64_t b = 0; b < nblocks(); ++b) {
+    const int l = blevel[b], r = owner[b];
+    const int32_t *idx = &index[3 * b];
+    if (r < 0 || r >= nranks_) throw std::invalid_argument("owner out of range");
+    if (st[b] == 1) {
+      for (int q = 0; q < 8; ++q) {
+        const int c[3] = {2 * idx[0] + (q & 1), 2 * idx[1] + ((q >> 1) & 1), 2 * idx[2] + (q >> 2)};
+        put(r, l + 1, c);  // refine_1 / refine_2 allocate the children where the parent is (5227-5271)
+      }
+    } else if (st[b] == -1) {
+      if (idx[0] % 2 == 0 && idx[1] % 2 == 0 && idx[2] % 2 == 0) {  // the base block's rank receives the octet (4729-4804)
+        const int c[3] = {idx[0] / 2, idx[1] / 2, idx[2] / 2};
+        put(r, l - 1, c);
+      }
+    } else {
+      const int c[3] = {idx[0], idx[1], idx[2]};
+      put(r, l, c);
+    }
+  }
+  int64_t mx = 0, mn = INT64_MAX, total = 0;
+  for (auto &v : list) {
+    std::sort(v.begin(), v.end());  // slots of `adapted` are in blockID_2 order (Info::operator<)
+    mx = std::max<int64_t>(mx, (int64_t)v.size());
+    mn = std::min<int64_t>(mn, (int64_t)v.size());
+    total += (int64_t)v.size();
+  }
+  if (mn == 0 || (double)mx / (double)mn > 1.01) {  // Balance_Global (4906-5021): even cut of the rank-major concatenation
+    int r = 0;
+    int64_t left = total / nranks_ + (0 < total % nranks_ ? 1 : 0);
+    for (auto &v : list)
+      for (int32_t s : v) {
+        while (left == 0) { ++r; left = total / nranks_ + (r < total % nranks_ ? 1 : 0); }
+        new_owner[s] = r;
+        --left;
+      }
+    return;
+  }
+  for (int r = 0; r < nranks_; ++r)
+    for (int32_t s : list[r]) new_owner[s] = r;
+  for (int r = 0; r < nranks_; ++r) {  // Balance_Diffusion (4821-4905)
+    const int64_t my = (int64_t)list[r].size();
+    const int64_t fl = r == 0 ? 0 : (my - (int64_t)list[r - 1].size()) / 4;
+    const int64_t fr = r == nranks_ - 1 ? 0 : (my - (int64_t)list[r + 1].size()) / 4;
+    for (int64_t i = 0; i < fl; ++i) new_owner[list[r][i]] = r - 1;
+    for (int64_t i = 0; i < fr; ++i) new_owner[list[r][my - 1 - i]] = r + 1;
+  }
+}
+
 int32_t Grid::slot_of_index(int i, int j, int k) const {
   const int64_t z = sfc->forward(level, i, j, k);
   if (z < z_begin || z >= z_begin + z_count) return -1;

@@ -68,6 +68,10 @@ struct Grid {
   void valid_states(int8_t *states) const;
   // leaves after MeshAdaptation::Adapt (5086-5159) applied the valid states
   void adapted_leaves(const int8_t *states, std::vector<int32_t> &levels, std::vector<int64_t> &Zs) const;
+  // owner rank of every leaf of `adapted` (= this mesh after Adapt with `states`) when the leaves of this mesh are spread over
+  // `nranks` ranks as owner[nb] says: children stay with the refined parent, a compressed octet's parent appears on the rank of
+  // its base block (LoadBalancer::PrepareCompression 4729-4804), then Balance_Diffusion / Balance_Global (4805-5021)
+  void adapted_owners(const int32_t *owner, const int8_t *states, int nranks, const Grid &adapted, int32_t *new_owner) const;
   // the same blocks as a multi-level mesh object (for uniform one-rank grids; a multi-level grid returns a copy of itself)
   std::unique_ptr<Grid> as_mesh() const;
 

@@ -72,6 +72,16 @@ class Grid:
         lib().cup3d_grid_destroy(h)
         return t[:, 0].astype(np.int32), t[:, 1].copy()
 
+    def adapted_owners(self, owner, states, nranks, adapted):
+        """Rank of every leaf of `adapted` (a Grid built from self.adapted_leaves(states)) after MeshAdaptation::Adapt and the
+        LoadBalancer on `nranks` ranks, given the rank of every leaf of this mesh (cup3d_grid_adapted_owners)."""
+        ow = np.ascontiguousarray(owner, dtype=np.int32)
+        st = np.ascontiguousarray(states, dtype=np.int8)
+        out = np.zeros(adapted.nblocks, dtype=np.int32)
+        check(lib().cup3d_grid_adapted_owners(self.handle, ow.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), int(nranks),
+                                              adapted.handle, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def interface(self):
         """Multi-level meshes: (faces[ne,2] = 6*slot+face, kind; fine4[ne,4]; nbr27[nb,27]), see cup3d_grid_interface."""
         ne = lib().cup3d_grid_ninterface_faces(self.handle)

@@ -85,6 +85,14 @@ int cup3d_grid_interface(const cup3d_grid_t *, int32_t *faces2, int32_t *fine4, 
  * always of the multi-level kind); cup3d_adapt_transfer (below) moves the field data. */
 int cup3d_grid_valid_states(const cup3d_grid_t *, signed char *states);
 int cup3d_grid_adapted(const cup3d_grid_t *, const signed char *states, cup3d_grid_t **out);
+/* Ownership of the adapted mesh's leaves on several ranks = what MeshAdaptation::Adapt + LoadBalancer (main.cpp:4660-5022, 5086-5159)
+ * leave behind: children on the refined parent's rank, a compressed octet's parent on the rank of its base block (even indices;
+ * PrepareCompression 4729-4804), then Balance_Diffusion (4805-4905: (my - neighbour)/4 blocks to each neighbour) or, when
+ * max/min > 1.01 or a rank is empty, Balance_Global (4906-5021: even cut of the rank-major order).  `mesh`: all leaves of all ranks
+ * (cup3d_grid_create_mesh), owner[nblocks] their ranks, states the valid states, adapted = cup3d_grid_adapted(mesh, states);
+ * new_owner[nblocks of adapted].  Integer contract for the multi-rank multi-level path (block migration itself is not built yet). */
+int cup3d_grid_adapted_owners(const cup3d_grid_t *mesh, const int32_t *owner, const signed char *states, int nranks,
+                              const cup3d_grid_t *adapted, int32_t *new_owner);
 void cup3d_grid_destroy(cup3d_grid_t *);
 long cup3d_grid_nblocks(const cup3d_grid_t *);        /* local blocks = m_vInfo.size() */
 long cup3d_grid_nblocks_global(const cup3d_grid_t *);

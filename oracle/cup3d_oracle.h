@@ -133,6 +133,8 @@ void orc_mesh_update_tmpv(const orc_mesh *, double *tmpV, const double *chi_fiel
  * on the adapted mesh (RefineBlocks 5493-5565 from the old mesh's tensorial tiles, compress 5272-5329, copies) */
 void orc_mesh_valid_states(const orc_mesh *, signed char *states);
 long orc_mesh_adapted_leaves(const orc_mesh *, const signed char *states, int *levels, long long *Zs);
+/* ownership of the adapted mesh's leaves on several ranks (LoadBalancer, main.cpp:4660-5022) */
+void orc_mesh_adapted_owners(const orc_mesh *old_mesh, const int *owner, const signed char *states, int nranks, const orc_mesh *new_mesh, int *new_owner);
 void orc_mesh_transfer(const orc_mesh *old_mesh, const orc_mesh *new_mesh, const double *f_old, double *f_new, int nc, int is_vector); /* octree states of the 27 neighbour positions of every block */
 #ifdef __cplusplus
 }

@@ -1255,6 +1255,68 @@ long orc_mesh_adapted_leaves(const orc_mesh *m, const signed char *st, int *leve
   return n;
 }
 
+/* Block ownership after MeshAdaptation::Adapt on several ranks (main.cpp:5086-5159 + LoadBalancer 4660-5022).
+ * `mo` = the old mesh (all leaves of all ranks, m_vInfo order), owner[b] = rank of leaf b (ranks own contiguous runs of the
+ * order), st = valid states, `mn` = the adapted mesh; new_owner[slot of mn] receives the rank after the adaptation:
+ *   - the children of a refined block are created on the parent's rank (refine_1/refine_2, 5227-5271);
+ *   - the eight siblings of a compressed octet are first gathered on the rank of the base block, the one with even indices
+ *     (PrepareCompression 4729-4804), so the parent appears there;
+ *   - Balance_Diffusion (4805-4905) with the block counts after the adaptation: if max/min > 1.01 (or a rank is empty) ->
+ *     Balance_Global (4906-5021): the rank-major concatenation of the sorted per-rank lists is cut into `size` pieces, the first
+ *     total % size one block longer; else each rank passes (my - neighbour)/4 blocks (C integer division) from the start of
+ *     its sorted list to the left neighbour / from the end to the right one.
+ * Pinned against the reference run under a real MPI (tests/golden/adapt_mpi.npz). */
+static int cmp_long(const void *a, const void *b) { const long x = *(const long *)a, y = *(const long *)b; return (x > y) - (x < y); }
+void orc_mesh_adapted_owners(const orc_mesh *mo, const int *owner, const signed char *st, int nranks, const orc_mesh *mn, int *new_owner) {
+  long **list = (long **)calloc(nranks, sizeof(long *));
+  long *cnt = (long *)calloc(nranks, sizeof(long));
+  for (int r = 0; r < nranks; r++) list[r] = (long *)malloc(sizeof(long) * (mn->nblocks + 1));
+  for (long b = 0; b < mo->nblocks; b++) {
+    const int l = mo->level[b], *idx = &mo->index[3 * b], r = owner[b];
+    if (st[b] == 1) {
+      for (int q = 0; q < 8; q++) {
+        const int c[3] = {2 * idx[0] + (q & 1), 2 * idx[1] + ((q >> 1) & 1), 2 * idx[2] + (q >> 2)};
+        list[r][cnt[r]++] = leaf_at(mn, l + 1, c);
+      }
+    } else if (st[b] == -1) {
+      if (idx[0] % 2 == 0 && idx[1] % 2 == 0 && idx[2] % 2 == 0) {
+        const int c[3] = {idx[0] / 2, idx[1] / 2, idx[2] / 2};
+        list[r][cnt[r]++] = leaf_at(mn, l - 1, c);
+      }
+    } else
+      list[r][cnt[r]++] = leaf_at(mn, l, idx);
+  }
+  long mx = cnt[0], mi = cnt[0], total = 0;
+  for (int r = 0; r < nranks; r++) {
+    qsort(list[r], cnt[r], sizeof(long), cmp_long); /* slots of mn are in blockID_2 order */
+    if (cnt[r] > mx) mx = cnt[r];
+    if (cnt[r] < mi) mi = cnt[r];
+    total += cnt[r];
+  }
+  if (mi == 0 || (double)mx / mi > 1.01) { /* 4817-4820 */
+    long pos = 0;
+    int r = 0;
+    long left = total / nranks + (0 < total % nranks ? 1 : 0);
+    for (int q = 0; q < nranks; q++)
+      for (long i = 0; i < cnt[q]; i++) {
+        while (left == 0) { r++; left = total / nranks + (r < total % nranks ? 1 : 0); }
+        new_owner[list[q][i]] = r;
+        left--;
+        pos++;
+      }
+  } else {
+    for (int r = 0; r < nranks; r++)
+      for (long i = 0; i < cnt[r]; i++) new_owner[list[r][i]] = r;
+    for (int r = 0; r < nranks; r++) {
+      const long fl = r == 0 ? 0 : (cnt[r] - cnt[r - 1]) / 4, fr = r == nranks - 1 ? 0 : (cnt[r] - cnt[r + 1]) / 4; /* 4836-4839 */
+      for (long i = 0; i < fl; i++) new_owner[list[r][i]] = r - 1;
+      for (long i = 0; i < fr; i++) new_owner[list[r][cnt[r] - 1 - i]] = r + 1;
+    }
+  }
+  for (int r = 0; r < nranks; r++) free(list[r]);
+  free(list); free(cnt);
+}
+
 /* field data on the adapted mesh (refine_1 + RefineBlocks 5227-5249, 5493-5565 from the parent's tensorial [-1,2) tile on
  * the OLD mesh; compress 5272-5329; unchanged blocks copied) */
 void orc_mesh_transfer(const orc_mesh *mo, const orc_mesh *mn, const double *fo, double *fn, int nc, int is_vector) {

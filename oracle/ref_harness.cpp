@@ -292,8 +292,15 @@ int main(int argc, char **argv) {
       Field F = field_of(sd, fname);
       auto buf = read_file(path);
       const size_t per = 512 * F.ncomp;
-      if (buf.size() != F.infos->size() * per * 8) { fprintf(stderr, "loadb %s: size mismatch\n", fname.c_str()); exit(2); }
-      for (size_t i = 0; i < F.infos->size(); i++) memcpy((*F.infos)[i].block, buf.data() + i * per * 8, per * 8);
+      /* several ranks: the file holds all blocks in rank-major (= global blockID_2) order; this rank's slice starts after the
+         blocks of the lower ranks */
+      std::vector<long long> counts(::sim.size, 0);
+      long long mine = (long long)F.infos->size();
+      MPI_Allgather(&mine, 1, MPI_LONG_LONG, counts.data(), 1, MPI_LONG_LONG, MPI_COMM_WORLD);
+      size_t first = 0, total = 0;
+      for (int r = 0; r < ::sim.size; r++) { if (r < ::sim.rank) first += counts[r]; total += counts[r]; }
+      if (buf.size() != total * per * 8) { fprintf(stderr, "loadb %s: size mismatch\n", fname.c_str()); exit(2); }
+      for (size_t i = 0; i < F.infos->size(); i++) memcpy((*F.infos)[i].block, buf.data() + (first + i) * per * 8, per * 8);
     } else if (cmd == "obstacle") {
       /* `obstacle <file>`: add ONE synthetic obstacle (the reference's own obstacles are fish whose geometry needs GSL): a
          plain Obstacle whose ObstacleBlocks (7256-7263: chi[8][8][8], udef[8][8][8][3]) are read from the file together with its

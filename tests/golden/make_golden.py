@@ -366,6 +366,78 @@ def partition_cases():
     np.savez_compressed(os.path.join(HERE, "partition_mpi.npz"), **out)
 
 
+def _mpi_tables(wd, name, n):
+    return [O.read_tables(os.path.join(wd, f"{name}.r{r}"))[0] for r in range(n)]
+
+
+def _octet_threshold(t, linf, k):
+    mx = {}
+    for row, v in zip(t, linf):
+        key = (int(row[0]), int(row[2]) // 2, int(row[3]) // 2, int(row[4]) // 2)
+        mx[key] = max(mx.get(key, 0.0), float(v))
+    s = sorted(mx.values())
+    return float(np.sqrt(s[k - 1] * s[k]))
+
+
+def adapt_mpi_cases():
+    """Block ownership after Simulation::adaptMesh on several ranks of a REAL MPI (oracle/_ref/ref_tool_mpi): per transition the
+    global block table before and after with the owner rank of every block.  Covers refinement (children stay), compression of
+    octets that straddle ranks (PrepareCompression), Balance_Global and the Balance_Diffusion path (max/min <= 1.01)."""
+    out, k = {}, 0
+
+    def store(bpd, lmax, bc, n, T0, T1, what):
+        nonlocal k
+        old, new = np.concatenate(T0), np.concatenate(T1)
+        assert np.all(np.diff(old[:, 5]) > 0) and np.all(np.diff(new[:, 5]) > 0)      # ranks own contiguous runs of the global order
+        out[f"t{k}_meta"] = np.array(list(bpd) + [lmax] + [O.BC[b] for b in bc] + [n])
+        out[f"t{k}_old"], out[f"t{k}_new"] = old, new
+        out[f"t{k}_old_owner"] = np.concatenate([np.full(len(t), r, dtype=np.int32) for r, t in enumerate(T0)])
+        out[f"t{k}_new_owner"] = np.concatenate([np.full(len(t), r, dtype=np.int32) for r, t in enumerate(T1)])
+        print("adapt_mpi", k, what, bpd, lmax, n, [len(t) for t in T0], "->", [len(t) for t in T1], "levels", np.bincount(old[:, 0]), "->", np.bincount(new[:, 0]))
+        k += 1
+
+    # refinement only, from the Gaussian vortex
+    for bpd, lmax, bc, n, passes, rtol in (((2, 2, 2), 3, ("periodic", "wall", "freespace"), 3, 2, 2.0), ((3, 2, 2), 4, ("periodic", "freespace", "wall"), 5, 3, 1.0)):
+        wd = O.tempfile.mkdtemp(prefix="golden_")
+        script = amr_mesh_script(wd, bpd, 0, rtol) + ["tables t0.bin"]
+        for p in range(passes):
+            script += ["adapt", "zero chi", f"tables t{p + 1}.bin"]
+        O.run_ref_mpi(script, O.ref_args(bpd, lmax, 0, EXT, bc), n, workdir=wd)
+        T = [_mpi_tables(wd, f"t{p}.bin", n) for p in range(passes + 1)]
+        for p in range(passes):
+            store(bpd, lmax, bc, n, T[p], T[p + 1], "refine")
+    # refinement + compression / compression only, from block-ordered fields loaded into the mesh of a first run
+    for bpd, lmax, bc, n, pre_passes, lstart, seed, mode in (((2, 2, 2), 3, ("freespace", "wall", "periodic"), 3, 2, 0, 12, "octets"),
+                                                             ((2, 2, 2), 4, ("periodic",) * 3, 5, 0, 3, 9, "dip1"),
+                                                             ((2, 2, 2), 4, ("periodic", "wall", "freespace"), 4, 0, 3, 7, "dip1"),
+                                                             ((2, 2, 2), 4, ("periodic",) * 3, 3, 0, 3, 11, "dip40"),
+                                                             ((1, 2, 2), 4, ("wall", "periodic", "periodic"), 7, 0, 3, 13, "dip150")):
+        wd = O.tempfile.mkdtemp(prefix="golden_")
+        pre = amr_mesh_script(wd, bpd, pre_passes) if lstart == 0 else ["zero chi"]
+        args = O.ref_args(bpd, lmax, lstart, EXT, bc)
+        O.run_ref_mpi(pre + ["tables t.bin"], args, n, workdir=wd)
+        T0 = _mpi_tables(wd, "t.bin", n)
+        t = np.concatenate(T0)
+        rng = np.random.default_rng(seed)
+        if mode == "octets":
+            vel, _ = octet_fields(t, seed)
+        else:  # a smooth amplitude dip around one block: the vorticity of a random field scales with the local amplitude
+            h = EXT / (8 * max(bpd) * 2 ** t[:, 0].astype(float))
+            ctr = (t[:, 2:5] + 0.5) * 8 * h[:, None]
+            d = np.abs(ctr - ctr[rng.integers(len(t))])
+            d = np.minimum(d, EXT - d)
+            amp = 1.0 - 0.999 * np.exp(-(d ** 2).sum(axis=1) / ((3 if mode == "dip1" else 8) * 8 * h) ** 2)
+            vel = rng.uniform(-1, 1, (len(t), 8, 8, 8, 3)) * amp[:, None, None, None, None]
+        vel.tofile(os.path.join(wd, "velb.bin"))
+        O.run_ref_mpi(pre + ["loadb vel velb.bin", "op vorticity", "dump tmpV w.bin"], args, n, workdir=wd)
+        w = np.concatenate([O.read_blocks(os.path.join(wd, f"w.bin.r{r}"), len(T0[r]), 3) for r in range(n)])
+        linf = np.sqrt((w ** 2).sum(axis=-1)).reshape(len(t), -1).max(axis=1)
+        rt, ct = (float(np.quantile(linf, 0.75)), float(np.quantile(linf, 0.4))) if mode == "octets" else (1e9, _octet_threshold(t, linf, int(mode[3:])))
+        O.run_ref_mpi(pre + ["loadb vel velb.bin", f"amrtol {rt!r} {ct!r}", "adapt", "tables t2.bin"], args, n, workdir=wd)
+        store(bpd, lmax, bc, n, T0, _mpi_tables(wd, "t2.bin", n), mode)
+    np.savez_compressed(os.path.join(HERE, "adapt_mpi.npz"), **out)
+
+
 def sfc_cases():
     out = {}
     for bpd, lmax in SFC_CASES:
@@ -392,3 +464,4 @@ if __name__ == "__main__":
     implicit_cases()
     if O.have_ref_tool_mpi():
         partition_cases()
+        adapt_mpi_cases()

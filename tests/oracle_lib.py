@@ -109,6 +109,7 @@ def lib():
     L.orc_mesh_adapted_leaves.restype = C.c_long
     L.orc_mesh_adapted_leaves.argtypes = [vp, _bp, _ip, _lp]
     L.orc_mesh_transfer.argtypes = [vp, vp, _dp, _dp, C.c_int, C.c_int]
+    L.orc_mesh_adapted_owners.argtypes = [vp, _ip, _bp, C.c_int, vp, _ip]
     L.orc_mesh_vorticity.argtypes = [vp, _dp, _dp]
     L.orc_mesh_tag.argtypes = [vp, _dp, C.c_int, C.c_double, C.c_double, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]
     L.orc_mesh_project_obst.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.POINTER(SolveInfo), C.c_long, _lp, _dp, _dp]
@@ -323,6 +324,12 @@ class OracleMesh:
         lv, zs = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int64)
         n = lib().orc_mesh_adapted_leaves(self.m, st, lv, zs)
         return OracleMesh(self.bpd, self.level_max, self.maxextent, self.bc, lv[:n], zs[:n])
+
+    def adapted_owners(self, owner, states, nranks, new_mesh):
+        """Rank of every leaf of `new_mesh` (= self.adapted(states)) after MeshAdaptation::Adapt + LoadBalancer on `nranks` ranks."""
+        out = np.zeros(new_mesh.nb, dtype=np.int32)
+        lib().orc_mesh_adapted_owners(self.m, np.ascontiguousarray(owner, dtype=np.int32), np.ascontiguousarray(states, dtype=np.int8), nranks, new_mesh.m, out)
+        return out
 
     def transfer(self, new_mesh, field):
         nc = 3 if field.ndim == 5 else 1

@@ -319,3 +319,39 @@ def test_block_tables_for_every_small_box_shape():
             g = cu.Grid(bpd, lmax, lev, 1.0, (1, 1, 1))
             o = O.OracleGrid(bpd, lmax, lev, 1.0, (1, 1, 1))
             assert np.array_equal(g.tables, o.tables), (bpd, lmax, lev)
+
+
+def _states_from_tables(old, new):
+    """Valid states of the old leaves implied by the new leaf set: still there -> Leave, children there -> Refine, else Compress."""
+    have = {(int(r[0]), int(r[2]), int(r[3]), int(r[4])) for r in new}
+    st = np.zeros(len(old), dtype=np.int8)
+    for b, (l, _, i, j, k, _) in enumerate(old):
+        if (int(l), int(i), int(j), int(k)) in have:
+            continue
+        st[b] = 1 if (int(l) + 1, 2 * int(i), 2 * int(j), 2 * int(k)) in have else -1
+    return st
+
+
+def test_block_ownership_after_adaptation_equals_the_reference_under_real_mpi(golden_dir):
+    """tests/golden/adapt_mpi.npz: Simulation::adaptMesh of the reference on 3-7 ranks of a real MPI.  The owner rank of every block
+    of the adapted mesh -- children with the refined parent, compressed octets gathered on the base block's rank, Balance_Global
+    and Balance_Diffusion of the LoadBalancer (main.cpp:4660-5022) -- from cup3d_grid_adapted_owners and from the oracle."""
+    z = np.load(os.path.join(golden_dir, "adapt_mpi.npz"))
+    k, modes = 0, set()
+    while f"t{k}_meta" in z:
+        bx, by, bz, lmax, b0, b1, b2, nranks = (int(v) for v in z[f"t{k}_meta"])
+        old, new, ow_old, ow_new = z[f"t{k}_old"], z[f"t{k}_new"], z[f"t{k}_old_owner"], z[f"t{k}_new_owner"]
+        st = _states_from_tables(old, new)
+        g_old = cu.Grid((bx, by, bz), lmax, 0, 1.0, (b0, b1, b2), leaves=(old[:, 0].astype(np.int32), old[:, 1].copy()))
+        lv, zs = g_old.adapted_leaves(st)
+        g_new = cu.Grid((bx, by, bz), lmax, 0, 1.0, (b0, b1, b2), leaves=(lv, zs))
+        assert np.array_equal(g_new.tables, new), k              # the adapted block list itself (integer contract, one more pin)
+        assert np.array_equal(g_old.adapted_owners(ow_old, st, nranks, g_new), ow_new), k
+        m_old = O.OracleMesh((bx, by, bz), lmax, 1.0, (b0, b1, b2), old[:, 0], old[:, 1])
+        m_new = m_old.adapted(st)
+        assert np.array_equal(m_new.tables, new) and np.array_equal(m_old.adapted_owners(ow_old, st, nranks, m_new), ow_new), k
+        cnt = np.bincount(ow_new, minlength=nranks)
+        modes.add("even" if cnt.max() - cnt.min() <= 1 else "diffusion")
+        modes.add("compress" if (st == -1).any() else "refine")
+        k += 1
+    assert k >= 10 and modes == {"even", "diffusion", "compress", "refine"}
