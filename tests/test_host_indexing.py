@@ -177,6 +177,16 @@ def test_bad_arguments_are_reported():
     assert b"bpd" in L.cup3d_last_error()
     ok = np.array([1, 1, 1], dtype=np.int32)
     assert L.cup3d_grid_create_uniform(ok, 1, 0, 1.0, bc, 0, 2, C.byref(h)) == -1   # fewer blocks than ranks
+    # a NULL handle is rejected before anything touches the device (no GPU needed): status code, no crash
+    u = np.zeros(3)
+    assert L.cup3d_advect_diffuse(None, 0.1, 0.1, u) == -1
+    assert L.cup3d_advect_diffuse_implicit(None, 0.1, 0.1, u, None, None) == -1
+    assert L.cup3d_advect_implicit(None, 0.1, 0.1, u) == -1
+    assert L.cup3d_diffusion_rhs(None) == -1 and L.cup3d_diffusion_lhs(None, 0, 0.1, 0.1) == -1
+    assert L.cup3d_diffusion_preconditioner(None, 0.1, 0.1) == -1 and L.cup3d_diffusion_solve(None, 0, 0.1, 0.1, None, None) == -1
+    assert L.cup3d_penalization(None, 0.1, 1.0, 1, 0, None) == -1 and L.cup3d_update_tmpv(None, 0, None) == -1
+    assert L.cup3d_sim_upload_block_list(None, 0, 0, None, None) == -1 and L.cup3d_sim_download_block_list(None, 0, 0, None, None) == -1
+    assert L.cup3d_grid_adapted_owners(None, None, None, 2, None, None) == -1
 
 
 def test_compute_fails_loudly_without_gpu():
