@@ -84,6 +84,50 @@ int cup3d_grid_interface(const cup3d_grid_t *gh, int32_t *faces2, int32_t *fine4
   if (nbr27) memcpy(nbr27, g->nbr27.data(), g->nbr27.size() * sizeof(int32_t));
   return CUP3D_OK;
 }
+int cup3d_grid_rank_view(const cup3d_grid_t *gh, const int32_t *owner, int rank, int nranks, cup3d_grid_t **out) {
+  if (!gh || !owner || !out) return CUP3D_EINVAL;
+  const Grid *g = reinterpret_cast<const Grid *>(gh);
+  try {
+    std::unique_ptr<Grid> tmp;
+    const Grid *m = g;
+    if (!g->multilevel) { tmp = g->as_mesh(); m = tmp.get(); }
+    *out = reinterpret_cast<cup3d_grid_t *>(m->rank_view(owner, rank, nranks).release());
+  } catch (const std::exception &e) {
+    set_error("cup3d_grid_rank_view: %s", e.what());
+    return CUP3D_EINVAL;
+  }
+  return CUP3D_OK;
+}
+int cup3d_grid_view_sizes(const cup3d_grid_t *gh, long out[6]) {
+  if (!gh || !out) return CUP3D_EINVAL;
+  const Grid *g = reinterpret_cast<const Grid *>(gh);
+  if (g->n_local < 0) { set_error("cup3d_grid_view_sizes: not a rank view"); return CUP3D_EINVAL; }
+  out[0] = (long)g->n_local;
+  out[1] = (long)g->nghost();
+  out[2] = (long)g->n_local_faces;
+  out[3] = (long)(g->n_amr_faces() - g->n_local_faces);
+  out[4] = (long)g->send_blocks.size();
+  out[5] = (long)g->send_flux_faces.size();
+  return CUP3D_OK;
+}
+int cup3d_grid_view_plan(const cup3d_grid_t *gh, int32_t *global_slot, int32_t *global_face, int32_t *send_blocks, long *send_block_count,
+                         long *recv_block_count, int32_t *send_flux_faces, long *send_flux_count, long *recv_flux_count) {
+  if (!gh) return CUP3D_EINVAL;
+  const Grid *g = reinterpret_cast<const Grid *>(gh);
+  if (g->n_local < 0) { set_error("cup3d_grid_view_plan: not a rank view"); return CUP3D_EINVAL; }
+  auto cp = [](int32_t *dst, const std::vector<int32_t> &v) { if (dst && !v.empty()) memcpy(dst, v.data(), v.size() * sizeof(int32_t)); };
+  cp(global_slot, g->global_slot);
+  cp(global_face, g->global_face);
+  cp(send_blocks, g->send_blocks);
+  cp(send_flux_faces, g->send_flux_faces);
+  for (int p = 0; p < g->nranks; ++p) {
+    if (send_block_count) send_block_count[p] = (long)g->send_block_count[p];
+    if (recv_block_count) recv_block_count[p] = (long)g->recv_block_count[p];
+    if (send_flux_count) send_flux_count[p] = (long)g->send_flux_count[p];
+    if (recv_flux_count) recv_flux_count[p] = (long)g->recv_flux_count[p];
+  }
+  return CUP3D_OK;
+}
 int cup3d_grid_valid_states(const cup3d_grid_t *gh, signed char *states) {
   if (!gh || !states) return CUP3D_EINVAL;
   const Grid *g = reinterpret_cast<const Grid *>(gh);

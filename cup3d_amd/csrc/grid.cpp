@@ -242,6 +242,147 @@ Grid::Grid(const int bpd_[3], int level_max_, double maxextent_, const int bc_[3
   slot_of_z.clear();
 }
 
+Grid::Grid(const Grid &p, int)
+    : level_max(p.level_max), level(p.level), maxextent(p.maxextent), h(p.h), rank(0), nranks(1), total_blocks(p.total_blocks), z_begin(0),
+      z_count(p.z_count) {
+  for (int d = 0; d < 3; ++d) { bpd[d] = p.bpd[d]; bc[d] = p.bc[d]; nbd[d] = p.nbd[d]; }
+  sfc.reset(new HilbertCurve(bpd[0], bpd[1], bpd[2], level_max));
+  multilevel = true;
+  send_count.assign(1, 0);
+  recv_count.assign(1, 0);
+}
+
+// One rank's view of this (global, multi-level) mesh: see grid.hpp.  The tables are the global ones renumbered, so what a kernel
+// reads through them on rank r is what it reads on one rank -- provided the ghost blocks / ghost face fluxes hold the owners' data,
+// which is what the two exchange plans are for.  (In the reference every rank keeps the whole octree too: Grid::Octree with the
+// owner in TreePosition, main.cpp:815-855; SynchronizerMPI_AMR::_Setup 1979-2286 derives its messages from it.)
+std::unique_ptr<Grid> Grid::rank_view(const int32_t *owner, int rank_, int nranks_) const {
+  if (!multilevel || n_local >= 0) throw std::invalid_argument("rank_view needs a global multi-level mesh");
+  if (!owner || nranks_ < 1 || rank_ < 0 || rank_ >= nranks_) throw std::invalid_argument("bad rank / nranks");
+  const int64_t nb = nblocks(), ne = n_amr_faces();
+  for (int64_t s = 0; s < nb; ++s)
+    if (owner[s] < 0 || owner[s] >= nranks_) throw std::invalid_argument("owner out of range");
+  // which leaves / fine faces does a rank need from others?  needed_by[s] = bit set of ranks (<= 64 ranks per node group is
+  // plenty here; use a vector<bool> matrix for generality)
+  auto view_of = [&](int r, std::vector<int32_t> &ghost, std::vector<int32_t> &gfaces) {
+    std::vector<char> want(nb, 0), wantf(ne, 0);
+    for (int64_t s = 0; s < nb; ++s) {
+      if (owner[s] != r) continue;
+      for (int c = 0; c < 27; ++c) {
+        const int32_t v = nbr27[27 * s + c];
+        if (v >= kNbrCoarser) { if (owner[v - kNbrCoarser] != r) want[v - kNbrCoarser] = 1; }
+        else if (v >= 0 && owner[v] != r) want[v] = 1;
+      }
+    }
+    for (int64_t e = 0; e < ne; ++e) {
+      const int64_t s = amr_faces[2 * e] / 6;
+      if (owner[s] != r || amr_faces[2 * e + 1] != 1) continue;
+      for (int B = 0; B < 4; ++B) {
+        const int32_t fe = amr_fine[4 * e + B];
+        const int32_t fs = amr_faces[2 * fe] / 6;
+        if (owner[fs] != r) { want[fs] = 1; wantf[fe] = 1; }
+      }
+    }
+    ghost.clear();
+    gfaces.clear();
+    for (int p = 0; p < nranks_; ++p) {  // (owner, global order)
+      if (p == r) continue;
+      for (int64_t s = 0; s < nb; ++s) if (want[s] && owner[s] == p) ghost.push_back((int32_t)s);
+      for (int64_t e = 0; e < ne; ++e) if (wantf[e] && owner[amr_faces[2 * e] / 6] == p) gfaces.push_back((int32_t)e);
+    }
+  };
+  std::vector<int32_t> ghost, gfaces;
+  view_of(rank_, ghost, gfaces);
+
+  std::unique_ptr<Grid> v(new Grid(*this, 0));
+  Grid &V = *v;
+  V.rank = rank_;
+  V.nranks = nranks_;
+  V.send_count.assign(nranks_, 0);  // no face-slab plan: everything remote arrives as ghost blocks
+  V.recv_count.assign(nranks_, 0);
+  // slot maps
+  std::vector<int32_t> local;
+  for (int64_t s = 0; s < nb; ++s) if (owner[s] == rank_) local.push_back((int32_t)s);
+  if (local.empty()) throw std::invalid_argument("a rank without blocks");
+  V.n_local = (int64_t)local.size();
+  V.global_slot = local;
+  V.global_slot.insert(V.global_slot.end(), ghost.begin(), ghost.end());
+  std::vector<int32_t> to_view(nb, -1);
+  for (size_t i = 0; i < V.global_slot.size(); ++i) to_view[V.global_slot[i]] = (int32_t)i;
+  const size_t nv = V.global_slot.size();
+  V.Z.resize(nv); V.id2.resize(nv); V.index.resize(3 * nv); V.blevel.resize(nv); V.hb.resize(nv);
+  V.at_.assign(level_max, std::vector<int32_t>());
+  for (int l = 0; l < level_max; ++l) V.at_[l].assign(at_[l].size(), -1);
+  for (size_t i = 0; i < nv; ++i) {
+    const int32_t g = V.global_slot[i];
+    V.Z[i] = Z[g]; V.id2[i] = id2[g]; V.blevel[i] = blevel[g]; V.hb[i] = hb[g];
+    for (int d = 0; d < 3; ++d) V.index[3 * i + d] = index[3 * g + d];
+  }
+  for (int l = 0; l < level_max; ++l)
+    for (size_t k = 0; k < at_[l].size(); ++k)
+      if (at_[l][k] >= 0 && to_view[at_[l][k]] >= 0) V.at_[l][k] = to_view[at_[l][k]];
+  V.ghost_owner.resize(ghost.size());
+  for (size_t i = 0; i < ghost.size(); ++i) V.ghost_owner[i] = owner[ghost[i]];
+  // interface faces: local ones in global order, then the ghost fine faces
+  std::vector<int32_t> face_to_view(ne, -1);
+  V.global_face.clear();
+  for (int64_t e = 0; e < ne; ++e)
+    if (owner[amr_faces[2 * e] / 6] == rank_) { face_to_view[e] = (int32_t)V.global_face.size(); V.global_face.push_back((int32_t)e); }
+  V.n_local_faces = (int64_t)V.global_face.size();
+  for (int32_t e : gfaces) { face_to_view[e] = (int32_t)V.global_face.size(); V.global_face.push_back(e); }
+  const size_t nfv = V.global_face.size();
+  V.amr_faces.resize(2 * nfv);
+  V.amr_fine.assign(4 * nfv, -1);
+  for (int d = 0; d < 3; ++d) V.fix_faces[d].clear();
+  for (size_t i = 0; i < nfv; ++i) {
+    const int32_t e = V.global_face[i];
+    const int32_t gs = amr_faces[2 * e] / 6, f = amr_faces[2 * e] % 6;
+    V.amr_faces[2 * i] = 6 * to_view[gs] + f;
+    V.amr_faces[2 * i + 1] = amr_faces[2 * e + 1];
+    if ((int64_t)i < V.n_local_faces && amr_faces[2 * e + 1] == 1) {
+      V.fix_faces[f >> 1].push_back((int32_t)i);
+      for (int B = 0; B < 4; ++B) V.amr_fine[4 * i + B] = face_to_view[amr_fine[4 * e + B]];
+    }
+  }
+  // neighbour tables of the local blocks
+  V.nbr.assign(6 * (size_t)V.n_local, 0);
+  V.nbr27.assign(27 * (size_t)V.n_local, kNbrSkipped);
+  V.corner_slot = -1;
+  for (int64_t i = 0; i < V.n_local; ++i) {
+    const int32_t g = local[i];
+    if (g == corner_slot) V.corner_slot = (int32_t)i;
+    for (int c = 0; c < 27; ++c) {
+      const int32_t x = nbr27[27 * (size_t)g + c];
+      V.nbr27[27 * i + c] = x >= kNbrCoarser ? kNbrCoarser + to_view[x - kNbrCoarser] : (x >= 0 ? to_view[x] : x);
+    }
+    for (int f = 0; f < 6; ++f) {
+      const int32_t x = nbr[6 * (size_t)g + f];
+      V.nbr[6 * i + f] = x >= kNbrHalo ? kNbrHalo + face_to_view[x - kNbrHalo] : (x >= 0 ? to_view[x] : x);
+    }
+  }
+  V.inner.resize(V.n_local);
+  for (int64_t i = 0; i < V.n_local; ++i) V.inner[i] = (int32_t)i;
+  V.boundary.clear();
+  V.total_blocks = nb;
+  // exchange plans: what I receive from p is the (p-owned) part of my ghost list; what I send to p is the (me-owned) part of p's
+  V.recv_block_count.assign(nranks_, 0);
+  V.recv_flux_count.assign(nranks_, 0);
+  for (int32_t g : ghost) V.recv_block_count[owner[g]]++;
+  for (int32_t e : gfaces) V.recv_flux_count[owner[amr_faces[2 * e] / 6]]++;
+  V.send_block_count.assign(nranks_, 0);
+  V.send_flux_count.assign(nranks_, 0);
+  V.send_blocks.clear();
+  V.send_flux_faces.clear();
+  std::vector<int32_t> pg, pf;
+  for (int p = 0; p < nranks_; ++p) {
+    if (p == rank_) continue;
+    view_of(p, pg, pf);
+    for (int32_t g : pg) if (owner[g] == rank_) { V.send_blocks.push_back(to_view[g]); V.send_block_count[p]++; }
+    for (int32_t e : pf) if (owner[amr_faces[2 * e] / 6] == rank_) { V.send_flux_faces.push_back(face_to_view[e]); V.send_flux_count[p]++; }
+  }
+  return v;
+}
+
 int32_t Grid::leaf(int l, const int c[3]) const {
   if (l < 0 || l >= level_max || at_.empty()) return -1;
   int w[3];
@@ -258,6 +399,7 @@ std::unique_ptr<Grid> Grid::as_mesh() const {
 
 void Grid::valid_states(int8_t *st) const {
   if (!multilevel) throw std::invalid_argument("valid_states needs a multi-level mesh object (Grid::as_mesh)");
+  if (n_local >= 0) throw std::invalid_argument("valid_states needs the global mesh, not one rank's view");
   const int64_t nb = nblocks();
   for (int64_t b = 0; b < nb; ++b)
     if ((st[b] == 1 && blevel[b] == level_max - 1) || (st[b] == -1 && blevel[b] == 0)) st[b] = 0;
@@ -310,6 +452,7 @@ void Grid::valid_states(int8_t *st) const {
 
 void Grid::adapted_leaves(const int8_t *st, std::vector<int32_t> &levels, std::vector<int64_t> &Zs) const {
   if (!multilevel) throw std::invalid_argument("adapted_leaves needs a multi-level mesh object (Grid::as_mesh)");
+  if (n_local >= 0) throw std::invalid_argument("adapted_leaves needs the global mesh, not one rank's view");
   levels.clear();
   Zs.clear();
   for (int64_t b = 0; b < nblocks(); ++b) {

@@ -82,7 +82,27 @@ struct Grid {
   // (domain face with a boundary condition, BlockLab::load 3696-3701), -2 = owned by another rank
   std::vector<int32_t> neighbours27() const;
 
-  int64_t nblocks() const { return (int64_t)Z.size(); }
+  int64_t nblocks() const { return n_local >= 0 ? n_local : (int64_t)Z.size(); }
+
+  // ---- one rank's view of a multi-level mesh that is spread over several ranks (rank_view).  Block slots [0, n_local) are the
+  // rank's own leaves (global order), [n_local, n_local + nghost()) are GHOST leaves: every remote leaf a local block's tables
+  // refer to (same-level or coarser neighbours of the 27-point neighbourhood, finer leaves behind coarse/fine faces), ordered by
+  // (owner, global order) so that each peer's blocks arrive as one contiguous run.  Z/id2/index/blevel/hb cover all visible
+  // slots; nbr/nbr27 only the local ones.  Interface faces: the local blocks' faces first (n_local_faces, global order), then
+  // the fine faces of ghost blocks that local coarse-side faces need for the restriction and the flux correction, ordered by
+  // (owner, owner's face order).  -1 / empty on ordinary grids.
+  int64_t n_local = -1, n_local_faces = -1;
+  int64_t nghost() const { return n_local >= 0 ? (int64_t)Z.size() - n_local : 0; }
+  std::vector<int32_t> global_slot;   // [visible slots] slot in the global mesh
+  std::vector<int32_t> global_face;   // [interface faces of the view] interface-face index in the global mesh
+  std::vector<int32_t> ghost_owner;   // [nghost]
+  // exchange plans, peer-major: whole blocks before every stencil kernel, face-flux arrays after every flux-corrected one
+  std::vector<int32_t> send_blocks;       // local slots, in the receiver's ghost order
+  std::vector<int64_t> send_block_count, recv_block_count;   // [nranks]
+  std::vector<int32_t> send_flux_faces;   // local interface faces (fine side), in the receiver's ghost-face order
+  std::vector<int64_t> send_flux_count, recv_flux_count;     // [nranks]
+  std::unique_ptr<Grid> rank_view(const int32_t *owner, int rank, int nranks) const;
+  Grid(const Grid &proto, int basics_only);  // box, curve and spacing of `proto`, no blocks (used by rank_view)
   int owner_of(int64_t z) const;
   static void partition(int64_t total, int rank, int nranks, int64_t *begin, int64_t *count);
 };

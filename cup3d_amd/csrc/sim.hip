@@ -254,6 +254,10 @@ int cup3d_profile_read(cup3d_profile_entry *e, int max, int *n) {
 int cup3d_sim_create(const cup3d_grid_t *gh, cup3d_sim_t **out) {
   if (!gh || !out) return CUP3D_EINVAL;
   const Grid *g = reinterpret_cast<const Grid *>(gh);
+  if (g->n_local >= 0) {  // Grid::rank_view: the topology and the exchange plans exist, the device transport does not yet
+    set_error("multi-level meshes spread over several ranks: the ghost-block / face-flux exchange is not built on the device yet");
+    return CUP3D_ESTATE;
+  }
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess) { set_error("cup3d_sim_create: no HIP device (call cup3d_device_init first)"); return CUP3D_EDEVICE; }
   if (g->nranks > 1 && !comm() && !virtual_ranks()) { set_error("grid spans %d ranks but cup3d_comm_init was not called", g->nranks); return CUP3D_ESTATE; }

@@ -82,6 +82,11 @@ class Grid:
                                               adapted.handle, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def rank_view(self, owner, rank, nranks):
+        """One rank's view of this multi-level mesh when its leaves are spread over `nranks` ranks as owner[nblocks] says
+        (cup3d_grid_rank_view): a RankView with the renumbered tables and the ghost-block / face-flux exchange plans."""
+        return RankView(self, owner, rank, nranks)
+
     def interface(self):
         """Multi-level meshes: (faces[ne,2] = 6*slot+face, kind; fine4[ne,4]; nbr27[nb,27]), see cup3d_grid_interface."""
         ne = lib().cup3d_grid_ninterface_faces(self.handle)
@@ -115,6 +120,43 @@ class Grid:
     def scatter_to_global(self, blocks, glob):
         for s, (i, j, k) in enumerate(self.index):
             glob[8 * k:8 * k + 8, 8 * j:8 * j + 8, 8 * i:8 * i + 8] = blocks[s]
+
+
+class RankView:
+    """Host-side view of a multi-level mesh from one rank (Grid.rank_view): local blocks, ghost blocks, interface faces, neighbour tables
+    in the view's slot numbering, and the two exchange plans.  The device transport is not built yet (cup3d_sim_create refuses it)."""
+
+    def __init__(self, mesh, owner, rank, nranks):
+        ow = np.ascontiguousarray(owner, dtype=np.int32)
+        h = C.c_void_p()
+        check(lib().cup3d_grid_rank_view(mesh.handle, ow.ctypes.data_as(C.c_void_p), int(rank), int(nranks), C.byref(h)))
+        self.handle, self.rank, self.nranks = h, int(rank), int(nranks)
+        sz = (C.c_long * 6)()
+        check(lib().cup3d_grid_view_sizes(h, sz))
+        self.nlocal, self.nghost, self.nfaces_local, self.nfaces_ghost, nsb, nsf = (int(v) for v in sz)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        self.global_slot = np.zeros(self.nlocal + self.nghost, dtype=np.int32)
+        self.global_face = np.zeros(max(self.nfaces_local + self.nfaces_ghost, 1), dtype=np.int32)
+        self.send_blocks, self.send_flux_faces = np.zeros(max(nsb, 1), dtype=np.int32), np.zeros(max(nsf, 1), dtype=np.int32)
+        counts = [np.zeros(nranks, dtype=np.int64) for _ in range(4)]
+        check(lib().cup3d_grid_view_plan(h, p(self.global_slot), p(self.global_face), p(self.send_blocks), p(counts[0]), p(counts[1]),
+                                         p(self.send_flux_faces), p(counts[2]), p(counts[3])))
+        self.global_face = self.global_face[:self.nfaces_local + self.nfaces_ghost]
+        self.send_blocks, self.send_flux_faces = self.send_blocks[:nsb], self.send_flux_faces[:nsf]
+        self.send_block_count, self.recv_block_count, self.send_flux_count, self.recv_flux_count = counts
+        self.nbr = np.zeros((self.nlocal, 6), dtype=np.int32)
+        check(lib().cup3d_grid_neighbours(h, self.nbr.reshape(-1)))
+        nf = self.nfaces_local + self.nfaces_ghost
+        self.faces, self.fine = np.zeros((max(nf, 1), 2), dtype=np.int32), np.zeros((max(nf, 1), 4), dtype=np.int32)
+        self.nbr27 = np.zeros((self.nlocal, 27), dtype=np.int32)
+        check(lib().cup3d_grid_interface(h, p(self.faces), p(self.fine), p(self.nbr27)))
+        self.faces, self.fine = self.faces[:nf], self.fine[:nf]
+
+    def __del__(self):
+        try:
+            lib().cup3d_grid_destroy(self.handle)
+        except Exception:
+            pass
 
 
 class SimulationData:

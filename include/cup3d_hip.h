@@ -93,6 +93,20 @@ int cup3d_grid_adapted(const cup3d_grid_t *, const signed char *states, cup3d_gr
  * new_owner[nblocks of adapted].  Integer contract for the multi-rank multi-level path (block migration itself is not built yet). */
 int cup3d_grid_adapted_owners(const cup3d_grid_t *mesh, const int32_t *owner, const signed char *states, int nranks,
                               const cup3d_grid_t *adapted, int32_t *new_owner);
+/* One rank's view of a multi-level mesh whose leaves are spread over several ranks (what SynchronizerMPI_AMR::_Setup 1979-2286 and
+ * FluxCorrectionMPI::prepare 2680-2824 derive from the shared octree): block slots [0, nlocal) are the rank's own leaves, then GHOST
+ * leaves -- every remote leaf the neighbour tables of a local block refer to -- ordered by (owner, global order); interface faces:
+ * the local blocks' first, then the fine faces of ghost blocks whose fluxes / cells the local coarse-side faces need.  The tables
+ * (cup3d_grid_neighbours, cup3d_grid_interface) are the global ones renumbered, so a kernel reads through them what it would read on
+ * one rank once the two exchanges of cup3d_grid_view_plan have run.  HOST SIDE ONLY this round: cup3d_sim_create refuses a view (the
+ * device transport for it is the next step); tests pin the plans against the global tables. */
+int cup3d_grid_rank_view(const cup3d_grid_t *mesh, const int32_t *owner, int rank, int nranks, cup3d_grid_t **view);
+/* out: local blocks, ghost blocks, local interface faces, ghost faces, blocks sent per exchange, face-flux arrays sent per exchange */
+int cup3d_grid_view_sizes(const cup3d_grid_t *view, long out[6]);
+/* any pointer may be NULL.  global_slot[nlocal+nghost], global_face[nfaces]: position in the global mesh; send_blocks[]: local slots in
+ * peer-major order (each peer's run in that peer's ghost order), counts per rank; the same for the face-flux arrays */
+int cup3d_grid_view_plan(const cup3d_grid_t *view, int32_t *global_slot, int32_t *global_face, int32_t *send_blocks, long *send_block_count,
+                         long *recv_block_count, int32_t *send_flux_faces, long *send_flux_count, long *recv_flux_count);
 void cup3d_grid_destroy(cup3d_grid_t *);
 long cup3d_grid_nblocks(const cup3d_grid_t *);        /* local blocks = m_vInfo.size() */
 long cup3d_grid_nblocks_global(const cup3d_grid_t *);

@@ -109,3 +109,67 @@ def test_halo_exchange_over_gloo(world, bpd, level, bc, nc, w):
         p.join(60)
     assert all(r[1] == "ok" for r in res), res
     assert sum(r[2] for r in res) > 0
+
+
+# ------------------------------------------------------------------ multi-level meshes: ghost blocks + face fluxes of Grid.rank_view
+def amr_worker(rank, world, port, golden, q):
+    import cup3d_amd as cu
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = np.load(golden)
+        t = g["tables"]
+        mesh = cu.Grid(tuple(int(b) for b in g["bpd"]), int(g["level_max"]), 0, 1.0, tuple(int(b) for b in g["bc"]),
+                       leaves=(t[:, 0].astype(np.int32), t[:, 1].copy()))
+        nb = mesh.nblocks
+        owner = (np.arange(nb) * world // nb).astype(np.int32)            # contiguous runs of the global order
+        v = mesh.rank_view(owner, rank, world)
+        faces, _, _ = mesh.interface()
+        rng = np.random.default_rng(11)
+        field = rng.uniform(-1, 1, (nb, 3, 512))                          # a global field and global face fluxes, same on every rank
+        flux = rng.uniform(-1, 1, (len(faces), 3, 64))
+        mine = np.zeros((v.nlocal + v.nghost, 3, 512))
+        mine[:v.nlocal] = field[v.global_slot[:v.nlocal]]                 # a rank holds its own blocks ...
+        myflux = np.zeros((len(v.faces), 3, 64))
+        myflux[:v.nfaces_local] = flux[v.global_face[:v.nfaces_local]]    # ... and computes the fluxes of its own faces
+        for data, send_list, scount, rcount, first in ((mine, v.send_blocks, v.send_block_count, v.recv_block_count, v.nlocal),
+                                                        (myflux, v.send_flux_faces, v.send_flux_count, v.recv_flux_count, v.nfaces_local)):
+            per = data[0].size
+            sendbuf = torch.from_numpy(np.ascontiguousarray(data[send_list]).reshape(-1)) if len(send_list) else torch.zeros(0, dtype=torch.float64)
+            recv_t = torch.from_numpy(data[first:].reshape(-1))           # ghosts are received in place, one contiguous run per peer
+            reqs, so, ro = [], 0, 0
+            for p in range(world):
+                ns, nr = int(scount[p]) * per, int(rcount[p]) * per
+                if ns:
+                    reqs.append(dist.isend(sendbuf[so:so + ns], p))
+                if nr:
+                    reqs.append(dist.irecv(recv_t[ro:ro + nr], p))
+                so += ns
+                ro += nr
+            for r in reqs:
+                r.wait()
+        assert np.array_equal(mine, field[v.global_slot]) and np.array_equal(myflux, flux[v.global_face])
+        q.put((rank, "ok", v.nghost + v.nfaces_ghost))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, "fail", repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,name", [(2, "amr_mixed_l12"), (3, "amr_periodic_l01")])
+def test_ghost_block_and_flux_exchange_over_gloo(world, name, golden_dir):
+    """The two exchanges a multi-level mesh spread over ranks needs (whole ghost blocks before a stencil kernel, face-flux arrays
+    after a flux-corrected one), carried out with the plans of cup3d_grid_rank_view over gloo: afterwards every visible slot /
+    interface face of a rank holds the data of the global mesh."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=amr_worker, args=(r, world, port, os.path.join(golden_dir, name + ".npz"), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == "ok" for r in res), res
+    assert sum(r[2] for r in res) > 0

@@ -365,3 +365,89 @@ def test_block_ownership_after_adaptation_equals_the_reference_under_real_mpi(go
         modes.add("compress" if (st == -1).any() else "refine")
         k += 1
     assert k >= 10 and modes == {"even", "diffusion", "compress", "refine"}
+
+
+# ------------------------------------------------------------------ multi-level meshes spread over ranks (host planner)
+def _decode(x, to_global_slot, to_global_face):
+    """a neighbour-table entry of a rank view -> the same entry in global numbering"""
+    H, Cc = cu.capi.NBR_HALO, cu.capi.NBR_COARSER
+    if x >= H:
+        return H + int(to_global_face[x - H])
+    if x >= Cc:
+        return Cc + int(to_global_slot[x - Cc])
+    return int(to_global_slot[x]) if x >= 0 else int(x)
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5])
+def test_rank_views_of_a_multilevel_mesh(golden_dir, nranks):
+    """Grid.rank_view: the tables a rank sees are the global ones renumbered (so a kernel reads through them what it reads on one
+    rank), every remote block / fine face they refer to is a ghost, no ghost is superfluous, and the send lists of the owners match
+    the ghost order of the receivers -- checked by carrying out both exchanges on arrays of global ids."""
+    for name, bpd, lmax, bc, lv, zs, _ in _mesh_cases(golden_dir):
+        mesh = cu.Grid(bpd, lmax, 0, 1.0, bc, leaves=(lv, zs))
+        nb = mesh.nblocks
+        faces, fine, n27 = mesh.interface()
+        nbr = mesh.neighbours()
+        a = np.zeros(nranks + 1, dtype=np.int64)       # contiguous runs of the global order, as the reference's ranks own them
+        for r in range(nranks):
+            a[r + 1] = a[r] + nb // nranks + (1 if r < nb % nranks else 0)
+        owner = np.repeat(np.arange(nranks), np.diff(a)).astype(np.int32)
+        views = [mesh.rank_view(owner, r, nranks) for r in range(nranks)]
+        assert sum(v.nlocal for v in views) == nb
+        assert all(v.nghost > 0 for v in views) and any(v.nfaces_ghost > 0 for v in views)
+        for r, v in enumerate(views):
+            gs, gf = v.global_slot, v.global_face
+            assert np.array_equal(gs[:v.nlocal], np.where(owner == r)[0])
+            assert (owner[gs[v.nlocal:]] != r).all() and len(set(gs.tolist())) == len(gs)
+            # tables of the local blocks == global tables, renumbered
+            for i in range(v.nlocal):
+                g = gs[i]
+                assert [_decode(int(x), gs, gf) for x in v.nbr[i]] == nbr[g].tolist(), (name, r, i)
+                assert [_decode(int(x), gs, gf) for x in v.nbr27[i]] == n27[g].tolist(), (name, r, i)
+            used_slots, used_faces = set(), set()
+            for i in range(v.nlocal):
+                for x in v.nbr27[i].tolist():
+                    if x >= cu.capi.NBR_COARSER:
+                        used_slots.add(x - cu.capi.NBR_COARSER)
+                    elif x >= 0:
+                        used_slots.add(x)
+            for e in range(len(v.faces)):
+                slot, f = divmod(int(v.faces[e, 0]), 6)
+                assert gs[slot] * 6 + f == faces[gf[e], 0] and v.faces[e, 1] == faces[gf[e], 1]
+                if e < v.nfaces_local:
+                    assert slot < v.nlocal
+                    if v.faces[e, 1] == 1:   # coarse side: the four fine faces, in the view's numbering
+                        assert [int(gf[x]) for x in v.fine[e]] == fine[gf[e]].tolist()
+                        used_faces.update(int(x) for x in v.fine[e])
+                        used_slots.update(int(v.faces[x, 0]) // 6 for x in v.fine[e])
+                else:
+                    assert slot >= v.nlocal and v.faces[e, 1] == 0
+            assert set(range(v.nlocal, v.nlocal + v.nghost)) <= used_slots            # no superfluous ghost block
+            assert set(range(v.nfaces_local, len(v.faces))) <= used_faces             # ... or ghost face
+            assert max(used_slots) < v.nlocal + v.nghost
+        # the two exchanges, carried out on global ids: every ghost slot / ghost face receives its owner's entry
+        for r, v in enumerate(views):
+            got_b = np.full(v.nlocal + v.nghost, -1)
+            got_b[:v.nlocal] = v.global_slot[:v.nlocal]
+            got_f = np.full(len(v.faces), -1)
+            got_f[:v.nfaces_local] = v.global_face[:v.nfaces_local]
+            pos_b, pos_f = v.nlocal, v.nfaces_local
+            for p, w in enumerate(views):
+                if p == r:
+                    assert v.recv_block_count[p] == 0 and v.recv_flux_count[p] == 0
+                    continue
+                sb0 = int(w.send_block_count[:r].sum())
+                sent = w.global_slot[w.send_blocks[sb0:sb0 + int(w.send_block_count[r])]]      # what p packs for r
+                assert len(sent) == v.recv_block_count[p]
+                got_b[pos_b:pos_b + len(sent)] = sent
+                pos_b += len(sent)
+                sf0 = int(w.send_flux_count[:r].sum())
+                sentf = w.global_face[w.send_flux_faces[sf0:sf0 + int(w.send_flux_count[r])]]
+                assert len(sentf) == v.recv_flux_count[p] and (w.send_flux_faces[sf0:sf0 + len(sentf)] < w.nfaces_local).all()
+                got_f[pos_f:pos_f + len(sentf)] = sentf
+                pos_f += len(sentf)
+            assert np.array_equal(got_b, v.global_slot) and np.array_equal(got_f, v.global_face), (name, r)
+    # the device transport for rank views is not built yet: loud refusal, not a wrong answer (needs no GPU to check the message)
+    h = C.c_void_p()
+    rc = L.cup3d_sim_create(views[0].handle, C.byref(h))
+    assert rc != 0 and b"not built on the device yet" in L.cup3d_last_error()
