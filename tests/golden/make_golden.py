@@ -185,9 +185,12 @@ def amr_case(name, bpd, lmax, bc, passes, seed, full):
                solve_iters=[int(r["iters"]) for r in recs if r["op"] == "solve"][0],
                pr_iters=[int(r["iters"]) for r in recs if r["op"] == "project"][0])
     if full:
-        out.update(lab_vel34=np.fromfile(os.path.join(wd, "lab_vel34.bin")).reshape(nb, 14, 14, 14, 3),
-                   lab_p12=np.fromfile(os.path.join(wd, "lab_p12.bin")).reshape(nb, 10, 10, 10, 1),
-                   lab_v12t=np.fromfile(os.path.join(wd, "lab_v12t.bin")).reshape(nb, 10, 10, 10, 3),
+        def lab(f, L, nc, s, e, tens):   # cells the reference never defines (stale memory) are cleared: reproducible files
+            a = np.fromfile(os.path.join(wd, f)).reshape(nb, L, L, L, nc)
+            a[:, ~O.lab_mask(s, e, tens)] = 0.0
+            return a
+        out.update(lab_vel34=lab("lab_vel34.bin", 14, 3, -3, 4, False), lab_p12=lab("lab_p12.bin", 10, 1, -1, 2, False),
+                   lab_v12t=lab("lab_v12t.bin", 10, 3, -1, 2, True),
                    precond=rb("precond.bin", 1), solve=rb("solve.bin", 1), divp=rb("divp.bin", 3)[..., 0].copy(), gradp=rb("gradp.bin", 3))
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "blocks", nb, "levels", sorted(set(t1[:, 0].tolist())), "solve iters", out["solve_iters"], "project iters", out["pr_iters"])

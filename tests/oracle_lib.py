@@ -475,6 +475,18 @@ def run_ref_mpi(script_lines, args, nranks, workdir=None, timeout=3600):
     return wd
 
 
+def lab_mask(s, e, tens):
+    """Cells of the [s,e) tile the reference defines: all of them when the tile is built tensorially
+    (use_averages), else only faces (edge/corner ghosts are never read by the kernels and hold stale memory)."""
+    L = 8 + e - s - 1
+    if tens or s < -2 or e > 3:
+        return np.ones((L, L, L), bool)
+    idx = np.arange(L) + s
+    out = ~((idx >= 0) & (idx < 8))
+    cnt = out[:, None, None].astype(int) + out[None, :, None].astype(int) + out[None, None, :].astype(int)
+    return cnt <= 1
+
+
 def read_blocks(path, nb, ncomp):
     a = np.fromfile(path, dtype=np.float64)
     shape = (nb, 8, 8, 8, 3) if ncomp == 3 else (nb, 8, 8, 8)
