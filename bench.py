@@ -22,7 +22,6 @@ import argparse
 import ctypes as C
 import json
 import os
-import subprocess
 import sys
 import time
 
