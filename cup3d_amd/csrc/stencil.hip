@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256) k_sum_blocks(const double *__restrict__ v
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 __global__ void __launch_bounds__(64) k_sum_final(const double *__restrict__ part, int n, double *__restrict__ out) {
-  double s = threadIdx.x < n ? part[threadIdx.x] : 0.0;
+  double s = (int)threadIdx.x < n ? part[threadIdx.x] : 0.0;
   s = wave_sum(s);
   if (threadIdx.x == 0) out[0] = s;
 }
