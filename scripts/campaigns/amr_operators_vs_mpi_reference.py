@@ -8,7 +8,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 5)
 BCS = ["periodic", "wall", "freespace"]
 bad = done = 0
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 16):
-    bpd = tuple(int(v) for v in rng.integers(1, 4, 3))
+    bpd = tuple(int(v) for v in rng.integers(int(os.environ.get('MINBPD', '1')), 4, 3))
     if bpd[0] * bpd[1] * bpd[2] > 12: bpd = (2, 2, 2)
     lmax = int(rng.integers(3, 5))
     bc = tuple(BCS[int(v)] for v in rng.integers(0, 3, 3))
