@@ -132,6 +132,8 @@ DEBUG_SIGNATURES = {
     "cup3d_debug_advdiff_stage": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, _dp]),
     "cup3d_debug_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "cup3d_debug_amr_slabs": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
+    "cup3d_debug_virtual_comm": (C.c_int, [C.c_int]),
+    "cup3d_debug_wave_sum": (C.c_int, [_dp, _dp]),
 }
 
 _lib = None

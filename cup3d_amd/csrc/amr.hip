@@ -441,6 +441,10 @@ int amr_fill_ghosts(Sim *s, const double *field, int nc, int w, double *slabs) {
 
 int amr_flux_fix(Sim *s, int nfc, double *out, int out_nc) {
   AmrDev a{s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_nbr, s->d_index, -1};
+  {  // rank views: the fluxes of fine faces owned by other ranks arrive first (FluxCorrectionMPI, main.cpp:2848-2945)
+    int rc = view_exchange_flux(s, nfc);
+    if (rc) return rc;
+  }
   ProfileScope ps("amr_flux_fix");
   for (int d = 0; d < 3; ++d) {
     const unsigned n = (unsigned)s->grid->fix_faces[d].size();

@@ -11,7 +11,10 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "sim.hpp"
 
@@ -63,24 +66,179 @@ static int load_rccl() {
     }                                                                         \
   } while (0)
 
-int halo_exchange(Sim *s, const double *field, int nc, int w) {
+// ------------------------------------------------------------------ in-process transport (TEST SUPPORT)
+// "Virtual communicator": the ranks of a run are host THREADS of one process on one GPU, each driving its own Sim through the
+// ordinary entry points; the two exchange patterns and the all-reduce are carried out by device copies between the ranks' buffers,
+// ordered by host barriers (all ranks enqueue on the same stream, so enqueue order is execution order).  Everything else -- the
+// partition, the plans, the pack kernels, the inner/boundary split, which rank owns the corner cell, the order of the collectives
+// in solve() -- is the code the RCCL path runs.  The driver has 8-GPU nodes, the builder's boxes have one GPU: this is how the
+// multi-rank control flow is executed before it meets RCCL.
+struct VComm {
+  int n = 0;
+  std::vector<Sim *> sims;
+  std::vector<double *> ptr;
+  double *d_tmp = nullptr;  // [n][16]
+  std::mutex m;
+  std::condition_variable cv;
+  int waiting = 0;
+  long gen = 0;
+  bool failed = false;
+  void barrier() {
+    std::unique_lock<std::mutex> lk(m);
+    const long g0 = gen;
+    if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); }
+    else cv.wait(lk, [&] { return gen != g0; });
+  }
+};
+static VComm *g_vcomm = nullptr;
+VComm *vcomm() { return g_vcomm; }
+void vcomm_register(Sim *s) {
+  if (g_vcomm && s->grid->nranks == g_vcomm->n) g_vcomm->sims[s->grid->rank] = s;
+}
+void vcomm_unregister(Sim *s) {
+  if (!g_vcomm) return;
+  for (auto &p : g_vcomm->sims) if (p == s) p = nullptr;
+}
+
+struct VPtrs { const double *p[16]; };
+__global__ void k_vreduce(VPtrs v, int nranks, int n, int is_max, double *__restrict__ out) {
+  const int i = threadIdx.x;
+  if (i >= n) return;
+  double a = v.p[0][i];
+  for (int r = 1; r < nranks; ++r) a = is_max ? fmax(a, v.p[r][i]) : a + v.p[r][i];  // rank order: identical bits on every rank
+  out[i] = a;
+}
+
+bool scalars_cross_ranks(const Sim *s) {
+  if (g_vcomm) return s->grid->nranks > 1;
+  if (g_virtual_ranks) return false;
+  return s->grid->nranks > 1 || (debug_option("force_allreduce") && comm());
+}
+// the stream the scalar all-reduces are enqueued on: the communication stream where there is one (every RCCL call of the library is
+// issued from that stream, in the same order on all ranks), else the compute stream
+hipStream_t scalar_stream(const Sim *s) {
+  if (g_vcomm || g_virtual_ranks || !s->comm_stream) return stream();
+  return s->comm_stream;
+}
+
+// copy `count[p]` items of `per` doubles from every peer's send buffer (peer-major, so my share of p's buffer starts after what p
+// sends to the ranks before me) to dst, in rank order
+template <class CountOf>
+static int vcomm_pull(Sim *s, double *dst, size_t per, const std::vector<int64_t> &recv_count, CountOf send_count_of) {
+  VComm *vc = g_vcomm;
   const Grid *g = s->grid;
-  if (g->multilevel) return amr_fill_ghosts(s, field, nc, w, s->halo_recv);  // coarse/fine ghost slabs take the halo slabs' place
-  if (g->nranks == 1 || g_virtual_ranks) return CUP3D_OK;
+  vc->barrier();  // every rank has enqueued its pack
+  size_t ro = 0;
+  for (int p = 0; p < g->nranks; ++p) {
+    const size_t nr = (size_t)recv_count[p] * per;
+    if (!nr) continue;
+    Sim *src = vc->sims[p];
+    if (!src) { set_error("virtual communicator: rank %d has no sim", p); return CUP3D_ESTATE; }
+    const std::vector<int64_t> &sc = send_count_of(src->grid);
+    size_t so = 0;
+    for (int q = 0; q < g->rank; ++q) so += (size_t)sc[q] * per;
+    if ((size_t)sc[g->rank] * per != nr) { set_error("plan mismatch between ranks %d and %d", p, g->rank); return CUP3D_ESTATE; }
+    CUP3D_HIP(hipMemcpyAsync(dst + ro, src->halo_send + so, nr * sizeof(double), hipMemcpyDeviceToDevice, stream()));
+    ro += nr;
+  }
+  vc->barrier();  // nobody packs again before every copy is enqueued
+  return CUP3D_OK;
+}
+
+// ------------------------------------------------------------------ rank views of a multi-level mesh (Grid::rank_view)
+// Before a stencil kernel: the blocks of `field` other ranks' tables refer to travel whole into the ghost slot range
+// [n_local, n_local + nghost) (SynchronizerMPI_AMR::sync / fetch, main.cpp:2356-2544, which ships sub-boxes and coarse shadow cells;
+// whole 8^3 blocks make every consumer -- same-level copies, restriction, the coarse shadow tile of the interpolation -- read the
+// owner's bits through the renumbered tables with no second code path).  After a flux-corrected kernel: the face-flux arrays of fine
+// faces whose coarse neighbour lives elsewhere (FluxCorrectionMPI::FillBlockCases, 2848-2945).
+__global__ void __launch_bounds__(256) k_pack_blocks(const double *__restrict__ field, const int32_t *__restrict__ slots, int nc, double *__restrict__ out) {
+  const double *src = field + (size_t)slots[blockIdx.x] * nc * 512;
+  double *dst = out + (size_t)blockIdx.x * nc * 512;
+  for (int i = threadIdx.x; i < nc * 512; i += 256) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(64) k_pack_flux(const double *__restrict__ flux, const int32_t *__restrict__ faces, int nfc, double *__restrict__ out) {
+  const double *src = flux + (size_t)faces[blockIdx.x] * nfc * 64;
+  double *dst = out + (size_t)blockIdx.x * nfc * 64;
+  for (int c = 0; c < nfc; ++c) dst[c * 64 + threadIdx.x] = src[c * 64 + threadIdx.x];
+}
+
+// items of `per` doubles: packed send buffer -> peers; received runs land contiguously at dst.  RCCL on the communication stream
+// (compute stream <-> communication stream hand-off by events), or the in-process transport.
+static int view_transfer(Sim *s, double *dst, size_t per, const std::vector<int64_t> &send_count, const std::vector<int64_t> &recv_count, bool flux) {
+  const Grid *g = s->grid;
+  if (g_vcomm) {
+    if (flux) return vcomm_pull(s, dst, per, recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_flux_count; });
+    return vcomm_pull(s, dst, per, recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_block_count; });
+  }
+  Comm *c = comm();
+  if (!c) { set_error("multi-rank mesh without cup3d_comm_init"); return CUP3D_ESTATE; }
+  CUP3D_NCCL(c->GroupStart());
+  size_t so = 0, ro = 0;
+  for (int p = 0; p < g->nranks; ++p) {
+    const size_t ns = (size_t)send_count[p] * per, nr = (size_t)recv_count[p] * per;
+    if (ns) CUP3D_NCCL(c->Send(s->halo_send + so, ns, ncclDouble, p, c->comm, s->comm_stream));
+    if (nr) CUP3D_NCCL(c->Recv(dst + ro, nr, ncclDouble, p, c->comm, s->comm_stream));
+    so += ns;
+    ro += nr;
+  }
+  CUP3D_NCCL(c->GroupEnd());
+  return CUP3D_OK;
+}
+
+int view_exchange_blocks(Sim *s, double *field, int nc) {
+  const Grid *g = s->grid;
+  if (g->n_local < 0 || g->nranks == 1) return CUP3D_OK;
+  ProfileScope ps("ghost_block_exchange");
+  hipStream_t st = g_vcomm ? stream() : s->comm_stream;
+  if (st != stream()) {
+    CUP3D_HIP(hipEventRecord(s->ev_h1, stream()));
+    CUP3D_HIP(hipStreamWaitEvent(st, s->ev_h1, 0));
+  }
+  const unsigned nsend = (unsigned)g->send_blocks.size();
+  if (nsend) hipLaunchKernelGGL(k_pack_blocks, dim3(nsend), dim3(256), 0, st, field, s->d_send_blocks, nc, s->halo_send);
+  CUP3D_HIP(hipGetLastError());
+  int rc = view_transfer(s, field + (size_t)g->n_local * nc * 512, (size_t)nc * 512, g->send_block_count, g->recv_block_count, false);
+  if (rc) return rc;
+  if (st != stream()) {
+    CUP3D_HIP(hipEventRecord(s->ev_h2, st));
+    CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
+  }
+  return CUP3D_OK;
+}
+
+int view_exchange_flux(Sim *s, int nfc) {
+  const Grid *g = s->grid;
+  if (g->n_local < 0 || g->nranks == 1) return CUP3D_OK;
+  ProfileScope ps("face_flux_exchange");
+  hipStream_t st = g_vcomm ? stream() : s->comm_stream;
+  if (st != stream()) {
+    CUP3D_HIP(hipEventRecord(s->ev_h1, stream()));
+    CUP3D_HIP(hipStreamWaitEvent(st, s->ev_h1, 0));
+  }
+  const unsigned nsend = (unsigned)g->send_flux_faces.size();
+  if (nsend) hipLaunchKernelGGL(k_pack_flux, dim3(nsend), dim3(64), 0, st, s->d_flux, s->d_send_flux, nfc, s->halo_send);
+  CUP3D_HIP(hipGetLastError());
+  int rc = view_transfer(s, s->d_flux + (size_t)g->n_local_faces * nfc * 64, (size_t)nfc * 64, g->send_flux_count, g->recv_flux_count, true);
+  if (rc) return rc;
+  if (st != stream()) {
+    CUP3D_HIP(hipEventRecord(s->ev_h2, st));
+    CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
+  }
+  return CUP3D_OK;
+}
+
+// ------------------------------------------------------------------ face-slab halo exchange of uniform grids
+static int slab_transfer(Sim *s, size_t per_face, hipStream_t st) {
+  const Grid *g = s->grid;
+  if (g_vcomm) return vcomm_pull(s, s->halo_recv, per_face, g->recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_count; });
   Comm *c = comm();
   if (!c) { set_error("multi-rank grid without cup3d_comm_init"); return CUP3D_ESTATE; }
-  const size_t per_face = (size_t)nc * w * 64;
-  ProfileScope ps("halo_exchange");
-  {
-    int rc = launch_pack(s, field, nc, w, stream());
-    if (rc) return rc;
-  }
   CUP3D_NCCL(c->GroupStart());
   size_t so = 0, ro = 0;
   for (int p = 0; p < g->nranks; ++p) {
     const size_t ns = (size_t)g->send_count[p] * per_face, nr = (size_t)g->recv_count[p] * per_face;
-    if (ns) CUP3D_NCCL(c->Send(s->halo_send + so, ns, ncclDouble, p, c->comm, stream()));
-    if (nr) CUP3D_NCCL(c->Recv(s->halo_recv + ro, nr, ncclDouble, p, c->comm, stream()));
+    if (ns) CUP3D_NCCL(c->Send(s->halo_send + so, ns, ncclDouble, p, c->comm, st));
+    if (nr) CUP3D_NCCL(c->Recv(s->halo_recv + ro, nr, ncclDouble, p, c->comm, st));
     so += ns;
     ro += nr;
   }
@@ -94,40 +252,55 @@ int halo_exchange(Sim *s, const double *field, int nc, int w) {
 // for the slabs before the boundary blocks are launched.
 int halo_begin(Sim *s, const double *field, int nc, int w) {
   const Grid *g = s->grid;
-  if (g->multilevel) return amr_fill_ghosts(s, field, nc, w, s->halo_recv);
-  if (g->nranks == 1 || g_virtual_ranks) return CUP3D_OK;
-  Comm *c = comm();
-  if (!c) { set_error("multi-rank grid without cup3d_comm_init"); return CUP3D_ESTATE; }
-  const size_t per_face = (size_t)nc * w * 64;
-  // the field (and the previous consumers of the slab buffers) live on the compute stream
-  CUP3D_HIP(hipEventRecord(s->ev_h1, stream()));
-  CUP3D_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_h1, 0));
-  {
-    int rc = launch_pack(s, field, nc, w, s->comm_stream);
+  if (g->multilevel) {
+    int rc = view_exchange_blocks(s, const_cast<double *>(field), nc);  // no-op unless the mesh is spread over ranks
     if (rc) return rc;
+    return amr_fill_ghosts(s, field, nc, w, s->halo_recv);  // coarse/fine ghost slabs take the halo slabs' place
   }
-  CUP3D_NCCL(c->GroupStart());
-  size_t so = 0, ro = 0;
-  for (int p = 0; p < g->nranks; ++p) {
-    const size_t ns = (size_t)g->send_count[p] * per_face, nr = (size_t)g->recv_count[p] * per_face;
-    if (ns) CUP3D_NCCL(c->Send(s->halo_send + so, ns, ncclDouble, p, c->comm, s->comm_stream));
-    if (nr) CUP3D_NCCL(c->Recv(s->halo_recv + ro, nr, ncclDouble, p, c->comm, s->comm_stream));
-    so += ns;
-    ro += nr;
+  if (g->nranks == 1 || (g_virtual_ranks && !g_vcomm)) return CUP3D_OK;
+  const size_t per_face = (size_t)nc * w * 64;
+  hipStream_t st = g_vcomm ? stream() : s->comm_stream;
+  // the field (and the previous consumers of the slab buffers) live on the compute stream
+  if (st != stream()) {
+    CUP3D_HIP(hipEventRecord(s->ev_h1, stream()));
+    CUP3D_HIP(hipStreamWaitEvent(st, s->ev_h1, 0));
   }
-  CUP3D_NCCL(c->GroupEnd());
-  CUP3D_HIP(hipEventRecord(s->ev_h2, s->comm_stream));
+  {
+    ProfileScope ps("halo_exchange");
+    int rc = launch_pack(s, field, nc, w, st);
+    if (rc) return rc;
+    if ((rc = slab_transfer(s, per_face, st))) return rc;
+  }
+  if (st != stream()) CUP3D_HIP(hipEventRecord(s->ev_h2, st));
   return CUP3D_OK;
 }
 int halo_finish(Sim *s) {
-  if (s->grid->nranks == 1 || g_virtual_ranks) return CUP3D_OK;
+  if (s->grid->multilevel || s->grid->nranks == 1 || g_virtual_ranks || g_vcomm) return CUP3D_OK;
   CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
   return CUP3D_OK;
 }
+int halo_exchange(Sim *s, const double *field, int nc, int w) {
+  int rc = halo_begin(s, field, nc, w);
+  if (rc) return rc;
+  return halo_finish(s);
+}
 
 int allreduce(Sim *s, double *d_buf, int n, bool is_max, hipStream_t st) {
-  // "force_allreduce": TEST SUPPORT, run the RCCL call on a 1-rank communicator to exercise the plumbing on one GPU
-  if ((s->grid->nranks == 1 && !(debug_option("force_allreduce") && comm())) || g_virtual_ranks) return CUP3D_OK;
+  if (!scalars_cross_ranks(s)) return CUP3D_OK;
+  if (g_vcomm) {
+    VComm *vc = g_vcomm;
+    const int r = s->grid->rank;
+    if (n > 16 || vc->n > 16) { set_error("virtual communicator: at most 16 ranks / 16 values"); return CUP3D_EINVAL; }
+    vc->ptr[r] = d_buf;
+    vc->barrier();  // every rank's operand is enqueued
+    VPtrs v;
+    for (int q = 0; q < vc->n; ++q) v.p[q] = vc->ptr[q];
+    hipLaunchKernelGGL(k_vreduce, dim3(1), dim3(64), 0, stream(), v, vc->n, n, is_max ? 1 : 0, vc->d_tmp + 16 * r);
+    CUP3D_HIP(hipGetLastError());
+    vc->barrier();  // every rank has read the operands
+    CUP3D_HIP(hipMemcpyAsync(d_buf, vc->d_tmp + 16 * r, n * sizeof(double), hipMemcpyDeviceToDevice, stream()));
+    return CUP3D_OK;
+  }
   Comm *c = comm();
   if (!c) { set_error("multi-rank grid without cup3d_comm_init"); return CUP3D_ESTATE; }
   CUP3D_NCCL(c->AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, is_max ? ncclMax : ncclSum, c->comm, st));
@@ -177,6 +350,27 @@ int cup3d_comm_finalize(void) {
 
 // TEST SUPPORT: several ranks' sims in one process on one GPU; exchanges become no-ops
 int cup3d_debug_virtual_ranks(int on) { g_virtual_ranks = on != 0; return CUP3D_OK; }
+
+// TEST SUPPORT: in-process communicator over `nranks` host threads (see VComm above); nranks = 0 tears it down.  Create it before
+// the sims of the run (they register themselves by rank), then call the ordinary entry points from one thread per rank.
+int cup3d_debug_virtual_comm(int nranks) {
+  if (nranks < 0 || nranks > 16) return CUP3D_EINVAL;
+  if (g_vcomm) {
+    if (g_vcomm->d_tmp) hipFree(g_vcomm->d_tmp);
+    delete g_vcomm;
+    g_vcomm = nullptr;
+    g_virtual_ranks = false;
+  }
+  if (nranks == 0) return CUP3D_OK;
+  VComm *vc = new VComm();
+  vc->n = nranks;
+  vc->sims.assign(nranks, nullptr);
+  vc->ptr.assign(nranks, nullptr);
+  if (hipMalloc((void **)&vc->d_tmp, (size_t)nranks * 16 * sizeof(double)) != hipSuccess) { delete vc; set_error("virtual communicator: hipMalloc failed"); return CUP3D_EDEVICE; }
+  g_vcomm = vc;
+  g_virtual_ranks = true;
+  return CUP3D_OK;
+}
 
 // TEST SUPPORT: fill `dst`'s halo slabs for (field, nc, w) by packing directly from peer
 // sims living in the same process on the same GPU ("virtual ranks").  Exercises the plan

@@ -60,7 +60,7 @@ static cup3d_poisson_params diffusion_params(const cup3d_poisson_params *pp) {
   cup3d_poisson_params P;
   cup3d_poisson_default_params(&P);  // 1e-6 / 1e-4 are also sim.DiffusionErrorTol / DiffusionErrorTolRel (15369-15370)
   if (pp) P = *pp;
-  P.block_solver = 0;  // the direct block solve is written for the Poisson coefficient only
+  if (P.block_solver != 2) P.block_solver = 0;  // block CG only (2 = reference association): the direct block solve is written for the Poisson coefficient
   return P;
 }
 

@@ -117,35 +117,41 @@ extern "C" int cup3d_penalization(cup3d_sim_t *h, double dt, double lambda, int 
   for (int k = 0; k < nobst; ++k) {  // obstacles one after the other, as KernelPenalization::operator() visits them (13849-13852)
     cup3d_obstacle &o = obst[k];
     for (int d = 0; d < 3; ++d) o.force[d] = o.torque[d] = 0.0;
-    if (o.nblocks <= 0) continue;
-    if (!o.slots || !o.chi || !o.udef) return CUP3D_EINVAL;
-    DevBuf slots, geom, chi, udef, forces;
-    ObstItems it;
-    int rc = stage(s, o, slots, geom, chi, udef, &it);
-    if (rc) return rc;
-    if ((rc = forces.alloc((size_t)o.nblocks * 6 * sizeof(double)))) return rc;
-    {
-      ProfileScope ps("penalization");
-      hipLaunchKernelGGL(k_penalize, dim3((unsigned)o.nblocks), dim3(256), 0, stream(), it, s->vel, s->chi, dt, lambdaFac, implicit ? 1 : 0, o.cm[0], o.cm[1],
-                         o.cm[2], o.vel[0], o.vel[1], o.vel[2], o.omega[0], o.omega[1], o.omega[2], (double *)forces.p);
-    }
-    CUP3D_HIP(hipGetLastError());
-    std::vector<double> F((size_t)o.nblocks * 6);
-    CUP3D_HIP(hipMemcpyAsync(F.data(), forces.p, F.size() * sizeof(double), hipMemcpyDeviceToHost, stream()));
-    CUP3D_HIP(hipStreamSynchronize(stream()));
-    // kernelFinalizePenalizationForce (13913-13938): block totals in block (slot) order
-    std::vector<long> order(o.nblocks);
-    for (long i = 0; i < o.nblocks; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](long a, long b) { return o.slots[a] < o.slots[b]; });
+    // A rank whose share of the grid this obstacle does not touch still takes part in the all-reduce below with M = 0: the
+    // reference issues MPI_Allreduce(M, 6) for every obstacle on every rank (13931), and skipping it here would pair this rank's
+    // NEXT collective with the other ranks' 6-double sum.
     double M[6] = {0, 0, 0, 0, 0, 0};
-    for (long i : order)
-      for (int q = 0; q < 6; ++q) M[q] += F[(size_t)i * 6 + q];
-    if (s->grid->nranks > 1) {  // MPI_Allreduce(M, 6), 13931
-      double *d = s->d_red;
-      CUP3D_HIP(hipMemcpyAsync(d, M, 6 * sizeof(double), hipMemcpyHostToDevice, stream()));
-      if ((rc = allreduce(s, d, 6, false, stream()))) return rc;
-      CUP3D_HIP(hipMemcpyAsync(M, d, 6 * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    int rc;
+    if (o.nblocks > 0) {
+      if (!o.slots || !o.chi || !o.udef) return CUP3D_EINVAL;
+      DevBuf slots, geom, chi, udef, forces;
+      ObstItems it;
+      if ((rc = stage(s, o, slots, geom, chi, udef, &it))) return rc;
+      if ((rc = forces.alloc((size_t)o.nblocks * 6 * sizeof(double)))) return rc;
+      {
+        ProfileScope ps("penalization");
+        hipLaunchKernelGGL(k_penalize, dim3((unsigned)o.nblocks), dim3(256), 0, stream(), it, s->vel, s->chi, dt, lambdaFac, implicit ? 1 : 0, o.cm[0], o.cm[1],
+                           o.cm[2], o.vel[0], o.vel[1], o.vel[2], o.omega[0], o.omega[1], o.omega[2], (double *)forces.p);
+      }
+      CUP3D_HIP(hipGetLastError());
+      std::vector<double> F((size_t)o.nblocks * 6);
+      CUP3D_HIP(hipMemcpyAsync(F.data(), forces.p, F.size() * sizeof(double), hipMemcpyDeviceToHost, stream()));
       CUP3D_HIP(hipStreamSynchronize(stream()));
+      // kernelFinalizePenalizationForce (13913-13938): block totals in block (slot) order
+      std::vector<long> order(o.nblocks);
+      for (long i = 0; i < o.nblocks; ++i) order[i] = i;
+      std::sort(order.begin(), order.end(), [&](long a, long b) { return o.slots[a] < o.slots[b]; });
+      for (long i : order)
+        for (int q = 0; q < 6; ++q) M[q] += F[(size_t)i * 6 + q];
+    }
+    if (scalars_cross_ranks(s)) {  // MPI_Allreduce(M, 6), 13931; on the stream every RCCL call of the library uses
+      double *d = s->d_red;
+      hipStream_t cs = scalar_stream(s);
+      CUP3D_HIP(hipStreamSynchronize(stream()));
+      CUP3D_HIP(hipMemcpyAsync(d, M, 6 * sizeof(double), hipMemcpyHostToDevice, cs));
+      if ((rc = allreduce(s, d, 6, false, cs))) return rc;
+      CUP3D_HIP(hipMemcpyAsync(M, d, 6 * sizeof(double), hipMemcpyDeviceToHost, cs));
+      CUP3D_HIP(hipStreamSynchronize(cs));
     }
     for (int d = 0; d < 3; ++d) { o.force[d] = M[d]; o.torque[d] = M[3 + d]; }
   }

@@ -43,10 +43,50 @@ __device__ __forceinline__ double mad(double a, double b, double c) {
 // exactly.  The x-1 / x+1 reads of the lanes at x = 0 / 7, which would fetch a cell of the neighbouring row, go to the zero row.
 // HELM: diffusion_kernels::getZImplParallel (main.cpp:10534-10579) -- the same block CG with centre coefficient
 // -6 - h^2/nu/dt (10570) instead of -6, for the Helmholtz solves of the implicit diffusion.
-template <bool FMA, bool HELM = false>
+// V2 (production): the same iteration with three changes that only touch HOW it is evaluated.  The r01 kernel (V2 = false, kept
+// for A/B timing and as the reference-association variant) issued 181 VALU instructions per CG iteration per wavefront, 86 of them
+// the stencil and the updates; the SIMD's FP64 issue slots (4 cycles per wave64 instruction) AND the CU's LDS pipe (ds_read2_b64 is
+// serviced at half the ds_read_b64 rate, MI355X_MICROARCH.md LDS table) were both ~90 % busy, so only fewer instructions help:
+//  * the two wave-wide sums go to the otherwise idle FP64 MATRIX pipe: v_mfma_f64_16x16x4_f64 with B = ones sums the lanes
+//    {i, i+16, i+32, i+48}; every lane then holds four of the sixteen partial sums, adds them (3 v_add_f64) and a second MFMA
+//    leaves the wavefront total in every lane: 3 VALU instructions instead of 12 DPP moves + 6 adds + 2 readlanes + hazard nops
+//    per reduction (this is a cross-lane reduction on an idle pipe, not a reformulation of the stencil as a GEMM);
+//  * the x/y-neighbour reads are volatile so that the compiler keeps them as 32 ds_read_b64 (2 LDS cycles each) with the z-plane
+//    offset in the instruction instead of 16 ds_read2_b64 (8 cycles each) + per-plane address arithmetic;
+//  * rr / (a2 + 1e-55) and ss / (rr + 1e-55) use v_rcp_f64 + two Newton steps + one residual correction (8 instructions, result
+//    within 1 ulp of the IEEE quotient) instead of the 12-instruction IEEE expansion -- FMA variant only.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double wave_sum_mfma(double v) {
+  const double4_t zero = {0.0, 0.0, 0.0, 0.0};
+  double4_t d = __builtin_amdgcn_mfma_f64_16x16x4f64(v, 1.0, zero, 0, 0, 0);  // D[i][j] = sum_k A[i][k]: lanes i, i+16, i+32, i+48
+  const double t = (d[0] + d[1]) + (d[2] + d[3]);                              // the four rows of D this lane holds
+  d = __builtin_amdgcn_mfma_f64_16x16x4f64(t, 1.0, zero, 0, 0, 0);            // the four 16-lane rows hold disjoint quarters of the rows of D
+  return d[0];
+}
+__device__ __forceinline__ double fast_div(double n, double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-d, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  const double q = n * y;
+  return __builtin_fma(__builtin_fma(-d, q, n), y, q);
+}
+template <bool V2>
+__device__ __forceinline__ double cg_sum(double v) {
+  if constexpr (V2) return wave_sum_mfma(v);
+  else return wave_sum(v);
+}
+template <bool FAST>
+__device__ __forceinline__ double cg_div(double n, double d) {
+  if constexpr (FAST) return fast_div(n, d);
+  else return n / d;
+}
+
+template <bool FMA, bool HELM = false, bool V2 = true>
 __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, double *out, double *__restrict__ block_sums, double nu, double dt) {
-  // (86 VGPRs -> 5 waves/SIMD.  Forcing 6 with amdgpu_waves_per_eu spills five values that are reloaded every iteration: 0.476
-  //  vs 0.431 ms at 256^3, so the natural allocation stays.)
+  // (r01 kernel: 86 VGPRs -> 5 waves/SIMD.  Forcing 6 with amdgpu_waves_per_eu spills five values that are reloaded every iteration:
+  //  0.476 vs 0.431 ms at 256^3, so the natural allocation stays.)
   __shared__ double P[8 * 80];
   const int slot = block_slot(g);
   if (slot < 0) return;
@@ -56,6 +96,9 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
   // x-1 / x+1 reads of the edge lanes are redirected to the zero row of the same plane, at the one bank the other lanes of the
   // half-wave leave free (address 7 for x = 0, address 0 for x = 7): still conflict-free, and no masking arithmetic
   const int am = (l & 7) == 0 ? 7 : base - 1, ap = (l & 7) == 7 ? 0 : base + 1;
+  // V2: volatile LDS pointers (address space kept, or the loads become flat): one ds_read_b64 per access, plane offset immediate
+  typedef const volatile __attribute__((address_space(3))) double lds_cvd;
+  lds_cvd *Pam = (lds_cvd *)(P + am), *Pap = (lds_cvd *)(P + ap), *Pym = (lds_cvd *)(P + base - 8), *Pyp = (lds_cvd *)(P + base + 8);
   const double invh = 1 / block_h(g, slot);  // main.cpp:14723
   double centre = -6.0;
   if constexpr (HELM) { const double hq = block_h(g, slot); centre = -6.0 - hq * hq / nu / dt; }
@@ -68,7 +111,7 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
     p[z] = r[z];
     x[z] = 0;
   }
-  rr = wave_sum(rr);
+  rr = cg_sum<V2>(rr);
   const double kRel = 1e-7 * 1e-7, kAbs = 1e-16 * 1e-16;  // kSqrNorm{Rel,Abs}Criterion, 14619-14624
   const double sqrNorm0 = (double)1 / (512 * 512) * rr;    // 14734
   if (sqrNorm0 >= 1e-32) {                                  // else: block stays 0 (14735-14736)
@@ -80,17 +123,24 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
       double a2 = 0;
 #pragma unroll
       for (int z = 0; z < 8; ++z) {                         // kernelPoissonGetZInner, 14662-14682
-        double t = mad<FMA>(centre, p[z], P[z * 80 + am] + P[z * 80 + ap]);
-        t += P[z * 80 + base - 8];
-        t += P[z * 80 + base + 8];
+        double t;
+        if constexpr (V2) {
+          t = mad<FMA>(centre, p[z], Pam[z * 80] + Pap[z * 80]);
+          t += Pym[z * 80];
+          t += Pyp[z * 80];
+        } else {
+          t = mad<FMA>(centre, p[z], P[z * 80 + am] + P[z * 80 + ap]);
+          t += P[z * 80 + base - 8];
+          t += P[z * 80 + base + 8];
+        }
         t += z > 0 ? p[z - 1] : 0.0;
         t += z < 7 ? p[z + 1] : 0.0;
         Ax[z] = t;
         a2 = mad<FMA>(p[z], t, a2);
       }
       __syncthreads();
-      a2 = wave_sum(a2);
-      const double a = rr / (a2 + 1e-55);                   // 14684
+      a2 = cg_sum<V2>(a2);
+      const double a = cg_div<V2 && FMA>(rr, a2 + 1e-55);   // 14684
       double ss = 0;
 #pragma unroll
       for (int z = 0; z < 8; ++z) {
@@ -98,8 +148,8 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
         r[z] = mad<FMA>(-a, Ax[z], r[z]);                   // subAndSumSqr, 14636-14638
         ss = mad<FMA>(r[z], r[z], ss);
       }
-      ss = wave_sum(ss);
-      const double beta = ss / (rr + 1e-55);                // 14690
+      ss = cg_sum<V2>(ss);
+      const double beta = cg_div<V2 && FMA>(ss, rr + 1e-55);  // 14690
       const double sqrNorm = (double)1 / (512 * 512) * ss;  // 14691
       if (sqrNorm < kRel * sqrNorm0 || sqrNorm < kAbs) break;  // 14692-14694 (returns -1)
 #pragma unroll
@@ -116,7 +166,7 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
   }
   if (block_sums) {  // sum(z*h^3) of this block for the mean constraint of the LHS that follows (9283-9294)
     const double hq = block_h(g, slot), h3 = hq * hq * hq;
-    sx = wave_sum(sx * h3);
+    sx = cg_sum<V2>(sx * h3);
     if (l == 0) block_sums[slot] = sx;
   }
 }
@@ -210,6 +260,13 @@ __global__ void __launch_bounds__(64) k_precond_fdm(GridDev g, const double *in,
   }
 }
 
+// TEST SUPPORT: the two wave-wide sums of one 64-value vector: out[0..63] = MFMA form per lane, out[64..127] = DPP form per lane
+__global__ void __launch_bounds__(64) k_debug_wave_sum(const double *__restrict__ in, double *__restrict__ out) {
+  const double v = in[threadIdx.x];
+  out[threadIdx.x] = wave_sum_mfma(v);
+  out[64 + threadIdx.x] = wave_sum(v);
+}
+
 static int fdm_setup() {
   if (g_invD) return CUP3D_OK;
   double Q[8][4], lam[8], invD[512];
@@ -240,12 +297,17 @@ int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
     return CUP3D_OK;
   }
   ProfileScope ps("poisson_block_cg");
-  // Production contracts a*b+c into FMAs here (and only here): the result of this kernel sits behind two wave reductions per
-  // iteration whose summation order already differs from the CPU's, FMA moves it by ~1e-15 relative (the CG's own truncation
-  // is 1e-7), and with the conflict-free LDS layout the kernel is VALU-issue/dependency bound, where the contraction is worth
-  // 10 % (0.571 vs 0.634 ms at 256^3).  cup3d_debug_set_option("precond_no_fma", 1) selects the uncontracted association.
-  if (!debug_option("precond_no_fma")) hipLaunchKernelGGL((k_precond<true, false>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, sums, 0.0, 0.0);
-  else hipLaunchKernelGGL((k_precond<false, false>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, sums, 0.0, 0.0);
+  // Production (block_solver 0) contracts a*b+c into FMAs here (and only here) and evaluates the wave sums / the two divisions as
+  // described above k_precond: its result sits behind two wave reductions per iteration whose summation order already differs from
+  // the CPU's, and the CG's own truncation is 1e-7, so this is a tolerance-level deviation (tests: <= 2e-5 of the reference's z,
+  // measured ~1e-7).  block_solver 2 = the reference's association (no contraction, IEEE divisions); 3 = the round-1 kernel.
+  const dim3 G(launch_groups(g)), B(64);
+  switch (s->block_solver) {
+    case 0: hipLaunchKernelGGL((k_precond<true, false, true>), G, B, 0, stream(), g, in, out, sums, 0.0, 0.0); break;
+    case 2: hipLaunchKernelGGL((k_precond<false, false, true>), G, B, 0, stream(), g, in, out, sums, 0.0, 0.0); break;
+    case 3: hipLaunchKernelGGL((k_precond<true, false, false>), G, B, 0, stream(), g, in, out, sums, 0.0, 0.0); break;
+    default: set_error("unknown block_solver %d", s->block_solver); return CUP3D_EINVAL;
+  }
   CUP3D_HIP(hipGetLastError());
   s->sums_of = want_sums ? out : nullptr;  // block sums of `out` are fresh: the next LHS of `out` reuses them
   return CUP3D_OK;
@@ -254,8 +316,8 @@ int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
 int launch_precond_diffusion(Sim *s, const double *in, double *out, const HelmholtzOp &op) {
   GridDev g = s->gdev();
   ProfileScope ps("diffusion_block_cg");
-  if (!debug_option("precond_no_fma")) hipLaunchKernelGGL((k_precond<true, true>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, (double *)nullptr, op.nu, op.dt);
-  else hipLaunchKernelGGL((k_precond<false, true>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, (double *)nullptr, op.nu, op.dt);
+  if (s->block_solver != 2) hipLaunchKernelGGL((k_precond<true, true, true>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, (double *)nullptr, op.nu, op.dt);
+  else hipLaunchKernelGGL((k_precond<false, true, true>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, (double *)nullptr, op.nu, op.dt);
   CUP3D_HIP(hipGetLastError());
   s->sums_of = nullptr;
   return CUP3D_OK;
@@ -266,26 +328,6 @@ struct Vecs {
   double *v[NVEC];
   const double *xin;  // where the second loop reads x from: v[X_], or the x_opt snapshot right after one was taken (see solve())
 };
-
-template <int K>
-__device__ __forceinline__ void emit_partials(double (&acc)[K], double *__restrict__ partials) {
-  __shared__ double red[4];
-#pragma unroll
-  for (int i = 0; i < K; ++i) {
-    const double s = group_sum<4>(acc[i], red);
-    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * 8 + i] = s;
-  }
-}
-
-__global__ void __launch_bounds__(256) k_reduce_partials(const double *__restrict__ partials, int ngroups, int k, double *__restrict__ out) {
-  __shared__ double red[4];
-  for (int i = 0; i < k; ++i) {
-    double s = 0;
-    for (int j = threadIdx.x; j < ngroups; j += 256) s += partials[(size_t)j * 8 + i];
-    s = group_sum<4>(s, red);
-    if (threadIdx.x == 0) out[i] = s;
-  }
-}
 
 #define GRID_STRIDE(j, n) for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < (n); j += (long)gridDim.x * 256)
 // 16 B per lane (double2): n is a multiple of 512
@@ -323,14 +365,14 @@ __global__ void __launch_bounds__(256) k_resid0(Vecs V, long n) {
   GRID_STRIDE(j, n) { const double d = V.v[R_][j] - V.v[R0][j]; V.v[R0][j] = d; V.v[R_][j] = d; }
 }
 // r0.r0, r0.w  (14436-14440 and 14578-14581)
-__global__ void __launch_bounds__(256) k_dots_r0(Vecs V, long n, double *__restrict__ partials) {
+__global__ void __launch_bounds__(256) k_dots_r0(Vecs V, long n, RedOut ro) {
   double acc[2] = {0, 0};
   GRID_STRIDE(j, n) { const double a = V.v[R0][j]; acc[0] += a * a; acc[1] += a * V.v[W_][j]; }
-  emit_partials<2>(acc, partials);
+  grid_sum_finish<2>(acc, ro);
 }
 // first fused loop, k % 50 != 0   (14454-14464)
 template <bool NT>
-__global__ void __launch_bounds__(256) k_loop1(Vecs V, long n, double alpha, double beta, double omega, double *__restrict__ partials) {
+__global__ void __launch_bounds__(256) k_loop1(Vecs V, long n, double alpha, double beta, double omega, RedOut ro) {
   double acc[2] = {0, 0};
   GRID_STRIDE2(j, n) {
     const double2 rhat = LD2(V.v[RHAT]), w = LD2(V.v[W_]), shat0 = LD2(V.v[SHAT]), z0 = LD2(V.v[Z_]);
@@ -345,13 +387,13 @@ __global__ void __launch_bounds__(256) k_loop1(Vecs V, long n, double alpha, dou
     acc[0] = dot2(q, y, acc[0]);
     acc[1] = dot2(y, y, acc[1]);
   }
-  emit_partials<2>(acc, partials);
+  grid_sum_finish<2>(acc, ro);
 }
 // k % 50 == 0 variants   (14467-14480)
 __global__ void __launch_bounds__(256) k_loop1_phat(Vecs V, long n, double beta, double omega) {
   GRID_STRIDE(j, n) V.v[PHAT][j] = V.v[RHAT][j] + beta * (V.v[PHAT][j] - omega * V.v[SHAT][j]);
 }
-__global__ void __launch_bounds__(256) k_loop1_tail(Vecs V, long n, double alpha, double *__restrict__ partials) {
+__global__ void __launch_bounds__(256) k_loop1_tail(Vecs V, long n, double alpha, RedOut ro) {
   double acc[2] = {0, 0};
   GRID_STRIDE(j, n) {
     const double q = V.v[R_][j] - alpha * V.v[S_][j];
@@ -361,11 +403,11 @@ __global__ void __launch_bounds__(256) k_loop1_tail(Vecs V, long n, double alpha
     acc[0] += q * y;
     acc[1] += y * y;
   }
-  emit_partials<2>(acc, partials);
+  grid_sum_finish<2>(acc, ro);
 }
 // second fused loop, k % 50 != 0   (14503-14515)
 template <bool NT>
-__global__ void __launch_bounds__(256) k_loop2(Vecs V, long n, double alpha, double omega, double *__restrict__ partials) {
+__global__ void __launch_bounds__(256) k_loop2(Vecs V, long n, double alpha, double omega, RedOut ro) {
   double acc[7] = {0, 0, 0, 0, 0, 0, 0};
   GRID_STRIDE2(j, n) {
     const double2 qhat = LD2(V.v[QHAT]), y = LD2(V.v[Y_]), r0 = LD2(V.v[R0]);
@@ -382,7 +424,7 @@ __global__ void __launch_bounds__(256) k_loop2(Vecs V, long n, double alpha, dou
     acc[5] = dot2(r0, r0, acc[5]);  // norm_2
     acc[6] = dot2(r, r, acc[6]);    // norm
   }
-  emit_partials<7>(acc, partials);
+  grid_sum_finish<7>(acc, ro);
 }
 // k % 50 == 0 variants   (14518-14537)
 __global__ void __launch_bounds__(256) k_loop2_x(Vecs V, long n, double alpha, double omega) {
@@ -391,7 +433,7 @@ __global__ void __launch_bounds__(256) k_loop2_x(Vecs V, long n, double alpha, d
 __global__ void __launch_bounds__(256) k_true_resid(Vecs V, long n) {
   GRID_STRIDE(j, n) V.v[R_][j] = V.v[B_][j] - V.v[R_][j];
 }
-__global__ void __launch_bounds__(256) k_dots7(Vecs V, long n, double *__restrict__ partials) {
+__global__ void __launch_bounds__(256) k_dots7(Vecs V, long n, RedOut ro) {
   double acc[7] = {0, 0, 0, 0, 0, 0, 0};
   GRID_STRIDE(j, n) {
     const double r0 = V.v[R0][j], r = V.v[R_][j];
@@ -403,7 +445,7 @@ __global__ void __launch_bounds__(256) k_dots7(Vecs V, long n, double *__restric
     acc[5] += r0 * r0;
     acc[6] += r * r;
   }
-  emit_partials<7>(acc, partials);
+  grid_sum_finish<7>(acc, ro);
 }
 __global__ void __launch_bounds__(256) k_copy(const double *__restrict__ src, double *__restrict__ dst, long n) {
   GRID_STRIDE(j, n) dst[j] = src[j];
@@ -415,13 +457,13 @@ __global__ void __launch_bounds__(256) k_sub_divp(double *__restrict__ lhs, cons
 }
 // sum(p*vv), sum(vv)   (15111-15121)
 __global__ void __launch_bounds__(256) k_mean_dots(const double *__restrict__ p, long n, double vv, const double *__restrict__ hb,
-                                                   double *__restrict__ partials) {
+                                                   RedOut ro) {
   double acc[2] = {0, 0};
   GRID_STRIDE(j, n) {
     if (hb) { const double h = hb[j >> 9]; vv = h * h * h; }
     acc[0] += p[j] * vv; acc[1] += vv;
   }
-  emit_partials<2>(acc, partials);
+  grid_sum_finish<2>(acc, ro);
 }
 // p -= avg ; (p += pOld)   (15127-15145)
 __global__ void __launch_bounds__(256) k_shift_mean(double *__restrict__ p, const double *__restrict__ pold, long n, double avg) {
@@ -443,14 +485,27 @@ static unsigned vec_groups(long n) {
 
 struct Reducer {
   Sim *s;
-  unsigned groups;
-  // finalise `k` dot products from the per-group partials, all-reduce, start the read-back
+  // where the kernel that ends with grid_sum_finish puts its totals: d_red always; the pinned host mirror directly when no
+  // all-reduce has to run in between
+  bool direct() const { return !(s->grid->nranks > 1 || (debug_option("force_allreduce") && comm())); }
+  RedOut out() const { return RedOut{s->d_partials, s->d_counters, s->d_red, direct() ? s->h_red_dev : nullptr}; }
+  // the k totals are in d_red when the work enqueued so far completes: all-reduce (communication stream), start the read-back
   int begin(int k) {
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, stream(), s->d_partials, (int)groups, k, s->d_red);
-    int rc = allreduce(s, s->d_red, k, false, stream());
+    if (direct()) {
+      CUP3D_HIP(hipEventRecord(s->ev_a, stream()));
+      return CUP3D_OK;
+    }
+    // MPI_Iallreduce (14486, 14546): on the communication stream, so that the preconditioner + LHS enqueued next on the compute
+    // stream overlap it; every RCCL call of the library is issued from that one stream, in the same order on all ranks
+    hipStream_t cs = scalar_stream(s);
+    if (cs != stream()) {
+      CUP3D_HIP(hipEventRecord(s->ev_b, stream()));
+      CUP3D_HIP(hipStreamWaitEvent(cs, s->ev_b, 0));
+    }
+    int rc = allreduce(s, s->d_red, k, false, cs);
     if (rc) return rc;
-    CUP3D_HIP(hipMemcpyAsync(s->h_red, s->d_red, k * sizeof(double), hipMemcpyDeviceToHost, stream()));
-    CUP3D_HIP(hipEventRecord(s->ev_a, stream()));
+    CUP3D_HIP(hipMemcpyAsync(s->h_red, s->d_red, k * sizeof(double), hipMemcpyDeviceToHost, cs));
+    CUP3D_HIP(hipEventRecord(s->ev_a, cs));
     return CUP3D_OK;
   }
   int wait() {
@@ -462,7 +517,7 @@ struct Reducer {
 static int ensure_vectors(Sim *s) {
   if (s->sv[0]) return CUP3D_OK;
   for (int i = 0; i < NVEC; ++i) {
-    int rc = sim_alloc(&s->sv[i], (size_t)s->nb * 512, s);
+    int rc = sim_alloc(&s->sv[i], (size_t)s->nvis * 512, s);  // nvis: the LHS reads ghost blocks of any of them on a rank view
     if (rc) return rc;
   }
   return CUP3D_OK;
@@ -486,7 +541,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   const int mc = helm ? 0 : P.mean_constraint;
   const int max_restarts = helm ? 0x7fffffff : P.max_restarts;
   const double eps = 1e-100;
-  Reducer red{s, G};
+  Reducer red{s};
   auto LHS = [&](int in, int out) {  // _lhs, 9365-9393 / 6836-6875
     return helm ? launch_lhs_diffusion(s, V.v[in], V.v[out], *helm) : launch_lhs(s, V.v[in], V.v[out], mc);
   };
@@ -500,7 +555,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   TRY(LHS(X_, R0));
   { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_resid0, V, N); }
   TRY(PRE(R0, RHAT)); TRY(LHS(RHAT, W_)); TRY(PRE(W_, WHAT)); TRY(LHS(WHAT, T_));
-  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots_r0, V, N, s->d_partials); }
+  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots_r0, V, N, red.out()); }
   TRY(red.begin(2)); TRY(red.wait());
   double alpha = s->h_red[0] / (s->h_red[1] + eps);  // 14443
   double r0r_prev = s->h_red[0];
@@ -512,12 +567,12 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   for (k = 0; k < P.max_iter; ++k) {
     if (k % 50 != 0) {
       ProfileScope ps("bicgstab_loop1");
-      if (!debug_option("loops_no_nt")) LAUNCH_VEC(k_loop1<true>, V, N, alpha, beta, omega, s->d_partials);
-      else LAUNCH_VEC(k_loop1<false>, V, N, alpha, beta, omega, s->d_partials);
+      if (!debug_option("loops_no_nt")) LAUNCH_VEC(k_loop1<true>, V, N, alpha, beta, omega, red.out());
+      else LAUNCH_VEC(k_loop1<false>, V, N, alpha, beta, omega, red.out());
     } else {
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_loop1_phat, V, N, beta, omega); }
       TRY(LHS(PHAT, S_)); TRY(PRE(S_, SHAT)); TRY(LHS(SHAT, Z_));
-      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_loop1_tail, V, N, alpha, s->d_partials); }
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_loop1_tail, V, N, alpha, red.out()); }
     }
     TRY(red.begin(2));                       // MPI_Iallreduce(2), 14486
     TRY(PRE(Z_, ZHAT)); TRY(LHS(ZHAT, V_));  // overlapped with the reduction read-back, 14488-14489
@@ -525,8 +580,8 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     omega = s->h_red[0] / (s->h_red[1] + eps);  // 14493
     if (k % 50 != 0) {
       ProfileScope ps("bicgstab_loop2");
-      if (!debug_option("loops_no_nt")) LAUNCH_VEC(k_loop2<true>, V, N, alpha, omega, s->d_partials);
-      else LAUNCH_VEC(k_loop2<false>, V, N, alpha, omega, s->d_partials);
+      if (!debug_option("loops_no_nt")) LAUNCH_VEC(k_loop2<true>, V, N, alpha, omega, red.out());
+      else LAUNCH_VEC(k_loop2<false>, V, N, alpha, omega, red.out());
     } else {
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_loop2_x, V, N, alpha, omega); }
     }
@@ -535,7 +590,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       TRY(LHS(X_, R_));
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_true_resid, V, N); }
       TRY(PRE(R_, RHAT)); TRY(LHS(RHAT, W_));
-      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots7, V, N, s->d_partials); }
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots7, V, N, red.out()); }
     }
     TRY(red.begin(7));                       // MPI_Iallreduce(7), 14546
     TRY(PRE(W_, WHAT)); TRY(LHS(WHAT, T_));  // 14548-14549
@@ -554,7 +609,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       restarts++;
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_copy, V.v[R_], V.v[R0], N); }
       TRY(PRE(R0, RHAT)); TRY(LHS(RHAT, W_));
-      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots_r0, V, N, s->d_partials); }
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots_r0, V, N, red.out()); }
       TRY(red.begin(2));
       TRY(PRE(W_, WHAT)); TRY(LHS(WHAT, T_));
       TRY(red.wait());
@@ -600,6 +655,22 @@ void cup3d_poisson_default_params(cup3d_poisson_params *p) {
   p->tol = 1e-6; p->tol_rel = 1e-4; p->mean_constraint = 1; p->max_iter = 1000; p->max_restarts = 100; p->block_solver = 0;
 }
 
+// TEST SUPPORT: see k_debug_wave_sum (in64 -> out128, host arrays)
+int cup3d_debug_wave_sum(const double *in64, double *out128) {
+  if (!in64 || !out128) return CUP3D_EINVAL;
+  double *d = nullptr;
+  CUP3D_HIP(hipMalloc((void **)&d, 192 * sizeof(double)));
+  hipError_t e = hipMemcpy(d, in64, 64 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_debug_wave_sum, dim3(1), dim3(64), 0, stream(), d, d + 64);
+    e = hipStreamSynchronize(stream());
+    if (e == hipSuccess) e = hipMemcpy(out128, d + 64, 128 * sizeof(double), hipMemcpyDeviceToHost);
+  }
+  hipFree(d);
+  if (e != hipSuccess) return hip_fail(e, "cup3d_debug_wave_sum", __FILE__, __LINE__);
+  return CUP3D_OK;
+}
+
 int cup3d_preconditioner(cup3d_sim_t *h, int block_solver) {
   if (!h) return CUP3D_EINVAL;
   Sim *s = reinterpret_cast<Sim *>(h);
@@ -624,9 +695,12 @@ int cup3d_pressure_project(cup3d_sim_t *h, double dt, int step, const cup3d_pois
   const unsigned G = vec_groups(N), Gs = vec_groups_simple(N);
   const bool second_order = step > 2;  // sim.step > sim.step_2nd_start (= 2), main.cpp:15087, 15355
   if (second_order) { ProfileScope ps("project_pointwise"); LAUNCH_VEC_S(k_copy, s->pres, s->pold, N); }  // pOld, 15075
-  // tmpV = 0 (15076-15078) matters only as the udef lab of KernelPressureRHS; without
-  // obstacles the RHS kernel does not read it (adding -0*fac*0 is the identity).
+  // tmpV = 0 (15076-15078) matters only as the udef lab of KernelPressureRHS; without obstacles the RHS kernel does not read it
+  // (adding -0*fac*0 is the identity).  With a resident chi it does: unless the caller has placed udef there since the last
+  // projection (upload / fill / cup3d_update_tmpv), tmpV still holds the previous step's gradP scratch and is cleared here.
+  if (s->chi_nonzero && !s->udef_nonzero) TRY(cup3d_sim_fill(h, CUP3D_FIELD_TMPV, 0.0));
   TRY(cup3d_pressure_rhs(h, dt));
+  s->udef_nonzero = false;
   if (second_order) {
     TRY(cup3d_div_pressure(h));
     ProfileScope ps("project_pointwise");
@@ -636,8 +710,8 @@ int cup3d_pressure_project(cup3d_sim_t *h, double dt, int step, const cup3d_pois
   }
   TRY(solve(s, P, r));
   const double hh = s->grid->h, vv = hh * hh * hh;
-  { ProfileScope ps("project_pointwise"); LAUNCH_VEC(k_mean_dots, s->pres, N, vv, s->d_hb, s->d_partials); }
-  Reducer red{s, G};
+  Reducer red{s};
+  { ProfileScope ps("project_pointwise"); LAUNCH_VEC(k_mean_dots, s->pres, N, vv, s->d_hb, red.out()); }
   TRY(red.begin(2)); TRY(red.wait());                        // MPI_Allreduce(2), 15123
   const double avg = s->h_red[0] / s->h_red[1];              // 15126
   { ProfileScope ps("project_pointwise"); LAUNCH_VEC_S(k_shift_mean, s->pres, second_order ? s->pold : (const double *)nullptr, N, avg); }

@@ -251,75 +251,84 @@ int cup3d_profile_read(cup3d_profile_entry *e, int max, int *n) {
   return CUP3D_OK;
 }
 
-int cup3d_sim_create(const cup3d_grid_t *gh, cup3d_sim_t **out) {
-  if (!gh || !out) return CUP3D_EINVAL;
-  const Grid *g = reinterpret_cast<const Grid *>(gh);
-  if (g->n_local >= 0) {  // Grid::rank_view: the topology and the exchange plans exist, the device transport does not yet
-    set_error("multi-level meshes spread over several ranks: the ghost-block / face-flux exchange is not built on the device yet");
-    return CUP3D_ESTATE;
-  }
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess) { set_error("cup3d_sim_create: no HIP device (call cup3d_device_init first)"); return CUP3D_EDEVICE; }
-  if (g->nranks > 1 && !comm() && !virtual_ranks()) { set_error("grid spans %d ranks but cup3d_comm_init was not called", g->nranks); return CUP3D_ESTATE; }
-  Sim *s = new Sim();
+static int sim_build(Sim *s, const Grid *g) {
   s->grid = g;
   s->nb = g->nblocks();
-  const size_t nb = (size_t)s->nb;
+  s->nvis = (int64_t)g->Z.size();  // rank views: local + ghost blocks
+  const size_t nb = (size_t)s->nb, nv = (size_t)s->nvis;
+  const bool view = g->n_local >= 0;
   int rc;
-#define A(ptr, n) if ((rc = sim_alloc(&(ptr), (n), s)) != CUP3D_OK) { cup3d_sim_destroy((cup3d_sim_t *)s); return rc; }
-  A(s->vel, nb * 1536) A(s->vel2, nb * 1536) A(s->tmpV, nb * 1536)
-  A(s->pres, nb * 512) A(s->lhs, nb * 512) A(s->chi, nb * 512) A(s->pold, nb * 512)
+  auto up = [&](int32_t **d, const std::vector<int32_t> &v) -> int {
+    if (v.empty()) { *d = nullptr; return CUP3D_OK; }
+    CUP3D_HIP(hipMalloc((void **)d, v.size() * sizeof(int32_t)));
+    CUP3D_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return CUP3D_OK;
+  };
+#define A(ptr, n) if ((rc = sim_alloc(&(ptr), (n), s)) != CUP3D_OK) return rc;
+  A(s->vel, nv * 1536) A(s->vel2, nv * 1536) A(s->tmpV, nv * 1536)
+  A(s->pres, nv * 512) A(s->lhs, nv * 512) A(s->chi, nv * 512) A(s->pold, nv * 512)
   s->max_groups = 4096;
   A(s->d_partials, (size_t)s->max_groups * 8 + nb) A(s->d_red, 16)
-#undef A
   CUP3D_HIP(hipHostMalloc((void **)&s->h_red, 16 * sizeof(double), hipHostMallocDefault));
-  CUP3D_HIP(hipMalloc((void **)&s->d_nbr, nb * 6 * sizeof(int32_t)));
-  CUP3D_HIP(hipMemcpy(s->d_nbr, g->nbr.data(), nb * 6 * sizeof(int32_t), hipMemcpyHostToDevice));
+  CUP3D_HIP(hipHostGetDevicePointer((void **)&s->h_red_dev, s->h_red, 0));
+  CUP3D_HIP(hipMalloc((void **)&s->d_counters, 4 * sizeof(unsigned)));
+  CUP3D_HIP(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned), g_stream));
+  if ((rc = up(&s->d_nbr, g->nbr))) return rc;
   if (g->nranks > 1) {
-    auto up = [&](int32_t **d, const std::vector<int32_t> &v) -> int {
-      if (v.empty()) { *d = nullptr; return CUP3D_OK; }
-      CUP3D_HIP(hipMalloc((void **)d, v.size() * sizeof(int32_t)));
-      CUP3D_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-      return CUP3D_OK;
-    };
-    if ((rc = up(&s->d_inner, g->inner)) || (rc = up(&s->d_boundary, g->boundary)) || (rc = up(&s->d_send_faces, g->send_faces))) {
-      cup3d_sim_destroy((cup3d_sim_t *)s);
-      return rc;
-    }
-    const size_t slab = 3 * 3 * 64;  // widest exchange: 3 components x 3 layers
-    if (g->n_recv_faces) { if ((rc = sim_alloc(&s->halo_recv, (size_t)g->n_recv_faces * slab, s))) { cup3d_sim_destroy((cup3d_sim_t *)s); return rc; } }
-    if (!g->send_faces.empty()) { if ((rc = sim_alloc(&s->halo_send, g->send_faces.size() * slab, s))) { cup3d_sim_destroy((cup3d_sim_t *)s); return rc; } }
+    if ((rc = up(&s->d_inner, g->inner)) || (rc = up(&s->d_boundary, g->boundary)) || (rc = up(&s->d_send_faces, g->send_faces))) return rc;
     CUP3D_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
   }
+  if (g->nranks > 1 && !g->multilevel) {
+    const size_t slab = 3 * 3 * 64;  // widest exchange: 3 components x 3 layers
+    if (g->n_recv_faces) A(s->halo_recv, (size_t)g->n_recv_faces * slab)
+    if (!g->send_faces.empty()) A(s->halo_send, g->send_faces.size() * slab)
+  }
   if (g->multilevel) {
-    auto up = [&](int32_t **d, const std::vector<int32_t> &v) -> int {
-      if (v.empty()) { *d = nullptr; return CUP3D_OK; }
-      CUP3D_HIP(hipMalloc((void **)d, v.size() * sizeof(int32_t)));
-      CUP3D_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-      return CUP3D_OK;
-    };
+    // ghost slabs are produced for the LOCAL interface faces only (a view also lists the fine faces of ghost blocks, whose
+    // flux arrays arrive from their owners)
+    const int64_t nlf = view ? g->n_local_faces : g->n_amr_faces();
     std::vector<int32_t> lr, lp;
-    for (int64_t e = 0; e < g->n_amr_faces(); ++e) (g->amr_faces[2 * e + 1] ? lr : lp).push_back((int32_t)e);
+    for (int64_t e = 0; e < nlf; ++e) (g->amr_faces[2 * e + 1] ? lr : lp).push_back((int32_t)e);
     s->n_restrict = (unsigned)lr.size();
     s->n_prolong = (unsigned)lp.size();
     if ((rc = up(&s->d_amr_faces, g->amr_faces)) || (rc = up(&s->d_amr_fine, g->amr_fine)) || (rc = up(&s->d_nbr27, g->nbr27)) ||
         (rc = up(&s->d_index, g->index)) || (rc = up(&s->d_restrict_list, lr)) || (rc = up(&s->d_prolong_list, lp)) ||
-        (rc = up(&s->d_fix_list[0], g->fix_faces[0])) || (rc = up(&s->d_fix_list[1], g->fix_faces[1])) || (rc = up(&s->d_fix_list[2], g->fix_faces[2]))) {
-      cup3d_sim_destroy((cup3d_sim_t *)s);
+        (rc = up(&s->d_fix_list[0], g->fix_faces[0])) || (rc = up(&s->d_fix_list[1], g->fix_faces[1])) || (rc = up(&s->d_fix_list[2], g->fix_faces[2])))
       return rc;
-    }
-    if ((rc = sim_alloc(&s->d_hb, nb, s))) { cup3d_sim_destroy((cup3d_sim_t *)s); return rc; }
-    CUP3D_HIP(hipMemcpy(s->d_hb, g->hb.data(), nb * sizeof(double), hipMemcpyHostToDevice));
+    A(s->d_hb, nv)
+    CUP3D_HIP(hipMemcpy(s->d_hb, g->hb.data(), nv * sizeof(double), hipMemcpyHostToDevice));
     const size_t ne = (size_t)std::max<int64_t>(g->n_amr_faces(), 1);
     // ghost slabs: widest use = 3 components x 3 layers; the pressure RHS keeps a second set (udef) behind the first
-    if ((rc = sim_alloc(&s->halo_recv, ne * 9 * 64, s))) { cup3d_sim_destroy((cup3d_sim_t *)s); return rc; }
-    if ((rc = sim_alloc(&s->d_flux, ne * 3 * 64, s))) { cup3d_sim_destroy((cup3d_sim_t *)s); return rc; }
+    A(s->halo_recv, ne * 9 * 64)
+    A(s->d_flux, ne * 3 * 64)
+    if (view) {
+      if ((rc = up(&s->d_send_blocks, g->send_blocks)) || (rc = up(&s->d_send_flux, g->send_flux_faces))) return rc;
+      const size_t need = std::max(g->send_blocks.size() * 1536, g->send_flux_faces.size() * 3 * 64);
+      if (need) A(s->halo_send, need)
+    }
   }
+#undef A
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_a, hipEventDisableTiming));
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_b, hipEventDisableTiming));
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_h1, hipEventDisableTiming));
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_h2, hipEventDisableTiming));
   CUP3D_HIP(hipStreamSynchronize(g_stream));
+  return CUP3D_OK;
+}
+
+int cup3d_sim_create(const cup3d_grid_t *gh, cup3d_sim_t **out) {
+  if (!gh || !out) return CUP3D_EINVAL;
+  const Grid *g = reinterpret_cast<const Grid *>(gh);
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("cup3d_sim_create: no HIP device (call cup3d_device_init first)"); return CUP3D_EDEVICE; }
+  if (g->nranks > 1 && !comm() && !virtual_ranks()) { set_error("grid spans %d ranks but cup3d_comm_init was not called", g->nranks); return CUP3D_ESTATE; }
+  Sim *s = new Sim();
+  const int rc = sim_build(s, g);
+  if (rc != CUP3D_OK) {  // whatever was allocated so far goes back (an out-of-memory at 512^3 must not strand the slabs already made)
+    cup3d_sim_destroy(reinterpret_cast<cup3d_sim_t *>(s));
+    return rc;
+  }
+  vcomm_register(s);
   *out = reinterpret_cast<cup3d_sim_t *>(s);
   return CUP3D_OK;
 }
@@ -327,17 +336,19 @@ int cup3d_sim_create(const cup3d_grid_t *gh, cup3d_sim_t **out) {
 void cup3d_sim_destroy(cup3d_sim_t *h) {
   if (!h) return;
   Sim *s = reinterpret_cast<Sim *>(h);
+  vcomm_unregister(s);
   hipStreamSynchronize(g_stream);
   double *ptrs[] = {s->vel, s->vel2, s->tmpV, s->pres, s->lhs, s->chi, s->pold, s->d_partials, s->d_red, s->d_stage, s->halo_recv, s->halo_send,
                     s->d_hb, s->d_flux};
   for (double *p : ptrs) if (p) hipFree(p);
   for (double *p : s->sv) if (p) hipFree(p);
   if (s->h_red) hipHostFree(s->h_red);
+  if (s->d_counters) hipFree(s->d_counters);
   if (s->h_stage) hipHostFree(s->h_stage);
   if (s->h_stage_slots) hipHostFree(s->h_stage_slots);
   if (s->d_stage_slots) hipFree(s->d_stage_slots);
   int32_t *ip[] = {s->d_nbr, s->d_inner, s->d_boundary, s->d_send_faces, s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_index,
-                   s->d_restrict_list, s->d_prolong_list, s->d_fix_list[0], s->d_fix_list[1], s->d_fix_list[2]};
+                   s->d_restrict_list, s->d_prolong_list, s->d_fix_list[0], s->d_fix_list[1], s->d_fix_list[2], s->d_send_blocks, s->d_send_flux};
   for (int32_t *p : ip) if (p) hipFree(p);
   if (s->comm_stream) hipStreamDestroy(s->comm_stream);
   if (s->ev_a) hipEventDestroy(s->ev_a);
@@ -359,6 +370,7 @@ int cup3d_sim_device_ptr(cup3d_sim_t *h, int field, void **ptr) {
 
 static int mark_written(Sim *s, int field) {
   if (field == CUP3D_FIELD_CHI) s->chi_nonzero = true;   // obstacles present: KernelPressureRHS must read chi/udef
+  if (field == CUP3D_FIELD_TMPV) s->udef_nonzero = true;  // the caller placed udef in tmpV for the next projection
   return CUP3D_OK;
 }
 
@@ -514,6 +526,7 @@ int cup3d_sim_fill(cup3d_sim_t *h, int field, double value) {
   hipLaunchKernelGGL(k_fill, dim3(stride_groups(n)), dim3(256), 0, g_stream, p, n, value);
   CUP3D_HIP(hipGetLastError());
   if (field == CUP3D_FIELD_CHI) s->chi_nonzero = value != 0.0;
+  if (field == CUP3D_FIELD_TMPV) s->udef_nonzero = true;
   return CUP3D_OK;
 }
 
@@ -527,10 +540,15 @@ int cup3d_max_u(cup3d_sim_t *h, const double uinf[3], double *umax) {
     hipLaunchKernelGGL(k_max_final, dim3(1), dim3(256), 0, g_stream, s->d_partials, (int)groups, s->d_red);
   }
   CUP3D_HIP(hipGetLastError());
-  int rc = allreduce(s, s->d_red, 1, /*is_max=*/true, g_stream);  // MPI_Allreduce MAX, main.cpp:8620
+  hipStream_t cs = scalar_stream(s);  // MPI_Allreduce MAX, main.cpp:8620 -- on the stream every RCCL call of the library uses
+  if (cs != g_stream) {
+    CUP3D_HIP(hipEventRecord(s->ev_b, g_stream));
+    CUP3D_HIP(hipStreamWaitEvent(cs, s->ev_b, 0));
+  }
+  int rc = allreduce(s, s->d_red, 1, /*is_max=*/true, cs);
   if (rc) return rc;
-  CUP3D_HIP(hipMemcpyAsync(s->h_red, s->d_red, sizeof(double), hipMemcpyDeviceToHost, g_stream));
-  CUP3D_HIP(hipStreamSynchronize(g_stream));
+  CUP3D_HIP(hipMemcpyAsync(s->h_red, s->d_red, sizeof(double), hipMemcpyDeviceToHost, cs));
+  CUP3D_HIP(hipStreamSynchronize(cs));
   *umax = s->h_red[0];
   return CUP3D_OK;
 }

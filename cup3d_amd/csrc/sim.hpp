@@ -58,14 +58,16 @@ __device__ __forceinline__ double block_h(const GridDev &g, int slot) { return g
 
 struct Sim {
   const Grid *grid = nullptr;
-  int64_t nb = 0;
+  int64_t nb = 0;    // local blocks: what the kernels sweep and what crosses the host boundary
+  int64_t nvis = 0;  // block slots of every field array: nb + the ghost blocks of a rank view (Grid::rank_view), else nb
   // topology on device
   int32_t *d_nbr = nullptr, *d_inner = nullptr, *d_boundary = nullptr, *d_send_faces = nullptr;
   // fields
   double *vel = nullptr, *vel2 = nullptr, *tmpV = nullptr;    // [nb][3][512]
   double *pres = nullptr, *lhs = nullptr, *chi = nullptr;     // [nb][512]
   double *pold = nullptr;
-  bool chi_nonzero = false, udef_nonzero = false;
+  bool chi_nonzero = false;   // chi was uploaded / filled non-zero: the pressure RHS reads chi and udef (= tmpV)
+  bool udef_nonzero = false;  // tmpV holds the udef of the NEXT projection (uploaded, filled or cup3d_update_tmpv since the last one)
   int block_solver = 0;  // cup3d_poisson_params.block_solver of the running solve
   int scalar_bc_dir = -1;  // >= 0 while a Helmholtz solve of the implicit diffusion runs: domain-face rule of the scalar tiles
   // solver vectors (allocated on first solve), each [nb][512]
@@ -75,6 +77,8 @@ struct Sim {
   double *d_red = nullptr;       // [16] final reduced scalars
   const double *sums_of = nullptr;  // vector whose per-block sums (mean constraint) are current in d_partials' tail
   double *h_red = nullptr;       // pinned host mirror
+  double *h_red_dev = nullptr;   // the same memory as the device sees it (kernels store the reduced scalars there directly)
+  unsigned *d_counters = nullptr;  // [4] tickets of grid_sum_finish (tile.hpp), zero between launches
   int max_groups = 0;
   // staging for host transfers
   double *d_stage = nullptr;
@@ -85,6 +89,7 @@ struct Sim {
   int32_t *d_amr_faces = nullptr, *d_amr_fine = nullptr, *d_nbr27 = nullptr, *d_index = nullptr;
   int32_t *d_restrict_list = nullptr, *d_prolong_list = nullptr, *d_fix_list[3] = {nullptr, nullptr, nullptr};
   unsigned n_restrict = 0, n_prolong = 0;
+  int32_t *d_send_blocks = nullptr, *d_send_flux = nullptr;  // rank views: exchange plans (comm.hip)
   double *d_hb = nullptr, *d_flux = nullptr;
   // halo buffers (multi-rank)
   double *halo_recv = nullptr, *halo_send = nullptr;  // n faces x 3 comps x 3 layers x 64
@@ -105,6 +110,12 @@ int halo_begin(Sim *s, const double *field, int ncomp, int w);
 int halo_finish(Sim *s);
 // sum / max all-reduce of n doubles resident in device memory; no-op on one rank
 int allreduce(Sim *s, double *d_buf, int n, bool is_max, hipStream_t st);
+bool scalars_cross_ranks(const Sim *s);   // does allreduce() do anything for this sim?
+hipStream_t scalar_stream(const Sim *s);  // the stream all-reduces are enqueued on (communication stream where there is one)
+// rank views of a multi-level mesh: face-flux arrays of remote fine faces -> ghost face range of d_flux (before k_flux_fix)
+int view_exchange_flux(Sim *s, int nfc);
+void vcomm_register(Sim *s);    // in-process test communicator (comm.hip)
+void vcomm_unregister(Sim *s);
 
 // multi-level meshes: ghost slabs of every interface face of `field` for a w-deep star stencil -> slabs;
 // flux correction of `out` (out_nc components per block, the first nfc corrected) from s->d_flux

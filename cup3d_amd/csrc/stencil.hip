@@ -190,18 +190,31 @@ __global__ void __launch_bounds__(256) k_lhs(GridDev g, const double *__restrict
   }
 }
 
-// deterministic two-stage sum of n per-block values: 64 workgroups -> 64 partials -> out[0]
-__global__ void __launch_bounds__(256) k_sum_blocks(const double *__restrict__ v, int n, double *__restrict__ part) {
+// deterministic sum of n per-block values in ONE launch: 64 workgroups -> 64 partials, the last workgroup to arrive totals them in
+// index order (tile.hpp, grid_sum_finish) and, on one rank with bMeanConstraint == 1, writes the row of the corner cell:
+// LHS(0,0,0) = avgP (main.cpp:9299-9304).  (Round 1 spent three launches on this, four times per BiCGSTAB iteration.)
+__global__ void __launch_bounds__(256) k_mean_finish(const double *__restrict__ v, int n, double *__restrict__ part, unsigned *counter,
+                                                     double *__restrict__ total, double *__restrict__ corner_out) {
   __shared__ double red[4];
+  __shared__ int is_last;
   double s = 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) s += v[i];
   s = group_sum<4>(s, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = s;
-}
-__global__ void __launch_bounds__(64) k_sum_final(const double *__restrict__ part, int n, double *__restrict__ out) {
-  double s = (int)threadIdx.x < n ? part[threadIdx.x] : 0.0;
-  s = wave_sum(s);
-  if (threadIdx.x == 0) out[0] = s;
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = s;
+    __threadfence();
+    is_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last || threadIdx.x >= 64) return;
+  __threadfence();
+  double t = (int)threadIdx.x < (int)gridDim.x ? part[threadIdx.x] : 0.0;
+  t = wave_sum(t);
+  if (threadIdx.x == 0) {
+    total[0] = t;
+    if (corner_out) corner_out[0] = t;
+    *counter = 0;
+  }
 }
 // mean-constraint fix-ups of ComputeLHS::operator(), main.cpp:9299-9326
 __global__ void k_lhs_corner(double *__restrict__ out, const double *__restrict__ in, const double *__restrict__ avg, int corner_slot, int mode) {
@@ -424,12 +437,23 @@ int launch_lhs(Sim *s, const double *p, double *out, int mc) {
   const int corner = s->grid->corner_slot;
   if (need_sum) {
     ProfileScope ps("poisson_mean_sum");
-    hipLaunchKernelGGL(k_sum_blocks, dim3(64), dim3(256), 0, stream(), block_sums, (int)s->nb, s->d_partials);
-    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64), 0, stream(), s->d_partials, 64, s->d_red + 8);
-    if ((rc = allreduce(s, s->d_red + 8, 1, false, stream()))) return rc;  // MPI_Iallreduce, main.cpp:9295
-    if (mc == 1) {
-      if (corner >= 0) hipLaunchKernelGGL(k_lhs_corner, dim3(1), dim3(1), 0, stream(), out, p, s->d_red + 8, corner, 1);
-    } else {
+    const bool across = scalars_cross_ranks(s);
+    double *corner_out = (!across && mc == 1 && corner >= 0) ? out + (size_t)corner * 512 : nullptr;
+    hipLaunchKernelGGL(k_mean_finish, dim3(64), dim3(256), 0, stream(), block_sums, (int)s->nb, s->d_partials, s->d_counters + 1, s->d_red + 8, corner_out);
+    if (across) {  // MPI_Iallreduce, main.cpp:9295 -- on the communication stream like every RCCL call; the fix-up below waits for it
+      hipStream_t cs = scalar_stream(s);
+      if (cs != stream()) {
+        CUP3D_HIP(hipEventRecord(s->ev_b, stream()));
+        CUP3D_HIP(hipStreamWaitEvent(cs, s->ev_b, 0));
+      }
+      if ((rc = allreduce(s, s->d_red + 8, 1, false, cs))) return rc;
+      if (cs != stream()) {
+        CUP3D_HIP(hipEventRecord(s->ev_h1, cs));
+        CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h1, 0));
+      }
+      if (mc == 1 && corner >= 0) hipLaunchKernelGGL(k_lhs_corner, dim3(1), dim3(1), 0, stream(), out, p, s->d_red + 8, corner, 1);
+    }
+    if (mc == 2) {
       const double h = s->grid->h;
       hipLaunchKernelGGL(k_lhs_add_mean, dim3(2048), dim3(256), 0, stream(), out, s->nb * 512L, s->d_red + 8, h * h * h, s->d_hb);
     }

@@ -75,4 +75,46 @@ __device__ __forceinline__ double group_sum(double v, double *scratch /* >= NW d
   return t;
 }
 
+// Grid-wide deterministic sums finished inside the producing launch (no separate 1-workgroup reduction kernel and, on one rank, no
+// device-to-host copy): every workgroup stores its K partial sums, takes a ticket from an agent-scope counter, and the LAST one to
+// arrive adds the partials of all workgroups in index order (the order does not depend on which workgroup is last) and stores the
+// totals -- to device memory for the all-reduce / later kernels and, when `host` is set, to the pinned host mirror the solver's
+// scalar recurrences read.  Release/acquire at agent scope: the partials cross XCDs (per-XCD L2s are not coherent).
+struct RedOut {
+  double *partials;   // [gridDim.x][8]
+  unsigned *counter;  // zero before the launch; reset by the last workgroup
+  double *out;        // [K] device
+  double *host;       // [K] pinned host memory mapped into the device, or nullptr
+};
+template <int K>
+__device__ __forceinline__ void grid_sum_finish(double (&acc)[K], const RedOut &ro) {
+  __shared__ double red[4];
+  __shared__ int is_last;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const double s = group_sum<4>(acc[i], red);
+    if (threadIdx.x == 0) ro.partials[(size_t)blockIdx.x * 8 + i] = s;
+  }
+  if (threadIdx.x == 0) {
+    __threadfence();  // release the partials at agent scope
+    is_last = atomicAdd(ro.counter, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();  // acquire the other workgroups' partials
+  for (int i = 0; i < K; ++i) {
+    double s = 0;
+    for (int j = threadIdx.x; j < (int)gridDim.x; j += 256) s += ro.partials[(size_t)j * 8 + i];
+    s = group_sum<4>(s, red);
+    if (threadIdx.x == 0) {
+      ro.out[i] = s;
+      if (ro.host) ro.host[i] = s;
+    }
+  }
+  if (threadIdx.x == 0) {
+    *ro.counter = 0;
+    if (ro.host) __threadfence_system();
+  }
+}
+
 }  // namespace cup3d

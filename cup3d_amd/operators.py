@@ -123,14 +123,23 @@ class Grid:
 
 
 class RankView:
-    """Host-side view of a multi-level mesh from one rank (Grid.rank_view): local blocks, ghost blocks, interface faces, neighbour tables
-    in the view's slot numbering, and the two exchange plans.  The device transport is not built yet (cup3d_sim_create refuses it)."""
+    """One rank's view of a multi-level mesh whose leaves are spread over ranks (Grid.rank_view): local blocks, ghost blocks, interface
+    faces, neighbour tables in the view's slot numbering, and the two exchange plans (whole ghost blocks before a stencil kernel,
+    face-flux arrays after a flux-corrected one).  SimulationData(view=...) runs the operators on it."""
 
     def __init__(self, mesh, owner, rank, nranks):
         ow = np.ascontiguousarray(owner, dtype=np.int32)
         h = C.c_void_p()
         check(lib().cup3d_grid_rank_view(mesh.handle, ow.ctypes.data_as(C.c_void_p), int(rank), int(nranks), C.byref(h)))
         self.handle, self.rank, self.nranks = h, int(rank), int(nranks)
+        self.bpd, self.bc, self.levelMax, self.level, self.maxextent, self.multilevel = mesh.bpd, mesh.bc, mesh.levelMax, mesh.level, mesh.maxextent, True
+        self.nblocks = lib().cup3d_grid_nblocks(h)
+        self.nblocks_global = lib().cup3d_grid_nblocks_global(h)
+        self.tables = np.zeros((self.nblocks, 6), dtype=np.int64)
+        self.geom = np.zeros((self.nblocks, 4), dtype=np.float64)
+        check(lib().cup3d_grid_tables(h, self.tables, self.geom))
+        self.index = self.tables[:, 2:5]
+        self.h = mesh.h
         sz = (C.c_long * 6)()
         check(lib().cup3d_grid_view_sizes(h, sz))
         self.nlocal, self.nghost, self.nfaces_local, self.nfaces_ghost, nsb, nsf = (int(v) for v in sz)
@@ -167,7 +176,7 @@ class SimulationData:
                  BC_x="freespace", BC_y="freespace", BC_z="freespace", uinf=(0.0, 0.0, 0.0), uMax_forced=0.0,
                  poissonTol=1e-6, poissonTolRel=1e-4, bMeanConstraint=1, poissonSolver="hip_iterative", rampup=100,
                  blockSolver=0, leaves=None, implicitDiffusion=False, diffusionTol=1e-6, diffusionTolRel=1e-4,
-                 rank=0, nranks=1, device=None):
+                 rank=0, nranks=1, device=None, view=None):
         if device is not None or not capi._device_ready:
             capi.device_init(0 if device is None else device)
         self.bpdx, self.bpdy, self.bpdz = bpdx, bpdy, bpdz
@@ -175,7 +184,9 @@ class SimulationData:
         self.levelStart = levelMax - 1 if levelStart is None else levelStart
         self.maxextent = float(extent)
         # leaves=(levels, Zs): run on that multi-level mesh instead of the uniform grid at levelStart
-        self.grid = Grid((bpdx, bpdy, bpdz), levelMax, self.levelStart, self.maxextent, (BC_x, BC_y, BC_z), rank, nranks, leaves=leaves)
+        # view=RankView: this rank's share of a multi-level mesh spread over several ranks (ghost blocks + exchange plans)
+        self.grid = view if view is not None else Grid((bpdx, bpdy, bpdz), levelMax, self.levelStart, self.maxextent, (BC_x, BC_y, BC_z), rank, nranks,
+                                                       leaves=leaves)
         # extents / hmin as in _preprocessArguments, main.cpp:15394-15415
         aux = 1 << (levelMax - 1)
         nfe = [bpdx * aux * 8, bpdy * aux * 8, bpdz * aux * 8]

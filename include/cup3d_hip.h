@@ -165,7 +165,9 @@ int cup3d_sim_download_block_list(cup3d_sim_t *, int field, long n, const int32_
 int cup3d_sim_upload(cup3d_sim_t *, int field, const double *blocks);
 int cup3d_sim_download(cup3d_sim_t *, int field, double *blocks);
 int cup3d_sim_fill(cup3d_sim_t *, int field, double value);
-/* raw device pointer of a field slab [nb][nc][512] (for zero-copy hosts) */
+/* raw device pointer of a field slab [nb][nc][512] (for zero-copy hosts).  The VEL pointer is valid until the next operator that
+ * advects (cup3d_advect_diffuse, cup3d_advect_diffuse_implicit, cup3d_advect_implicit): those write the new velocity into a second
+ * buffer and swap the two, so re-query it after every such call; the other fields never move. */
 int cup3d_sim_device_ptr(cup3d_sim_t *, int field, void **ptr);
 
 /* AdvectionDiffusion::operator()(dt) (main.cpp:9640-9728): low-storage RK3 of
@@ -183,8 +185,14 @@ typedef struct {
   int max_iter;        /* 1000 (main.cpp:14449) */
   int max_restarts;    /* 100  (main.cpp:14374) */
   int block_solver;    /* how the block preconditioner M^-1 (getZImplParallel, 14704-14745) is evaluated:
-                          0 = the reference's block-local CG, restated iteration for iteration (FMA-contracted on the device);
-                          1 = direct block solve by fast diagonalisation (same operator, exact to rounding) */
+                          0 = the reference's block-local CG, iteration for iteration, as the device evaluates it fastest: a*b+c
+                              contracted to FMA, the two wave-wide sums on the FP64 matrix pipe, the two divisions by reciprocal +
+                              Newton refinement (<= 1 ulp from the IEEE quotient).  Differs from the reference's z at the 1e-7 level of
+                              the CG's own truncation (tests bound it by 2e-5);
+                          1 = direct block solve by fast diagonalisation (same operator, exact to rounding);
+                          2 = the block CG in the reference's association: no FMA contraction, IEEE divisions (only the ORDER of the
+                              512-term sums differs from the CPU); slower, for parity checks;
+                          3 = the round-1 kernel (FMA, DPP reductions), kept for A/B timing */
 } cup3d_poisson_params;
 typedef struct {
   int iterations; /* BiCGSTAB iterations performed (= 7-double reductions, main.cpp:14546) */
@@ -209,7 +217,8 @@ int cup3d_div_pressure(cup3d_sim_t *);
 /* KernelGradP (main.cpp:15146): tmpV = -0.5*dt*h^2 * central grad(pres) */
 int cup3d_grad_p(cup3d_sim_t *, double dt);
 /* PressureProjection::operator()(dt) (main.cpp:15061-15160), obstacle-free or with
- * chi/udef already resident (tmpV is zeroed exactly as at 15076-15078). */
+ * chi/udef already resident: tmpV must hold udef (upload / fill / cup3d_update_tmpv after the previous projection); if it was not
+ * touched since, it is zeroed as at 15076-15078. */
 int cup3d_pressure_project(cup3d_sim_t *, double dt, int step, const cup3d_poisson_params *, cup3d_poisson_result *);
 
 /* ---------------------------------------------------------------------------

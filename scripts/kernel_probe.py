@@ -105,22 +105,21 @@ def main():
         rng = np.random.default_rng(0)
         inputs = {"rhs": rhs, "noise": rng.uniform(-1, 1, rhs.shape)}
         for name, x in inputs.items():
-            for solver, fma in ((0, 0), (0, 1), (1, 0)):
-                check(lib().cup3d_debug_set_option(b"precond_no_fma", 0 if fma else 1))
+            for solver in (2, 0, 3, 1):
+                fma = int(solver != 2)
                 sim.upload("pres", x)
                 check(lib().cup3d_preconditioner(sim.handle, solver))
-                ref = sim.download("pres") if (solver, fma) == (0, 0) else ref  # reference point: uncontracted block CG
+                ref = sim.download("pres") if solver == 2 else ref  # reference point: uncontracted block CG
                 err = float(np.abs(sim.download("pres") - ref).max() / np.abs(ref).max())
                 lib().cup3d_device_synchronize()
                 lib().cup3d_profile_reset()
                 for _ in range(a.reps):
                     sim.upload("pres", x)
                     check(lib().cup3d_preconditioner(sim.handle, solver))
-                key = "poisson_block_fdm" if solver else "poisson_block_cg"
+                key = "poisson_block_fdm" if solver == 1 else "poisson_block_cg"
                 n, ms = profile()[key]
-                print(json.dumps({"probe": key, "size": a.size, "input": name, "fma": fma, "avg_ms": round(ms / n, 4),
+                print(json.dumps({"probe": key, "size": a.size, "input": name, "block_solver": solver, "fma": fma, "avg_ms": round(ms / n, 4),
                                   "max_rel_diff_vs_cg": err}))
-        check(lib().cup3d_debug_set_option(b"precond_no_fma", 0))
     else:
         bc = "periodic" if a.kernel == "adv" else "wall"
         sim = make(a.size, bc)
