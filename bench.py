@@ -31,9 +31,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# FP64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) x 2.4 GHz = 78.6 TFLOP/s (= half the guide's 157.3 TF FP32 vector
+# figure; AMD's public MI355X FP64-vector number).  A wave64 FP64 instruction occupies its SIMD for 4 cycles, FMA or not.
+FP64_PEAK_TFLOPS = 78.6
+# block CG, algorithmic FP64 work per cell per CG iteration (kernelPoissonGetZInner + the updates, main.cpp:14662-14699):
+# stencil 1 FMA + 5 adds, p.Ap 1 FMA, x 1 FMA, r 1 FMA, r.r 1 FMA, p 1 FMA  =  6 FMA + 5 add = 17 flop in 11 instructions
+BLOCK_CG_FLOPS_PER_CELL_ITER = 17.0
 # algorithmic HBM bytes per cell per launch, SURVEY.md §8(d)
 ALGO_BYTES = {
-    "advdiff_stage": 96.0,     # vel 24 in + tmpV 24 in + vel' 24 out + tmpV 24 out
+    "advdiff_stage": 96.0,     # RK stages 2, 3: vel 24 in + tmpV 24 in + vel' 24 out + tmpV 24 out
+    "advdiff_stage1": 72.0,    # RK stage 1 reads no tmpV (it is zero there)
     "bicgstab_loop1": 144.0,   # 11 reads + 7 writes
     "bicgstab_loop2": 128.0,   # 12 reads + 4 writes
     "poisson_lhs": 16.0,       # p in, Ap out
@@ -77,7 +84,7 @@ def cpu_baseline(size_cpu, steps, threads):
             its = [r for r in recs if r["op"] == "steps"][0]["iters"]
             return {"value": size_cpu ** 3 * steps / sec / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "reference",
                     "sample": f"reference main.cpp operators, {size_cpu}^3 all-wall TGV, {steps} steps from step 21, "
-                              f"{sec:.2f} s, {its / steps:.1f} BiCGSTAB its/step"}
+                              f"{sec:.2f} s, {its / steps:.1f} BiCGSTAB its/step", "bicgstab_iters_per_step": its / steps, "size": size_cpu}
         except Exception as e:  # fall through to the port
             sys.stderr.write(f"bench: ref_tool failed ({e}); timing the oracle port instead\n")
     g = O.OracleGrid((1, 1, 1), level + 1, level, 2 * np.pi, ("wall",) * 3)
@@ -187,8 +194,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=512, help="cells per side (power of two >= 16)")
-    ap.add_argument("--cpu-size", type=int, default=128)
-    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-size", type=int, default=256, help="cells per side of the CPU-baseline sample (512 needs ~35 GB and minutes per step)")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0: all host cores")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--stencil-only", action="store_true", help="BASELINE configs[1]: periodic, advect-diffuse only")
     ap.add_argument("--block-solver", type=int, default=0, help="0: block CG as in the reference, 1: direct block solve")
@@ -287,6 +295,9 @@ def main():
     lib().cup3d_profile_read(ents, 64, C.byref(n))
     lib().cup3d_profile_enable(0)
     prof = {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n.value)}
+    tot, nblk = C.c_long(0), C.c_long(0)
+    lib().cup3d_debug_block_cg_iterations(sim.handle, C.byref(tot), C.byref(nblk))
+    a.cg_iters_per_block = tot.value / nblk.value if nblk.value else None
 
     alt = None
     if not a.stencil_only and not a.no_alt and not a.implicit_diffusion:
@@ -319,6 +330,17 @@ def main():
         dist.destroy_process_group()
 
 
+def ref_iters(a):
+    """BiCGSTAB iterations per step of the REFERENCE on this very workload, from the recorded campaign run
+    (scripts/campaigns/baseline_sizes_vs_reference.py -> profiles/r02/reference_step_<size>.json); None if never recorded."""
+    f = os.path.join(ROOT, "profiles", "r02", f"reference_step_{a.size}.json")
+    if a.stencil_only or a.implicit_diffusion or not os.path.exists(f):
+        return None
+    rec = json.load(open(f))
+    return {"value": rec["ref_iters_per_step"], "device_in_the_same_run": rec["device_iters_per_step"], "steps": len(rec["steps"]),
+            "source": f"profiles/r02/reference_step_{a.size}.json (compiled reference, one step from step 21)"}
+
+
 def report(a, sim, prof, sec, iters, world, alt=None):
     cells = float(a.size) ** 3
     cells_local = sim.nblocks * 512.0
@@ -334,11 +356,22 @@ def report(a, sim, prof, sec, iters, world, alt=None):
         e = {"kernel": name, "launches": launches, "avg_ms": round(avg_ms, 5), "share": round(ms / total_ms, 4)}
         if name in ALGO_BYTES:
             ach = ALGO_BYTES[name] * cells_local / (avg_ms * 1e-3) / 1e9
+            tr = traffic.get(f"{name}@{a.size}")
             e.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(f"{name}@{a.size}")})
-        if name == "poisson_block_cg":
-            e["note"] = ("one wavefront per block, <= 100 CG iterations in registers: bound by FP64 issue and dependent chains, not by HBM "
-                         "(SQ counters in profiles/r01/pmc_block_preconditioner_sq_after.txt); its HBM traffic equals the algorithmic 16 B/cell")
+                      "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr})
+            if tr is not None:  # a recorded PMC measurement of this kernel at this size, not a quantity of this run
+                e["traffic_source"] = traffic.get("_source", "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)")
+        if name == "poisson_block_cg" and getattr(a, "cg_iters_per_block", None):
+            # The block CG moves exactly its 16 B/cell (PMC) and sits at < 0.15 of the HBM roof: HBM is the wrong roof.  It is
+            # bound by FP64 instruction issue: algorithmic flops = 17 per cell per CG iteration x the iterations the blocks of the
+            # last launch actually took (counted on the device), against the FP64 vector peak.
+            flops = BLOCK_CG_FLOPS_PER_CELL_ITER * 512.0 * a.cg_iters_per_block * sim.nblocks
+            tf = flops / (avg_ms * 1e-3) / 1e12
+            e.update({"bound": "fp64", "achieved": round(tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_PEAK_TFLOPS, 4),
+                      "hbm_frac": e["frac"], "cg_iterations_per_block": round(a.cg_iters_per_block, 2),
+                      "note": ("one wavefront per 8^3 block, <= 100 CG iterations in registers; flops = 17/cell/CG-iteration x counted iterations "
+                               "(6 FMA + 5 add: 11 issue slots, so 17/22 = 0.77 of peak is the ceiling of this instruction mix); wave sums on the "
+                               "FP64 matrix pipe; HBM traffic = the algorithmic 16 B/cell (hbm_frac)")})
         kernels.append(e)
     with_roof = [k for k in kernels if "achieved" in k]
     dominant = with_roof[0] if with_roof else None
@@ -354,6 +387,7 @@ def report(a, sim, prof, sec, iters, world, alt=None):
                    else f"taylor-green {a.size}^3 uniform periodic, advect-diffuse RK3 only",
                    "cells": int(cells), "blocks": int(cells // 512), "block": "8^3", "partition": f"hilbert-range x{world}",
                    "bicgstab_iters_per_step": round(float(np.mean(iters)), 2) if iters else None,
+                   "ref_iters_per_step": ref_iters(a),
                    "nu": a.nu, "implicit_diffusion": bool(a.implicit_diffusion),
                    "helmholtz_iters_per_step (3 solves)": getattr(a, "diffusion_iters", None),
                    "block_preconditioner": ("block CG (reference algorithm)", "direct block solve (fast diagonalisation)")[a.block_solver]},
@@ -364,9 +398,13 @@ def report(a, sim, prof, sec, iters, world, alt=None):
     if alt is not None:
         out["alt"] = alt
     if not a.no_cpu and world == 1:
-        # the reference's OpenMP regions (one lab per thread, master-polled halo loop, 5594-5640) stop
-        # scaling long before a 256-thread host is full: cap at 32 threads and say so in `cores`
-        out["cpu_baseline"] = cpu_baseline(a.cpu_size, a.cpu_steps, min(32, os.cpu_count() or 1))
+        # the reference on ALL host cores (count stated in `cores`), 512^3 if the box allowed it in the time the default
+        # run has, else 256^3: a 512^3 step of the reference takes minutes and ~35 GB, so the sample is 256^3 (2 steps, 10-30 s).
+        # Round 1's sample (128^3 on 32 threads: cache-friendlier, fewer iterations) stays beside it as cpu_baseline_128.
+        threads = a.cpu_threads or (os.cpu_count() or 1)
+        out["cpu_baseline"] = cpu_baseline(a.cpu_size, a.cpu_steps, threads)
+        if a.cpu_size != 128:
+            out["cpu_baseline_128"] = cpu_baseline(128, 10, min(32, os.cpu_count() or 1))
     print(json.dumps(out))
     sys.stdout.flush()
 

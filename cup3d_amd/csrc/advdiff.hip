@@ -399,7 +399,7 @@ static int advdiff_stage(Sim *s, int rk, double dt, double nu, const double uinf
       GridDev g = split ? s->gdev(pass == 1, pass == 0) : s->gdev();
       if (pass == 1 && (rc = halo_finish(s))) return rc;
       if (g.nblocks == 0) continue;
-      ProfileScope ps("advdiff_stage");
+      ProfileScope ps(rk == 0 ? "advdiff_stage1" : "advdiff_stage");  // stage 1 reads no tmpV: 72 instead of 96 B/cell
       const dim3 G(launch_groups(g));
 #define ADV(FIRST, CPT, VAR) hipLaunchKernelGGL((k_advdiff<FIRST, CPT, VAR>), G, dim3(512 / CPT), 0, stream(), g, a)
 #define ADV2(CPT, VAR) do { if (rk == 0) ADV(true, CPT, VAR); else ADV(false, CPT, VAR); } while (0)

@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -83,11 +84,19 @@ struct VComm {
   int waiting = 0;
   long gen = 0;
   bool failed = false;
-  void barrier() {
+  // false: a rank did not arrive within 30 s (it failed or diverged in control flow) -- every waiter then gives up, so
+  // a broken run ends with an error instead of a hang
+  bool barrier() {
     std::unique_lock<std::mutex> lk(m);
+    if (failed) return false;
     const long g0 = gen;
-    if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); }
-    else cv.wait(lk, [&] { return gen != g0; });
+    if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); return true; }
+    if (!cv.wait_for(lk, std::chrono::seconds(30), [&] { return gen != g0 || failed; }) || failed) {
+      failed = true;
+      cv.notify_all();
+      return false;
+    }
+    return true;
   }
 };
 static VComm *g_vcomm = nullptr;
@@ -127,7 +136,7 @@ template <class CountOf>
 static int vcomm_pull(Sim *s, double *dst, size_t per, const std::vector<int64_t> &recv_count, CountOf send_count_of) {
   VComm *vc = g_vcomm;
   const Grid *g = s->grid;
-  vc->barrier();  // every rank has enqueued its pack
+  if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the exchange"); return CUP3D_ECOMM; }  // every rank has enqueued its pack
   size_t ro = 0;
   for (int p = 0; p < g->nranks; ++p) {
     const size_t nr = (size_t)recv_count[p] * per;
@@ -141,7 +150,7 @@ static int vcomm_pull(Sim *s, double *dst, size_t per, const std::vector<int64_t
     CUP3D_HIP(hipMemcpyAsync(dst + ro, src->halo_send + so, nr * sizeof(double), hipMemcpyDeviceToDevice, stream()));
     ro += nr;
   }
-  vc->barrier();  // nobody packs again before every copy is enqueued
+  if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the exchange"); return CUP3D_ECOMM; }  // nobody packs again before every copy is enqueued
   return CUP3D_OK;
 }
 
@@ -292,12 +301,12 @@ int allreduce(Sim *s, double *d_buf, int n, bool is_max, hipStream_t st) {
     const int r = s->grid->rank;
     if (n > 16 || vc->n > 16) { set_error("virtual communicator: at most 16 ranks / 16 values"); return CUP3D_EINVAL; }
     vc->ptr[r] = d_buf;
-    vc->barrier();  // every rank's operand is enqueued
+    if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the all-reduce"); return CUP3D_ECOMM; }  // every rank's operand is enqueued
     VPtrs v;
     for (int q = 0; q < vc->n; ++q) v.p[q] = vc->ptr[q];
     hipLaunchKernelGGL(k_vreduce, dim3(1), dim3(64), 0, stream(), v, vc->n, n, is_max ? 1 : 0, vc->d_tmp + 16 * r);
     CUP3D_HIP(hipGetLastError());
-    vc->barrier();  // every rank has read the operands
+    if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the all-reduce"); return CUP3D_ECOMM; }  // every rank has read the operands
     CUP3D_HIP(hipMemcpyAsync(d_buf, vc->d_tmp + 16 * r, n * sizeof(double), hipMemcpyDeviceToDevice, stream()));
     return CUP3D_OK;
   }

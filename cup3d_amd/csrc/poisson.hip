@@ -84,7 +84,8 @@ __device__ __forceinline__ double cg_div(double n, double d) {
 }
 
 template <bool FMA, bool HELM = false, bool V2 = true>
-__global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, double *out, double *__restrict__ block_sums, double nu, double dt) {
+__global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, double *out, double *__restrict__ block_sums, double nu, double dt,
+                                                int *__restrict__ iters_out) {
   // (r01 kernel: 86 VGPRs -> 5 waves/SIMD.  Forcing 6 with amdgpu_waves_per_eu spills five values that are reloaded every iteration:
   //  0.476 vs 0.431 ms at 256^3, so the natural allocation stays.)
   __shared__ double P[8 * 80];
@@ -114,9 +115,11 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
   rr = cg_sum<V2>(rr);
   const double kRel = 1e-7 * 1e-7, kAbs = 1e-16 * 1e-16;  // kSqrNorm{Rel,Abs}Criterion, 14619-14624
   const double sqrNorm0 = (double)1 / (512 * 512) * rr;    // 14734
+  int kdone = 0;
   if (sqrNorm0 >= 1e-32) {                                  // else: block stays 0 (14735-14736)
     __syncthreads();
     for (int k = 0; k < 100; ++k) {                         // 14739
+      kdone = k + 1;
 #pragma unroll
       for (int z = 0; z < 8; ++z) P[z * 80 + base] = p[z];
       __syncthreads();
@@ -164,6 +167,7 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
     out[(size_t)slot * 512 + z * 64 + l] = x[z];
     sx += x[z];
   }
+  if (iters_out && l == 0) iters_out[slot] = kdone;  // measurement only (cup3d_profile_enable): CG iterations this block took
   if (block_sums) {  // sum(z*h^3) of this block for the mean constraint of the LHS that follows (9283-9294)
     const double hq = block_h(g, slot), h3 = hq * hq * hq;
     sx = cg_sum<V2>(sx * h3);
@@ -302,10 +306,15 @@ int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
   // the CPU's, and the CG's own truncation is 1e-7, so this is a tolerance-level deviation (tests: <= 2e-5 of the reference's z,
   // measured ~1e-7).  block_solver 2 = the reference's association (no contraction, IEEE divisions); 3 = the round-1 kernel.
   const dim3 G(launch_groups(g)), B(64);
+  int *it = nullptr;
+  if (profile_on()) {  // per-block CG iteration counts of the launch, for the FP64 roofline of bench.py (cup3d_debug_block_cg_iterations)
+    if (!s->d_cg_iters) CUP3D_HIP(hipMalloc((void **)&s->d_cg_iters, (size_t)s->nb * sizeof(int)));
+    it = s->d_cg_iters;
+  }
   switch (s->block_solver) {
-    case 0: hipLaunchKernelGGL((k_precond<true, false, true>), G, B, 0, stream(), g, in, out, sums, 0.0, 0.0); break;
-    case 2: hipLaunchKernelGGL((k_precond<false, false, true>), G, B, 0, stream(), g, in, out, sums, 0.0, 0.0); break;
-    case 3: hipLaunchKernelGGL((k_precond<true, false, false>), G, B, 0, stream(), g, in, out, sums, 0.0, 0.0); break;
+    case 0: hipLaunchKernelGGL((k_precond<true, false, true>), G, B, 0, stream(), g, in, out, sums, 0.0, 0.0, it); break;
+    case 2: hipLaunchKernelGGL((k_precond<false, false, true>), G, B, 0, stream(), g, in, out, sums, 0.0, 0.0, it); break;
+    case 3: hipLaunchKernelGGL((k_precond<true, false, false>), G, B, 0, stream(), g, in, out, sums, 0.0, 0.0, it); break;
     default: set_error("unknown block_solver %d", s->block_solver); return CUP3D_EINVAL;
   }
   CUP3D_HIP(hipGetLastError());
@@ -316,8 +325,8 @@ int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
 int launch_precond_diffusion(Sim *s, const double *in, double *out, const HelmholtzOp &op) {
   GridDev g = s->gdev();
   ProfileScope ps("diffusion_block_cg");
-  if (s->block_solver != 2) hipLaunchKernelGGL((k_precond<true, true, true>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, (double *)nullptr, op.nu, op.dt);
-  else hipLaunchKernelGGL((k_precond<false, true, true>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, (double *)nullptr, op.nu, op.dt);
+  if (s->block_solver != 2) hipLaunchKernelGGL((k_precond<true, true, true>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, (double *)nullptr, op.nu, op.dt, (int *)nullptr);
+  else hipLaunchKernelGGL((k_precond<false, true, true>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, (double *)nullptr, op.nu, op.dt, (int *)nullptr);
   CUP3D_HIP(hipGetLastError());
   s->sums_of = nullptr;
   return CUP3D_OK;
@@ -655,6 +664,22 @@ void cup3d_poisson_default_params(cup3d_poisson_params *p) {
   p->tol = 1e-6; p->tol_rel = 1e-4; p->mean_constraint = 1; p->max_iter = 1000; p->max_restarts = 100; p->block_solver = 0;
 }
 
+// MEASUREMENT SUPPORT: CG iterations of the last block-CG launch made while cup3d_profile_enable(1) was on, summed over the blocks
+int cup3d_debug_block_cg_iterations(cup3d_sim_t *h, long *total, long *nblocks) {
+  if (!h || !total || !nblocks) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  *total = 0;
+  *nblocks = 0;
+  if (!s->d_cg_iters) return CUP3D_OK;
+  std::vector<int> v((size_t)s->nb);
+  CUP3D_HIP(hipMemcpy(v.data(), s->d_cg_iters, v.size() * sizeof(int), hipMemcpyDeviceToHost));
+  long t = 0;
+  for (int x : v) t += x;
+  *total = t;
+  *nblocks = (long)s->nb;
+  return CUP3D_OK;
+}
+
 // TEST SUPPORT: see k_debug_wave_sum (in64 -> out128, host arrays)
 int cup3d_debug_wave_sum(const double *in64, double *out128) {
   if (!in64 || !out128) return CUP3D_EINVAL;
@@ -698,7 +723,7 @@ int cup3d_pressure_project(cup3d_sim_t *h, double dt, int step, const cup3d_pois
   // tmpV = 0 (15076-15078) matters only as the udef lab of KernelPressureRHS; without obstacles the RHS kernel does not read it
   // (adding -0*fac*0 is the identity).  With a resident chi it does: unless the caller has placed udef there since the last
   // projection (upload / fill / cup3d_update_tmpv), tmpV still holds the previous step's gradP scratch and is cleared here.
-  if (s->chi_nonzero && !s->udef_nonzero) TRY(cup3d_sim_fill(h, CUP3D_FIELD_TMPV, 0.0));
+  if ((s->chi_nonzero || s->grid->nranks > 1) && !s->udef_nonzero) TRY(cup3d_sim_fill(h, CUP3D_FIELD_TMPV, 0.0));
   TRY(cup3d_pressure_rhs(h, dt));
   s->udef_nonzero = false;
   if (second_order) {

@@ -27,6 +27,7 @@ hipStream_t stream() { return g_stream; }
 
 struct ProfileRec { int idx; hipEvent_t a, b; };
 static bool g_prof_on = false;
+bool profile_on() { return g_prof_on; }
 static std::vector<std::string> g_prof_names;
 static std::vector<long> g_prof_launches;
 static std::vector<double> g_prof_ms;
@@ -344,6 +345,7 @@ void cup3d_sim_destroy(cup3d_sim_t *h) {
   for (double *p : s->sv) if (p) hipFree(p);
   if (s->h_red) hipHostFree(s->h_red);
   if (s->d_counters) hipFree(s->d_counters);
+  if (s->d_cg_iters) hipFree(s->d_cg_iters);
   if (s->h_stage) hipHostFree(s->h_stage);
   if (s->h_stage_slots) hipHostFree(s->h_stage_slots);
   if (s->d_stage_slots) hipFree(s->d_stage_slots);

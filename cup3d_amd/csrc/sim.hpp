@@ -29,6 +29,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 hipStream_t stream();  // compute stream (cup3d_set_stream)
 int debug_option(const char *name);  // cup3d_debug_set_option; 0 when unset (production behaviour)
+bool profile_on();                   // cup3d_profile_enable
 
 // ---- per-kernel timing (cup3d_profile_*) ----
 struct ProfileScope {
@@ -79,6 +80,7 @@ struct Sim {
   double *h_red = nullptr;       // pinned host mirror
   double *h_red_dev = nullptr;   // the same memory as the device sees it (kernels store the reduced scalars there directly)
   unsigned *d_counters = nullptr;  // [4] tickets of grid_sum_finish (tile.hpp), zero between launches
+  int *d_cg_iters = nullptr;       // [nb] CG iterations per block of the last block-CG launch (only while profiling)
   int max_groups = 0;
   // staging for host transfers
   double *d_stage = nullptr;
@@ -114,6 +116,8 @@ bool scalars_cross_ranks(const Sim *s);   // does allreduce() do anything for th
 hipStream_t scalar_stream(const Sim *s);  // the stream all-reduces are enqueued on (communication stream where there is one)
 // rank views of a multi-level mesh: face-flux arrays of remote fine faces -> ghost face range of d_flux (before k_flux_fix)
 int view_exchange_flux(Sim *s, int nfc);
+// ... and whole blocks of `field` -> ghost slot range, before the ghost slabs of a stencil kernel are built (no-op elsewhere)
+int view_exchange_blocks(Sim *s, double *field, int nc);
 void vcomm_register(Sim *s);    // in-process test communicator (comm.hip)
 void vcomm_unregister(Sim *s);
 

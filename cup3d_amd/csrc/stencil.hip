@@ -480,10 +480,13 @@ int cup3d_pressure_rhs(cup3d_sim_t *h, double dt) {
   if (!h) return CUP3D_EINVAL;
   Sim *s = reinterpret_cast<Sim *>(h);
   int rc;
-  const bool obst = s->chi_nonzero;
+  // several ranks: every rank takes the chi / udef path (adding -0*fac*0 where there is no obstacle is the identity), because the
+  // udef exchange below is a collective and chi_nonzero is per-rank state (an obstacle covers blocks of some ranks only)
+  const bool obst = s->chi_nonzero || s->grid->nranks > 1;
   double *halo_u = nullptr;
   if (obst && s->grid->multilevel) {
     halo_u = s->halo_recv + (size_t)s->grid->n_amr_faces() * 3 * 64;
+    if ((rc = view_exchange_blocks(s, s->tmpV, 3))) return rc;  // rank views: udef of the ghost blocks
     if ((rc = amr_fill_ghosts(s, s->tmpV, 3, 1, halo_u))) return rc;
   } else if (obst && s->grid->nranks > 1) {
     // udef slabs go to the second half of the receive buffer (each exchange uses <= 3*64 per face of 9*64)

@@ -152,7 +152,7 @@ def oracle_project(m, name, f, dt, step, tol, tolrel):
 
 
 @pytest.mark.parametrize("name", MESHES)
-@pytest.mark.parametrize("block_solver", [0, 1])
+@pytest.mark.parametrize("block_solver", [0, 1, 2])
 def test_poisson_path(golden_dir, name, block_solver):
     m, sim, f = make(golden_dir, name, blockSolver=block_solver)
     dt = 0.01

@@ -1,0 +1,289 @@
+"""The multi-rank control flow of the hot path executed on ONE GPU: the ranks of a run are host threads of this process, each
+driving its own device mirror through the ordinary C-ABI entry points, and an in-process communicator (cup3d_debug_virtual_comm)
+stands in for RCCL -- device copies between the ranks' pack buffers, a rank-ordered sum for the all-reduces, host barriers for
+the ordering.  Everything else is the code that runs under `torch.distributed.run`: the Hilbert-range partition, the halo plans,
+the pack kernels, the inner/boundary split, the ghost-block and face-flux exchanges of multi-level meshes
+(SynchronizerMPI_AMR::fetch 2423-2544, FluxCorrectionMPI 2848-2945), which rank owns the corner cell of the mean constraint, and
+the order of the collectives inside PoissonSolverAMR::solve (14363-14616).  MI355X only (-m gpu).
+
+Stated bounds
+  * stencil operators (advect-diffuse RK3, LHS without the mean row, pressure RHS with chi / udef, divP, gradP, vorticity):
+    BIT-EXACT against the one-rank oracle, on uniform grids and on multi-level meshes spread over 2 / 3 / 5 ranks;
+  * findMaxU: exact (max is order independent);
+  * projection: the dot products are summed per rank and then over ranks, another rounding than on one rank, so the comparison is
+    at tight Poisson tolerance (1e-12 / 1e-10 on both sides): max|dp| <= 1e-6 max|p|, max|du| <= 1e-6 max|correction|, equal
+    restart counts; at the default tolerance the returned iterate satisfies the reference's stopping rule.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import cup3d_amd as cu
+import oracle_lib as O
+from cup3d_amd.capi import check, lib
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+EXT = 2 * np.pi
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    cu.device_init(0)
+
+
+def run_ranks(fn, nranks):
+    """fn(rank) on one host thread per rank; the first exception of any rank is re-raised."""
+    errs = [None] * nranks
+
+    def work(r):
+        try:
+            fn(r)
+        except BaseException as e:  # noqa: BLE001
+            errs[r] = e
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for e in errs:
+        if e is not None:
+            raise e
+
+
+class VirtualComm:
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        check(lib().cup3d_debug_virtual_comm(self.n))
+        return self
+
+    def __exit__(self, *a):
+        lib().cup3d_device_synchronize()
+        lib().cup3d_debug_virtual_comm(0)
+
+
+# ------------------------------------------------------------------ uniform grids: face-slab halos + the solver's all-reduces
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+@pytest.mark.parametrize("bc", [("periodic", "periodic", "periodic"), ("wall", "periodic", "freespace")])
+def test_uniform_grid_full_step_over_ranks(nranks, bc):
+    bpd, lmax, level = (2, 2, 2), 2, 1
+    o = O.OracleGrid(bpd, lmax, level, EXT, bc)
+    rng = np.random.default_rng(9)
+    NX, NY, NZ = o.ncell
+    velg, presg = rng.uniform(-1, 1, (NZ, NY, NX, 3)), rng.uniform(-1, 1, (NZ, NY, NX))
+    dt, nu, uinf = 0.02, 0.01, np.array([0.1, 0.2, -0.3])
+    kw = dict(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=level, extent=EXT, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], nu=nu, uinf=uinf)
+    # one-rank device run of the same thing (tight tolerance) for the solver comparison
+    one = cu.SimulationData(poissonTol=1e-12, poissonTolRel=1e-10, **kw)
+    one.upload("vel", one.grid.to_blocks(velg))
+    cu.AdvectionDiffusion(one)(dt)
+    one.step = 5
+    r_one = cu.PressureProjection(one)(dt)
+    vel_one, pres_one = np.zeros_like(velg), np.zeros_like(presg)
+    one.grid.scatter_to_global(one.download("vel"), vel_one)
+    one.grid.scatter_to_global(one.download("pres"), pres_one)
+    ref, tmp = o.to_blocks(velg), np.zeros((o.nb, 8, 8, 8, 3))
+    o.advect_diffuse(ref, tmp, dt, nu, uinf)
+    adv_ref = o.to_global(ref)
+    out = {}
+    with VirtualComm(nranks):
+        sims = [cu.SimulationData(rank=r, nranks=nranks, poissonTol=1e-12, poissonTolRel=1e-10, **kw) for r in range(nranks)]
+        assert sum(s.nblocks for s in sims) == o.nb
+
+        def rank(r):
+            s = sims[r]
+            s.upload("vel", s.grid.to_blocks(velg))
+            umax = cu.findMaxU(s)
+            cu.AdvectionDiffusion(s)(dt)
+            adv = s.download("vel")
+            s.step = 5
+            res = cu.PressureProjection(s)(dt)
+            out[r] = (umax, adv, s.download("vel"), s.download("pres"), res.iterations, res.restarts)
+
+        run_ranks(rank, nranks)
+        got_adv, got_vel, got_pres = np.zeros_like(velg), np.zeros_like(velg), np.zeros_like(presg)
+        for r, s in enumerate(sims):
+            s.grid.scatter_to_global(out[r][1], got_adv)
+            s.grid.scatter_to_global(out[r][2], got_vel)
+            s.grid.scatter_to_global(out[r][3], got_pres)
+        del sims
+    assert all(out[r][0] == np.abs(velg + uinf).max() for r in range(nranks))
+    assert np.array_equal(got_adv, adv_ref)                              # halo slabs + inner/boundary split: bit-exact
+    assert len({(out[r][4], out[r][5]) for r in range(nranks)}) == 1     # every rank took the same path through solve()
+    assert out[0][5] == r_one.restarts
+    corr = np.abs(vel_one - adv_ref).max()
+    assert np.abs(got_pres - pres_one).max() <= 1e-6 * np.abs(pres_one).max()
+    assert np.abs(got_vel - vel_one).max() <= 1e-6 * corr
+
+
+def test_uniform_grid_default_tolerance_over_ranks():
+    """Default Poisson tolerances on 3 ranks: the iterate the sharded solver returns satisfies the reference's stopping rule, with
+    the residual evaluated by the ORACLE's operator on the gathered field."""
+    bpd, lmax, level, bc, nranks = (2, 2, 2), 3, 2, ("wall", "wall", "wall"), 3
+    o = O.OracleGrid(bpd, lmax, level, EXT, bc)
+    vel = o.taylor_green([EXT] * 3, 1.0)
+    velg = o.to_global(vel)
+    dt = 0.3 * o.h
+    b = o.pressure_rhs(vel, np.zeros_like(vel), np.zeros((o.nb, 8, 8, 8)), dt)
+    bg = o.to_global(b)
+    kw = dict(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=level, extent=EXT, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2])
+    out = {}
+    with VirtualComm(nranks):
+        sims = [cu.SimulationData(rank=r, nranks=nranks, **kw) for r in range(nranks)]
+
+        def rank(r):
+            s = sims[r]
+            s.upload("vel", s.grid.to_blocks(velg))
+            check(lib().cup3d_pressure_rhs(s.handle, dt))
+            rhs = s.download("lhs")
+            s.fill("pres", 0.0)
+            res = cu.makePoissonSolver(s).solve()
+            out[r] = (rhs, s.download("pres"), res.iterations, res.norm0)
+
+        run_ranks(rank, nranks)
+        got_b, got_x = np.zeros_like(bg), np.zeros_like(bg)
+        for r, s in enumerate(sims):
+            s.grid.scatter_to_global(out[r][0], got_b)
+            s.grid.scatter_to_global(out[r][1], got_x)
+        del sims
+    assert np.array_equal(got_b, bg)
+    x = o.to_blocks(got_x)
+    b0 = b.copy()
+    b0[int(np.where((o.index == 0).all(axis=1))[0][0]), 0, 0, 0] = 0.0
+    res = np.linalg.norm((b0 - o.lhs(x, 1)).ravel())
+    res0 = np.linalg.norm(b0.ravel())
+    assert abs(out[0][3] - res0) <= 1e-10 * res0
+    assert res <= max(1e-6, 1e-4 * res0) * (1 + 1e-6), (res, res0, out[0][2])
+    xo = np.zeros_like(b)
+    info = o.solve(b.copy(), xo)
+    assert out[0][2] <= 1.3 * info.iters + 5, (out[0][2], info.iters)
+
+
+# ------------------------------------------------------------------ multi-level meshes spread over ranks (rank views)
+def _mesh_case(name):
+    if name == "l012_wall":
+        bpd, lmax, bc = (2, 2, 2), 3, ("wall", "freespace", "wall")
+        lv, zs = O.build_balanced_mesh(bpd, lmax, bc, [(0, 0, 0, 0), (1, 0, 0, 0)])
+    elif name == "l012_periodic":
+        bpd, lmax, bc = (2, 2, 2), 3, ("periodic", "periodic", "periodic")
+        lv, zs = O.build_balanced_mesh(bpd, lmax, bc, [(0, 1, 1, 1), (1, 2, 2, 2), (1, 3, 3, 3)])
+    else:  # a non-cubic box, mixed boundary conditions
+        bpd, lmax, bc = (3, 2, 2), 3, ("periodic", "wall", "freespace")
+        lv, zs = O.build_balanced_mesh(bpd, lmax, bc, [(0, 2, 1, 0), (1, 4, 2, 1), (0, 0, 0, 1)])
+    return bpd, lmax, bc, lv, zs
+
+
+def _owners(nb, nranks, kind, seed=0):
+    if kind == "ranges":  # contiguous runs of the m_vInfo order, the shape GridMPI / LoadBalancer leave behind
+        return (np.arange(nb) * nranks // nb).astype(np.int32)
+    rng = np.random.default_rng(seed)  # scattered ownership: every neighbour relation crosses ranks somewhere
+    ow = rng.integers(0, nranks, nb).astype(np.int32)
+    ow[:nranks] = np.arange(nranks)
+    return ow
+
+
+@pytest.mark.parametrize("nranks,kind", [(2, "ranges"), (3, "ranges"), (5, "ranges"), (3, "scattered")])
+@pytest.mark.parametrize("name", ["l012_wall", "l012_periodic", "l012_box322"])
+def test_multilevel_mesh_over_ranks_stencils_bitexact(name, nranks, kind):
+    bpd, lmax, bc, lv, zs = _mesh_case(name)
+    m = O.OracleMesh(bpd, lmax, EXT, bc, lv, zs)
+    mesh = cu.operators.Grid(bpd, lmax, 0, EXT, bc, leaves=(lv, zs))
+    assert np.array_equal(mesh.tables, m.tables)
+    nb = m.nb
+    owner = _owners(nb, nranks, kind, seed=len(name))
+    rng = np.random.default_rng(5)
+    f = dict(vel=rng.uniform(-1, 1, (nb, 8, 8, 8, 3)), pres=rng.uniform(-1, 1, (nb, 8, 8, 8)), udef=rng.uniform(-1, 1, (nb, 8, 8, 8, 3)),
+             chi=(rng.uniform(0, 1, (nb, 8, 8, 8)) > 0.7) * rng.uniform(0, 1, (nb, 8, 8, 8)))
+    dt, nu, uinf = 0.01, 0.02, (0.1, -0.2, 0.3)
+    ref = dict(adv=m.advect_diffuse(f["vel"], dt, nu, uinf)[0], lhs=m.lhs(f["pres"], 0), rhs=m.pressure_rhs(f["vel"], f["udef"], f["chi"], dt),
+               rhs0=m.pressure_rhs(f["vel"], np.zeros_like(f["vel"]), np.zeros_like(f["pres"]), dt), divp=m.div_pressure(f["pres"])[..., 0],
+               gradp=m.grad_p(f["pres"], dt), vort=m.vorticity(f["vel"]), maxu=m.max_u(f["vel"], uinf))
+    got = {k: np.zeros_like(v) for k, v in ref.items() if k != "maxu"}
+    maxu = [None] * nranks
+    kw = dict(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=0, extent=EXT, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], nu=nu, uinf=uinf)
+    with VirtualComm(nranks):
+        views = [mesh.rank_view(owner, r, nranks) for r in range(nranks)]
+        sims = [cu.SimulationData(view=views[r], **kw) for r in range(nranks)]
+        assert sum(v.nghost for v in views) > 0
+
+        def rank(r):
+            s, v = sims[r], views[r]
+            mine = v.global_slot[:v.nlocal]
+            s.upload("vel", f["vel"][mine])
+            maxu[r] = cu.findMaxU(s)
+            cu.AdvectionDiffusion(s)(dt)
+            got["adv"][mine] = s.download("vel")
+            s.upload("pres", f["pres"][mine])
+            s.bMeanConstraint = 0
+            cu.ComputeLHS(s)(0)
+            got["lhs"][mine] = s.download("lhs")
+            s.upload("vel", f["vel"][mine]); s.upload("tmpV", f["udef"][mine]); s.upload("chi", f["chi"][mine])
+            check(lib().cup3d_pressure_rhs(s.handle, dt))
+            got["rhs"][mine] = s.download("lhs")
+            s.fill("chi", 0.0); s.fill("tmpV", 0.0)
+            check(lib().cup3d_pressure_rhs(s.handle, dt))
+            got["rhs0"][mine] = s.download("lhs")
+            check(lib().cup3d_div_pressure(s.handle))
+            got["divp"][mine] = s.download("tmpV")[..., 0]
+            check(lib().cup3d_grad_p(s.handle, dt))
+            got["gradp"][mine] = s.download("tmpV")
+            cu.ComputeVorticity(s)(0)
+            got["vort"][mine] = s.download("tmpV")
+
+        run_ranks(rank, nranks)
+        del sims, views
+    assert all(u == ref["maxu"] for u in maxu)
+    for k in got:
+        assert np.array_equal(got[k], ref[k]), (name, nranks, kind, k, np.abs(got[k] - ref[k]).max())
+
+
+@pytest.mark.parametrize("nranks,kind", [(2, "ranges"), (3, "scattered")])
+@pytest.mark.parametrize("name", ["l012_wall", "l012_box322"])
+def test_multilevel_mesh_over_ranks_projection(name, nranks, kind):
+    """PressureProjection (second-order pressure path, mean constraint 1) on a three-level mesh spread over ranks, tight tolerance on
+    both sides, against the one-rank oracle; two steps of advect-diffuse + projection stay together."""
+    bpd, lmax, bc, lv, zs = _mesh_case(name)
+    m = O.OracleMesh(bpd, lmax, EXT, bc, lv, zs)
+    mesh = cu.operators.Grid(bpd, lmax, 0, EXT, bc, leaves=(lv, zs))
+    nb = m.nb
+    owner = _owners(nb, nranks, kind, seed=7)
+    rng = np.random.default_rng(11)
+    vel0, pres0 = rng.uniform(-1, 1, (nb, 8, 8, 8, 3)), rng.uniform(-1, 1, (nb, 8, 8, 8))
+    dt, nu = 0.01, 0.02
+    v, p = vel0.copy(), pres0.copy()
+    info, _, _ = m.project(v, p, dt, 5, tol=1e-12, tol_rel=1e-10)
+    corr = np.abs(v - vel0).max()
+    v2, _ = m.advect_diffuse(v, dt, nu, (0, 0, 0))
+    p2 = p.copy()
+    m.project(v2, p2, dt, 6, tol=1e-12, tol_rel=1e-10)
+    got_v, got_p, got_v2 = np.zeros_like(v), np.zeros_like(p), np.zeros_like(v)
+    its = [None] * nranks
+    kw = dict(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=0, extent=EXT, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], nu=nu,
+              poissonTol=1e-12, poissonTolRel=1e-10)
+    with VirtualComm(nranks):
+        views = [mesh.rank_view(owner, r, nranks) for r in range(nranks)]
+        sims = [cu.SimulationData(view=views[r], **kw) for r in range(nranks)]
+
+        def rank(r):
+            s, vw = sims[r], views[r]
+            mine = vw.global_slot[:vw.nlocal]
+            s.upload("vel", vel0[mine]); s.upload("pres", pres0[mine])
+            s.step = 5
+            res = cu.PressureProjection(s)(dt)
+            its[r] = (res.iterations, res.restarts)
+            got_v[mine], got_p[mine] = s.download("vel"), s.download("pres")
+            cu.AdvectionDiffusion(s)(dt)
+            s.step = 6
+            cu.PressureProjection(s)(dt)
+            got_v2[mine] = s.download("vel")
+
+        run_ranks(rank, nranks)
+        del sims, views
+    assert len(set(its)) == 1
+    assert its[0][0] <= 1.3 * info.iters + 5, (its, info.iters)
+    assert np.abs(got_p - p).max() <= 1e-6 * np.abs(p).max()
+    assert np.abs(got_v - v).max() <= 1e-6 * corr
+    assert np.abs(got_v2 - v2).max() <= 1e-6 * max(corr, np.abs(v2 - v).max())

@@ -13,8 +13,12 @@ Stated tolerances
       preconditioner     max|dz| <= 2e-5 * max|z|  (the reference's block CG stops at a 1e-7 relative
                          residual; measured 1e-7 for both device evaluations)
       default tolerance  iterations <= 1.3 * reference + 5;  the returned pressure satisfies the reference's
-      (1e-6 / 1e-4)      stopping rule (checked with the ORACLE's operator);  fields within LOOSE = 5 % of the
-                         pressure / of the projection's velocity correction (two valid iterates of one solve)
+      (1e-6 / 1e-4)      stopping rule ||b - A x|| <= tau = max(poissonTol, poissonTolRel ||r0||), checked with the ORACLE's operator.
+                         Device and reference pressure are then two valid iterates of one solve, which bounds their difference
+                         d through the operator, not through a percentage:  || A d ||_2 <= 2 tau  away from the row of the mean
+                         constraint (mean removal and pOld only shift d by a constant, which A annihilates), and the velocity
+                         difference IS the gradient update of d:  dv = -(dt / 2h) grad_c(d), asserted to 1e-12.
+                         (SURVEY 8c's  |du| <= 1e-8 U  cannot hold at a 1e-4 RELATIVE residual; it is asserted at the tight tolerance.)
       tight tolerance    with poissonTol 1e-12 / poissonTolRel 1e-10 on both sides the solves converge to the
       (1e-12 / 1e-10)    same discrete solution:  max|dp| <= 1e-6 * max|p|,  max|du| <= 1e-7 * max|correction|
     The tight-tolerance comparison is the actual operator-level parity statement for the Poisson path.
@@ -52,16 +56,33 @@ def load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz"))
 
 
-LOOSE = 0.05  # two valid iterates of the same 1e-4-relative-residual solve, see the module docstring
-
-
 def iters_close(got, ref):
     return got <= 1.3 * ref + 5
 
 
-def assert_fields_close(got, ref, scale, what, tol=LOOSE):
+def assert_fields_close(got, ref, scale, what, tol):
     err = np.abs(got - ref).max()
     assert err <= tol * scale, f"{what}: max|d| = {err:.3e} > {tol} * {scale:.3e}"
+
+
+def assert_two_valid_iterates(o, index, p_dev, p_ref, tau, v_dev=None, v_ref=None, dt=None, h=None):
+    """p_dev, p_ref: pressures from two iterates that both satisfy ||b - A x|| <= tau (module docstring).  `o` is the oracle grid or
+    mesh (its lhs / grad_p are the reference's operators), h the spacing (scalar or per block)."""
+    d = np.ascontiguousarray(p_dev - p_ref)
+    Ad = o.lhs(d, 0)
+    for c in np.where((index == 0).all(axis=1))[0]:
+        Ad[c, 0, 0, 0] = 0.0
+    nrm = np.linalg.norm(Ad.ravel())
+    assert nrm <= 2.02 * tau + 1e-13 * np.abs(p_ref).max(), f"||A (p_dev - p_ref)|| = {nrm:.3e} > 2 tau = {2 * tau:.3e}"
+    if v_dev is not None:
+        hh = np.asarray(h, dtype=np.float64).reshape(-1, 1, 1, 1, 1) if np.ndim(h) else float(h)
+        want = o.grad_p(d, dt) / hh ** 3
+        err = np.abs((v_dev - v_ref) - want).max()
+        assert err <= 1e-12 * max(np.abs(v_ref).max(), 1.0), f"velocity difference is not the gradient update of the pressure difference: {err:.3e}"
+
+
+def tau_of(r, tol=1e-6, tol_rel=1e-4):
+    return max(tol, tol_rel * r.norm0)
 
 
 def assert_tight_projection_parity(sim, o, vel_before, pres_before, dt, step):
@@ -153,7 +174,23 @@ def test_golden_stencil_operators_bit_exact(golden_dir, name):
     assert np.array_equal(cu.MeshAdaptation(rt, ct).Tag(sim, "tmpV"), m.tag(w, rt, ct))
 
 
-@pytest.mark.parametrize("block_solver", [0, 1])
+def test_wave_sum_on_the_matrix_pipe():
+    """The wave-wide sum the production block CG uses (two v_mfma_f64_16x16x4_f64 with a ones matrix + three adds): exact on
+    integers (every lane receives the total), and to rounding on random data, like the DPP form it replaces."""
+    import math
+    rng = np.random.default_rng(3)
+    for v in (np.arange(64, dtype=np.float64) * 3 - 17, np.float64(2) ** rng.integers(-20, 20, 64), rng.uniform(-1, 1, 64), rng.normal(size=64) * 1e8):
+        out = np.zeros(128)
+        cu.capi.check(cu.lib().cup3d_debug_wave_sum(np.ascontiguousarray(v), out))
+        exact = math.fsum(v.tolist())
+        bound = 64 * np.finfo(np.float64).eps * np.abs(v).sum()
+        assert len(set(out[:64].tolist())) == 1 and len(set(out[64:].tolist())) == 1
+        assert abs(out[0] - exact) <= bound and abs(out[64] - exact) <= bound
+        if np.all(v == np.round(v)) and np.abs(v).sum() < 2 ** 50:
+            assert out[0] == exact and out[64] == exact
+
+
+@pytest.mark.parametrize("block_solver", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", FIELD_CASES)
 def test_golden_preconditioner(golden_dir, name, block_solver):
     z = load(golden_dir, name)
@@ -164,7 +201,7 @@ def test_golden_preconditioner(golden_dir, name, block_solver):
     assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("block_solver", [0, 1])
+@pytest.mark.parametrize("block_solver", [0, 1, 2])
 @pytest.mark.parametrize("name", FIELD_CASES)
 def test_golden_poisson_solve(golden_dir, name, block_solver):
     z = load(golden_dir, name)
@@ -175,9 +212,9 @@ def test_golden_poisson_solve(golden_dir, name, block_solver):
     r = cu.makePoissonSolver(sim).solve()
     got, ref = sim.download("pres"), z["solve"]
     assert iters_close(r.iterations, int(z["solve_iters"]))
-    assert_fields_close(got, ref, np.abs(ref).max(), "pressure")
-    # independent of the oracle: the returned iterate satisfies the reference's stopping rule
+    # the returned iterate satisfies the reference's stopping rule, so does the reference's: bound on the difference
     o = O.OracleGrid(z["bpd"], int(z["level_max"]), int(z["level"]), float(z["extent"]), [int(b) for b in z["bc"]])
+    assert_two_valid_iterates(o, g.index, got, ref, tau_of(r))
     b = g.to_blocks(z["rhs_in"]).copy()
     b[np.where((g.index == 0).all(axis=1))[0][0], 0, 0, 0] = 0.0
     res = np.linalg.norm((b - o.lhs(got, 1)).ravel())
@@ -199,9 +236,8 @@ def test_golden_projection(golden_dir, name, tag, step, block_solver):
     r = cu.PressureProjection(sim)(float(z["dt"]))
     assert iters_close(r.iterations, int(z[tag + "_iters"]))
     v, p = sim.download("vel"), sim.download("pres")
-    assert_fields_close(p, z[tag + "_pres"], np.abs(z[tag + "_pres"]).max(), "pressure")
-    assert_fields_close(v, z[tag + "_vel"], np.abs(z[tag + "_vel"] - g.to_blocks(z["vel_in"])).max(), "velocity")
     o = O.OracleGrid(z["bpd"], int(z["level_max"]), int(z["level"]), float(z["extent"]), [int(b) for b in z["bc"]])
+    assert_two_valid_iterates(o, g.index, p, z[tag + "_pres"], tau_of(r), v, z[tag + "_vel"], float(z["dt"]), g.h)
     assert_tight_projection_parity(sim, o, g.to_blocks(z["vel_in"]), g.to_blocks(z["pres_in"]), float(z["dt"]), sim.step)
 
 
@@ -221,7 +257,8 @@ def test_trajectory_against_reference(golden_dir, block_solver):
         assert iters_close(sim.last_poisson.iterations, int(z["iters"][n]))
         # smooth periodic flow: the projection correction is small and the trajectories stay within 1e-4
         assert np.abs(sim.download("vel") - z["vel"][n + 1]).max() <= 1e-4
-        assert_fields_close(sim.download("pres"), z["pres"][n], max(1e-3, np.abs(z["pres"][n]).max()), "pressure")
+        # (a trajectory: the pressures of step n come from velocities that already differ by the previous steps' solver error)
+        assert_fields_close(sim.download("pres"), z["pres"][n], max(1e-3, np.abs(z["pres"][n]).max()), "pressure", 0.05)
 
 
 def test_trajectory_64_cubed_ten_steps():
@@ -289,9 +326,7 @@ def test_oracle_random_fields(bpd, lmax, level, bc):
     pref = np.zeros((o.nb, 8, 8, 8))
     info, _, _ = o.project(ref, pref, dt, 3)
     assert iters_close(r.iterations, info.iters)
-    corr = np.abs(ref - before).max()
-    assert_fields_close(sim.download("vel"), ref, corr, "velocity")
-    assert_fields_close(sim.download("pres"), pref, np.abs(pref).max(), "pressure")
+    assert_two_valid_iterates(o, o.index, sim.download("pres"), pref, tau_of(r), sim.download("vel"), ref, dt, o.h)
     assert_tight_projection_parity(sim, o, before, np.zeros((o.nb, 8, 8, 8)), dt, 3)
 
 
@@ -472,6 +507,52 @@ def test_full_size_256_poisson_properties(block_solver):
     assert np.abs(d).max() <= 1e-5 * np.abs(xs).max()
 
 
+def _omp_threads(n):
+    """more OpenMP threads for the oracle than the suite's default (conftest caps it for the tiny cases)"""
+    try:
+        gomp = C.CDLL("libgomp.so.1")
+        old = gomp.omp_get_max_threads()
+        gomp.omp_set_num_threads(int(n))
+        return lambda: gomp.omp_set_num_threads(old)
+    except OSError:
+        return lambda: None
+
+
+@pytest.mark.timeout(900)
+def test_baseline_256_cubed_against_the_oracle():
+    """BASELINE configs[1] at its own size -- 256^3 periodic Taylor-Green (32 768 blocks), compared with the ORACLE, not through
+    properties: one AdvectionDiffusion bit-exact; one PressureProjection at the default tolerances: iteration count, the two
+    iterates within the stopping rule's bound, the velocity difference equal to the gradient update of the pressure difference.
+    (Tight-tolerance runs at this size and the 512^3 reference step are campaigns: scripts/campaigns/baseline_sizes_vs_reference.py,
+    logs under profiles/.)"""
+    restore = _omp_threads(min(64, os.cpu_count() or 1))
+    try:
+        ext = 2 * np.pi
+        bc = ("periodic",) * 3
+        o = O.OracleGrid((1, 1, 1), 6, 5, ext, bc)
+        sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=6, levelStart=5, extent=ext, nu=0.01, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2])
+        assert o.nb == 32768 and np.array_equal(sim.grid.tables, o.tables)
+        vel = o.taylor_green([ext] * 3, 1.0)
+        vel[..., 2] = 0.3 * vel[..., 0] * vel[..., 1]   # a third component, so that every term of the stencil is exercised
+        sim.upload("vel", vel)
+        dt = 0.3 * o.h
+        cu.AdvectionDiffusion(sim)(dt)
+        ref, tmp = vel.copy(), np.zeros_like(vel)
+        o.advect_diffuse(ref, tmp, dt, 0.01)
+        del tmp, vel
+        assert np.array_equal(sim.download("vel"), ref)
+        sim.step = 21
+        sim.upload("pres", np.zeros((o.nb, 8, 8, 8)))
+        r = cu.PressureProjection(sim)(dt)
+        pref = np.zeros((o.nb, 8, 8, 8))
+        info, _, _ = o.project(ref, pref, dt, 21)
+        print(f"256^3 periodic TGV, default tolerances: device {r.iterations} BiCGSTAB iterations, oracle (= reference) {info.iters}")
+        assert iters_close(r.iterations, info.iters), (r.iterations, info.iters)
+        assert_two_valid_iterates(o, o.index, sim.download("pres"), pref, tau_of(r), sim.download("vel"), ref, dt, o.h)
+    finally:
+        restore()
+
+
 def test_medium_128_oracle_advect_diffuse_and_solver():
     """128^3 (4096 blocks) against the oracle: advect-diffuse bit-exact, one Poisson solve with a
     manufactured right-hand side within tolerance."""
@@ -493,8 +574,7 @@ def test_medium_128_oracle_advect_diffuse_and_solver():
     pref = np.zeros((o.nb, 8, 8, 8))
     info, _, _ = o.project(ref, pref, dt, 4)
     assert iters_close(r.iterations, info.iters)
-    assert_fields_close(sim.download("vel"), ref, np.abs(ref - before).max(), "velocity")
-    assert_fields_close(sim.download("pres"), pref, np.abs(pref).max(), "pressure")
+    assert_two_valid_iterates(o, o.index, sim.download("pres"), pref, tau_of(r), sim.download("vel"), ref, dt, o.h)
 
 
 def test_rccl_plumbing_on_one_rank():
