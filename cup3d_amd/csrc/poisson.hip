@@ -36,6 +36,16 @@ __device__ __forceinline__ double mad(double a, double b, double c) {
   if constexpr (FMA) return __builtin_fma(a, b, c);
   else return a * b + c;
 }
+// p <- beta p + r written so that the result lands in p's own registers: the compiler turns __builtin_fma(beta, p, r) into the
+// two-operand v_fmac_f64 (destination tied to the addend r), which costs a copy of r before and a register rotation after --
+// 2 extra moves per cell and iteration in an issue-bound loop.  The three-operand v_fma_f64 has no such tie.
+template <bool FMA>
+__device__ __forceinline__ double p_update(double beta, double p, double r) {
+  if constexpr (!FMA) return beta * p + r;
+  double o;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(beta), "v"(p), "v"(r));
+  return o;
+}
 // LDS layout: [z][row = y + 1 (rows 0 and 9 stay zero)][x], pitch 8 doubles and NO x halo.  With the 10x10-pitched tile of the
 // first version half of all LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50, and the waves
 // spent 35 % of their cycles in SQ_WAIT_INST_LDS: profiles/r01/pmc_block_preconditioner_sq.txt): a 64-bit access is served 32
@@ -72,9 +82,9 @@ __device__ __forceinline__ double fast_div(double n, double d) {
   const double q = n * y;
   return __builtin_fma(__builtin_fma(-d, q, n), y, q);
 }
-template <bool V2>
+template <bool MFMA>
 __device__ __forceinline__ double cg_sum(double v) {
-  if constexpr (V2) return wave_sum_mfma(v);
+  if constexpr (MFMA) return wave_sum_mfma(v);
   else return wave_sum(v);
 }
 template <bool FAST>
@@ -83,11 +93,14 @@ __device__ __forceinline__ double cg_div(double n, double d) {
   else return n / d;
 }
 
-template <bool FMA, bool HELM = false, bool V2 = true>
+// EV = how the iteration is evaluated, a bit set: 1 = wave sums on the matrix pipe, 2 = single-width volatile LDS reads,
+// 4 = reciprocal divisions (FMA variants only), 8 = three-operand FMA for the p update (p_update above)
+template <bool FMA, bool HELM = false, int EV = 0>
 __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, double *out, double *__restrict__ block_sums, double nu, double dt,
                                                 int *__restrict__ iters_out) {
   // (r01 kernel: 86 VGPRs -> 5 waves/SIMD.  Forcing 6 with amdgpu_waves_per_eu spills five values that are reloaded every iteration:
   //  0.476 vs 0.431 ms at 256^3, so the natural allocation stays.)
+  constexpr bool V2 = (EV & 1) != 0, LDSV = (EV & 2) != 0, FDIV = (EV & 4) != 0 && FMA;
   __shared__ double P[8 * 80];
   const int slot = block_slot(g);
   if (slot < 0) return;
@@ -127,7 +140,7 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
 #pragma unroll
       for (int z = 0; z < 8; ++z) {                         // kernelPoissonGetZInner, 14662-14682
         double t;
-        if constexpr (V2) {
+        if constexpr (LDSV) {
           t = mad<FMA>(centre, p[z], Pam[z * 80] + Pap[z * 80]);
           t += Pym[z * 80];
           t += Pyp[z * 80];
@@ -143,7 +156,7 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
       }
       __syncthreads();
       a2 = cg_sum<V2>(a2);
-      const double a = cg_div<V2 && FMA>(rr, a2 + 1e-55);   // 14684
+      const double a = cg_div<FDIV>(rr, a2 + 1e-55);        // 14684
       double ss = 0;
 #pragma unroll
       for (int z = 0; z < 8; ++z) {
@@ -152,11 +165,11 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
         ss = mad<FMA>(r[z], r[z], ss);
       }
       ss = cg_sum<V2>(ss);
-      const double beta = cg_div<V2 && FMA>(ss, rr + 1e-55);  // 14690
+      const double beta = cg_div<FDIV>(ss, rr + 1e-55);       // 14690
       const double sqrNorm = (double)1 / (512 * 512) * ss;  // 14691
       if (sqrNorm < kRel * sqrNorm0 || sqrNorm < kAbs) break;  // 14692-14694 (returns -1)
 #pragma unroll
-      for (int z = 0; z < 8; ++z) p[z] = mad<FMA>(beta, p[z], r[z]);   // 14698-14699
+      for (int z = 0; z < 8; ++z) p[z] = (EV & 8) ? p_update<FMA>(beta, p[z], r[z]) : mad<FMA>(beta, p[z], r[z]);   // 14698-14699
       rr = ss;
       if (rr <= 0) break;                                   // 14741
     }
@@ -172,6 +185,137 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
     const double hq = block_h(g, slot), h3 = hq * hq * hq;
     sx = cg_sum<V2>(sx * h3);
     if (l == 0) block_sums[slot] = sx;
+  }
+}
+
+// ------------------------------------------------------------------ block CG, two blocks per wavefront
+// The full-wave kernel above spends more than half of its FP64 issue slots on work that does not scale with the cells: two
+// wave-wide sums (12 DPP moves + 6 adds + read-lanes + hazard nops each), two divisions, loop control.  Here a HALF-wave owns a
+// block -- lane = (x, y pair), 16 cells per lane -- so one instruction stream serves two blocks and that overhead is shared:
+//   * sums over 32 lanes: four DPP steps inside the 16-lane rows, then v_permlane16_swap (gfx950) exchanges the two rows of each
+//     half, and every lane of a half holds its block's total (no read-lane, no select);
+//   * the y-neighbour of row 2j is row 2j+1 of the same lane and vice versa: 3 LDS reads per cell instead of 4;
+//   * LDS rows are stored in the order 0,2,4,6,8 | -1,1,3,5,7 (pitch 8, no x halo): the four rows a half-wave touches in any of its
+//     six reads / two writes always fall into four different 8-bank groups, and the x-1 / x+1 reads of the edge lanes go to one
+//     zero cell at the bank the others leave free -- every DS access is conflict-free and single-width;
+//   * a block that has converged (or is skipped, 14735) just stops updating x and r (its half is masked); the wave leaves the loop
+//     when both are done.  Block i of the pair runs exactly the iteration the full-wave kernel runs; only the order of the 512-term
+//     sums differs (16 per lane, then the lane tree).
+__device__ __forceinline__ double half_sum(double v) {
+  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  v += dpp_move<0x140>(v);  // row_mirror: every lane of a 16-lane row holds the row total
+  const long long b = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);  // rows 0<->1 and 2<->3
+  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double a = __builtin_bit_cast(double, ((long long)rh[0] << 32) | (long long)rl[0]);
+  const double c = __builtin_bit_cast(double, ((long long)rh[1] << 32) | (long long)rl[1]);
+  return a + c;
+}
+
+template <bool FMA, bool HELM = false>
+__global__ void __launch_bounds__(64) k_precond_pair(GridDev g, int pchunk, const double *in, double *out, double *__restrict__ block_sums, double nu, double dt,
+                                                     int *__restrict__ iters_out) {
+  __shared__ double P[2 * 8 * 80];
+  typedef const volatile __attribute__((address_space(3))) double lds_cvd;
+  const int l = threadIdx.x, half = l >> 5, li = l & 31, x = li & 7, yp = li >> 3;
+  const int pi = ((int)blockIdx.x & 7) * pchunk + ((int)blockIdx.x >> 3);  // XCD-aware, as block_slot()
+  const int bi = 2 * pi + half;
+  const bool have = bi < g.nblocks;
+  const int slot = have ? (g.list ? g.list[bi] : bi) : 0;
+  for (int i = l; i < 1280; i += 64) P[i] = 0.0;
+  double *Pb = P + half * 640;
+  // row slots: even rows 0,2,4,6,8 -> 0..4, odd rows -1,1,3,5,7 -> 5..9; slots 4 (row 8) and 5 (row -1) stay zero
+  const int s0 = yp, s1 = 6 + yp;                       // own rows y0 = 2 yp, y1 = 2 yp + 1
+  double *W0 = Pb + s0 * 8 + x, *W1 = Pb + s1 * 8 + x;  // writes
+  lds_cvd *Xm0 = (lds_cvd *)(Pb + (x == 0 ? 47 : s0 * 8 + x - 1)), *Xp0 = (lds_cvd *)(Pb + (x == 7 ? 40 : s0 * 8 + x + 1));
+  lds_cvd *Xm1 = (lds_cvd *)(Pb + (x == 0 ? 47 : s1 * 8 + x - 1)), *Xp1 = (lds_cvd *)(Pb + (x == 7 ? 40 : s1 * 8 + x + 1));
+  lds_cvd *Ym0 = (lds_cvd *)(Pb + (5 + yp) * 8 + x);    // row y0 - 1
+  lds_cvd *Yp1 = (lds_cvd *)(Pb + (yp + 1) * 8 + x);    // row y1 + 1
+  const double hq = block_h(g, slot), invh = 1 / hq;     // main.cpp:14723
+  double centre = -6.0;
+  if constexpr (HELM) centre = -6.0 - hq * hq / nu / dt;
+  const size_t o0 = (size_t)slot * 512 + (2 * yp) * 8 + x;  // cell (x, y0, z = 0); y1: + 8; z: + 64
+  double r0[8], r1[8], p0[8], p1[8], x0[8], x1[8], A0[8], A1[8];
+  double rr = 0;
+#pragma unroll
+  for (int z = 0; z < 8; ++z) {
+    r0[z] = have ? invh * in[o0 + z * 64] : 0.0;
+    r1[z] = have ? invh * in[o0 + z * 64 + 8] : 0.0;
+    rr = mad<FMA>(r0[z], r0[z], rr);
+    rr = mad<FMA>(r1[z], r1[z], rr);
+    p0[z] = r0[z]; p1[z] = r1[z];
+    x0[z] = 0; x1[z] = 0;
+  }
+  rr = half_sum(rr);
+  const double kRel = 1e-7 * 1e-7, kAbs = 1e-16 * 1e-16;  // kSqrNorm{Rel,Abs}Criterion, 14619-14624
+  const double sqrNorm0 = (double)1 / (512 * 512) * rr;    // 14734
+  bool active = have && sqrNorm0 >= 1e-32;                  // else: block stays 0 (14735-14736)
+  int kdone = 0;
+  __syncthreads();
+  for (int k = 0; k < 100; ++k) {                           // 14739
+    if (!__any(active)) break;
+    if (active) kdone = k + 1;
+#pragma unroll
+    for (int z = 0; z < 8; ++z) { W0[z * 80] = p0[z]; W1[z * 80] = p1[z]; }
+    __syncthreads();
+    double a2 = 0;
+#pragma unroll
+    for (int z = 0; z < 8; ++z) {                           // kernelPoissonGetZInner, 14662-14682
+      double t = mad<FMA>(centre, p0[z], Xm0[z * 80] + Xp0[z * 80]);
+      t += Ym0[z * 80];
+      t += p1[z];
+      t += z > 0 ? p0[z - 1] : 0.0;
+      t += z < 7 ? p0[z + 1] : 0.0;
+      A0[z] = t;
+      a2 = mad<FMA>(p0[z], t, a2);
+      double u = mad<FMA>(centre, p1[z], Xm1[z * 80] + Xp1[z * 80]);
+      u += p0[z];
+      u += Yp1[z * 80];
+      u += z > 0 ? p1[z - 1] : 0.0;
+      u += z < 7 ? p1[z + 1] : 0.0;
+      A1[z] = u;
+      a2 = mad<FMA>(p1[z], u, a2);
+    }
+    __syncthreads();
+    a2 = half_sum(a2);
+    const double a = cg_div<FMA>(rr, a2 + 1e-55);           // 14684
+    double ss = 0;
+    if (active) {
+#pragma unroll
+      for (int z = 0; z < 8; ++z) {
+        x0[z] = mad<FMA>(a, p0[z], x0[z]);                  // 14688
+        x1[z] = mad<FMA>(a, p1[z], x1[z]);
+        r0[z] = mad<FMA>(-a, A0[z], r0[z]);                 // subAndSumSqr, 14636-14638
+        r1[z] = mad<FMA>(-a, A1[z], r1[z]);
+      }
+    }
+#pragma unroll
+    for (int z = 0; z < 8; ++z) { ss = mad<FMA>(r0[z], r0[z], ss); ss = mad<FMA>(r1[z], r1[z], ss); }
+    ss = half_sum(ss);
+    const double beta = cg_div<FMA>(ss, rr + 1e-55);        // 14690
+    const double sqrNorm = (double)1 / (512 * 512) * ss;    // 14691
+    if (sqrNorm < kRel * sqrNorm0 || sqrNorm < kAbs) active = false;  // 14692-14694: this block is done
+#pragma unroll
+    for (int z = 0; z < 8; ++z) { p0[z] = p_update<FMA>(beta, p0[z], r0[z]); p1[z] = p_update<FMA>(beta, p1[z], r1[z]); }  // 14698-14699
+    rr = ss;
+    if (rr <= 0) active = false;                            // 14741
+  }
+  if (!have) return;
+  double sx = 0;
+#pragma unroll
+  for (int z = 0; z < 8; ++z) {
+    out[o0 + z * 64] = x0[z];
+    out[o0 + z * 64 + 8] = x1[z];
+    sx += x0[z];
+    sx += x1[z];
+  }
+  if (iters_out && li == 0) iters_out[slot] = kdone;
+  if (block_sums) {  // sum(z*h^3) of this block for the mean constraint of the LHS that follows (9283-9294)
+    sx = half_sum(sx * (hq * hq * hq));
+    if (li == 0) block_sums[slot] = sx;
   }
 }
 
@@ -288,6 +432,9 @@ static int fdm_setup() {
   return CUP3D_OK;
 }
 
+// evaluation of the production block CG (EV bits of k_precond); measured on MI355X: see profiles/r02/probe_block_cg_variants.jsonl
+constexpr int kCgProduction = 0;
+
 int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
   GridDev g = s->gdev();
   double *sums = want_sums ? s->d_partials + (size_t)s->max_groups * 8 : nullptr;
@@ -311,12 +458,39 @@ int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
     if (!s->d_cg_iters) CUP3D_HIP(hipMalloc((void **)&s->d_cg_iters, (size_t)s->nb * sizeof(int)));
     it = s->d_cg_iters;
   }
+#define CG(FMA_, EV_) hipLaunchKernelGGL((k_precond<FMA_, false, EV_>), G, B, 0, stream(), g, in, out, sums, 0.0, 0.0, it)
   switch (s->block_solver) {
-    case 0: hipLaunchKernelGGL((k_precond<true, false, true>), G, B, 0, stream(), g, in, out, sums, 0.0, 0.0, it); break;
-    case 2: hipLaunchKernelGGL((k_precond<false, false, true>), G, B, 0, stream(), g, in, out, sums, 0.0, 0.0, it); break;
-    case 3: hipLaunchKernelGGL((k_precond<true, false, false>), G, B, 0, stream(), g, in, out, sums, 0.0, 0.0, it); break;
+    case 0:  // production: kCgProduction, or (tuning) the evaluation selected with cup3d_debug_set_option("cg_variant", 8 + bits)
+      switch (debug_option("cg_variant") >= 8 ? debug_option("cg_variant") - 8 : kCgProduction) {
+        case 0: CG(true, 0); break;
+        case 1: CG(true, 1); break;
+        case 2: CG(true, 2); break;
+        case 3: CG(true, 3); break;
+        case 4: CG(true, 4); break;
+        case 5: CG(true, 5); break;
+        case 6: CG(true, 6); break;
+        case 7: CG(true, 7); break;
+        case 8: CG(true, 8); break;
+        case 9: CG(true, 9); break;
+        case 10: CG(true, 10); break;
+        case 11: CG(true, 11); break;
+        case 12: CG(true, 12); break;
+        case 13: CG(true, 13); break;
+        case 14: CG(true, 14); break;
+        case 15: CG(true, 15); break;
+        default: set_error("unknown cg_variant"); return CUP3D_EINVAL;
+      }
+      break;
+    case 2: CG(false, 0); break;
+    case 3: CG(true, 0); break;
+    case 4: {  // two blocks per wavefront
+      const int pchunk = ((g.nblocks + 1) / 2 + 7) / 8;
+      hipLaunchKernelGGL((k_precond_pair<true, false>), dim3(8 * pchunk), B, 0, stream(), g, pchunk, in, out, sums, 0.0, 0.0, it);
+      break;
+    }
     default: set_error("unknown block_solver %d", s->block_solver); return CUP3D_EINVAL;
   }
+#undef CG
   CUP3D_HIP(hipGetLastError());
   s->sums_of = want_sums ? out : nullptr;  // block sums of `out` are fresh: the next LHS of `out` reuses them
   return CUP3D_OK;
@@ -325,8 +499,8 @@ int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
 int launch_precond_diffusion(Sim *s, const double *in, double *out, const HelmholtzOp &op) {
   GridDev g = s->gdev();
   ProfileScope ps("diffusion_block_cg");
-  if (s->block_solver != 2) hipLaunchKernelGGL((k_precond<true, true, true>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, (double *)nullptr, op.nu, op.dt, (int *)nullptr);
-  else hipLaunchKernelGGL((k_precond<false, true, true>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, (double *)nullptr, op.nu, op.dt, (int *)nullptr);
+  if (s->block_solver != 2) hipLaunchKernelGGL((k_precond<true, true, kCgProduction>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, (double *)nullptr, op.nu, op.dt, (int *)nullptr);
+  else hipLaunchKernelGGL((k_precond<false, true, 0>), dim3(launch_groups(g)), dim3(64), 0, stream(), g, in, out, (double *)nullptr, op.nu, op.dt, (int *)nullptr);
   CUP3D_HIP(hipGetLastError());
   s->sums_of = nullptr;
   return CUP3D_OK;

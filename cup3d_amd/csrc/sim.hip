@@ -2,6 +2,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <map>
+#include <thread>
 
 #include "sim.hpp"
 #include "tile.hpp"
@@ -183,6 +184,19 @@ __global__ void __launch_bounds__(256) k_forcing(double *__restrict__ vel, long 
   }
 }
 
+// fn(i) for i in [0, n) on the calling thread plus up to 15 helpers (contiguous ranges)
+template <class F>
+static void host_parallel(size_t n, F fn) {
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t nt = std::min<size_t>(std::min<size_t>(16, hw ? hw : 1), (n + 255) / 256);
+  if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+  std::vector<std::thread> th;
+  th.reserve(nt - 1);
+  auto range = [&](size_t t) { const size_t b = n * t / nt, e = n * (t + 1) / nt; for (size_t i = b; i < e; ++i) fn(i); };
+  for (size_t t = 1; t < nt; ++t) th.emplace_back(range, t);
+  range(0);
+  for (auto &t : th) t.join();
+}
 static unsigned stride_groups(long n) {
   long g = (n + 255) / 256;
   return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -348,6 +362,7 @@ void cup3d_sim_destroy(cup3d_sim_t *h) {
   if (s->d_cg_iters) hipFree(s->d_cg_iters);
   if (s->h_stage) hipHostFree(s->h_stage);
   if (s->h_stage_slots) hipHostFree(s->h_stage_slots);
+  for (hipEvent_t e : s->ev_stage) if (e) hipEventDestroy(e);
   if (s->d_stage_slots) hipFree(s->d_stage_slots);
   int32_t *ip[] = {s->d_nbr, s->d_inner, s->d_boundary, s->d_send_faces, s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_index,
                    s->d_restrict_list, s->d_prolong_list, s->d_fix_list[0], s->d_fix_list[1], s->d_fix_list[2], s->d_send_blocks, s->d_send_flux};
@@ -420,15 +435,20 @@ int cup3d_sim_download(cup3d_sim_t *h, int field, double *blocks) {
   return CUP3D_OK;
 }
 
-// One pointer per block (Info::block of the reference's per-block allocations,
-// main.cpp:877-884): gather through a pinned staging buffer in chunks.
+// One pointer per block (Info::block of the reference's per-block allocations, main.cpp:877-884).  The host side of this boundary
+// is 262 144 separate 4-12 KiB allocations at 512^3, so the transfer is a gather (or scatter) on the host plus a PCIe copy plus the
+// AoS <-> SoA kernel.  Round 1 did the three one after the other, with one host thread: 11 GB/s down, 55 GB/s up.  Now:
+//   * the gather / scatter runs on up to 16 host threads (a single core copies ~10 GB/s, PCIe Gen5 x16 carries ~55);
+//   * two pinned staging buffers and two device staging buffers alternate, so that the host works on chunk k+1 while chunk k is on
+//     the bus and in the layout kernel (events, no stream synchronisation inside the loop).
 static int ensure_stage(Sim *s) {
   if (s->h_stage) return CUP3D_OK;
-  s->stage_blocks = 4096;
-  CUP3D_HIP(hipHostMalloc((void **)&s->h_stage, s->stage_blocks * 1536 * sizeof(double), hipHostMallocDefault));
-  CUP3D_HIP(hipMalloc((void **)&s->d_stage, s->stage_blocks * 1536 * sizeof(double)));
+  s->stage_blocks = 8192;  // per buffer: 96 MiB of vector blocks
+  CUP3D_HIP(hipHostMalloc((void **)&s->h_stage, 2 * s->stage_blocks * 1536 * sizeof(double), hipHostMallocDefault));
+  CUP3D_HIP(hipMalloc((void **)&s->d_stage, 2 * s->stage_blocks * 1536 * sizeof(double)));
   CUP3D_HIP(hipHostMalloc((void **)&s->h_stage_slots, s->stage_blocks * sizeof(int32_t), hipHostMallocDefault));
   CUP3D_HIP(hipMalloc((void **)&s->d_stage_slots, s->stage_blocks * sizeof(int32_t)));
+  for (int i = 0; i < 2; ++i) CUP3D_HIP(hipEventCreateWithFlags(&s->ev_stage[i], hipEventDisableTiming));
   return CUP3D_OK;
 }
 int cup3d_sim_upload_blocks(cup3d_sim_t *h, int field, const void *const *ptrs) {
@@ -438,15 +458,21 @@ int cup3d_sim_upload_blocks(cup3d_sim_t *h, int field, const void *const *ptrs) 
   double *dst = s->field(field, &nc);
   if (!dst) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
   if ((rc = ensure_stage(s))) return rc;
-  const size_t per = 512 * (size_t)nc;
-  for (size_t b0 = 0; b0 < (size_t)s->nb; b0 += s->stage_blocks) {
+  const size_t per = 512 * (size_t)nc, cap = s->stage_blocks * 1536;
+  int k = 0;
+  for (size_t b0 = 0; b0 < (size_t)s->nb; b0 += s->stage_blocks, ++k) {
     const size_t n = std::min(s->stage_blocks, (size_t)s->nb - b0);
-    for (size_t i = 0; i < n; ++i) memcpy(s->h_stage + i * per, ptrs[b0 + i], per * sizeof(double));
-    CUP3D_HIP(hipMemcpyAsync(s->d_stage, s->h_stage, n * per * sizeof(double), hipMemcpyHostToDevice, g_stream));
-    hipLaunchKernelGGL(k_aos_to_soa, dim3((unsigned)((n * per + 255) / 256)), dim3(256), 0, g_stream, s->d_stage, dst + b0 * per, (long)n * 512, nc);
+    const int buf = k & 1;
+    double *hs = s->h_stage + buf * cap, *ds = s->d_stage + buf * cap;
+    if (k >= 2) CUP3D_HIP(hipEventSynchronize(s->ev_stage[buf]));  // the copy that last read this pinned buffer is done
+    host_parallel(n, [&](size_t i) { memcpy(hs + i * per, ptrs[b0 + i], per * sizeof(double)); });
+    CUP3D_HIP(hipMemcpyAsync(ds, hs, n * per * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    CUP3D_HIP(hipEventRecord(s->ev_stage[buf], g_stream));
+    if (nc == 1) CUP3D_HIP(hipMemcpyAsync(dst + b0 * per, ds, n * per * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
+    else hipLaunchKernelGGL(k_aos_to_soa, dim3((unsigned)((n * per + 255) / 256)), dim3(256), 0, g_stream, ds, dst + b0 * per, (long)n * 512, nc);
     CUP3D_HIP(hipGetLastError());
-    CUP3D_HIP(hipStreamSynchronize(g_stream));
   }
+  CUP3D_HIP(hipStreamSynchronize(g_stream));
   return mark_written(s, field);
 }
 int cup3d_sim_download_blocks(cup3d_sim_t *h, int field, void *const *ptrs) {
@@ -456,14 +482,28 @@ int cup3d_sim_download_blocks(cup3d_sim_t *h, int field, void *const *ptrs) {
   double *src = s->field(field, &nc);
   if (!src) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
   if ((rc = ensure_stage(s))) return rc;
-  const size_t per = 512 * (size_t)nc;
-  for (size_t b0 = 0; b0 < (size_t)s->nb; b0 += s->stage_blocks) {
-    const size_t n = std::min(s->stage_blocks, (size_t)s->nb - b0);
-    hipLaunchKernelGGL(k_soa_to_aos, dim3((unsigned)((n * per + 255) / 256)), dim3(256), 0, g_stream, src + b0 * per, s->d_stage, (long)n * 512, nc);
-    CUP3D_HIP(hipGetLastError());
-    CUP3D_HIP(hipMemcpyAsync(s->h_stage, s->d_stage, n * per * sizeof(double), hipMemcpyDeviceToHost, g_stream));
-    CUP3D_HIP(hipStreamSynchronize(g_stream));
-    for (size_t i = 0; i < n; ++i) memcpy(ptrs[b0 + i], s->h_stage + i * per, per * sizeof(double));
+  const size_t per = 512 * (size_t)nc, cap = s->stage_blocks * 1536;
+  const size_t nchunks = ((size_t)s->nb + s->stage_blocks - 1) / s->stage_blocks;
+  auto issue = [&](size_t c) -> int {  // layout kernel + copy of chunk c into pinned buffer c & 1
+    const size_t b0 = c * s->stage_blocks, n = std::min(s->stage_blocks, (size_t)s->nb - b0);
+    const int buf = (int)(c & 1);
+    double *hs = s->h_stage + buf * cap, *ds = s->d_stage + buf * cap;
+    if (nc == 1) CUP3D_HIP(hipMemcpyAsync(hs, src + b0 * per, n * per * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    else {
+      hipLaunchKernelGGL(k_soa_to_aos, dim3((unsigned)((n * per + 255) / 256)), dim3(256), 0, g_stream, src + b0 * per, ds, (long)n * 512, nc);
+      CUP3D_HIP(hipGetLastError());
+      CUP3D_HIP(hipMemcpyAsync(hs, ds, n * per * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    }
+    CUP3D_HIP(hipEventRecord(s->ev_stage[buf], g_stream));
+    return CUP3D_OK;
+  };
+  if (nchunks && (rc = issue(0))) return rc;
+  for (size_t c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks && (rc = issue(c + 1))) return rc;  // the next chunk travels while this one is scattered on the host
+    const size_t b0 = c * s->stage_blocks, n = std::min(s->stage_blocks, (size_t)s->nb - b0);
+    const double *hs = s->h_stage + (c & 1) * cap;
+    CUP3D_HIP(hipEventSynchronize(s->ev_stage[c & 1]));
+    host_parallel(n, [&](size_t i) { memcpy(ptrs[b0 + i], hs + i * per, per * sizeof(double)); });
   }
   return CUP3D_OK;
 }

@@ -84,7 +84,8 @@ struct Sim {
   int max_groups = 0;
   // staging for host transfers
   double *d_stage = nullptr;
-  double *h_stage = nullptr;  // pinned
+  double *h_stage = nullptr;  // pinned; two buffers of stage_blocks vector blocks each, like d_stage
+  hipEvent_t ev_stage[2] = {nullptr, nullptr};
   size_t stage_blocks = 0;
   int32_t *d_stage_slots = nullptr, *h_stage_slots = nullptr;  // block lists of the partial transfers (cup3d_sim_*_block_list)
   // multi-level mesh tables (amr.hip); all nullptr / 0 on uniform grids

@@ -17,6 +17,8 @@
 #pragma once
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <utility>
 #include <vector>
 
 #include "../../include/cup3d_hip.h"
@@ -134,36 +136,71 @@ private:
       device_ready = true;
     }
     const int level = I.empty() ? sim.levelStart : I[0].level;
-    bool uniform = true;
-    for (const Info &b : I) uniform = uniform && b.level == level;
     const int bpd[3] = {sim.bpdx, sim.bpdy, sim.bpdz};
     const int bc[3] = {(int)sim.BCx_flag, (int)sim.BCy_flag, (int)sim.BCz_flag};  // enum BCflag == CUP3D_BC_*
-    if (uniform) {
+    // the device topology must be the reference's own: same blocks, same order, same h
+    auto matches = [&](cup3d_grid_t *g) {
+      const long nb = cup3d_grid_nblocks(g);
+      if ((size_t)nb != I.size()) return false;
+      std::vector<long long> tab(6 * (size_t)nb);
+      std::vector<double> geom(4 * (size_t)nb);
+      CUP3D_HIP_CALL(cup3d_grid_tables(g, tab.data(), geom.data()));
+      for (long i = 0; i < nb; ++i)
+        if (!(tab[6 * i] == I[i].level && tab[6 * i + 1] == I[i].Z && tab[6 * i + 5] == I[i].blockID_2 && geom[4 * i] == I[i].h)) return false;
+      return true;
+    };
+    // (1) one level, every rank still owning its contiguous Hilbert range (GridMPI's initial partition, 2970-2986): face-slab halos
+    int not_uniform = 0;
+    for (const Info &b : I) not_uniform |= b.level != level;
+    if (!not_uniform) {
       CUP3D_HIP_CALL(cup3d_grid_create_uniform(bpd, sim.levelMax, level, sim.maxextent, bc, rank, size, &grid));
-    } else {
-      // multi-level mesh after MeshAdaptation: the leaves of m_vInfo; coarse/fine ghosts and flux correction run on the
-      // device (amr.hip).  One rank this round: cross-rank coarse/fine faces need the flux-correction messages of
-      // FluxCorrectionMPI (main.cpp:2825-2935) on RCCL.
-      if (size > 1) {
-        fprintf(stderr, "cup3d_hip: multi-level (AMR) meshes are supported on one rank only\n");
-        fflush(0);
-        MPI_Abort(sim.comm, 1);
-      }
+      if (!matches(grid)) { not_uniform = 1; cup3d_grid_destroy(grid); grid = nullptr; }
+    }
+    if (size > 1) {  // the choice of transport is collective
+      int any = 0;
+      MPI_Allreduce(&not_uniform, &any, 1, MPI_INT, MPI_MAX, sim.comm);
+      if (any && grid) { cup3d_grid_destroy(grid); grid = nullptr; }
+      not_uniform = any;
+    }
+    if (not_uniform && size == 1) {
+      // (2) multi-level mesh after MeshAdaptation on one rank: the leaves of m_vInfo; coarse/fine ghosts and flux correction run on
+      // the device (amr.hip)
       std::vector<int32_t> lv(I.size());
       std::vector<int64_t> zs(I.size());
       for (size_t i = 0; i < I.size(); ++i) { lv[i] = I[i].level; zs[i] = I[i].Z; }
       CUP3D_HIP_CALL(cup3d_grid_create_mesh(bpd, sim.levelMax, sim.maxextent, bc, (long)I.size(), lv.data(), zs.data(), &grid));
+    } else if (not_uniform) {
+      // (3) multi-level mesh (or a one-level mesh the LoadBalancer has re-dealt) spread over ranks: every rank assembles the global
+      // leaf list with its owners -- the information the reference keeps in Grid::Octree on every rank (815-855) -- and takes its view
+      // of it: ghost blocks + the two exchange plans (whole ghost blocks before a stencil kernel, face fluxes after a corrected one;
+      // what SynchronizerMPI_AMR::_Setup 1979-2286 and FluxCorrectionMPI::prepare 2680-2824 derive from the octree)
+      int nloc = (int)I.size();
+      std::vector<int> counts(size), displs(size);
+      MPI_Allgather(&nloc, 1, MPI_INT, counts.data(), 1, MPI_INT, sim.comm);
+      long total = 0;
+      for (int r = 0; r < size; ++r) { displs[r] = (int)(2 * total); total += counts[r]; counts[r] *= 2; }
+      std::vector<long long> mine(2 * (size_t)nloc), all(2 * (size_t)total);
+      for (int i = 0; i < nloc; ++i) { mine[2 * i] = I[i].level; mine[2 * i + 1] = I[i].Z; }
+      MPI_Allgatherv(mine.data(), 2 * nloc, MPI_LONG_LONG, all.data(), counts.data(), displs.data(), MPI_LONG_LONG, sim.comm);
+      std::vector<int32_t> lv((size_t)total), own_in((size_t)total);
+      std::vector<int64_t> zs((size_t)total);
+      for (int r = 0, k = 0; r < size; ++r)
+        for (int i = 0; i < counts[r] / 2; ++i, ++k) { lv[k] = (int32_t)all[2 * k]; zs[k] = all[2 * k + 1]; own_in[k] = r; }
+      cup3d_grid_t *mesh = nullptr;
+      CUP3D_HIP_CALL(cup3d_grid_create_mesh(bpd, sim.levelMax, sim.maxextent, bc, total, lv.data(), zs.data(), &mesh));
+      // the mesh object orders the leaves by blockID_2: owners follow through (level, Z)
+      std::vector<long long> tab(6 * (size_t)total);
+      std::vector<double> geom(4 * (size_t)total);
+      CUP3D_HIP_CALL(cup3d_grid_tables(mesh, tab.data(), geom.data()));
+      std::map<std::pair<long long, long long>, int32_t> owner_of;
+      for (long k = 0; k < total; ++k) owner_of[{lv[k], zs[k]}] = own_in[k];
+      std::vector<int32_t> owner((size_t)total);
+      for (long k = 0; k < total; ++k) owner[k] = owner_of[{tab[6 * k], tab[6 * k + 1]}];
+      CUP3D_HIP_CALL(cup3d_grid_rank_view(mesh, owner.data(), rank, size, &grid));
+      cup3d_grid_destroy(mesh);
     }
-    // the device topology must be the reference's own: same blocks, same order, same h
-    const long nb = cup3d_grid_nblocks(grid);
-    std::vector<long long> tab(6 * (size_t)nb);
-    std::vector<double> geom(4 * (size_t)nb);
-    CUP3D_HIP_CALL(cup3d_grid_tables(grid, tab.data(), geom.data()));
-    bool ok = (size_t)nb == I.size();
-    for (long i = 0; ok && i < nb; ++i)
-      ok = tab[6 * i] == I[i].level && tab[6 * i + 1] == I[i].Z && tab[6 * i + 5] == I[i].blockID_2 && geom[4 * i] == I[i].h;
-    if (!ok) {
-      fprintf(stderr, "cup3d_hip: device topology differs from the host grid (blocks %ld vs %zu)\n", nb, I.size());
+    if (!matches(grid)) {
+      fprintf(stderr, "cup3d_hip: device topology differs from the host grid (blocks %ld vs %zu)\n", cup3d_grid_nblocks(grid), I.size());
       fflush(0);
       MPI_Abort(sim.comm, 1);
     }
@@ -328,6 +365,22 @@ public:
   }
 };
 
+// One DeviceMirror per SimulationData, shared by every HIP-backed operator / solver built for it.
+inline std::shared_ptr<DeviceMirror> mirror_of(SimulationData &sim) {
+  static std::map<SimulationData *, std::weak_ptr<DeviceMirror>> reg;
+  std::shared_ptr<DeviceMirror> m = reg[&sim].lock();
+  if (!m) { m = std::make_shared<DeviceMirror>(sim); reg[&sim] = m; }
+  return m;
+}
+
+// makePoissonSolver (main.cpp:14747-14758) with the slot the reference reserves for a GPU solver filled in: -poissonSolver
+// "cuda_iterative" (the reference's own name for it, 14750) or "hip_iterative" gives the device solver behind PoissonSolverBase;
+// every other value is handed to the reference's factory unchanged ("iterative" -> PoissonSolverAMR, unknown -> its error).
+inline std::shared_ptr<PoissonSolverBase> makePoissonSolver(SimulationData &s) {
+  if (s.poissonSolver == "cuda_iterative" || s.poissonSolver == "hip_iterative") return std::make_shared<PoissonSolverHIP>(s, mirror_of(s));
+  return ::makePoissonSolver(s);
+}
+
 struct Installed {
   std::shared_ptr<DeviceMirror> mirror;
   std::shared_ptr<Operator> advdiff;  // AdvectionDiffusionHIP, or AdvectionDiffusionImplicitHIP with -implicitDiffusion 1
@@ -345,7 +398,7 @@ struct Installed {
 // FixMassFlux in between, every operator round-trips in full as before.
 inline Installed install(SimulationData &sim, int resident = -1) {
   Installed r;
-  r.mirror = std::make_shared<DeviceMirror>(sim);
+  r.mirror = mirror_of(sim);
   if (resident < 0) {
     const char *e = getenv("CUP3D_HIP_RESIDENT");
     resident = e ? atoi(e) : 0;

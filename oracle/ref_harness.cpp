@@ -32,6 +32,7 @@
  *      advdiff_implicit <dt> | advect | diffrhs | diffprecond | difflhs <dir> | diffsolve <dir>   (implicit diffusion;
  *      `set dt`, `set nu`, `set difftol`, `set difftolrel`; value = number of 6-double reductions = solver iterations)
  *   hip on                 (ref_tool_hip only) route advdiff/project/steps through the HIP drop-in
+ *   hipsolver <key>        (ref_tool_hip only) sim.pressureSolver = cup3d_hip::makePoissonSolver(sim) with sim.poissonSolver = key
  *   lab <field> <s> <e> <tensorial> <file>   ghosted tiles of every block (BlockLab::load)
  *   loadb <field> <file>   block-order load (multi-level meshes)
  *   amrtol <rt> <ct> | adapt | tagvel <rt> <ct> <file>   mesh-adaptation hooks (refine/compress everything)
@@ -260,6 +261,16 @@ int main(int argc, char **argv) {
       static cup3d_hip::Installed inst;
       inst = cup3d_hip::install(sd, v == "resident" ? 1 : -1);  /* `hip resident`: vel stays in HBM between the two operators */
       hip_adv = inst.advdiff; hip_proj = inst.projection;
+#else
+      fprintf(stderr, "ref_tool: built without CUP3D_WITH_HIP\n"); exit(2);
+#endif
+    } else if (cmd == "hipsolver") {
+      /* `hipsolver <key>`: sim.poissonSolver = key; sim.pressureSolver = cup3d_hip::makePoissonSolver(sim) -- the reference's factory
+         (main.cpp:14747-14758) with the GPU slot it reserves ("cuda_iterative") filled in; `op solve` then runs through it */
+      std::string key; script >> key;
+#ifdef CUP3D_WITH_HIP
+      sd.poissonSolver = key;
+      sd.pressureSolver = cup3d_hip::makePoissonSolver(sd);
 #else
       fprintf(stderr, "ref_tool: built without CUP3D_WITH_HIP\n"); exit(2);
 #endif

@@ -77,6 +77,7 @@ static inline int MPI_Allreduce(const void *s, void *r, int n, MPI_Datatype t, M
 static inline int MPI_Iallreduce(const void *s, void *r, int n, MPI_Datatype t, MPI_Op, MPI_Comm, MPI_Request *q) { CUP3D_STUB_COUNT_IALLREDUCE(n); *q = 0; return cup3d_stub_copy(s, r, n, t); }
 static inline int MPI_Reduce(const void *s, void *r, int n, MPI_Datatype t, MPI_Op, int, MPI_Comm) { return cup3d_stub_copy(s, r, n, t); }
 static inline int MPI_Allgather(const void *s, int n, MPI_Datatype t, void *r, int, MPI_Datatype, MPI_Comm) { return cup3d_stub_copy(s, r, n, t); }
+static inline int MPI_Allgatherv(const void *s, int n, MPI_Datatype t, void *r, const int *, const int *, MPI_Datatype, MPI_Comm) { return cup3d_stub_copy(s, r, n, t); } /* the HIP drop-in shim */
 static inline int MPI_Iallgather(const void *s, int n, MPI_Datatype t, void *r, int, MPI_Datatype, MPI_Comm, MPI_Request *q) { *q = 0; return cup3d_stub_copy(s, r, n, t); }
 static inline int MPI_Bcast(void *, int, MPI_Datatype, int, MPI_Comm) { return 0; } /* used by the HIP drop-in shim only */
 static inline int MPI_Exscan(const void *, void *, int, MPI_Datatype, MPI_Op, MPI_Comm) { return 0; /* rank 0: recvbuf undefined by the standard */ }

@@ -37,7 +37,7 @@ def make(size, bc="periodic"):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["adv", "pre", "one", "loops", "pcie"])
+    ap.add_argument("what", choices=["adv", "pre", "one", "loops", "pcie", "cgvar"])
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--variants", default="0,1,2,3")
     ap.add_argument("--kernel", default="adv")
@@ -97,6 +97,33 @@ def main():
                               "loop2_ms": round(p["bicgstab_loop2"][1] / p["bicgstab_loop2"][0], 4)}))
         check(lib().cup3d_debug_set_option(b"vec_groups", 0))
         check(lib().cup3d_debug_set_option(b"loops_no_nt", 0))
+    elif a.what == "cgvar":
+        # the eight evaluations of the production block CG (bit 0: wave sums on the matrix pipe, 1: single-width LDS reads,
+        # 2: reciprocal divisions) on solver-like input, against the reference-association kernel (block_solver 2)
+        sim = make(a.size, "wall")
+        check(lib().cup3d_pressure_rhs(sim.handle, 0.3 * sim.grid.h))
+        rhs = sim.download("lhs")
+        sim.upload("pres", rhs)
+        check(lib().cup3d_preconditioner(sim.handle, 2))
+        ref = sim.download("pres")
+        for bits in list(range(16)) + ["pair"]:
+            solver = 4 if bits == "pair" else 0
+            if solver == 0:
+                check(lib().cup3d_debug_set_option(b"cg_variant", 8 + bits))
+            sim.upload("pres", rhs)
+            check(lib().cup3d_preconditioner(sim.handle, solver))
+            err = float(np.abs(sim.download("pres") - ref).max() / np.abs(ref).max())
+            lib().cup3d_device_synchronize()
+            lib().cup3d_profile_reset()
+            for _ in range(a.reps):
+                sim.upload("pres", rhs)
+                check(lib().cup3d_preconditioner(sim.handle, solver))
+            n, ms = profile()["poisson_block_cg"]
+            rec = {"probe": "block_cg_variant", "size": a.size, "avg_ms": round(ms / n, 4), "max_rel_diff_vs_reference_association": err}
+            rec.update({"kernel": "two blocks per wavefront"} if bits == "pair" else
+                       {"bits": bits, "mfma_sums": bits & 1, "single_width_lds": (bits >> 1) & 1, "reciprocal_div": (bits >> 2) & 1, "fma3_p_update": (bits >> 3) & 1})
+            print(json.dumps(rec))
+        check(lib().cup3d_debug_set_option(b"cg_variant", 0))
     elif a.what == "pre":
         sim = make(a.size, "wall")
         # solver-like inputs: the pressure RHS of the initial field, then A M^-1 of it, then noise

@@ -67,6 +67,37 @@ def test_single_operators_through_the_shim(tmp_path):
     assert np.abs(res["cpu"]["prp"] - res["hip"]["prp"]).max() <= 0.05 * np.abs(res["cpu"]["prp"]).max()
 
 
+def test_poisson_solver_through_the_factory_key(tmp_path):
+    """-poissonSolver cuda_iterative: the slot makePoissonSolver (main.cpp:14747-14758) reserves for a GPU solver, filled by
+    cup3d_hip::makePoissonSolver; PoissonSolverBase::solve() contract: right-hand side in sim.lhs, initial guess and result in
+    sim.pres.  Both iterates satisfy the stopping rule; the key "iterative" still yields the reference's own solver (bit-equal
+    result), an unknown key the reference's own error."""
+    bpd, lmax, lstart, bc = (2, 2, 2), 2, 1, ("wall", "periodic", "freespace")
+    rng = np.random.default_rng(17)
+    n = 32
+    rhs, x0 = rng.uniform(-1, 1, (n, n, n)), rng.uniform(-1, 1, (n, n, n))
+    args = O.ref_args(bpd, lmax, lstart, 2 * np.pi, bc)
+    res = {}
+    for tag, tool, pre in (("cpu", O.REF_TOOL, []), ("hip", REF_HIP, ["hipsolver cuda_iterative"]), ("same", REF_HIP, ["hipsolver iterative"])):
+        d = tmp_path / tag
+        d.mkdir()
+        rhs.tofile(str(d / "rhs.bin")); x0.tofile(str(d / "x0.bin"))
+        rec = run(tool, pre + ["zero chi", "loadg lhs rhs.bin", "loadg pres x0.bin", "op solve", "dump pres x.bin"], args, str(d))
+        res[tag] = (O.read_blocks(str(d / "x.bin"), 64, 1), rec[-1]["iters"])
+    assert np.array_equal(res["cpu"][0], res["same"][0]) and res["cpu"][1] == res["same"][1]
+    o = O.OracleGrid(bpd, lmax, lstart, 2 * np.pi, bc)
+    b = o.to_blocks(rhs)
+    b[int(np.where((o.index == 0).all(axis=1))[0][0]), 0, 0, 0] = 0.0
+    res0 = np.linalg.norm((b - o.lhs(o.to_blocks(x0), 1)).ravel())
+    tau = max(1e-6, 1e-4 * res0)
+    for tag in ("cpu", "hip"):
+        assert np.linalg.norm((b - o.lhs(res[tag][0], 1)).ravel()) <= tau * (1 + 1e-6), tag
+    d = tmp_path / "bad"
+    d.mkdir()
+    with pytest.raises(subprocess.CalledProcessError):
+        run(REF_HIP, ["hipsolver no_such_solver"], args, str(d))
+
+
 def test_multilevel_mesh_through_the_shim(tmp_path):
     """The reference adapts its mesh (its own adaptMesh on a localised vortex: levels 1 and 2), then runs its pipeline on
     that multi-level mesh with the HIP operators: DeviceMirror rebuilds the device topology from m_vInfo's leaves

@@ -11,8 +11,9 @@ Stated bounds
     BIT-EXACT against the one-rank oracle, on uniform grids and on multi-level meshes spread over 2 / 3 / 5 ranks;
   * findMaxU: exact (max is order independent);
   * projection: the dot products are summed per rank and then over ranks, another rounding than on one rank, so the comparison is
-    at tight Poisson tolerance (1e-12 / 1e-10 on both sides): max|dp| <= 1e-6 max|p|, max|du| <= 1e-6 max|correction|, equal
-    restart counts; at the default tolerance the returned iterate satisfies the reference's stopping rule.
+    at tight Poisson tolerance (1e-12 / 1e-10 on both sides): max|dp| <= 1e-6 max|p|, max|du| <= 1e-6 max|correction|, identical
+    iteration / restart counts on all ranks of a run; at the default tolerance the returned iterate satisfies the reference's
+    stopping rule.
 """
 import threading
 
@@ -81,7 +82,7 @@ def test_uniform_grid_full_step_over_ranks(nranks, bc):
     one.upload("vel", one.grid.to_blocks(velg))
     cu.AdvectionDiffusion(one)(dt)
     one.step = 5
-    r_one = cu.PressureProjection(one)(dt)
+    cu.PressureProjection(one)(dt)
     vel_one, pres_one = np.zeros_like(velg), np.zeros_like(presg)
     one.grid.scatter_to_global(one.download("vel"), vel_one)
     one.grid.scatter_to_global(one.download("pres"), pres_one)
@@ -113,7 +114,8 @@ def test_uniform_grid_full_step_over_ranks(nranks, bc):
     assert all(out[r][0] == np.abs(velg + uinf).max() for r in range(nranks))
     assert np.array_equal(got_adv, adv_ref)                              # halo slabs + inner/boundary split: bit-exact
     assert len({(out[r][4], out[r][5]) for r in range(nranks)}) == 1     # every rank took the same path through solve()
-    assert out[0][5] == r_one.restarts
+    # (not compared with the one-rank run: this deep into the residual -- 1e-12 / 1e-10 -- whether a "serious breakdown" restart
+    #  fires, 14566, depends on the rounding of the dot products: 1 restart on 8 ranks vs 0 on one rank was observed)
     corr = np.abs(vel_one - adv_ref).max()
     assert np.abs(got_pres - pres_one).max() <= 1e-6 * np.abs(pres_one).max()
     assert np.abs(got_vel - vel_one).max() <= 1e-6 * corr
