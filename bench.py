@@ -41,6 +41,8 @@ BLOCK_CG_FLOPS_PER_CELL_ITER = 17.0
 ALGO_BYTES = {
     "advdiff_stage": 96.0,     # RK stages 2, 3: vel 24 in + tmpV 24 in + vel' 24 out + tmpV 24 out
     "advdiff_stage1": 72.0,    # RK stage 1 reads no tmpV (it is zero there)
+    "bicgstab_loop1_cg": 152.0,  # loop 1 fused with the block CG on z: 11 reads + 7 writes + zhat out (z never re-read)
+    "bicgstab_loop2_cg": 136.0,  # loop 2 fused with the block CG on w: 12 reads + 4 writes + what out
     "bicgstab_loop1": 144.0,   # 11 reads + 7 writes
     "bicgstab_loop2": 128.0,   # 12 reads + 4 writes
     "poisson_lhs": 16.0,       # p in, Ap out
@@ -201,6 +203,7 @@ def main():
     ap.add_argument("--stencil-only", action="store_true", help="BASELINE configs[1]: periodic, advect-diffuse only")
     ap.add_argument("--block-solver", type=int, default=0, help="0: block CG as in the reference, 1: direct block solve")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed region with the other block solver")
+    ap.add_argument("--no-fuse", action="store_true", help="A/B: vector loops and block CG as separate launches (round-1 structure)")
     ap.add_argument("--implicit-diffusion", action="store_true",
                     help="-implicitDiffusion 1: AdvectionDiffusionImplicit (upwind advection + three Helmholtz solves) instead of the explicit RK3")
     ap.add_argument("--nu", type=float, default=0.01)
@@ -228,6 +231,8 @@ def main():
 
     torch.cuda.set_device(local_rank)
     cu.device_init(local_rank)
+    if a.no_fuse:
+        check(lib().cup3d_debug_set_option(b"no_fuse", 1))
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -65,6 +65,7 @@ SIGNATURES = {
     "cup3d_grid_valid_states": (C.c_int, [_vp, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]),
     "cup3d_grid_adapted": (C.c_int, [_vp, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS"), C.POINTER(_vp)]),
     "cup3d_adapt_transfer": (C.c_int, [_vp, _vp, C.c_int]),
+    "cup3d_adapt_migrate": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "cup3d_grid_destroy": (None, [_vp]),
     "cup3d_grid_nblocks": (C.c_long, [_vp]),
     "cup3d_grid_nblocks_global": (C.c_long, [_vp]),

@@ -469,41 +469,54 @@ struct DevInts {
   }
   ~DevInts() { if (p) hipFree(p); }
 };
+struct DevBuf {
+  void *p = nullptr;
+  int alloc(size_t bytes) {
+    CUP3D_HIP(hipMalloc(&p, bytes));
+    return CUP3D_OK;
+  }
+  ~DevBuf() { if (p) hipFree(p); }
+};
+__global__ void __launch_bounds__(256) k_pack_blocks(const double *__restrict__ field, const int32_t *__restrict__ slots, int nc, double *__restrict__ out) {
+  const double *src = field + (size_t)slots[blockIdx.x] * nc * 512;
+  double *dst = out + (size_t)blockIdx.x * nc * 512;
+  for (int i = threadIdx.x; i < nc * 512; i += 256) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) k_unpack_blocks(const double *__restrict__ in, const int32_t *__restrict__ slots, int nc, double *__restrict__ field) {
+  const double *src = in + (size_t)blockIdx.x * nc * 512;
+  double *dst = field + (size_t)slots[blockIdx.x] * nc * 512;
+  for (int i = threadIdx.x; i < nc * 512; i += 256) dst[i] = src[i];
+}
 }  // namespace
 
-extern "C" int cup3d_adapt_transfer(cup3d_sim_t *src_h, cup3d_sim_t *dst_h, int field) {
-  if (!src_h || !dst_h) return CUP3D_EINVAL;
-  Sim *src = reinterpret_cast<Sim *>(src_h), *dst = reinterpret_cast<Sim *>(dst_h);
-  int nc, nc2;
-  const double *fs = src->field(field, &nc);
-  double *fd = dst->field(field, &nc2);
-  if (!fs || !fd) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
-  std::unique_ptr<Grid> mo_tmp, mn_tmp;
-  const Grid *mo = src->grid, *mn = dst->grid;
+
+// ---- data movement of MeshAdaptation::Adapt, shared by the one-rank and the multi-rank entry points.
+// `mo`: the OLD mesh as this rank sees it (a whole mesh, or a tensorial rank view whose ghost slots of `fs` hold the owners' data);
+// `blocks`: the blocks to produce, each with the slot of `fd` it goes to.  A block is a leaf of the old mesh (copied), a child of
+// one (refine_1 + RefineBlocks, 5227-5249, 5493-5565) or the parent of an octet of them (compress, 5272-5329).
+struct NewBlock { int level, idx[3]; int32_t dst; };
+static int adapt_produce(const Grid *mo, const std::vector<NewBlock> &blocks, const double *fs, double *fd, int nc) {
   std::vector<int32_t> pairs, octets, items, finer;
   try {
-    if (!mo->multilevel) { mo_tmp = mo->as_mesh(); mo = mo_tmp.get(); }
-    if (!mn->multilevel) { mn_tmp = mn->as_mesh(); mn = mn_tmp.get(); }
-    for (int d = 0; d < 3; ++d)
-      if (mo->bpd[d] != mn->bpd[d] || mo->bc[d] != mn->bc[d] || mo->level_max != mn->level_max) throw std::invalid_argument("the two meshes belong to different boxes");
-    std::vector<int32_t> item_of(mo->nblocks(), -1);
-    for (int64_t b = 0; b < mn->nblocks(); ++b) {
-      const int l = mn->blevel[b];
-      const int idx[3] = {mn->index[3 * b], mn->index[3 * b + 1], mn->index[3 * b + 2]};
+    std::vector<int32_t> item_of((size_t)mo->Z.size(), -1);
+    for (const NewBlock &nbk : blocks) {
+      const int l = nbk.level;
+      const int *idx = nbk.idx;
       const int32_t same = mo->leaf(l, idx);
-      if (same >= 0) { pairs.push_back((int32_t)b); pairs.push_back(same); continue; }
+      if (same >= 0) { pairs.push_back(nbk.dst); pairs.push_back(same); continue; }
       const int pidx[3] = {idx[0] >> 1, idx[1] >> 1, idx[2] >> 1};
       const int32_t par = l > 0 ? mo->leaf(l - 1, pidx) : -1;
       if (par >= 0) {
+        if (par >= mo->nblocks()) throw std::invalid_argument("a refined block is not local to the rank that has to refine it");
         if (item_of[par] < 0) {
           item_of[par] = (int32_t)(items.size() / 9);
           items.push_back(par);
           for (int q = 0; q < 8; ++q) items.push_back(-1);
         }
-        items[9 * (size_t)item_of[par] + 1 + (idx[0] & 1) + 2 * (idx[1] & 1) + 4 * (idx[2] & 1)] = (int32_t)b;
+        items[9 * (size_t)item_of[par] + 1 + (idx[0] & 1) + 2 * (idx[1] & 1) + 4 * (idx[2] & 1)] = nbk.dst;
         continue;
       }
-      octets.push_back((int32_t)b);
+      octets.push_back(nbk.dst);
       for (int q = 0; q < 8; ++q) {
         const int ci[3] = {2 * idx[0] + (q & 1), 2 * idx[1] + ((q >> 1) & 1), 2 * idx[2] + (q >> 2)};
         const int32_t cb = l + 1 < mo->level_max ? mo->leaf(l + 1, ci) : -1;
@@ -511,6 +524,8 @@ extern "C" int cup3d_adapt_transfer(cup3d_sim_t *src_h, cup3d_sim_t *dst_h, int 
         octets.push_back(cb);
       }
     }
+    // children of one parent are produced together or not at all on one rank; slots that stay -1 are children another rank's
+    // list holds -- impossible, since all eight go where the parent is refined
     for (size_t i = 0; i < items.size(); ++i)
       if (items[i] < 0) throw std::invalid_argument("a refined block lacks some of its children in the new mesh");
     // finer leaves behind every code of the refined parents, by octant of the parent
@@ -529,12 +544,15 @@ extern "C" int cup3d_adapt_transfer(cup3d_sim_t *src_h, cup3d_sim_t *dst_h, int 
             if (code[d] != 0 && bit) used = false;
             fi[d] = 2 * mo->index[3 * (size_t)pb + d] + (code[d] < 0 ? -1 : (code[d] > 0 ? 2 : bit));
           }
-          if (used) finer[(it * 27 + icode) * 8 + q] = mo->leaf(l + 1, fi);
+          if (!used) continue;
+          const int32_t fl = mo->leaf(l + 1, fi);
+          if (fl < 0) throw std::invalid_argument("a finer neighbour of a refined block is not visible on this rank");
+          finer[(it * 27 + icode) * 8 + q] = fl;
         }
       }
     }
   } catch (const std::exception &e) {
-    set_error("cup3d_adapt_transfer: %s", e.what());
+    set_error("mesh adaptation: %s", e.what());
     return CUP3D_EINVAL;
   }
   DevInts d_pairs, d_octets, d_items, d_finer, d_n27, d_nbr, d_index;
@@ -553,6 +571,113 @@ extern "C" int cup3d_adapt_transfer(cup3d_sim_t *src_h, cup3d_sim_t *dst_h, int 
   }
   CUP3D_HIP(hipGetLastError());
   CUP3D_HIP(hipStreamSynchronize(stream()));  // the index tables above are freed on return
+  return CUP3D_OK;
+}
+
+extern "C" int cup3d_adapt_transfer(cup3d_sim_t *src_h, cup3d_sim_t *dst_h, int field) {
+  if (!src_h || !dst_h) return CUP3D_EINVAL;
+  Sim *src = reinterpret_cast<Sim *>(src_h), *dst = reinterpret_cast<Sim *>(dst_h);
+  int nc, nc2;
+  const double *fs = src->field(field, &nc);
+  double *fd = dst->field(field, &nc2);
+  if (!fs || !fd) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+  if (src->grid->n_local >= 0 || dst->grid->n_local >= 0) { set_error("cup3d_adapt_transfer: meshes spread over ranks go through cup3d_adapt_migrate"); return CUP3D_EINVAL; }
+  std::unique_ptr<Grid> mo_tmp, mn_tmp;
+  const Grid *mo = src->grid, *mn = dst->grid;
+  std::vector<NewBlock> blocks;
+  try {
+    if (!mo->multilevel) { mo_tmp = mo->as_mesh(); mo = mo_tmp.get(); }
+    if (!mn->multilevel) { mn_tmp = mn->as_mesh(); mn = mn_tmp.get(); }
+    for (int d = 0; d < 3; ++d)
+      if (mo->bpd[d] != mn->bpd[d] || mo->bc[d] != mn->bc[d] || mo->level_max != mn->level_max) throw std::invalid_argument("the two meshes belong to different boxes");
+  } catch (const std::exception &e) {
+    set_error("cup3d_adapt_transfer: %s", e.what());
+    return CUP3D_EINVAL;
+  }
+  blocks.resize((size_t)mn->nblocks());
+  for (int64_t b = 0; b < mn->nblocks(); ++b)
+    blocks[b] = NewBlock{mn->blevel[b], {mn->index[3 * b], mn->index[3 * b + 1], mn->index[3 * b + 2]}, (int32_t)b};
+  return adapt_produce(mo, blocks, fs, fd, nc);
+}
+
+// ---- the same over ranks: MeshAdaptation::Adapt + the block traffic of the LoadBalancer (PrepareCompression 4729-4804, Balance_Diffusion
+// 4805-4905, Balance_Global 4906-5021).  The reference refines where the parent lives, gathers an octet on the rank of its base block,
+// compresses there, then ships whole blocks to even out the load; the END STATE -- every block of the adapted mesh, filled from the old
+// mesh's data, on the rank cup3d_grid_adapted_owners names -- is produced here in one hop: the rank that owns the ORIGIN of a new block
+// (the leaf itself, the refined parent, or the base block of the octet) builds it from its tensorial view of the old mesh and sends it
+// straight to the new owner.  Refinement and compression are block-local operations on identical inputs, so the fields equal the
+// one-rank adaptation bit for bit, wherever the blocks end up.
+extern "C" int cup3d_adapt_migrate(const cup3d_grid_t *old_mesh_h, const int32_t *old_owner, cup3d_sim_t *src_h, const cup3d_grid_t *new_mesh_h,
+                                   const int32_t *new_owner, cup3d_sim_t *dst_h, int field) {
+  if (!old_mesh_h || !old_owner || !src_h || !new_mesh_h || !new_owner || !dst_h) return CUP3D_EINVAL;
+  const Grid *om = reinterpret_cast<const Grid *>(old_mesh_h), *nm = reinterpret_cast<const Grid *>(new_mesh_h);
+  Sim *src = reinterpret_cast<Sim *>(src_h), *dst = reinterpret_cast<Sim *>(dst_h);
+  int nc, nc2;
+  const double *fs = src->field(field, &nc);
+  double *fd = dst->field(field, &nc2);
+  if (!fs || !fd) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+  if (!om->multilevel || !nm->multilevel || om->n_local >= 0 || nm->n_local >= 0) { set_error("cup3d_adapt_migrate needs the two GLOBAL mesh objects"); return CUP3D_EINVAL; }
+  const int me = src->grid->rank, nranks = src->grid->nranks;
+  if (dst->grid->rank != me || dst->grid->nranks != nranks) { set_error("cup3d_adapt_migrate: the two sims belong to different ranks"); return CUP3D_EINVAL; }
+  std::unique_ptr<Grid> tv;
+  std::vector<NewBlock> mine;               // what this rank produces, ordered by (consumer, new global slot)
+  std::vector<int64_t> send_count(nranks, 0), recv_count(nranks, 0);
+  std::vector<int32_t> recv_slots;          // local slots of dst in arrival order: by (producer, new global slot)
+  try {
+    tv = om->rank_view(old_owner, me, nranks, /*tensorial=*/true);
+    if (tv->n_local != src->nb) throw std::invalid_argument("the source sim does not hold this rank's blocks of the old mesh");
+    std::vector<std::vector<NewBlock>> by_consumer(nranks);
+    std::vector<std::vector<int32_t>> by_producer(nranks);
+    int32_t my_slot = 0;
+    for (int64_t b = 0; b < nm->nblocks(); ++b) {
+      const int l = nm->blevel[b];
+      const int idx[3] = {nm->index[3 * b], nm->index[3 * b + 1], nm->index[3 * b + 2]};
+      int32_t origin = om->leaf(l, idx);
+      if (origin < 0 && l > 0) { const int pi[3] = {idx[0] >> 1, idx[1] >> 1, idx[2] >> 1}; origin = om->leaf(l - 1, pi); }
+      if (origin < 0 && l + 1 < om->level_max) { const int ci[3] = {2 * idx[0], 2 * idx[1], 2 * idx[2]}; origin = om->leaf(l + 1, ci); }
+      if (origin < 0) throw std::invalid_argument("a block of the new mesh is neither a block, a child nor the parent of blocks of the old mesh");
+      const int producer = old_owner[origin], consumer = new_owner[b];
+      if (producer < 0 || producer >= nranks || consumer < 0 || consumer >= nranks) throw std::invalid_argument("owner out of range");
+      if (producer == me) by_consumer[consumer].push_back(NewBlock{l, {idx[0], idx[1], idx[2]}, 0});
+      if (consumer == me) by_producer[producer].push_back(my_slot++);
+    }
+    if (my_slot != dst->nb) throw std::invalid_argument("the destination sim does not hold this rank's blocks of the new mesh");
+    for (int p = 0; p < nranks; ++p) {
+      send_count[p] = (int64_t)by_consumer[p].size();
+      recv_count[p] = (int64_t)by_producer[p].size();
+      for (NewBlock &nbk : by_consumer[p]) { nbk.dst = (int32_t)mine.size(); mine.push_back(nbk); }
+      recv_slots.insert(recv_slots.end(), by_producer[p].begin(), by_producer[p].end());
+    }
+  } catch (const std::exception &e) {
+    set_error("cup3d_adapt_migrate: %s", e.what());
+    return CUP3D_EINVAL;
+  }
+  const size_t per = (size_t)nc * 512, nvis = tv->Z.size();
+  DevBuf F, prod, recv;
+  DevInts d_send, d_recv_slots;
+  int rc;
+  if ((rc = F.alloc(nvis * per * sizeof(double))) || (rc = prod.alloc(std::max<size_t>(mine.size(), 1) * per * sizeof(double))) ||
+      (rc = recv.alloc(std::max<size_t>(recv_slots.size(), 1) * per * sizeof(double))))
+    return rc;
+  // the old field on the tensorial view: local blocks, then the ghost blocks from their owners
+  CUP3D_HIP(hipMemcpyAsync(F.p, fs, (size_t)src->nb * per * sizeof(double), hipMemcpyDeviceToDevice, stream()));
+  {
+    DevBuf pack;
+    if ((rc = pack.alloc(std::max<size_t>(tv->send_blocks.size(), 1) * per * sizeof(double))) || (rc = d_send.upload(tv->send_blocks))) return rc;
+    if (!tv->send_blocks.empty())
+      hipLaunchKernelGGL(k_pack_blocks, dim3((unsigned)tv->send_blocks.size()), dim3(256), 0, stream(), (const double *)F.p, d_send.p, nc, (double *)pack.p);
+    CUP3D_HIP(hipGetLastError());
+    if ((rc = exchange_items(src, (const double *)pack.p, tv->send_block_count, (double *)F.p + (size_t)tv->n_local * per, tv->recv_block_count, per))) return rc;
+    CUP3D_HIP(hipStreamSynchronize(stream()));
+  }
+  if ((rc = adapt_produce(tv.get(), mine, (const double *)F.p, (double *)prod.p, nc))) return rc;
+  if ((rc = exchange_items(src, (const double *)prod.p, send_count, (double *)recv.p, recv_count, per))) return rc;
+  if (!recv_slots.empty()) {
+    if ((rc = d_recv_slots.upload(recv_slots))) return rc;
+    hipLaunchKernelGGL(k_unpack_blocks, dim3((unsigned)recv_slots.size()), dim3(256), 0, stream(), (const double *)recv.p, d_recv_slots.p, nc, fd);
+    CUP3D_HIP(hipGetLastError());
+  }
+  CUP3D_HIP(hipStreamSynchronize(stream()));
   return CUP3D_OK;
 }
 

@@ -78,6 +78,7 @@ struct VComm {
   int n = 0;
   std::vector<Sim *> sims;
   std::vector<double *> ptr;
+  std::vector<const std::vector<int64_t> *> counts;
   double *d_tmp = nullptr;  // [n][16]
   std::mutex m;
   std::condition_variable cv;
@@ -236,6 +237,55 @@ int view_exchange_flux(Sim *s, int nfc) {
   return CUP3D_OK;
 }
 
+// Generic peer-to-peer exchange of `per`-double items (mesh adaptation: ghost blocks of the tensorial view, then the produced blocks
+// on their way to their new owners).  send_count / recv_count per rank, own rank included (a device copy); buffers are peer-major.
+// Enqueued on the compute stream: adaptation is not overlapped with anything.
+int exchange_items(Sim *s, const double *sendbuf, const std::vector<int64_t> &send_count, double *recvbuf, const std::vector<int64_t> &recv_count, size_t per) {
+  const Grid *g = s->grid;
+  const int me = g->rank, n = g->nranks;
+  std::vector<size_t> so(n + 1, 0), ro(n + 1, 0);
+  for (int p = 0; p < n; ++p) { so[p + 1] = so[p] + (size_t)send_count[p] * per; ro[p + 1] = ro[p] + (size_t)recv_count[p] * per; }
+  if (send_count[me] != recv_count[me]) { set_error("exchange_items: inconsistent self count"); return CUP3D_EINVAL; }
+  if (send_count[me]) CUP3D_HIP(hipMemcpyAsync(recvbuf + ro[me], sendbuf + so[me], (size_t)send_count[me] * per * sizeof(double), hipMemcpyDeviceToDevice, stream()));
+  if (n == 1) return CUP3D_OK;
+  if (g_vcomm) {
+    VComm *vc = g_vcomm;
+    vc->ptr[me] = const_cast<double *>(sendbuf);
+    vc->counts[me] = &send_count;
+    if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the block exchange"); return CUP3D_ECOMM; }
+    for (int p = 0; p < n; ++p) {
+      if (p == me || !recv_count[p]) continue;
+      const std::vector<int64_t> &sc = *vc->counts[p];
+      size_t off = 0;
+      for (int q = 0; q < me; ++q) off += (size_t)sc[q] * per;
+      if (sc[me] != recv_count[p]) { set_error("exchange_items: rank %d sends %ld items, rank %d expects %ld", p, (long)sc[me], me, (long)recv_count[p]); return CUP3D_ESTATE; }
+      CUP3D_HIP(hipMemcpyAsync(recvbuf + ro[p], vc->ptr[p] + off, (size_t)recv_count[p] * per * sizeof(double), hipMemcpyDeviceToDevice, stream()));
+    }
+    CUP3D_HIP(hipStreamSynchronize(stream()));  // the peers may free their send buffers after the next barrier
+    if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the block exchange"); return CUP3D_ECOMM; }
+    return CUP3D_OK;
+  }
+  Comm *c = comm();
+  if (!c) { set_error("multi-rank mesh without cup3d_comm_init"); return CUP3D_ESTATE; }
+  hipStream_t st = s->comm_stream ? s->comm_stream : stream();
+  if (st != stream()) {
+    CUP3D_HIP(hipEventRecord(s->ev_h1, stream()));
+    CUP3D_HIP(hipStreamWaitEvent(st, s->ev_h1, 0));
+  }
+  CUP3D_NCCL(c->GroupStart());
+  for (int p = 0; p < n; ++p) {
+    if (p == me) continue;
+    if (send_count[p]) CUP3D_NCCL(c->Send(sendbuf + so[p], (size_t)send_count[p] * per, ncclDouble, p, c->comm, st));
+    if (recv_count[p]) CUP3D_NCCL(c->Recv(recvbuf + ro[p], (size_t)recv_count[p] * per, ncclDouble, p, c->comm, st));
+  }
+  CUP3D_NCCL(c->GroupEnd());
+  if (st != stream()) {
+    CUP3D_HIP(hipEventRecord(s->ev_h2, st));
+    CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
+  }
+  return CUP3D_OK;
+}
+
 // ------------------------------------------------------------------ face-slab halo exchange of uniform grids
 static int slab_transfer(Sim *s, size_t per_face, hipStream_t st) {
   const Grid *g = s->grid;
@@ -375,6 +425,7 @@ int cup3d_debug_virtual_comm(int nranks) {
   vc->n = nranks;
   vc->sims.assign(nranks, nullptr);
   vc->ptr.assign(nranks, nullptr);
+  vc->counts.assign(nranks, nullptr);
   if (hipMalloc((void **)&vc->d_tmp, (size_t)nranks * 16 * sizeof(double)) != hipSuccess) { delete vc; set_error("virtual communicator: hipMalloc failed"); return CUP3D_EDEVICE; }
   g_vcomm = vc;
   g_virtual_ranks = true;

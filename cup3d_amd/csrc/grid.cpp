@@ -256,7 +256,7 @@ Grid::Grid(const Grid &p, int)
 // reads through them on rank r is what it reads on one rank -- provided the ghost blocks / ghost face fluxes hold the owners' data,
 // which is what the two exchange plans are for.  (In the reference every rank keeps the whole octree too: Grid::Octree with the
 // owner in TreePosition, main.cpp:815-855; SynchronizerMPI_AMR::_Setup 1979-2286 derives its messages from it.)
-std::unique_ptr<Grid> Grid::rank_view(const int32_t *owner, int rank_, int nranks_) const {
+std::unique_ptr<Grid> Grid::rank_view(const int32_t *owner, int rank_, int nranks_, bool tensorial) const {
   if (!multilevel || n_local >= 0) throw std::invalid_argument("rank_view needs a global multi-level mesh");
   if (!owner || nranks_ < 1 || rank_ < 0 || rank_ >= nranks_) throw std::invalid_argument("bad rank / nranks");
   const int64_t nb = nblocks(), ne = n_amr_faces();
@@ -272,6 +272,21 @@ std::unique_ptr<Grid> Grid::rank_view(const int32_t *owner, int rank_, int nrank
         const int32_t v = nbr27[27 * s + c];
         if (v >= kNbrCoarser) { if (owner[v - kNbrCoarser] != r) want[v - kNbrCoarser] = 1; }
         else if (v >= 0 && owner[v] != r) want[v] = 1;
+        else if (v == kNbrFiner && tensorial) {  // the finer leaves behind this position, face / edge / corner alike
+          const int code[3] = {c % 3 - 1, (c / 3) % 3 - 1, c / 9 - 1};
+          for (int q = 0; q < 8; ++q) {
+            int fi[3];
+            bool used = true;
+            for (int d = 0; d < 3; ++d) {
+              const int bit = (q >> d) & 1;
+              if (code[d] != 0 && bit) used = false;
+              fi[d] = 2 * index[3 * s + d] + (code[d] < 0 ? -1 : (code[d] > 0 ? 2 : bit));
+            }
+            if (!used) continue;
+            const int32_t fs = leaf(blevel[s] + 1, fi);
+            if (fs >= 0 && owner[fs] != r) want[fs] = 1;
+          }
+        }
       }
     }
     for (int64_t e = 0; e < ne; ++e) {

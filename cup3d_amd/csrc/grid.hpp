@@ -101,7 +101,9 @@ struct Grid {
   std::vector<int64_t> send_block_count, recv_block_count;   // [nranks]
   std::vector<int32_t> send_flux_faces;   // local interface faces (fine side), in the receiver's ghost-face order
   std::vector<int64_t> send_flux_count, recv_flux_count;     // [nranks]
-  std::unique_ptr<Grid> rank_view(const int32_t *owner, int rank, int nranks) const;
+  // tensorial: also the finer leaves behind EDGE and CORNER positions become ghosts -- what the tensorial [-1,2) tile of mesh adaptation
+  // (refine_1 / RefineBlocks) averages down; the star-shaped stencils of the time step never read them
+  std::unique_ptr<Grid> rank_view(const int32_t *owner, int rank, int nranks, bool tensorial = false) const;
   Grid(const Grid &proto, int basics_only);  // box, curve and spacing of `proto`, no blocks (used by rank_view)
   int owner_of(int64_t z) const;
   static void partition(int64_t total, int rank, int nranks, int64_t *begin, int64_t *count);

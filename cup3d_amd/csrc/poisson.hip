@@ -95,15 +95,14 @@ __device__ __forceinline__ double cg_div(double n, double d) {
 
 // EV = how the iteration is evaluated, a bit set: 1 = wave sums on the matrix pipe, 2 = single-width volatile LDS reads,
 // 4 = reciprocal divisions (FMA variants only), 8 = three-operand FMA for the p update (p_update above)
-template <bool FMA, bool HELM = false, int EV = 0>
-__global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, double *out, double *__restrict__ block_sums, double nu, double dt,
-                                                int *__restrict__ iters_out) {
+// cg_block: the iteration itself, entered with r = the block's right-hand side / h already in registers (lane = (x, y), 8 z per lane) --
+// shared by the stand-alone preconditioner kernel and the kernels that produce that right-hand side on the fly (k_loop1_cg / k_loop2_cg)
+template <bool FMA, bool HELM, int EV>
+__device__ __forceinline__ void cg_block(const GridDev &g, int slot, double (&r)[8], double *out, double *__restrict__ block_sums, double nu, double dt,
+                                         int *__restrict__ iters_out, double *P) {
   // (r01 kernel: 86 VGPRs -> 5 waves/SIMD.  Forcing 6 with amdgpu_waves_per_eu spills five values that are reloaded every iteration:
   //  0.476 vs 0.431 ms at 256^3, so the natural allocation stays.)
   constexpr bool V2 = (EV & 1) != 0, LDSV = (EV & 2) != 0, FDIV = (EV & 4) != 0 && FMA;
-  __shared__ double P[8 * 80];
-  const int slot = block_slot(g);
-  if (slot < 0) return;
   const int l = threadIdx.x;
   const int base = ((l >> 3) + 1) * 8 + (l & 7);
   for (int i = l; i < 640; i += 64) P[i] = 0.0;
@@ -113,14 +112,12 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
   // V2: volatile LDS pointers (address space kept, or the loads become flat): one ds_read_b64 per access, plane offset immediate
   typedef const volatile __attribute__((address_space(3))) double lds_cvd;
   lds_cvd *Pam = (lds_cvd *)(P + am), *Pap = (lds_cvd *)(P + ap), *Pym = (lds_cvd *)(P + base - 8), *Pyp = (lds_cvd *)(P + base + 8);
-  const double invh = 1 / block_h(g, slot);  // main.cpp:14723
   double centre = -6.0;
   if constexpr (HELM) { const double hq = block_h(g, slot); centre = -6.0 - hq * hq / nu / dt; }
-  double r[8], p[8], x[8], Ax[8];
+  double p[8], x[8], Ax[8];
   double rr = 0;
 #pragma unroll
   for (int z = 0; z < 8; ++z) {
-    r[z] = invh * in[(size_t)slot * 512 + z * 64 + l];
     rr = mad<FMA>(r[z], r[z], rr);
     p[z] = r[z];
     x[z] = 0;
@@ -186,6 +183,19 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
     sx = cg_sum<V2>(sx * h3);
     if (l == 0) block_sums[slot] = sx;
   }
+}
+
+template <bool FMA, bool HELM = false, int EV = 0>
+__global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, double *out, double *__restrict__ block_sums, double nu, double dt,
+                                                int *__restrict__ iters_out) {
+  __shared__ double P[8 * 80];
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  const double invh = 1 / block_h(g, slot);  // main.cpp:14723
+  double r[8];
+#pragma unroll
+  for (int z = 0; z < 8; ++z) r[z] = invh * in[(size_t)slot * 512 + z * 64 + threadIdx.x];
+  cg_block<FMA, HELM, EV>(g, slot, r, out, block_sums, nu, dt, iters_out, P);
 }
 
 // ------------------------------------------------------------------ block CG, two blocks per wavefront
@@ -432,6 +442,11 @@ static int fdm_setup() {
   return CUP3D_OK;
 }
 
+static int *cg_iters_buffer(Sim *s) {  // per-block CG iteration counts of the last launch (measurement only)
+  if (!s->d_cg_iters && hipMalloc((void **)&s->d_cg_iters, (size_t)s->nb * sizeof(int)) != hipSuccess) return nullptr;
+  return s->d_cg_iters;
+}
+
 // evaluation of the production block CG (EV bits of k_precond); measured on MI355X: see profiles/r02/probe_block_cg_variants.jsonl
 constexpr int kCgProduction = 0;
 
@@ -453,11 +468,7 @@ int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
   // the CPU's, and the CG's own truncation is 1e-7, so this is a tolerance-level deviation (tests: <= 2e-5 of the reference's z,
   // measured ~1e-7).  block_solver 2 = the reference's association (no contraction, IEEE divisions); 3 = the round-1 kernel.
   const dim3 G(launch_groups(g)), B(64);
-  int *it = nullptr;
-  if (profile_on()) {  // per-block CG iteration counts of the launch, for the FP64 roofline of bench.py (cup3d_debug_block_cg_iterations)
-    if (!s->d_cg_iters) CUP3D_HIP(hipMalloc((void **)&s->d_cg_iters, (size_t)s->nb * sizeof(int)));
-    it = s->d_cg_iters;
-  }
+  int *it = profile_on() ? cg_iters_buffer(s) : nullptr;  // for the FP64 roofline of bench.py (cup3d_debug_block_cg_iterations)
 #define CG(FMA_, EV_) hipLaunchKernelGGL((k_precond<FMA_, false, EV_>), G, B, 0, stream(), g, in, out, sums, 0.0, 0.0, it)
   switch (s->block_solver) {
     case 0:  // production: kCgProduction, or (tuning) the evaluation selected with cup3d_debug_set_option("cg_variant", 8 + bits)
@@ -538,6 +549,129 @@ __device__ __forceinline__ double2 operator+(double2 a, double2 b) { return make
 __device__ __forceinline__ double2 operator-(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ double2 operator*(double s, double2 a) { return make_double2(s * a.x, s * a.y); }
 __device__ __forceinline__ double dot2(double2 a, double2 b, double acc) { acc += a.x * b.x; acc += a.y * b.y; return acc; }
+
+// ------------------------------------------------------------------ vector loop + block preconditioner in ONE launch
+// Per BiCGSTAB iteration the reference runs   loop 1 -> z ;  zhat = M^-1 z ;  v = A zhat   and   loop 2 -> w ;  what = M^-1 w ;  t = A what.
+// The fused vector loops are HBM-bound (6.2 TB/s, nothing for the FP64 units to do), the block CG that consumes their output is
+// bound by FP64 issue and LDS (0.1 of the HBM roof) -- run back to back they each leave the other resource idle, and together they
+// are 93 % of an iteration.  Here one wavefront owns one block from start to end: it streams the block's 512 cells of the 11 (12)
+// input vectors, writes the 7 (4) updated ones, keeps the block of z (w) in registers and runs the block CG on it straight away;
+// while it iterates, the other wavefronts of the SIMD are in their streaming phase, so the two bounds overlap instead of adding.
+// The arithmetic per cell is that of k_loop1 / k_loop2 and of cg_block, unchanged; the dot products are summed per block first
+// (wave tree) and the per-block values by k_sums_finish, another order than the grid-stride partials of the unfused kernels.
+// block_dots layout: [K][nb].
+struct Loop1Args { double alpha, beta, omega; };
+struct Loop2Args { double alpha, omega; const double *xin; };
+
+#define NTL(v, j) __builtin_nontemporal_load(&(v)[j])
+#define NTS(v, j, val) __builtin_nontemporal_store((val), &(v)[j])
+
+template <bool FMA, int EV>
+__global__ void __launch_bounds__(64) k_loop1_cg(GridDev g, Vecs V, Loop1Args a, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
+                                                 int *__restrict__ iters_out) {
+  __shared__ double P[8 * 80];
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  const int l = threadIdx.x;
+  const double invh = 1 / block_h(g, slot);
+  double r[8], d0 = 0, d1 = 0;
+  // plane zz + 1 is requested before plane zz is computed and stored (two planes = 22 x 512 B per wavefront in flight): the loads
+  // may alias the stores as far as the compiler knows, so the order has to be written out
+  // (block base pointers are wave-uniform -> scalar registers; the per-lane part of every address is one 32-bit offset)
+  const size_t bo = (size_t)slot * 512;
+  const double *const src[11] = {V.v[RHAT] + bo, V.v[W_] + bo, V.v[SHAT] + bo, V.v[Z_] + bo, V.v[PHAT] + bo, V.v[S_] + bo, V.v[WHAT] + bo, V.v[ZHAT] + bo,
+                                 V.v[T_] + bo, V.v[V_] + bo, V.v[R_] + bo};
+  double *const oP = V.v[PHAT] + bo, *const oS = V.v[S_] + bo, *const oSH = V.v[SHAT] + bo, *const oZ = V.v[Z_] + bo, *const oQ = V.v[Q_] + bo,
+               *const oQH = V.v[QHAT] + bo, *const oY = V.v[Y_] + bo;
+  double in[2][11];
+#pragma unroll
+  for (int i = 0; i < 11; ++i) in[0][i] = NTL(src[i], l);
+#pragma unroll
+  for (int zz = 0; zz < 8; ++zz) {  // first fused loop, 14454-14464, on plane zz of this block
+    const int j = zz * 64 + l;
+    if (zz < 7) {
+#pragma unroll
+      for (int i = 0; i < 11; ++i) in[(zz + 1) & 1][i] = NTL(src[i], j + 64);
+    }
+    const double *c = in[zz & 1];
+    const double rhat = c[0], w = c[1], shat0 = c[2], z0 = c[3];
+    const double phat = rhat + a.beta * (c[4] - a.omega * shat0);
+    const double sv = w + a.beta * (c[5] - a.omega * z0);
+    const double shat = c[6] + a.beta * (shat0 - a.omega * c[7]);
+    const double z = c[8] + a.beta * (z0 - a.omega * c[9]);
+    const double q = c[10] - a.alpha * sv;
+    const double qhat = rhat - a.alpha * shat;
+    const double y = w - a.alpha * z;
+    NTS(oP, j, phat); NTS(oS, j, sv); NTS(oSH, j, shat); NTS(oZ, j, z); NTS(oQ, j, q); NTS(oQH, j, qhat); NTS(oY, j, y);
+    d0 += q * y;
+    d1 += y * y;
+    r[zz] = invh * z;  // the right-hand side of the block solve, main.cpp:14723
+  }
+  d0 = wave_sum(d0);
+  d1 = wave_sum(d1);
+  if (l == 0) { block_dots[slot] = d0; block_dots[nb + slot] = d1; }
+  cg_block<FMA, false, EV>(g, slot, r, V.v[ZHAT], block_sums, 0.0, 0.0, iters_out, P);  // zhat = M^-1 z, 14488
+}
+
+template <bool FMA, int EV>
+__global__ void __launch_bounds__(64) k_loop2_cg(GridDev g, Vecs V, Loop2Args a, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
+                                                 int *__restrict__ iters_out) {
+  __shared__ double P[8 * 80];
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  const int l = threadIdx.x;
+  const double invh = 1 / block_h(g, slot);
+  double r[8], acc[6] = {0, 0, 0, 0, 0, 0};
+  const size_t bo = (size_t)slot * 512;
+  const double *const src[12] = {V.v[QHAT] + bo, V.v[Y_] + bo, V.v[R0] + bo, a.xin + bo, V.v[PHAT] + bo, V.v[Q_] + bo, V.v[WHAT] + bo, V.v[ZHAT] + bo,
+                                 V.v[T_] + bo, V.v[V_] + bo, V.v[S_] + bo, V.v[Z_] + bo};
+  double *const oX = V.v[X_] + bo, *const oR = V.v[R_] + bo, *const oRH = V.v[RHAT] + bo, *const oW = V.v[W_] + bo;
+  double in[2][12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) in[0][i] = NTL(src[i], l);
+#pragma unroll
+  for (int zz = 0; zz < 8; ++zz) {  // second fused loop, 14503-14515
+    const int j = zz * 64 + l;
+    if (zz < 7) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) in[(zz + 1) & 1][i] = NTL(src[i], j + 64);
+    }
+    const double *c = in[zz & 1];
+    const double qhat = c[0], y = c[1], r0 = c[2];
+    const double x = c[3] + a.alpha * c[4] + a.omega * qhat;
+    const double rv = c[5] - a.omega * y;
+    const double rhat = qhat - a.omega * (c[6] - a.alpha * c[7]);
+    const double w = y - a.omega * (c[8] - a.alpha * c[9]);
+    NTS(oX, j, x); NTS(oR, j, rv); NTS(oRH, j, rhat); NTS(oW, j, w);
+    acc[0] += r0 * rv;
+    acc[1] += r0 * w;
+    acc[2] += r0 * c[10];
+    acc[3] += r0 * c[11];
+    acc[4] += rv * rv;   // norm_1
+    acc[5] += r0 * r0;   // norm_2
+    r[zz] = invh * w;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double t = wave_sum(acc[i]);
+    if (l == 0) block_dots[(size_t)i * nb + slot] = t;
+    if (i == 4 && l == 0) block_dots[(size_t)6 * nb + slot] = t;  // norm = the same sum as norm_1 (14512-14514)
+  }
+  cg_block<FMA, false, EV>(g, slot, r, V.v[WHAT], block_sums, 0.0, 0.0, iters_out, P);  // what = M^-1 w, 14548
+}
+
+// K sums of nb per-block values each ([K][nb]) finished in one launch: 64 workgroups, the last one to arrive totals the partials
+template <int K>
+__global__ void __launch_bounds__(256) k_sums_finish(const double *__restrict__ v, long nb, RedOut ro) {
+  double acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double t = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (long)gridDim.x * 256) t += v[(size_t)k * nb + i];
+    acc[k] = t;
+  }
+  grid_sum_finish<K>(acc, ro);
+}
 
 // b = r = rhs, x = pres   (main.cpp:14408-14415)
 __global__ void __launch_bounds__(256) k_solver_init(Vecs V, const double *__restrict__ rhs, const double *__restrict__ pres, long n) {
@@ -698,6 +832,10 @@ struct Reducer {
 };
 
 static int ensure_vectors(Sim *s) {
+  if (!s->d_block_dots) {
+    int rc = sim_alloc(&s->d_block_dots, (size_t)7 * s->nb, s);
+    if (rc) return rc;
+  }
   if (s->sv[0]) return CUP3D_OK;
   for (int i = 0; i < NVEC; ++i) {
     int rc = sim_alloc(&s->sv[i], (size_t)s->nvis * 512, s);  // nvis: the LHS reads ghost blocks of any of them on a rank view
@@ -731,6 +869,12 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   auto PRE = [&](int in, int out) {  // _preconditioner, 9334-9364 / 6804-6835
     return helm ? launch_precond_diffusion(s, V.v[in], V.v[out], *helm) : launch_precond(s, V.v[in], V.v[out], mc > 0 && mc <= 2);
   };
+  // vector loop + block CG in one launch (k_loop1_cg / k_loop2_cg): the production path of the pressure solver with the block CG
+  const bool fuse = !helm && (P.block_solver == 0 || P.block_solver == 2) && !debug_option("no_fuse");
+  const bool want_sums = mc > 0 && mc <= 2;
+  double *const sums = want_sums ? s->d_partials + (size_t)s->max_groups * 8 : nullptr;
+  int *const cg_it = profile_on() ? cg_iters_buffer(s) : nullptr;
+  const GridDev gd = s->gdev();
 
   if ((mc == 1 || mc > 2) && s->grid->corner_slot >= 0)  // rhs(0,0,0) = 0, 14404-14407
     hipLaunchKernelGGL(k_set_one, dim3(1), dim3(1), 0, stream(), s->lhs, (size_t)s->grid->corner_slot * 512, 0.0);
@@ -748,7 +892,18 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   bool use_xopt = false;
   int restarts = 0, k;
   for (k = 0; k < P.max_iter; ++k) {
-    if (k % 50 != 0) {
+    const bool fused_now = fuse && k % 50 != 0;
+    if (fused_now) {
+      {
+        ProfileScope ps("bicgstab_loop1_cg");
+        const Loop1Args la{alpha, beta, omega};
+        if (P.block_solver == 0) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, la, s->d_block_dots, (long)s->nb, sums, cg_it);
+        else hipLaunchKernelGGL((k_loop1_cg<false, 0>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, la, s->d_block_dots, (long)s->nb, sums, cg_it);
+      }
+      s->sums_of = want_sums ? V.v[ZHAT] : nullptr;
+      ProfileScope ps("bicgstab_dots_finish");
+      hipLaunchKernelGGL(k_sums_finish<2>, dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, red.out());
+    } else if (k % 50 != 0) {
       ProfileScope ps("bicgstab_loop1");
       if (!debug_option("loops_no_nt")) LAUNCH_VEC(k_loop1<true>, V, N, alpha, beta, omega, red.out());
       else LAUNCH_VEC(k_loop1<false>, V, N, alpha, beta, omega, red.out());
@@ -758,10 +913,21 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_loop1_tail, V, N, alpha, red.out()); }
     }
     TRY(red.begin(2));                       // MPI_Iallreduce(2), 14486
-    TRY(PRE(Z_, ZHAT)); TRY(LHS(ZHAT, V_));  // overlapped with the reduction read-back, 14488-14489
+    if (!fused_now) TRY(PRE(Z_, ZHAT));      // overlapped with the reduction read-back, 14488-14489
+    TRY(LHS(ZHAT, V_));
     TRY(red.wait());
     omega = s->h_red[0] / (s->h_red[1] + eps);  // 14493
-    if (k % 50 != 0) {
+    if (fused_now) {
+      {
+        ProfileScope ps("bicgstab_loop2_cg");
+        const Loop2Args la{alpha, omega, V.xin};
+        if (P.block_solver == 0) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, la, s->d_block_dots, (long)s->nb, sums, cg_it);
+        else hipLaunchKernelGGL((k_loop2_cg<false, 0>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, la, s->d_block_dots, (long)s->nb, sums, cg_it);
+      }
+      s->sums_of = want_sums ? V.v[WHAT] : nullptr;
+      ProfileScope ps("bicgstab_dots_finish");
+      hipLaunchKernelGGL(k_sums_finish<7>, dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, red.out());
+    } else if (k % 50 != 0) {
       ProfileScope ps("bicgstab_loop2");
       if (!debug_option("loops_no_nt")) LAUNCH_VEC(k_loop2<true>, V, N, alpha, omega, red.out());
       else LAUNCH_VEC(k_loop2<false>, V, N, alpha, omega, red.out());
@@ -776,7 +942,8 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots7, V, N, red.out()); }
     }
     TRY(red.begin(7));                       // MPI_Iallreduce(7), 14546
-    TRY(PRE(W_, WHAT)); TRY(LHS(WHAT, T_));  // 14548-14549
+    if (!fused_now) TRY(PRE(W_, WHAT));      // 14548-14549
+    TRY(LHS(WHAT, T_));
     TRY(red.wait());
     const double r0r = s->h_red[0], r0w = s->h_red[1], r0s = s->h_red[2], r0z = s->h_red[3];
     const double norm_1 = s->h_red[4], norm_2 = s->h_red[5];

@@ -81,6 +81,7 @@ struct Sim {
   double *h_red_dev = nullptr;   // the same memory as the device sees it (kernels store the reduced scalars there directly)
   unsigned *d_counters = nullptr;  // [4] tickets of grid_sum_finish (tile.hpp), zero between launches
   int *d_cg_iters = nullptr;       // [nb] CG iterations per block of the last block-CG launch (only while profiling)
+  double *d_block_dots = nullptr;  // [7][nb] per-block dot products of the fused loop + block-CG kernels (poisson.hip)
   int max_groups = 0;
   // staging for host transfers
   double *d_stage = nullptr;
@@ -119,6 +120,8 @@ hipStream_t scalar_stream(const Sim *s);  // the stream all-reduces are enqueued
 int view_exchange_flux(Sim *s, int nfc);
 // ... and whole blocks of `field` -> ghost slot range, before the ghost slabs of a stencil kernel are built (no-op elsewhere)
 int view_exchange_blocks(Sim *s, double *field, int nc);
+// generic exchange of `per`-double items between ranks (own rank included), peer-major buffers; compute stream
+int exchange_items(Sim *s, const double *sendbuf, const std::vector<int64_t> &send_count, double *recvbuf, const std::vector<int64_t> &recv_count, size_t per);
 void vcomm_register(Sim *s);    // in-process test communicator (comm.hip)
 void vcomm_unregister(Sim *s);
 

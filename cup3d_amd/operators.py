@@ -260,22 +260,41 @@ class SimulationData:
         check(lib().cup3d_sim_download_block_list(self.handle, fid, len(sl), sl.ctypes.data_as(C.c_void_p), self._block_ptrs(out)))
         return out
 
+    def _like(self, **kw):
+        """A SimulationData with this one's run parameters on another mesh (leaves=... or view=...), run state carried along."""
+        new = SimulationData(bpdx=self.bpdx, bpdy=self.bpdy, bpdz=self.bpdz, levelMax=self.levelMax, levelStart=self.levelStart,
+                             extent=self.maxextent, nu=self.nu, CFL=self.CFL, BC_x=self.BCx_flag, BC_y=self.BCy_flag, BC_z=self.BCz_flag,
+                             uinf=self.uinf, uMax_forced=self.uMax_forced, poissonTol=self.PoissonErrorTol, poissonTolRel=self.PoissonErrorTolRel,
+                             bMeanConstraint=self.bMeanConstraint, poissonSolver=self.poissonSolver, rampup=self.rampup,
+                             blockSolver=self.blockSolver, implicitDiffusion=self.implicitDiffusion,
+                             diffusionTol=self.DiffusionErrorTol, diffusionTolRel=self.DiffusionErrorTolRel, **kw)
+        new.dt, new.dt_old, new.time, new.step, new.coefU = self.dt, self.dt_old, self.time, self.step, self.coefU.copy()
+        new.uMax_measured = self.uMax_measured
+        return new
+
     def adapted(self, states):
         """A new SimulationData on the mesh that MeshAdaptation::Adapt produces from (valid) `states`, with vel and pres
         moved over on the device (refine / compress / copy; chi, lhs and tmpV are adapted without data in the reference
         too, 15188-15190) and the run state carried along.  Simulation::adaptMesh's second half (15184-15193)."""
         lv, zs = self.grid.adapted_leaves(states)
-        new = SimulationData(bpdx=self.bpdx, bpdy=self.bpdy, bpdz=self.bpdz, levelMax=self.levelMax, levelStart=self.levelStart,
-                             extent=self.maxextent, nu=self.nu, CFL=self.CFL, BC_x=self.BCx_flag, BC_y=self.BCy_flag, BC_z=self.BCz_flag,
-                             uinf=self.uinf, uMax_forced=self.uMax_forced, poissonTol=self.PoissonErrorTol, poissonTolRel=self.PoissonErrorTolRel,
-                             bMeanConstraint=self.bMeanConstraint, poissonSolver=self.poissonSolver, rampup=self.rampup,
-                             blockSolver=self.blockSolver, leaves=(lv, zs), implicitDiffusion=self.implicitDiffusion,
-                             diffusionTol=self.DiffusionErrorTol, diffusionTolRel=self.DiffusionErrorTolRel)
+        new = self._like(leaves=(lv, zs))
         for f in ("vel", "pres"):
             check(lib().cup3d_adapt_transfer(self.handle, new.handle, FIELDS[f]))
-        new.dt, new.dt_old, new.time, new.step, new.coefU = self.dt, self.dt_old, self.time, self.step, self.coefU.copy()
-        new.uMax_measured = self.uMax_measured
         return new
+
+    def adapted_over_ranks(self, mesh, owner, states, rank, nranks):
+        """The same when the leaves of `mesh` (the GLOBAL mesh object) are spread over ranks as `owner` says and this SimulationData
+        lives on rank `rank`'s view of it: MeshAdaptation::Adapt + the LoadBalancer (main.cpp:4660-5022, 5086-5159).  Collective.
+        Returns (new SimulationData on this rank's view of the adapted mesh, the adapted global mesh, its owners)."""
+        lv, zs = mesh.adapted_leaves(states)
+        new_mesh = Grid(mesh.bpd, mesh.levelMax, 0, mesh.maxextent, mesh.bc, leaves=(lv, zs))
+        new_owner = mesh.adapted_owners(owner, states, nranks, new_mesh)
+        new = self._like(view=new_mesh.rank_view(new_owner, rank, nranks))
+        ow = np.ascontiguousarray(owner, dtype=np.int32)
+        for f in ("vel", "pres"):
+            check(lib().cup3d_adapt_migrate(mesh.handle, ow.ctypes.data_as(C.c_void_p), self.handle, new_mesh.handle,
+                                            new_owner.ctypes.data_as(C.c_void_p), new.handle, FIELDS[f]))
+        return new, new_mesh, new_owner
 
     def poisson_params(self):
         p = PoissonParams()
@@ -521,6 +540,25 @@ class Simulation:
         if (st != 0).any():
             self.__init__(s.adapted(st))
         return st
+
+    def adaptMeshOverRanks(self, mesh, owner, rank, nranks, Rtol, Ctol, allgather):
+        """Simulation::adaptMesh on a mesh spread over ranks.  mesh / owner: the global mesh object and the rank of every leaf (every
+        rank holds them, like the reference's Octree); allgather(int8 array of this rank's tags) -> list of every rank's tags (the
+        host's collective: MPI in the shim, torch.distributed or a thread barrier in the tests).  Returns (states, mesh, owner) -- the
+        new ones when the mesh changed; self.sim is then this rank's SimulationData on the adapted mesh."""
+        s = self.sim
+        ComputeVorticity(s)(0)
+        parts = allgather(MeshAdaptation(Rtol, Ctol).Tag(s, "tmpV"))
+        tags = np.zeros(mesh.nblocks, dtype=np.int8)
+        ow = np.asarray(owner)
+        for r in range(nranks):
+            tags[ow == r] = parts[r]          # a rank's blocks appear in the global order inside its view
+        st = mesh.valid_states(tags)
+        if not (st != 0).any():
+            return st, mesh, owner
+        new, new_mesh, new_owner = s.adapted_over_ranks(mesh, owner, st, rank, nranks)
+        self.__init__(new)
+        return st, new_mesh, new_owner
 
     def calcMaxTimestep(self):
         s = self.sim

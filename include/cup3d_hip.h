@@ -90,7 +90,7 @@ int cup3d_grid_adapted(const cup3d_grid_t *, const signed char *states, cup3d_gr
  * PrepareCompression 4729-4804), then Balance_Diffusion (4805-4905: (my - neighbour)/4 blocks to each neighbour) or, when
  * max/min > 1.01 or a rank is empty, Balance_Global (4906-5021: even cut of the rank-major order).  `mesh`: all leaves of all ranks
  * (cup3d_grid_create_mesh), owner[nblocks] their ranks, states the valid states, adapted = cup3d_grid_adapted(mesh, states);
- * new_owner[nblocks of adapted].  Integer contract for the multi-rank multi-level path (block migration itself is not built yet). */
+ * new_owner[nblocks of adapted].  cup3d_adapt_migrate (below) moves the field data accordingly. */
 int cup3d_grid_adapted_owners(const cup3d_grid_t *mesh, const int32_t *owner, const signed char *states, int nranks,
                               const cup3d_grid_t *adapted, int32_t *new_owner);
 /* One rank's view of a multi-level mesh whose leaves are spread over several ranks (what SynchronizerMPI_AMR::_Setup 1979-2286 and
@@ -98,8 +98,8 @@ int cup3d_grid_adapted_owners(const cup3d_grid_t *mesh, const int32_t *owner, co
  * leaves -- every remote leaf the neighbour tables of a local block refer to -- ordered by (owner, global order); interface faces:
  * the local blocks' first, then the fine faces of ghost blocks whose fluxes / cells the local coarse-side faces need.  The tables
  * (cup3d_grid_neighbours, cup3d_grid_interface) are the global ones renumbered, so a kernel reads through them what it would read on
- * one rank once the two exchanges of cup3d_grid_view_plan have run.  HOST SIDE ONLY this round: cup3d_sim_create refuses a view (the
- * device transport for it is the next step); tests pin the plans against the global tables. */
+ * one rank once the two exchanges of cup3d_grid_view_plan have run; cup3d_sim_create on a view allocates the ghost slots and the
+ * operators run those exchanges over RCCL (whole ghost blocks before a stencil kernel, face fluxes after a flux-corrected one). */
 int cup3d_grid_rank_view(const cup3d_grid_t *mesh, const int32_t *owner, int rank, int nranks, cup3d_grid_t **view);
 /* out: local blocks, ghost blocks, local interface faces, ghost faces, blocks sent per exchange, face-flux arrays sent per exchange */
 int cup3d_grid_view_sizes(const cup3d_grid_t *view, long out[6]);
@@ -239,6 +239,14 @@ int cup3d_tag_blocks(cup3d_sim_t *, int field, double rtol, double ctol, signed 
  * expansion from the parent's tensorial [-1,2) tile on the OLD mesh, coarse/fine ghosts included), the parent of a
  * compressed octet from compress (5272-5329).  Every block of dst must be a block, a child or the parent of blocks of src. */
 int cup3d_adapt_transfer(cup3d_sim_t *src, cup3d_sim_t *dst, int field);
+/* The same over ranks: MeshAdaptation::Adapt plus the block traffic of the LoadBalancer (PrepareCompression 4729-4804, Balance_Diffusion
+ * 4805-4905, Balance_Global 4906-5021) for one field.  old_mesh / new_mesh: the GLOBAL mesh objects before and after (cup3d_grid_adapted),
+ * old_owner / new_owner: the rank of every leaf (new_owner from cup3d_grid_adapted_owners); src / dst: this rank's sims on its views of
+ * the two (cup3d_grid_rank_view).  Collective over the ranks of the communicator.  Each block of the new mesh is built by the rank that
+ * owns its origin in the old mesh (the leaf itself, the refined parent, or the base block of a compressed octet) and sent straight to its
+ * new owner; the result equals the one-rank cup3d_adapt_transfer bit for bit, block by block. */
+int cup3d_adapt_migrate(const cup3d_grid_t *old_mesh, const int32_t *old_owner, cup3d_sim_t *src, const cup3d_grid_t *new_mesh,
+                        const int32_t *new_owner, cup3d_sim_t *dst, int field);
 /* Obstacle operators (the obstacles themselves -- geometry, chi/udef rasterisation, rigid-body integration -- stay on the host).
  * One cup3d_obstacle = the ObstacleBlocks of one Obstacle on this rank in the reference's own layout (struct ObstacleBlock,
  * main.cpp:7256-7263) plus its rigid motion. */

@@ -42,8 +42,11 @@ def main():
     ap.add_argument("--variants", default="0,1,2,3")
     ap.add_argument("--kernel", default="adv")
     ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--no-fuse", action="store_true")
     a = ap.parse_args()
     cu.device_init(0)
+    if a.no_fuse:
+        check(lib().cup3d_debug_set_option(b"no_fuse", 1))
     lib().cup3d_profile_enable(1)
     cells = float(a.size) ** 3
     if a.what == "adv":

@@ -15,6 +15,7 @@ Stated bounds
     iteration / restart counts on all ranks of a run; at the default tolerance the returned iterate satisfies the reference's
     stopping rule.
 """
+import os
 import threading
 
 import numpy as np
@@ -289,3 +290,136 @@ def test_multilevel_mesh_over_ranks_projection(name, nranks, kind):
     assert np.abs(got_p - p).max() <= 1e-6 * np.abs(p).max()
     assert np.abs(got_v - v).max() <= 1e-6 * corr
     assert np.abs(got_v2 - v2).max() <= 1e-6 * max(corr, np.abs(v2 - v).max())
+
+
+# ------------------------------------------------------------------ mesh adaptation over ranks: the LoadBalancer's block traffic
+def _states_from_tables(old, new):
+    """valid states of the old leaves that turn the old block list into the new one"""
+    have = {(int(l), int(i), int(j), int(k)) for l, _, i, j, k, _ in new}
+    st = np.zeros(len(old), dtype=np.int8)
+    for b, (l, _, i, j, k, _) in enumerate(old):
+        if (int(l), int(i), int(j), int(k)) in have:
+            continue
+        st[b] = 1 if (int(l) + 1, 2 * int(i), 2 * int(j), 2 * int(k)) in have else -1
+    return st
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 5])
+def test_block_migration_equals_one_rank_adaptation(golden_dir, case):
+    """tests/golden/adapt_mpi.npz holds transitions of the reference's adaptMesh under a REAL MPI: block list and owner rank of every
+    block before and after (children with the refined parent, octets gathered on the base block's rank, Balance_Diffusion /
+    Balance_Global).  cup3d_adapt_migrate carries vel and pres from the old ownership to the new one; every rank ends up with the
+    reference's block list for that rank, filled with exactly the bits the one-rank adaptation (itself pinned against the
+    reference) produces."""
+    z = np.load(os.path.join(golden_dir, "adapt_mpi.npz"))
+    bx, by, bz, lmax, b0, b1, b2, nranks = (int(v) for v in z[f"t{case}_meta"])
+    old, new, ow_old, ow_new = z[f"t{case}_old"], z[f"t{case}_new"], z[f"t{case}_old_owner"].astype(np.int32), z[f"t{case}_new_owner"].astype(np.int32)
+    st = _states_from_tables(old, new)
+    bpd, bc = (bx, by, bz), (b0, b1, b2)
+    g_old = cu.operators.Grid(bpd, lmax, 0, EXT, bc, leaves=(old[:, 0].astype(np.int32), old[:, 1].copy()))
+    assert np.array_equal(g_old.tables[:, :2], old[:, :2])
+    rng = np.random.default_rng(case)
+    nb = len(old)
+    vel, pres = rng.uniform(-1, 1, (nb, 8, 8, 8, 3)), rng.uniform(-1, 1, (nb, 8, 8, 8))
+    bcn = {0: "freespace", 1: "periodic", 2: "wall"}
+    kw = dict(bpdx=bx, bpdy=by, bpdz=bz, levelMax=lmax, levelStart=0, extent=EXT, BC_x=bcn[b0], BC_y=bcn[b1], BC_z=bcn[b2])
+    one = cu.SimulationData(leaves=(old[:, 0].astype(np.int32), old[:, 1].copy()), **kw)
+    one.upload("vel", vel); one.upload("pres", pres)
+    ref = one.adapted(st)
+    assert np.array_equal(ref.grid.tables[:, :2], new[:, :2])
+    vel_ref, pres_ref = ref.download("vel"), ref.download("pres")
+    got_v, got_p = np.zeros_like(vel_ref), np.zeros_like(pres_ref)
+    tabs = [None] * nranks
+    with VirtualComm(nranks):
+        views = [g_old.rank_view(ow_old, r, nranks) for r in range(nranks)]
+        sims = [cu.SimulationData(view=views[r], **kw) for r in range(nranks)]
+        news = [None] * nranks
+
+        def rank(r):
+            s, v = sims[r], views[r]
+            mine = v.global_slot[:v.nlocal]
+            s.upload("vel", vel[mine]); s.upload("pres", pres[mine])
+            n, new_mesh, new_owner = s.adapted_over_ranks(g_old, ow_old, st, r, nranks)
+            assert np.array_equal(new_owner, ow_new)      # the LoadBalancer's ownership rule, pinned against the MPI reference
+            sel = np.where(new_owner == r)[0]
+            tabs[r] = n.grid.tables
+            got_v[sel], got_p[sel] = n.download("vel"), n.download("pres")
+            news[r] = n
+
+        run_ranks(rank, nranks)
+        del sims, views, news
+    for r in range(nranks):
+        assert np.array_equal(tabs[r][:, :2], new[ow_new == r][:, :2]), r   # the reference's block list of that rank
+    assert np.array_equal(got_v, vel_ref) and np.array_equal(got_p, pres_ref)
+
+
+def test_adaptive_loop_on_three_ranks_equals_one_rank():
+    """adaptMesh every step (vorticity tags -> gathered -> ValidStates -> Adapt + LoadBalancer + block migration) alternating with the
+    advection-diffusion step, on 3 ranks and on one: block lists identical at every step, velocity bit-identical (every operator
+    involved is order independent), and the owners follow the LoadBalancer's rule."""
+    bpd, lmax, bc, nu, nranks = (2, 2, 2), 3, ("periodic", "wall", "freespace"), 0.05, 3
+    g0 = cu.operators.Grid(bpd, lmax, 0, EXT, bc)
+    lv, zs = g0.tables[:, 0].astype(np.int32), g0.tables[:, 1].copy()
+    geom, nb = g0.geom, g0.nblocks
+    ax = np.arange(8) + 0.5
+    vel = np.zeros((nb, 8, 8, 8, 3))
+    for b in range(nb):   # a compact vortex: refinement stays local
+        h = geom[b, 0]
+        Z, Y, X = np.meshgrid(geom[b, 3] + ax * h, geom[b, 2] + ax * h, geom[b, 1] + ax * h, indexing="ij")
+        gss = np.exp(-((X - 2.5) ** 2 + (Y - 3.0) ** 2 + (Z - 3.2) ** 2) / 0.8)
+        vel[b, ..., 0], vel[b, ..., 1], vel[b, ..., 2] = -(Y - 3.0) * gss, (X - 2.5) * gss, 0.2 * gss
+    kw = dict(bpdx=2, bpdy=2, bpdz=2, levelMax=lmax, levelStart=0, extent=EXT, nu=nu, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2])
+    one = cu.SimulationData(leaves=(lv, zs), **kw)
+    one.upload("vel", vel)
+    S1 = cu.Simulation(one)
+    cu.ComputeVorticity(one)(0)
+    w = one.download("tmpV")
+    linf = np.sqrt((w ** 2).sum(axis=-1)).reshape(nb, -1).max(axis=1)
+    rt, ct = float(np.quantile(linf, 0.6)), float(np.quantile(linf, 0.4))
+    dt, nsteps = 0.02, 5
+    ref = []
+    for n in range(nsteps):
+        S1.adaptMesh(rt, ct)
+        cu.AdvectionDiffusion(S1.sim)(dt)
+        ref.append((S1.sim.grid.tables.copy(), S1.sim.download("vel")))
+    assert len({len(t) for t, _ in ref}) >= 3
+    # three ranks
+    mesh = cu.operators.Grid(bpd, lmax, 0, EXT, bc, leaves=(lv, zs))
+    owner = (np.arange(nb) * nranks // nb).astype(np.int32)
+    gathered, bar = [None] * nranks, threading.Barrier(nranks)
+    state = [None] * nranks
+    got = [[None] * nranks for _ in range(nsteps)]
+    with VirtualComm(nranks):
+        views = [mesh.rank_view(owner, r, nranks) for r in range(nranks)]
+        sims = [cu.SimulationData(view=views[r], **kw) for r in range(nranks)]
+
+        def rank(r):
+            def allgather(a):
+                gathered[r] = a.copy()
+                bar.wait(timeout=60)
+                out = [g.copy() for g in gathered]
+                bar.wait(timeout=60)
+                return out
+            s = sims[r]
+            s.upload("vel", vel[views[r].global_slot[:views[r].nlocal]])
+            S, m, ow = cu.Simulation(s), mesh, owner
+            for n in range(nsteps):
+                _, m, ow = S.adaptMeshOverRanks(m, ow, r, nranks, rt, ct, allgather)
+                cu.AdvectionDiffusion(S.sim)(dt)
+                got[n][r] = (m.tables.copy(), np.asarray(ow).copy(), S.sim.grid.tables.copy(), S.sim.download("vel"))
+            state[r] = S
+
+        run_ranks(rank, nranks)
+        del sims, views, state
+    for n in range(nsteps):
+        tab, vref = ref[n]
+        gt, ow = got[n][0][0], got[n][0][1]
+        assert np.array_equal(gt, tab), n                                   # the global block list, bit-exactly
+        cnt = np.bincount(ow, minlength=nranks)
+        assert cnt.min() > 0
+        v = np.zeros_like(vref)
+        for r in range(nranks):
+            assert np.array_equal(got[n][r][1], ow)
+            assert np.array_equal(got[n][r][2], tab[ow == r]), (n, r)       # each rank holds its share, in the global order
+            v[ow == r] = got[n][r][3]
+        assert np.array_equal(v, vref), n
