@@ -391,48 +391,29 @@ static int mark_written(Sim *s, int field) {
   return CUP3D_OK;
 }
 
+int cup3d_sim_upload_blocks(cup3d_sim_t *h, int field, const void *const *ptrs);
+int cup3d_sim_download_blocks(cup3d_sim_t *h, int field, void *const *ptrs);
+
+// one contiguous host array [nb][8][8][8][nc]: the same pipelined, multi-threaded staging as the per-block form below (the host
+// memory is pageable either way)
 int cup3d_sim_upload(cup3d_sim_t *h, int field, const double *blocks) {
   if (!h || !blocks) return CUP3D_EINVAL;
   Sim *s = reinterpret_cast<Sim *>(h);
   int nc;
-  double *dst = s->field(field, &nc);
-  if (!dst) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
-  const long n = s->nb * 512L * nc;
-  if (nc == 1) {
-    CUP3D_HIP(hipMemcpyAsync(dst, blocks, n * sizeof(double), hipMemcpyHostToDevice, g_stream));
-  } else {
-    double *tmp;
-    CUP3D_HIP(hipMalloc((void **)&tmp, n * sizeof(double)));
-    CUP3D_HIP(hipMemcpyAsync(tmp, blocks, n * sizeof(double), hipMemcpyHostToDevice, g_stream));
-    hipLaunchKernelGGL(k_aos_to_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, tmp, dst, s->nb * 512L, nc);
-    CUP3D_HIP(hipGetLastError());
-    CUP3D_HIP(hipStreamSynchronize(g_stream));
-    CUP3D_HIP(hipFree(tmp));
-  }
-  CUP3D_HIP(hipStreamSynchronize(g_stream));
-  return mark_written(s, field);
+  if (!s->field(field, &nc)) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+  std::vector<const void *> ptrs((size_t)s->nb);
+  for (size_t i = 0; i < ptrs.size(); ++i) ptrs[i] = blocks + i * 512 * (size_t)nc;
+  return cup3d_sim_upload_blocks(h, field, ptrs.data());
 }
 
 int cup3d_sim_download(cup3d_sim_t *h, int field, double *blocks) {
   if (!h || !blocks) return CUP3D_EINVAL;
   Sim *s = reinterpret_cast<Sim *>(h);
   int nc;
-  double *src = s->field(field, &nc);
-  if (!src) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
-  const long n = s->nb * 512L * nc;
-  if (nc == 1) {
-    CUP3D_HIP(hipMemcpyAsync(blocks, src, n * sizeof(double), hipMemcpyDeviceToHost, g_stream));
-  } else {
-    double *tmp;
-    CUP3D_HIP(hipMalloc((void **)&tmp, n * sizeof(double)));
-    hipLaunchKernelGGL(k_soa_to_aos, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, src, tmp, s->nb * 512L, nc);
-    CUP3D_HIP(hipGetLastError());
-    CUP3D_HIP(hipMemcpyAsync(blocks, tmp, n * sizeof(double), hipMemcpyDeviceToHost, g_stream));
-    CUP3D_HIP(hipStreamSynchronize(g_stream));
-    CUP3D_HIP(hipFree(tmp));
-  }
-  CUP3D_HIP(hipStreamSynchronize(g_stream));
-  return CUP3D_OK;
+  if (!s->field(field, &nc)) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+  std::vector<void *> ptrs((size_t)s->nb);
+  for (size_t i = 0; i < ptrs.size(); ++i) ptrs[i] = blocks + i * 512 * (size_t)nc;
+  return cup3d_sim_download_blocks(h, field, ptrs.data());
 }
 
 // One pointer per block (Info::block of the reference's per-block allocations, main.cpp:877-884).  The host side of this boundary

@@ -70,7 +70,15 @@ def main():
         import time
         sim = make(a.size)
         vel = sim.download("vel")
-        for name, fn in (("upload_vel", lambda: sim.upload("vel", vel)), ("download_vel", lambda: sim.download("vel"))):
+        out = np.empty_like(vel)          # reused destination: the reference's blocks are resident pages, not fresh allocations
+        fid = cu.operators.FIELDS["vel"]
+        ptr_in = (C.c_void_p * sim.nblocks)(*[vel[i].ctypes.data for i in range(sim.nblocks)])   # one pointer per block, like Info::block
+        ptr_out = (C.c_void_p * sim.nblocks)(*[out[i].ctypes.data for i in range(sim.nblocks)])
+        cases = (("upload_vel_block_pointers", lambda: check(lib().cup3d_sim_upload_blocks(sim.handle, fid, ptr_in))),
+                 ("download_vel_block_pointers", lambda: check(lib().cup3d_sim_download_blocks(sim.handle, fid, ptr_out))),
+                 ("upload_vel_contiguous", lambda: check(lib().cup3d_sim_upload(sim.handle, fid, vel))),
+                 ("download_vel_contiguous", lambda: check(lib().cup3d_sim_download(sim.handle, fid, out))))
+        for name, fn in cases:
             fn()
             lib().cup3d_device_synchronize()
             t0 = time.perf_counter()
@@ -79,6 +87,7 @@ def main():
             lib().cup3d_device_synchronize()
             sec = (time.perf_counter() - t0) / a.reps
             print(json.dumps({"probe": name, "size": a.size, "GB": round(vel.nbytes / 1e9, 3), "seconds": round(sec, 4), "GBps": round(vel.nbytes / sec / 1e9, 2)}))
+        assert np.array_equal(out, vel)
     elif a.what == "loops":
         # grid size of the fused BiCGSTAB vector loops (cup3d_debug_set_option "vec_groups")
         sim = make(a.size, "wall")

@@ -67,6 +67,45 @@ def test_single_operators_through_the_shim(tmp_path):
     assert np.abs(res["cpu"]["prp"] - res["hip"]["prp"]).max() <= 0.05 * np.abs(res["cpu"]["prp"]).max()
 
 
+FISH_ARGS = ["-bMeanConstraint", "2", "-bpdx", "2", "-bpdy", "2", "-bpdz", "2", "-CFL", "0.4", "-Ctol", "0.1", "-extentx", "1", "-factory-content",
+             "StefanFish L=0.4 T=1.0 xpos=0.5 ypos=0.5 zpos=0.5 heightProfile=danio widthProfile=stefan bFixFrameOfRef=1", "-levelMax", "3",
+             "-levelStart", "1", "-nu", "0.001", "-poissonSolver", "iterative", "-Rtol", "5", "-tdump", "0", "-tend", "0", "-factory", "",
+             "-poissonTol", "1e-9", "-poissonTolRel", "1e-8"]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["hip on", "hip resident"])
+def test_fish_plumbing_run(tmp_path, mode):
+    """BASELINE configs[0]: a single carling-fish swimmer (StefanFish, the parameters of the reference's run.sh / fish.ipynb, one fish),
+    coarse 2-level AMR (levels 1 and 2 of a 2^3-block box, 148 blocks), one rank, 30 steps of the reference's own time loop --
+    CreateObstacles, adaptMesh (steps < 10 and every 20th, 15314), AdvectionDiffusion, UpdateObstacles, Penalization,
+    PressureProjection with chi / udef, ComputeForces -- once with the reference's CPU operators and once with the two hot-path
+    operators swapped for the HIP ones (default round-trip mode and resident mode).  Same binary otherwise, including the stand-ins
+    for the two GSL entry points (oracle/refbuild/gsl: nothing is claimed about GSL itself).  Block lists identical at both
+    check points; velocity, pressure and chi to solver round-off (Poisson tolerance 1e-9 / 1e-8 on both sides)."""
+    res = {}
+    script = ["op steps 12", "tables t12.bin", "op steps 18", "tables t30.bin", "dump vel v.bin", "dump pres p.bin", "dump chi c.bin"]
+    for tag, tool, pre in (("cpu", O.REF_TOOL, []), ("hip", REF_HIP, [mode])):
+        d = tmp_path / tag
+        d.mkdir()
+        with open(str(d / "script.txt"), "w") as f:
+            f.write("\n".join(pre + script) + "\n")
+        out = subprocess.run([tool, "script.txt", "--"] + FISH_ARGS, cwd=str(d), env=dict(os.environ, OMP_NUM_THREADS="8"), check=True,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800).stdout.decode()
+        its = [float(l.split()[3].split("=")[1]) for l in out.splitlines() if l.startswith("REF steps")]
+        t12, t30 = O.read_tables(str(d / "t12.bin"))[0], O.read_tables(str(d / "t30.bin"))[0]
+        nb = len(t30)
+        res[tag] = (t12, t30, O.read_blocks(str(d / "v.bin"), nb, 3), O.read_blocks(str(d / "p.bin"), nb, 1), O.read_blocks(str(d / "c.bin"), nb, 1), its)
+    c, h = res["cpu"], res["hip"]
+    assert np.array_equal(c[0], h[0]) and np.array_equal(c[1], h[1])            # the adapted block lists, bit-exactly
+    assert len(set(c[1][:, 0].tolist())) == 2 and len(c[1]) > 100               # two levels, the fish refined
+    assert (c[4] > 0).sum() > 100 and np.abs(c[2]).max() > 1e-3                 # there IS a fish, and it moves the fluid
+    assert np.abs(c[2] - h[2]).max() <= 1e-6 * np.abs(c[2]).max()
+    assert np.abs(c[3] - h[3]).max() <= 1e-4 * np.abs(c[3]).max()
+    assert np.abs(c[4] - h[4]).max() <= 1e-6
+    assert sum(h[5]) <= 1.3 * sum(c[5]) + 10, (h[5], c[5])
+
+
 def test_poisson_solver_through_the_factory_key(tmp_path):
     """-poissonSolver cuda_iterative: the slot makePoissonSolver (main.cpp:14747-14758) reserves for a GPU solver, filled by
     cup3d_hip::makePoissonSolver; PoissonSolverBase::solve() contract: right-hand side in sim.lhs, initial guess and result in
