@@ -100,8 +100,9 @@ __device__ __forceinline__ void face_element(int f, int e, int &nb_cell, int &ow
 // 1 IEEE division instead of div60 (A/B), 4 plain instead of nontemporal stores (A/B), 2/3 timing ablations with WRONG results
 // (2: no stencil arithmetic, 3: no ghost staging) -- cup3d_debug_set_option only.
 // AMR (multi-level meshes): spacing per block, face fluxes facD*(u_in - u_ghost) of the interface faces into g.flux
-// (main.cpp:9550-9637), and the stage is NOT fused with the Runge-Kutta update: tmpV receives the raw increment, which
-// k_flux_fix corrects before k_rk_update applies it (a.alpha is then the bare Williamson coefficient).
+// (main.cpp:9550-9637).  Only the blocks with a coarse-side interface face (g.raw) are edited by the flux correction afterwards:
+// they leave the raw increment in tmpV, which k_flux_fix corrects before k_rk_update_list applies it; every other block fuses the
+// Runge-Kutta update as on uniform grids (a.alpha is the bare Williamson coefficient here, divided by the block's h^3 in the kernel).
 // IMPLICIT: KernelAdvect of the implicit-diffusion integrator (main.cpp:9849-10029) on the same tile: tmpV = facD*lap(u) (+ the
 // same face fluxes), vel' = vel + facA*(u.grad)u/h^3.  The reference updates vel in place while other blocks still load their
 // tiles from it (its result depends on block order / thread timing); here every tile comes from the field on entry and the
@@ -292,7 +293,13 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double tn = (FIRST_STAGE ? 0.0 : told[k][c]) + res[c];  // o += ..., main.cpp:9546-9548
-      if (AMR) { tout[c * 512 + k * 256 + cell0] = tn; continue; }
+      if (AMR) {
+        if (g.raw[slot]) { tout[c * 512 + k * 256 + cell0] = tn; continue; }
+        const double ih3 = a.alpha / h3;                      // 9711-9712
+        vout[c * 512 + k * 256 + cell0] = uc[k][c] + tn * ih3;  // 9718-9720
+        tout[c * 512 + k * 256 + cell0] = tn * a.beta;          // 9721-9723
+        continue;
+      }
       if (VAR != 4) {  // streaming stores (and tmpV load above): both arrays are next touched a full sweep later (2.73 vs 2.87 ms)
         __builtin_nontemporal_store(uc[k][c] + tn * a.alpha, &vout[c * 512 + k * 256 + cell0]);  // V += tmpV*ih3, 9718-9720
         __builtin_nontemporal_store(tn * a.beta, &tout[c * 512 + k * 256 + cell0]);              // tmpV *= beta, 9721-9723
@@ -323,13 +330,17 @@ __global__ void __launch_bounds__(64) k_pack_faces(const double *__restrict__ fi
     }
 }
 
-// multi-level meshes: V += tmpV*alpha/h^3 ; tmpV *= beta (main.cpp:9709-9725) after the flux correction of tmpV
-__global__ void __launch_bounds__(256) k_rk_update(const double *__restrict__ hb, const double *__restrict__ vel, double *__restrict__ tmp,
-                                                   double *__restrict__ vel_out, double alpha, double beta, long n) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const double h = hb[i / 1536], ih3 = alpha / (h * h * h), tn = tmp[i];
-    vel_out[i] = vel[i] + tn * ih3;
-    tmp[i] = tn * beta;
+// multi-level meshes: V += tmpV*alpha/h^3 ; tmpV *= beta (main.cpp:9709-9725) after the flux correction of tmpV, for the blocks the
+// stage kernel left raw (one workgroup per listed block)
+__global__ void __launch_bounds__(256) k_rk_update_list(const int32_t *__restrict__ list, const double *__restrict__ hb, const double *__restrict__ vel,
+                                                        double *__restrict__ tmp, double *__restrict__ vel_out, double alpha, double beta) {
+  const int slot = list[blockIdx.x];
+  const double h = hb[slot], ih3 = alpha / (h * h * h);
+  for (int i = threadIdx.x; i < 1536; i += 256) {
+    const size_t o = (size_t)slot * 1536 + i;
+    const double tn = tmp[o];
+    vel_out[o] = vel[o] + tn * ih3;
+    tmp[o] = tn * beta;
   }
 }
 
@@ -380,6 +391,7 @@ static int advdiff_stage(Sim *s, int rk, double dt, double nu, const double uinf
     a.alpha = alpha[rk] / (h * h * h);  // ih3, main.cpp:9711-9712
     a.beta = beta[rk];
     if (s->grid->multilevel) {
+      a.alpha = alpha[rk];  // per-block h: divided in the kernel
       GridDev g = s->gdev();
       const dim3 G(launch_groups(g));
       {
@@ -390,7 +402,7 @@ static int advdiff_stage(Sim *s, int rk, double dt, double nu, const double uinf
       CUP3D_HIP(hipGetLastError());
       if ((rc = amr_flux_fix(s, 3, s->tmpV, 3))) return rc;  // compute(..., vel, tmpV) corrector, main.cpp:9708
       ProfileScope ps("advdiff_update");
-      hipLaunchKernelGGL(k_rk_update, dim3(2048), dim3(256), 0, stream(), s->d_hb, s->vel, s->tmpV, s->vel2, alpha[rk], beta[rk], s->nb * 1536L);
+      if (s->n_raw) hipLaunchKernelGGL(k_rk_update_list, dim3(s->n_raw), dim3(256), 0, stream(), s->d_raw_list, s->d_hb, s->vel, s->tmpV, s->vel2, alpha[rk], beta[rk]);
       CUP3D_HIP(hipGetLastError());
       std::swap(s->vel, s->vel2);
       return CUP3D_OK;

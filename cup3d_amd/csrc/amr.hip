@@ -399,6 +399,185 @@ __global__ void __launch_bounds__(256) k_refine(AmrDev a, RefineTab tab, const d
   }
 }
 
+// ---- compute<ScalarLab>(GradChiOnTmp(sim), sim.chi), main.cpp:8540-8600: the chi-driven half of adaptMesh's tagging input.
+// One workgroup per block builds the TENSORIAL [-2,3) tile of chi exactly as BlockLab::load does for that stencil -- same-level
+// neighbours copied (all 26 positions, two layers), finer ones averaged down, coarser ones interpolated from the 8^3 coarse shadow
+// tile (faces: the finite-difference mode for both layers, 4374-4612; edges and corners: TestInterp, 3883-3906), zero-gradient
+// domain faces last (Neumann3D 5929-6004, x-,x+,y-,y+,z-,z+) -- and then applies the operator: the cap of the vorticity on level
+// levelMaxVorticity - 1, the ordered scan (z, y, x over the block grown by `offset`) for the first cell with 1e-5 < chi < 0.9, which
+// flags the block with 1e10 and ends the scan, and the clearing of interior cells with chi > 0.9 met before it.  The scan is
+// evaluated in parallel through its one order dependence: the position of that first cell (an LDS atomicMin of the scan index).
+__device__ __forceinline__ int lix12(int x, int y, int z) { return ((z + 2) * 12 + (y + 2)) * 12 + (x + 2); }
+
+__global__ void __launch_bounds__(256) k_grad_chi(AmrDev a, const int32_t *__restrict__ finer_row, const int32_t *__restrict__ finer,
+                                                  const int32_t *__restrict__ blevel, int level_max, int lmv, double Rtol, double Ctol,
+                                                  const double *__restrict__ src, double *__restrict__ tmpV) {
+  __shared__ double lab[1728];
+  __shared__ double Ct[512];  // coarse shadow tile, coarse cells [-2,6)^3
+  __shared__ int first;
+  const int pb = blockIdx.x, t = threadIdx.x;
+  const int32_t *n27 = a.nbr27 + 27 * pb;
+  const int32_t *fin = finer_row[pb] >= 0 ? finer + (size_t)finer_row[pb] * 216 : nullptr;
+  const int par[3] = {a.index[3 * pb] & 1, a.index[3 * pb + 1] & 1, a.index[3 * pb + 2] & 1};
+  bool has_coarse = false;
+  for (int i = 0; i < 27; ++i) has_coarse = has_coarse || n27[i] >= kNbrCoarser;
+  if (t == 0) first = 0x7fffffff;
+  // A. centre, same-level neighbours, finer neighbours (averaged down)
+  for (int e = t; e < 1728; e += 256) {
+    const int l[3] = {e % 12 - 2, (e / 12) % 12 - 2, e / 144 - 2};
+    int code[3], loc[3], fl[3], q = 0;
+    for (int d = 0; d < 3; ++d) {
+      code[d] = l[d] < 0 ? -1 : (l[d] > 7 ? 1 : 0);
+      loc[d] = l[d] - 8 * code[d];
+      fl[d] = code[d] < 0 ? 8 + 2 * l[d] : (code[d] > 0 ? 2 * (l[d] - 8) : (2 * l[d]) & 7);
+      if (code[d] == 0 && l[d] >= 4) q |= 1 << d;
+    }
+    const int icode = (code[0] + 1) + 3 * (code[1] + 1) + 9 * (code[2] + 1);
+    const int n = n27[icode];
+    double v = 0.0;
+    if (n >= 0 && n < kNbrCoarser) v = src[(size_t)n * 512 + (loc[2] * 8 + loc[1]) * 8 + loc[0]];
+    else if (n == kNbrFiner && fin) v = avg_block(src + (size_t)fin[icode * 8 + q] * 512, fl[0], fl[1], fl[2]);
+    lab[e] = v;
+  }
+  __syncthreads();
+  if (has_coarse) {
+    // B. coarse shadow tile: own block averaged down, coarser leaves copied, same-level neighbours averaged down
+    for (int e = t; e < 512; e += 256) {
+      const int P[3] = {e % 8 - 2, (e / 8) % 8 - 2, e / 64 - 2};
+      int code[3];
+      for (int d = 0; d < 3; ++d) code[d] = P[d] < 0 ? -1 : (P[d] > 3 ? 1 : 0);
+      const int icode = (code[0] + 1) + 3 * (code[1] + 1) + 9 * (code[2] + 1);
+      const int n = n27[icode];
+      double v = 0.0;
+      if (icode == 13) {
+        double w[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w[q] = lab[lix12(2 * P[0] + (q & 1), 2 * P[1] + ((q >> 1) & 1), 2 * P[2] + (q >> 2))];
+        v = avg_down8(w);
+      } else if (n >= kNbrCoarser) {
+        v = src[(size_t)(n - kNbrCoarser) * 512 + ((par[2] * 4 + P[2] + 8) & 7) * 64 + ((par[1] * 4 + P[1] + 8) & 7) * 8 + ((par[0] * 4 + P[0] + 8) & 7)];
+      } else if (n >= 0) {
+        v = avg_block(src + (size_t)n * 512, 2 * P[0] - 8 * code[0], 2 * P[1] - 8 * code[1], 2 * P[2] - 8 * code[2]);
+      }
+      Ct[e] = v;
+    }
+    __syncthreads();
+    // C. zero-gradient domain faces on the coarse tile
+    for (int f = 0; f < 6; ++f) {
+      const int n = a.nbr[pb * 6 + f];
+      if (n >= 0) continue;
+      const int d = f >> 1, side = f & 1, d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+      if (t < 128) {
+        int p[3], q[3];
+        p[d] = side ? 4 + (t >> 6) : -1 - (t >> 6);
+        q[d] = side ? 3 : 0;
+        p[d1] = q[d1] = (t & 7) - 2;
+        p[d2] = q[d2] = ((t >> 3) & 7) - 2;
+        Ct[cix8(p[0], p[1], p[2])] = Ct[cix8(q[0], q[1], q[2])];
+      }
+      __syncthreads();
+    }
+    // D. ghosts behind coarser neighbours
+    for (int e = t; e < 1728; e += 256) {
+      const int l[3] = {e % 12 - 2, (e / 12) % 12 - 2, e / 144 - 2};
+      int code[3], X[3], bit[3], ncode = 0;
+      for (int d = 0; d < 3; ++d) {
+        code[d] = l[d] < 0 ? -1 : (l[d] > 7 ? 1 : 0);
+        ncode += code[d] != 0;
+        X[d] = l[d] >> 1;   // the coarse cell that holds this fine cell (-1 behind the low face, 4 behind the high one)
+        bit[d] = l[d] & 1;  // which of its two children along d
+      }
+      if (ncode == 0 || n27[(code[0] + 1) + 3 * (code[1] + 1) + 9 * (code[2] + 1)] < kNbrCoarser) continue;
+      double v;
+      if (ncode == 1) {  // face: finite-difference mode, both layers
+        const int ax = code[0] ? 0 : (code[1] ? 1 : 2), ax1 = ax == 0 ? 1 : 0, ax2 = ax == 2 ? 1 : 2;
+        const int st1 = ax1 == 0 ? 1 : 8, st2 = ax2 == 1 ? 8 : 64;
+        const int p1 = X[ax1], p2 = X[ax2];
+        const double dd1 = 0.25 * (2 * bit[ax1] - 1), dd2 = 0.25 * (2 * bit[ax2] - 1);
+        const double *coef1 = dd1 > 0 ? kCoefPlus : kCoefMinus, *coef2 = dd2 > 0 ? kCoefPlus : kCoefMinus;
+        const double *P0 = Ct + cix8(X[0], X[1], X[2]);
+        int pp1, pm1, pp2, pm2;
+        const double x1D = interp1d(P0, p1, st1, coef1, pp1, pm1);
+        const double x2D = interp1d(P0, p2, st2, coef2, pp2, pm2);
+        double mixed_coef = 1.0;
+        if (p1 != 0 && p1 != 3) mixed_coef *= 0.5;
+        if (p2 != 0 && p2 != 3) mixed_coef *= 0.5;
+#define PC(i, j) P0[((i) - p1) * st1 + ((j) - p2) * st2]
+        const double mixed = mixed_coef * dd1 * dd2 * ((PC(pm1, pm2) + PC(pp1, pp2)) - (PC(pp1, pm2) + PC(pm1, pp2)));
+#undef PC
+        const double av = (x1D + x2D) + mixed;
+        int cb[3] = {l[0], l[1], l[2]}, cc[3] = {l[0], l[1], l[2]};
+        cb[ax] = code[ax] > 0 ? 7 : 0;
+        cc[ax] = code[ax] > 0 ? 6 : 1;
+        const double bv = lab[lix12(cb[0], cb[1], cb[2])], cv = lab[lix12(cc[0], cc[1], cc[2])];
+        const int layer = code[ax] < 0 ? -1 - l[ax] : l[ax] - 8;
+        v = layer == 0 ? (1.0 / 15.0) * (8.0 * av + (10.0 * bv - 3.0 * cv)) : (1.0 / 15.0) * (24.0 * av + (-15.0 * bv + 6 * cv));  // 4601-4608
+      } else {  // edge / corner: TestInterp
+        const double *C0 = Ct;
+        auto Cc = [&](int i, int j, int k) -> double { return C0[cix8(X[0] - 1 + i, X[1] - 1 + j, X[2] - 1 + k)]; };
+        const double dudx = 0.125 * (Cc(2, 1, 1) - Cc(0, 1, 1));
+        const double dudy = 0.125 * (Cc(1, 2, 1) - Cc(1, 0, 1));
+        const double dudz = 0.125 * (Cc(1, 1, 2) - Cc(1, 1, 0));
+        const double dudxdy = 0.015625 * (Cc(0, 0, 1) + Cc(2, 2, 1) - Cc(2, 0, 1) - Cc(0, 2, 1));
+        const double dudxdz = 0.015625 * (Cc(0, 1, 0) + Cc(2, 1, 2) - Cc(2, 1, 0) - Cc(0, 1, 2));
+        const double dudydz = 0.015625 * (Cc(1, 0, 0) + Cc(1, 2, 2) - Cc(1, 2, 0) - Cc(1, 0, 2));
+        const double lap = Cc(1, 1, 1) + 0.03125 * (Cc(0, 1, 1) + Cc(2, 1, 1) + Cc(1, 0, 1) + Cc(1, 2, 1) + Cc(1, 1, 0) + Cc(1, 1, 2) + (-6.0) * Cc(1, 1, 1));
+        const double sx = bit[0] ? 1.0 : -1.0, sy = bit[1] ? 1.0 : -1.0, sz = bit[2] ? 1.0 : -1.0;
+        v = lap + sx * dudx + sy * dudy + sz * dudz + (sx * sy) * dudxdy + (sx * sz) * dudxdz + (sy * sz) * dudydz;
+      }
+      lab[e] = v;
+    }
+    __syncthreads();
+  }
+  // E. zero-gradient domain faces on the fine tile: both ghost layers, every transverse position, from the face cell
+  for (int f = 0; f < 6; ++f) {
+    const int n = a.nbr[pb * 6 + f];
+    if (n >= 0) continue;
+    const int d = f >> 1, side = f & 1, d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+    for (int i = t; i < 288; i += 256) {
+      const int layer = i / 144, r = i - 144 * layer;
+      int p[3], q[3];
+      p[d] = side ? 8 + layer : -1 - layer;
+      q[d] = side ? 7 : 0;
+      p[d1] = q[d1] = r % 12 - 2;
+      p[d2] = q[d2] = r / 12 - 2;
+      lab[lix12(p[0], p[1], p[2])] = lab[lix12(q[0], q[1], q[2])];
+    }
+    __syncthreads();
+  }
+  // F. the operator
+  double *T = tmpV + (size_t)pb * 1536;
+  const int level = blevel[pb];
+  if (level == lmv - 1 && lmv < level_max) {  // 8546-8557
+    for (int c = t; c < 512; c += 256) {
+      const double u0 = T[c], u1 = T[512 + c], u2 = T[1024 + c];
+      if (sqrt(u0 * u0 + u1 * u1 + u2 * u2) >= Rtol) { T[c] = 0.5 * (Rtol + Ctol); T[512 + c] = 0.0; T[1024 + c] = 0.0; }
+    }
+  }
+  const int off = level == level_max - 1 ? 2 : 1;
+  for (int e = t; e < 1728; e += 256) {
+    const int x = e % 12 - 2, y = (e / 12) % 12 - 2, z = e / 144 - 2;
+    if (x < -off || x >= 8 + off || y < -off || y >= 8 + off || z < -off || z >= 8 + off) continue;
+    double v = lab[e];
+    v = v < 1.0 ? v : 1.0;
+    v = v > 0.0 ? v : 0.0;
+    if (v > 0.00001 && v < 0.9) atomicMin(&first, e);  // e grows in the reference's scan order (z, y, x)
+  }
+  __syncthreads();
+  const int stop = first;
+  for (int c = t; c < 512; c += 256) {
+    const int x = c & 7, y = (c >> 3) & 7, z = c >> 6, e = lix12(x, y, z);
+    double v = lab[e];
+    v = v < 1.0 ? v : 1.0;
+    if (v > 0.9 && e < stop) { T[c] = 0.0; T[512 + c] = 0.0; T[1024 + c] = 0.0; }  // 8592-8597
+  }
+  __syncthreads();
+  if (stop != 0x7fffffff && t < 6) {  // 8567-8590 (six distinct cells among the eight assignments)
+    const int cx[6] = {3, 4, 3, 3, 4, 4}, cy[6] = {3, 3, 4, 3, 4, 3}, cz[6] = {3, 3, 3, 4, 4, 4};
+    T[(cz[t] * 8 + cy[t]) * 8 + cx[t]] = 1e10;
+  }
+}
+
 // unchanged blocks: copy; parents of compressed octets: compress (5272-5329) -- pairs[n][2] = dst slot, src slot;
 // octets[n][9] = dst slot, eight src slots (child = I + 2J + 4K)
 __global__ void __launch_bounds__(256) k_copy_blocks(const int32_t *__restrict__ pairs, const double *__restrict__ src, double *__restrict__ dst, int nc) {
@@ -678,6 +857,64 @@ extern "C" int cup3d_adapt_migrate(const cup3d_grid_t *old_mesh_h, const int32_t
     CUP3D_HIP(hipGetLastError());
   }
   CUP3D_HIP(hipStreamSynchronize(stream()));
+  return CUP3D_OK;
+}
+
+// compute<ScalarLab>(GradChiOnTmp(sim), sim.chi) (main.cpp:15182, 8540-8600): edits tmpV (= the vorticity of ComputeVorticity) from
+// the resident chi; with cup3d_compute_vorticity before and cup3d_tag_blocks after it, adaptMesh's decision input is complete for
+// runs with obstacles.  One rank (uniform grid or multi-level mesh).
+extern "C" int cup3d_grad_chi_on_tmp(cup3d_sim_t *h, double Rtol, double Ctol, int level_max_vorticity) {
+  if (!h) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  if (s->grid->nranks > 1) { set_error("cup3d_grad_chi_on_tmp: meshes spread over ranks are not supported yet (the tensorial chi tile needs edge / corner ghosts)"); return CUP3D_ESTATE; }
+  std::unique_ptr<Grid> tmp;
+  const Grid *mo = s->grid;
+  std::vector<int32_t> finer_row, finer;
+  try {
+    if (!mo->multilevel) { tmp = mo->as_mesh(); mo = tmp.get(); }
+    const int64_t nb = mo->nblocks();
+    finer_row.assign((size_t)nb, -1);
+    for (int64_t b = 0; b < nb; ++b) {
+      bool any = false;
+      for (int c = 0; c < 27; ++c) any = any || mo->nbr27[27 * (size_t)b + c] == kNbrFiner;
+      if (!any) continue;
+      finer_row[b] = (int32_t)(finer.size() / 216);
+      finer.resize(finer.size() + 216, -1);
+      int32_t *row = finer.data() + finer.size() - 216;
+      const int l = mo->blevel[b];
+      for (int icode = 0; icode < 27; ++icode) {
+        if (mo->nbr27[27 * (size_t)b + icode] != kNbrFiner) continue;
+        const int code[3] = {icode % 3 - 1, (icode / 3) % 3 - 1, icode / 9 - 1};
+        for (int q = 0; q < 8; ++q) {
+          int fi[3];
+          bool used = true;
+          for (int d = 0; d < 3; ++d) {
+            const int bit = (q >> d) & 1;
+            if (code[d] != 0 && bit) used = false;
+            fi[d] = 2 * mo->index[3 * (size_t)b + d] + (code[d] < 0 ? -1 : (code[d] > 0 ? 2 : bit));
+          }
+          if (used) row[icode * 8 + q] = mo->leaf(l + 1, fi);
+        }
+      }
+    }
+  } catch (const std::exception &e) {
+    set_error("cup3d_grad_chi_on_tmp: %s", e.what());
+    return CUP3D_EINVAL;
+  }
+  if (finer.empty()) finer.assign(216, -1);
+  DevInts d_row, d_finer, d_n27, d_nbr, d_index, d_level;
+  int rc;
+  if ((rc = d_row.upload(finer_row)) || (rc = d_finer.upload(finer)) || (rc = d_n27.upload(mo->nbr27)) || (rc = d_nbr.upload(mo->nbr)) ||
+      (rc = d_index.upload(mo->index)) || (rc = d_level.upload(mo->blevel)))
+    return rc;
+  AmrDev a{nullptr, nullptr, d_n27.p, d_nbr.p, d_index.p, -1};
+  {
+    ProfileScope ps("grad_chi_on_tmp");
+    hipLaunchKernelGGL(k_grad_chi, dim3((unsigned)mo->nblocks()), dim3(256), 0, stream(), a, d_row.p, d_finer.p, d_level.p, mo->level_max, level_max_vorticity, Rtol,
+                       Ctol, (const double *)s->chi, s->tmpV);
+  }
+  CUP3D_HIP(hipGetLastError());
+  CUP3D_HIP(hipStreamSynchronize(stream()));  // the tables above are freed on return
   return CUP3D_OK;
 }
 

@@ -81,6 +81,7 @@ GridDev Sim::gdev(bool boundary_only, bool inner_only) const {
   g.h = grid->h;
   g.hb = d_hb;
   g.flux = d_flux;
+  g.raw = d_raw_mask;
   if (boundary_only) {
     g.list = d_boundary;
     g.nblocks = (int)grid->boundary.size();
@@ -312,6 +313,17 @@ static int sim_build(Sim *s, const Grid *g) {
       return rc;
     A(s->d_hb, nv)
     CUP3D_HIP(hipMemcpy(s->d_hb, g->hb.data(), nv * sizeof(double), hipMemcpyHostToDevice));
+    {
+      std::vector<unsigned char> mask(std::max<size_t>(nb, 1), 0);
+      std::vector<int32_t> raw;
+      for (int64_t e = 0; e < nlf; ++e)
+        if (g->amr_faces[2 * e + 1] == 1) mask[(size_t)(g->amr_faces[2 * e] / 6)] = 1;
+      for (size_t b = 0; b < nb; ++b) if (mask[b]) raw.push_back((int32_t)b);
+      s->n_raw = (unsigned)raw.size();
+      CUP3D_HIP(hipMalloc((void **)&s->d_raw_mask, mask.size()));
+      CUP3D_HIP(hipMemcpy(s->d_raw_mask, mask.data(), mask.size(), hipMemcpyHostToDevice));
+      if ((rc = up(&s->d_raw_list, raw))) return rc;
+    }
     const size_t ne = (size_t)std::max<int64_t>(g->n_amr_faces(), 1);
     // ghost slabs: widest use = 3 components x 3 layers; the pressure RHS keeps a second set (udef) behind the first
     A(s->halo_recv, ne * 9 * 64)
@@ -365,7 +377,8 @@ void cup3d_sim_destroy(cup3d_sim_t *h) {
   for (hipEvent_t e : s->ev_stage) if (e) hipEventDestroy(e);
   if (s->d_stage_slots) hipFree(s->d_stage_slots);
   int32_t *ip[] = {s->d_nbr, s->d_inner, s->d_boundary, s->d_send_faces, s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_index,
-                   s->d_restrict_list, s->d_prolong_list, s->d_fix_list[0], s->d_fix_list[1], s->d_fix_list[2], s->d_send_blocks, s->d_send_flux};
+                   s->d_restrict_list, s->d_prolong_list, s->d_fix_list[0], s->d_fix_list[1], s->d_fix_list[2], s->d_send_blocks, s->d_send_flux, s->d_raw_list};
+  if (s->d_raw_mask) hipFree(s->d_raw_mask);
   for (int32_t *p : ip) if (p) hipFree(p);
   if (s->comm_stream) hipStreamDestroy(s->comm_stream);
   if (s->ev_a) hipEventDestroy(s->ev_a);

@@ -54,6 +54,9 @@ struct GridDev {
   // interface faces [(e*nc + c)][64] the kernel must fill (e = nbr - kNbrHalo); see amr.hip
   const double *hb;
   double *flux;
+  // multi-level meshes: 1 for the blocks that have a coarse-side interface face, i.e. whose result the flux correction still edits;
+  // the advect-diffuse stage leaves their raw increment in tmpV and fuses the Runge-Kutta update for all the others
+  const unsigned char *raw;
 };
 __device__ __forceinline__ double block_h(const GridDev &g, int slot) { return g.hb ? g.hb[slot] : g.h; }
 
@@ -94,6 +97,9 @@ struct Sim {
   int32_t *d_restrict_list = nullptr, *d_prolong_list = nullptr, *d_fix_list[3] = {nullptr, nullptr, nullptr};
   unsigned n_restrict = 0, n_prolong = 0;
   int32_t *d_send_blocks = nullptr, *d_send_flux = nullptr;  // rank views: exchange plans (comm.hip)
+  unsigned char *d_raw_mask = nullptr;  // [nb], see GridDev::raw
+  int32_t *d_raw_list = nullptr;        // the blocks with raw_mask set
+  unsigned n_raw = 0;
   double *d_hb = nullptr, *d_flux = nullptr;
   // halo buffers (multi-rank)
   double *halo_recv = nullptr, *halo_send = nullptr;  // n faces x 3 comps x 3 layers x 64

@@ -208,6 +208,7 @@ class SimulationData:
         self.handle = h
         self.pressureSolver = None
         self.last_poisson = None
+        self.Rtol, self.Ctol, self.levelMaxVorticity = 1e9, 0.0, levelMax   # -Rtol / -Ctol / -levelMaxVorticity (15340-15342)
         self.obstacles = []            # ObstacleData list (geometry and motion come from the host)
         self.lambda_penal = 1e6        # sim.lambda (-lambda)
         self.bImplicitPenalization = True
@@ -380,6 +381,15 @@ class ComputeVorticity(Operator):
         check(lib().cup3d_compute_vorticity(self.sim.handle))
 
 
+class GradChiOnTmp(Operator):
+    """compute<ScalarLab>(GradChiOnTmp(sim), sim.chi), main.cpp:15182 / 8540-8600: the chi-driven edit of the vorticity in tmpV that
+    precedes the tagging in adaptMesh (needs sim.Rtol, sim.Ctol, sim.levelMaxVorticity; chi resident)."""
+
+    def __call__(self, dt=0):
+        s = self.sim
+        check(lib().cup3d_grad_chi_on_tmp(s.handle, float(s.Rtol), float(s.Ctol), int(getattr(s, "levelMaxVorticity", s.levelMax))))
+
+
 class ObstacleData:
     """Host-side description of one obstacle for the device operators: the non-null ObstacleBlocks (block slots, chi, udef in the
     reference's layout, main.cpp:7256-7263) and the rigid motion (centre of mass, translation and angular velocity)."""
@@ -536,6 +546,9 @@ class Simulation:
         self.sim (and the operators bound to it) when the mesh changes; returns the valid states."""
         s = self.sim
         ComputeVorticity(s)(0)
+        if s.obstacles or getattr(s, "chi_resident", False):   # compute<ScalarLab>(GradChiOnTmp(sim), sim.chi), 15182
+            s.Rtol, s.Ctol = Rtol, Ctol
+            GradChiOnTmp(s)(0)
         st = s.grid.valid_states(MeshAdaptation(Rtol, Ctol).Tag(s, "tmpV"))
         if (st != 0).any():
             self.__init__(s.adapted(st))

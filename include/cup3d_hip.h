@@ -289,6 +289,12 @@ int cup3d_diffusion_solve(cup3d_sim_t *, int direction, double dt, double nu, co
 /* ComputeVorticity::operator() (8726-8746, KernelVorticity 8624-8645): tmpV <- curl(vel); any mesh */
 int cup3d_compute_vorticity(cup3d_sim_t *);
 
+/* compute<ScalarLab>(GradChiOnTmp(sim), sim.chi) (main.cpp:15182, 8540-8600): tmpV (the vorticity left by cup3d_compute_vorticity) edited
+ * from the resident chi on its tensorial [-2,3) tile -- blocks with an obstacle surface within reach are flagged (1e10), cells deep
+ * inside a body cleared, vorticity capped on level levelMaxVorticity - 1.  With cup3d_compute_vorticity before and cup3d_tag_blocks
+ * after, this is the decision input of Simulation::adaptMesh (15180-15183) for runs with obstacles.  One rank. */
+int cup3d_grad_chi_on_tmp(cup3d_sim_t *, double Rtol, double Ctol, int level_max_vorticity);
+
 /* per-kernel device time accounting (hipEvents on the compute stream) */
 int cup3d_profile_enable(int on);
 int cup3d_profile_reset(void);

@@ -122,6 +122,8 @@ void orc_mesh_advdiff_implicit(const orc_mesh *, double *vel, double *pres, doub
                                const double uinf[3], double tol, double tol_rel, int sequential, int iters[3]);
 void orc_mesh_vorticity(const orc_mesh *, const double *vel, double *tmpV); /* ComputeVorticity, main.cpp:8624-8746 */
 void orc_mesh_tag(const orc_mesh *, const double *field, int nc, double rtol, double ctol, signed char *states);
+/* compute<ScalarLab>(GradChiOnTmp(sim), sim.chi), main.cpp:8540-8600: tmpV (the vorticity) edited in place from chi */
+void orc_mesh_grad_chi_on_tmp(const orc_mesh *, const double *chi, double *tmpV, double Rtol, double Ctol, int level_max_vorticity);
 void orc_mesh_states(const orc_mesh *, int *out27);
 /* obstacle operators for one obstacle given by its ObstacleBlocks (ids, chi[n][512], udef[n][512][3]) and rigid = cm[3], vel[3],
  * omega[3]: KernelPenalization + kernelFinalizePenalizationForce (13841-13938), kernelUpdateTmpV (14948-14979) */

@@ -1139,6 +1139,46 @@ void orc_mesh_vorticity(const orc_mesh *m, const double *vel, double *tmpV) {
 #undef L
 }
 
+/* compute<ScalarLab>(GradChiOnTmp(sim), sim.chi), main.cpp:8540-8600 -- the chi-driven half of adaptMesh's tagging input (15180-15182):
+ * on the tensorial [-2,3) tile of chi (zero-gradient domain faces), scanned in z, y, x order over the block grown by `offset` cells
+ * (2 on the finest level, else 1): values are clamped to [0,1]; the FIRST cell with 1e-5 < chi < 0.9 (an obstacle surface within
+ * reach) writes 1e10 into tmpV.u[0] of the centre cells the reference lists (six distinct ones of its eight assignments) and ends
+ * the scan; interior cells with chi > 0.9 met BEFORE that are cleared (deep inside the body: no vorticity-driven refinement).
+ * Before the scan, on level levelMaxVorticity - 1 (when that is below levelMax) vorticity magnitudes >= Rtol are capped to
+ * (Rtol + Ctol) / 2 so that such blocks are neither refined nor compressed. */
+void orc_mesh_grad_chi_on_tmp(const orc_mesh *m, const double *chi, double *tmpV, double Rtol, double Ctol, int level_max_vorticity) {
+  tile_t t;
+  tile_init(&t, 1, 0, -2, 3, 1);
+  for (long b = 0; b < m->nblocks; b++) {
+    orc_mesh_lab(m, chi, b, &t);
+    double *T = tmpV + b * BS3 * 3;
+    if (m->level[b] == level_max_vorticity - 1 && level_max_vorticity < m->level_max)
+      for (int i = 0; i < BS3; i++) {
+        double *e = T + 3 * i;
+        if (sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) >= Rtol) { e[0] = 0.5 * (Rtol + Ctol); e[1] = 0.0; e[2] = 0.0; }
+      }
+    const int offset = m->level[b] == m->level_max - 1 ? 2 : 1;
+    int done = 0;
+    for (int z = -offset; z < BS + offset && !done; z++)
+      for (int y = -offset; y < BS + offset && !done; y++)
+        for (int x = -offset; x < BS + offset; x++) {
+          double v = FT(&t, x, y, z, 0);
+          v = v < 1.0 ? v : 1.0;   /* std::min(lab, 1.0), 8564 */
+          v = v > 0.0 ? v : 0.0;   /* std::max(lab, 0.0), 8565 */
+          if (v > 0.00001 && v < 0.9) {
+            static const int cc[6][3] = {{3, 3, 3}, {4, 3, 3}, {3, 4, 3}, {3, 3, 4}, {4, 4, 4}, {4, 3, 4}}; /* 8567-8590, duplicates dropped */
+            for (int q = 0; q < 6; q++) T[((cc[q][2] * BS + cc[q][1]) * BS + cc[q][0]) * 3] = 1e10;
+            done = 1;
+            break;
+          } else if (v > 0.9 && z >= 0 && z < BS && y >= 0 && y < BS && x >= 0 && x < BS) {
+            double *e = T + ((z * BS + y) * BS + x) * 3;
+            e[0] = 0.0; e[1] = 0.0; e[2] = 0.0;
+          }
+        }
+  }
+  tile_free(&t);
+}
+
 /* TagLoadedBlock (5566-5582) with the level clamps of TagBlocksVector (5207-5211) on every block of a mesh */
 void orc_mesh_tag(const orc_mesh *m, const double *f, int nc, double rtol, double ctol, signed char *states) {
   for (long b = 0; b < m->nblocks; b++) {

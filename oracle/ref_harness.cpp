@@ -250,6 +250,9 @@ int main(int argc, char **argv) {
       else if (k == "mean") sd.bMeanConstraint = (int)v;
       else if (k == "lambda") sd.lambda = v;
       else if (k == "implicit") sd.bImplicitPenalization = v != 0;
+      else if (k == "rtol") sd.Rtol = v;
+      else if (k == "ctol") sd.Ctol = v;
+      else if (k == "lmaxvort") sd.levelMaxVorticity = (int)v;
       else if (k == "difftol") sd.DiffusionErrorTol = v;
       else if (k == "difftolrel") sd.DiffusionErrorTolRel = v;
       else { fprintf(stderr, "ref_tool: unknown set key %s\n", k.c_str()); exit(2); }
@@ -400,6 +403,7 @@ int main(int argc, char **argv) {
           kernelFinalizePenalizationForce(sd);
         }
         else if (op == "vorticity") { ComputeVorticity w(sd); w(0); } /* first half of adaptMesh, main.cpp:15180-15181 */
+        else if (op == "gradchi") compute<ScalarLab>(GradChiOnTmp(sd), sd.chi);                      /* main.cpp:15182 */
         else if (op == "precond") {
 #pragma omp parallel
           { poisson_kernels::getZImplParallel(sd.presInfo()); }

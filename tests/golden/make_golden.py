@@ -229,6 +229,60 @@ def vorticity_cases():
     np.savez_compressed(os.path.join(HERE, "vorticity.npz"), **out)
 
 
+def blob_chi(t, geom, seed):
+    """A smooth body indicator on block-ordered cells: chi = 1 deep inside a few balls, 0 far away, a ramp of a few cells in between --
+    surfaces cross blocks, sit next to coarse/fine faces and leave most blocks untouched (the shape GradChiOnTmp exists for)."""
+    rng = np.random.default_rng(seed)
+    ax = np.arange(8) + 0.5
+    ext = (geom[:, 1:] + 8 * geom[:, :1]).max(axis=0)
+    centres = rng.uniform(0.2, 0.8, (3, 3)) * ext
+    radii = rng.uniform(0.12, 0.25, 3) * ext.min()
+    chi = np.zeros((len(t), 8, 8, 8))
+    for b in range(len(t)):
+        h = geom[b, 0]
+        Z, Y, X = np.meshgrid(geom[b, 3] + ax * h, geom[b, 2] + ax * h, geom[b, 1] + ax * h, indexing="ij")
+        d = np.full(X.shape, np.inf)
+        for c, r in zip(centres, radii):
+            d = np.minimum(d, np.sqrt((X - c[0]) ** 2 + (Y - c[1]) ** 2 + (Z - c[2]) ** 2) - r)
+        chi[b] = np.clip(0.5 - d / (4 * geom[:, 0].min()), -0.2, 1.3)   # values outside [0,1] exercise the clamp
+    return chi
+
+
+def grad_chi_cases():
+    """compute<ScalarLab>(GradChiOnTmp(sim), sim.chi) (main.cpp:8540-8600, the chi-driven half of adaptMesh's tagging input) on the
+    vorticity of existing cases, with a synthetic body indicator: tmpV after the operator, for levelMaxVorticity = levelMax and for
+    levelMaxVorticity = levelMax - 1 (the capping branch).  Stores the chi input and the outputs."""
+    out = {}
+    vz = np.load(os.path.join(HERE, "vorticity.npz"))
+    for name in ("f16_mixed", "amr_periodic_l01", "amr_mixed_l12"):
+        g = np.load(os.path.join(HERE, name + ".npz"))
+        bpd, lmax = tuple(int(b) for b in g["bpd"]), int(g["level_max"])
+        bc = tuple(O.BC_NAMES[int(b)] for b in g["bc"])
+        wd = O.tempfile.mkdtemp(prefix="golden_")
+        if name.startswith("amr"):
+            passes = [c for c in AMR_CASES if c[0] == name][0][4]
+            pre, lstart = amr_mesh_script(wd, bpd, passes), 0
+        else:
+            pre, lstart = ["zero chi"], int(g["level"])
+        args = O.ref_args(bpd, lmax, lstart, EXT, bc)
+        recs, wd = O.run_ref(pre + ["tables t.bin"], args, threads=1, workdir=wd)
+        t, geom = O.read_tables(os.path.join(wd, "t.bin"))
+        assert np.array_equal(t, g["tables"]), name
+        chi = blob_chi(t, geom, 77)
+        w = vz[name + "_vort"]
+        rt, ct = (float(v) for v in vz[name + "_tol"])
+        chi.tofile(os.path.join(wd, "chib.bin")); w.tofile(os.path.join(wd, "wb.bin"))
+        out[name + "_chi"] = chi
+        for tag, lmv in (("", lmax), ("_capped", lmax - 1)):
+            recs, wd = O.run_ref(pre + ["loadb chi chib.bin", "loadb tmpV wb.bin", f"set rtol {rt!r}", f"set ctol {ct!r}", f"set lmaxvort {lmv}", "op gradchi",
+                                        "dump tmpV out.bin"], args, threads=1, workdir=wd)
+            out[name + "_tmpV" + tag] = O.read_blocks(os.path.join(wd, "out.bin"), len(t), 3)
+        changed = (out[name + "_tmpV"] != w).any(axis=(1, 2, 3, 4))
+        print(name, "blocks", len(t), "changed by GradChiOnTmp", int(changed.sum()), "flagged 1e10", int((out[name + "_tmpV"][..., 0] == 1e10).any(axis=(1, 2, 3)).sum()),
+              "capped variant differs in", int((out[name + "_tmpV_capped"] != out[name + "_tmpV"]).any(axis=(1, 2, 3, 4)).sum()))
+    np.savez_compressed(os.path.join(HERE, "grad_chi.npz"), **out)
+
+
 def octet_fields(t, seed):
     """Block-ordered random fields whose amplitude is shared by the eight siblings of an octet (and scaled with the block
     size), so that whole octets get the same vorticity tag and compression survives ValidStates."""
@@ -463,6 +517,7 @@ if __name__ == "__main__":
         field_case(*c)
     traj_case()
     vorticity_cases()
+    grad_chi_cases()
     obstacle_cases()
     implicit_cases()
     if O.have_ref_tool_mpi():

@@ -117,6 +117,7 @@ def lib():
     L.orc_mesh_max_u.argtypes = [vp, _dp, _dp]
     L.orc_mesh_advect_implicit.argtypes = [vp, _dp, _dp, C.c_double, C.c_double, _dp, C.c_int]
     L.orc_mesh_diffusion_rhs.argtypes = [vp, _dp, _dp]
+    L.orc_mesh_grad_chi_on_tmp.argtypes = [vp, _dp, _dp, C.c_double, C.c_double, C.c_int]
     L.orc_mesh_diff_lhs.argtypes = [vp, _dp, _dp, C.c_int, C.c_double, C.c_double]
     L.orc_mesh_diff_precond.argtypes = [vp, _dp, C.c_double, C.c_double]
     L.orc_mesh_diff_solve.argtypes = [vp, _dp, _dp, C.c_int, C.c_double, C.c_double, C.POINTER(SolveInfo)]
@@ -280,6 +281,12 @@ class OracleMesh:
     def grad_p(self, pres, dt):
         out = np.zeros(pres.shape + (3,))
         lib().orc_mesh_grad_p(self.m, pres, out, dt)
+        return out
+
+    def grad_chi_on_tmp(self, chi, tmpV, Rtol, Ctol, level_max_vorticity=None):
+        """GradChiOnTmp (main.cpp:8540-8600): returns tmpV (the vorticity) edited from chi."""
+        out = np.ascontiguousarray(tmpV).copy()
+        lib().orc_mesh_grad_chi_on_tmp(self.m, np.ascontiguousarray(chi), out, Rtol, Ctol, self.level_max if level_max_vorticity is None else level_max_vorticity)
         return out
 
     def project(self, vel, pres, dt, step, tol=1e-6, tol_rel=1e-4, mean_constraint=1, chi=None):

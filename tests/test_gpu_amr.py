@@ -133,6 +133,32 @@ def test_stencil_operators_bitexact(golden_dir, name):
     assert np.array_equal(tags, m.tag(w, rt, ct)) and len(set(tags.tolist())) >= 2
 
 
+@pytest.mark.parametrize("name", ["f16_mixed", "amr_periodic_l01", "amr_mixed_l12"])
+def test_grad_chi_on_tmp_equals_the_reference(golden_dir, name):
+    """compute<ScalarLab>(GradChiOnTmp(sim), sim.chi) (main.cpp:8540-8600): the device edit of tmpV against the REFERENCE's own output
+    (tests/golden/grad_chi.npz) on a uniform grid and two multi-level meshes, with and without the levelMaxVorticity cap -- bit for
+    bit, which pins the tensorial [-2,3) tile of chi behind it (two ghost layers: copies, restriction, both interpolation modes,
+    zero-gradient domain faces) as well; then the tags that follow."""
+    z, vz = np.load(os.path.join(golden_dir, "grad_chi.npz")), np.load(os.path.join(golden_dir, "vorticity.npz"))
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    t = g["tables"]
+    bpd, lmax, bc = tuple(int(b) for b in g["bpd"]), int(g["level_max"]), tuple(BCN[int(b)] for b in g["bc"])
+    kw = dict(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, extent=float(g["extent"]), BC_x=bc[0], BC_y=bc[1], BC_z=bc[2])
+    sim = cu.SimulationData(levelStart=int(g["level"]), **kw) if "level" in g.files else cu.SimulationData(levelStart=0, leaves=(t[:, 0], t[:, 1]), **kw)
+    assert np.array_equal(sim.grid.tables, t)
+    rt, ct = (float(v) for v in vz[name + "_tol"])
+    sim.Rtol, sim.Ctol = rt, ct
+    sim.upload("chi", z[name + "_chi"])
+    for tag, lmv in (("", lmax), ("_capped", lmax - 1)):
+        sim.levelMaxVorticity = lmv
+        sim.upload("tmpV", vz[name + "_vort"])
+        cu.GradChiOnTmp(sim)(0)
+        got = sim.download("tmpV")
+        assert np.array_equal(got, z[name + "_tmpV" + tag]), (name, tag, int((got != z[name + "_tmpV" + tag]).any(axis=(1, 2, 3, 4)).sum()))
+        m = O.OracleMesh(bpd, lmax, float(g["extent"]), bc, t[:, 0], t[:, 1])
+        assert np.array_equal(cu.MeshAdaptation(rt, ct).Tag(sim, "tmpV"), m.tag(got, rt, ct))
+
+
 def sim_max_u(sim, uinf):
     out = C.c_double()
     check(lib().cup3d_max_u(sim.handle, np.asarray(uinf, dtype=np.float64), C.byref(out)))
