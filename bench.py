@@ -203,6 +203,7 @@ def main():
     ap.add_argument("--stencil-only", action="store_true", help="BASELINE configs[1]: periodic, advect-diffuse only")
     ap.add_argument("--block-solver", type=int, default=0, help="0: block CG as in the reference, 1: direct block solve")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed region with the other block solver")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host<->device transfer measurement behind `pcie_inclusive`")
     ap.add_argument("--no-fuse", action="store_true", help="A/B: vector loops and block CG as separate launches (round-1 structure)")
     ap.add_argument("--implicit-diffusion", action="store_true",
                     help="-implicitDiffusion 1: AdvectionDiffusionImplicit (upwind advection + three Helmholtz solves) instead of the explicit RK3")
@@ -304,6 +305,32 @@ def main():
     lib().cup3d_debug_block_cg_iterations(sim.handle, C.byref(tot), C.byref(nblk))
     a.cg_iters_per_block = tot.value / nblk.value if nblk.value else None
 
+    # PCIe-inclusive rate of the C++ shim (never `value`): the boundary hands over one host pointer per block; measured here through
+    # that very path (cup3d_sim_upload_blocks / _download_blocks on resident, reused host pages), then applied to the bytes the shim
+    # moves per step in its two modes
+    a.pcie = None
+    if world == 1 and not a.stencil_only and not a.implicit_diffusion and not a.no_pcie:
+        fid = cu.operators.FIELDS["vel"]
+        hv = np.empty((sim.nblocks, 8, 8, 8, 3))
+        ptrs = (C.c_void_p * sim.nblocks)(*[hv[i].ctypes.data for i in range(sim.nblocks)])
+        rates = {}
+        for name, fn in (("download", lambda: check(lib().cup3d_sim_download_blocks(sim.handle, fid, ptrs))),
+                         ("upload", lambda: check(lib().cup3d_sim_upload_blocks(sim.handle, fid, ptrs)))):
+            fn()
+            t0 = time.perf_counter()
+            fn()
+            rates[name] = hv.nbytes / (time.perf_counter() - t0) / 1e9
+        gb = hv.nbytes / 1e9
+        step_s = sec / a.steps
+        cells = float(a.size) ** 3
+        modes = {}
+        for mode, up, down in (("round_trip", 2 * gb + gb / 3, 4 * gb + gb / 3), ("resident", gb + gb / 3, 2 * gb + gb / 3)):
+            t = step_s + up / rates["upload"] + down / rates["download"]
+            modes[mode] = {"GB_up_per_step": round(up, 2), "GB_down_per_step": round(down, 2), "Mcell_updates_per_s": round(cells / t / 1e6, 2)}
+        a.pcie = {"upload_GBps": round(rates["upload"], 1), "download_GBps": round(rates["download"], 1), "shim_modes": modes,
+                  "note": "derived: device step time of this run + the shim's per-step transfers at the measured block-pointer rates"}
+        del hv, ptrs
+
     alt = None
     if not a.stencil_only and not a.no_alt and not a.implicit_diffusion:
         # same workload once more with the block preconditioner evaluated by the other method
@@ -402,6 +429,8 @@ def report(a, sim, prof, sec, iters, world, alt=None):
     }
     if alt is not None:
         out["alt"] = alt
+    if getattr(a, "pcie", None):
+        out["pcie_inclusive"] = a.pcie
     if not a.no_cpu and world == 1:
         # the reference on ALL host cores (count stated in `cores`), 512^3 if the box allowed it in the time the default
         # run has, else 256^3: a 512^3 step of the reference takes minutes and ~35 GB, so the sample is 256^3 (2 steps, 10-30 s).
