@@ -652,7 +652,7 @@ def test_kat_taylor_green_energy_decay():
 def test_partial_block_transfers():
     """cup3d_sim_upload_block_list / cup3d_sim_download_block_list: only the listed slots move (the blocks an obstacle covers, in
     the resident mode of the C++ shim), any order, lists longer than one staging chunk."""
-    sim = cu.SimulationData(bpdx=2, bpdy=2, bpdz=2, levelMax=4, levelStart=3, extent=1.0)   # 4096 blocks; staging chunk = 8192
+    sim = cu.SimulationData(bpdx=2, bpdy=2, bpdz=2, levelMax=4, levelStart=3, extent=1.0)   # 4096 blocks; staging chunk = 16384
     nb = sim.nblocks
     rng = np.random.default_rng(21)
     for field, shape in (("vel", (nb, 8, 8, 8, 3)), ("pres", (nb, 8, 8, 8))):
@@ -667,7 +667,7 @@ def test_partial_block_transfers():
         assert np.array_equal(sim.download(field), b)
         assert np.array_equal(sim.download_block_list(field, np.arange(nb, dtype=np.int32)), b)   # the full list, one chunk
         assert np.array_equal(sim.download_block_list(field, np.zeros(0, dtype=np.int32)), b[:0])
-        big = rng.integers(0, nb, 9000).astype(np.int32)                                            # two staging chunks (8192 blocks each), repeated slots
+        big = rng.integers(0, nb, 20000).astype(np.int32)                                            # two staging chunks (16384 blocks each), repeated slots
         assert np.array_equal(sim.download_block_list(field, big), b[big])
     from cup3d_amd.capi import Cup3dError
     with pytest.raises(Cup3dError):
