@@ -185,11 +185,11 @@ __global__ void __launch_bounds__(256) k_forcing(double *__restrict__ vel, long 
   }
 }
 
-// fn(i) for i in [0, n) on the calling thread plus up to 31 helpers (contiguous ranges)
+// fn(i) for i in [0, n) on the calling thread plus up to 15 helpers (contiguous ranges)
 template <class F>
 static void host_parallel(size_t n, F fn) {
   unsigned hw = std::thread::hardware_concurrency();
-  size_t nt = std::min<size_t>(std::min<size_t>(32, hw ? hw / 2 : 1), (n + 255) / 256);
+  size_t nt = std::min<size_t>(std::min<size_t>(16, hw ? hw : 1), (n + 255) / 256);
   if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
   std::vector<std::thread> th;
   th.reserve(nt - 1);
@@ -432,7 +432,7 @@ int cup3d_sim_download(cup3d_sim_t *h, int field, double *blocks) {
 // One pointer per block (Info::block of the reference's per-block allocations, main.cpp:877-884).  The host side of this boundary
 // is 262 144 separate 4-12 KiB allocations at 512^3, so the transfer is a gather (or scatter) on the host plus a PCIe copy plus the
 // AoS <-> SoA kernel.  Round 1 did the three one after the other, with one host thread: 11 GB/s down, 55 GB/s up.  Now:
-//   * the gather / scatter runs on up to 32 host threads (a single core copies ~10 GB/s, PCIe Gen5 x16 carries ~55);
+//   * the gather / scatter runs on up to 16 host threads (more were slower on the two-socket GPU host) (a single core copies ~10 GB/s, PCIe Gen5 x16 carries ~55);
 //   * two pinned staging buffers and two device staging buffers alternate, so that the host works on chunk k+1 while chunk k is on
 //     the bus and in the layout kernel (events, no stream synchronisation inside the loop).
 static int ensure_stage(Sim *s) {
