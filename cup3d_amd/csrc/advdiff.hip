@@ -311,6 +311,115 @@ __global__ void __launch_bounds__(512 / CPT) k_advdiff(GridDev g, AdvArgs a) {
   }
 }
 
+// ---- the same stage, one velocity component at a time (uniform grids).
+// k_advdiff stages the star tile of all three components at once: 48.8 KB of LDS and 110-132 VGPRs (every load of the block in
+// flight before the first LDS write) allow three workgroups per CU, and stage 1 -- 25 % less HBM traffic -- is no faster than stages
+// 2 and 3: the kernel is bound by how little of a block's load -> LDS -> compute -> store sequence three workgroups can overlap, not
+// by HBM.  The three components are independent once a cell's own velocity is known (the derivatives and the Laplacian of u_c read
+// the tile of u_c only; u, v, w at the cell come from registers), so this kernel keeps ONE component tile in LDS at a time, in two
+// alternating buffers (32.5 KB), with the ghost values of the next component requested while the current one is computed: fewer
+// registers, more workgroups per CU.  Arithmetic and association are those of k_advdiff: the results are bit-identical.
+template <bool FIRST_STAGE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_advdiff_c(GridDev g, AdvArgs a) {
+  __shared__ double tile[2][kCompStride];
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const double *__restrict__ own = a.vel + (size_t)slot * 1536;
+  const int x = lane & 7, z0 = (lane >> 3) & 3, y = 2 * wave + (lane >> 5);
+  const int cell0 = z0 * 64 + y * 8 + x;  // second cell: + 256
+  double uc[2][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) uc[k][c] = own[c * 512 + k * 256 + cell0];
+  const double *__restrict__ tp = a.tmp + (size_t)slot * 1536;
+  double *__restrict__ vout = a.vel_out + (size_t)slot * 1536;
+  double *__restrict__ tout = a.tmp + (size_t)slot * 1536;
+  // the ghost elements this thread stages, the same for every component: element e = t + 256 j of the 6 x 192 behind the faces
+  const double *gsrc[5];
+  int gstride[5], glds[5], gdir[5];
+  bool gon[5], gwall[5], gbc[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int e = t + 256 * j;
+    gon[j] = e < 1152;
+    const int f = gon[j] ? e / 192 : 0, idx = gon[j] ? e - 192 * f : 0;
+    int nb_cell, own_cell, lds, hal;
+    face_element(f, idx, nb_cell, own_cell, lds, hal);
+    const int n = g.nbr[slot * 6 + f];
+    glds[j] = lds;
+    gdir[j] = f >> 1;
+    gbc[j] = n < 0;
+    gwall[j] = n == -3;  // wall: every component negated; freespace: the normal one (main.cpp:6137-6153, 6384-6394)
+    if (n >= kNbrHalo) { gsrc[j] = a.halo + (size_t)(n - kNbrHalo) * 3 * 192 + hal; gstride[j] = 192; }
+    else if (n >= 0) { gsrc[j] = a.vel + (size_t)n * 1536 + nb_cell; gstride[j] = 512; }
+    else { gsrc[j] = own + own_cell; gstride[j] = 512; }
+  }
+  double gnext[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) gnext[j] = gon[j] ? gsrc[j][0] : 0.0;
+  const int xy = (y + 3) * kXYPitch + (x + 3);
+  const double h = g.h, h3 = h * h * h;
+  const double facA = -a.dt / h * h3 * 1.0;                 // main.cpp:9487 (coef = 1)
+  const double facD = (a.nu / h) * (a.dt / h) * h3 * 1.0;   // main.cpp:9488
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    double told[2] = {0.0, 0.0};
+    if (!FIRST_STAGE) {  // this component's tmpV: requested here, consumed after the stencil below
+#pragma unroll
+      for (int k = 0; k < 2; ++k) told[k] = __builtin_nontemporal_load(&tp[c * 512 + k * 256 + cell0]);
+    }
+    double gv[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) gv[j] = gnext[j];
+    if (c < 2) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) gnext[j] = gon[j] ? gsrc[j][(size_t)(c + 1) * gstride[j]] : 0.0;
+    }
+    double *L = tile[c & 1];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) L[(z0 + 4 * k) * kPlane + xy] = uc[k][c];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (gon[j]) L[glds[j]] = (gbc[j] && (gwall[j] || gdir[j] == c)) ? -gv[j] : gv[j];
+    __syncthreads();  // also: every thread is done computing component c - 1, whose buffer component c + 1 will overwrite
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int z = z0 + 4 * k;
+      int zo[7];
+#pragma unroll
+      for (int dz = -3; dz <= 3; ++dz) {
+        const int zz = z + dz;
+        zo[dz + 3] = (zz >= 0 && zz < 8) ? zz * kPlane + xy : kXYSize + (zz < 0 ? -1 - zz : zz - 5) * kZPitch + y * 8 + x;
+      }
+      const int b = z * kPlane + xy;
+      const double ua0 = uc[k][0] + a.u0, ua1 = uc[k][1] + a.u1, ua2 = uc[k][2] + a.u2;  // uAbs, 9492-9494
+      const bool p0 = ua0 > 0, p1 = ua1 > 0, p2 = ua2 > 0;
+      const double cc = uc[k][c];
+      const double xm1 = L[b - 1], xp1 = L[b + 1], ym1 = L[b - kXYPitch], yp1 = L[b + kXYPitch], zm1 = L[zo[2]], zp1 = L[zo[4]];
+      const double dx = upwind5<true>(p0, L[b - 3], L[b - 2], xm1, cc, xp1, L[b + 2], L[b + 3]);
+      const double dy = upwind5<true>(p1, L[b - 3 * kXYPitch], L[b - 2 * kXYPitch], ym1, cc, yp1, L[b + 2 * kXYPitch], L[b + 3 * kXYPitch]);
+      const double dz = upwind5<true>(p2, L[zo[0]], L[zo[1]], zm1, cc, zp1, L[zo[5]], L[zo[6]]);
+      const double sx = xp1 + xm1, sy = yp1 + ym1, sz = zp1 + zm1;
+      double lap, adv;  // the three components use three association orders, main.cpp:9531-9545
+      if (c == 0) {
+        lap = (sx + (sy + sz)) - 6 * cc;
+        adv = ua0 * dx + (ua1 * dy + ua2 * dz);
+      } else if (c == 1) {
+        lap = (sy + (sz + sx)) - 6 * cc;
+        adv = ua1 * dy + (ua2 * dz + ua0 * dx);
+      } else {
+        lap = (sz + (sx + sy)) - 6 * cc;
+        adv = ua2 * dz + (ua0 * dx + ua1 * dy);
+      }
+      const double tn = told[k] + (facA * adv + facD * lap);                                     // o += ..., main.cpp:9546-9548
+      __builtin_nontemporal_store(cc + tn * a.alpha, &vout[c * 512 + k * 256 + cell0]);          // V += tmpV*ih3, 9718-9720
+      __builtin_nontemporal_store(tn * a.beta, &tout[c * 512 + k * 256 + cell0]);                // tmpV *= beta, 9721-9723
+    }
+  }
+}
+
 // face slabs of `field` behind the faces listed in send_faces -> packed send buffer
 // [(s*nc + c)*w + gl][64]  (the device-side `pack`, main.cpp:1128-1157)
 __global__ void __launch_bounds__(64) k_pack_faces(const double *__restrict__ field, const int32_t *__restrict__ send_faces, int nc, int w,
@@ -415,13 +524,19 @@ static int advdiff_stage(Sim *s, int rk, double dt, double nu, const double uinf
       const dim3 G(launch_groups(g));
 #define ADV(FIRST, CPT, VAR) hipLaunchKernelGGL((k_advdiff<FIRST, CPT, VAR>), G, dim3(512 / CPT), 0, stream(), g, a)
 #define ADV2(CPT, VAR) do { if (rk == 0) ADV(true, CPT, VAR); else ADV(false, CPT, VAR); } while (0)
-      switch (debug_option("advdiff_variant")) {  // 0 = production
+      switch (debug_option("advdiff_variant")) {  // 0 = production; 1 and 4 are A/B variants with the SAME results
         case 0: ADV2(2, 0); break;
         case 1: ADV2(2, 1); break;
+        case 4: ADV2(2, 4); break;
+        case 5:  // one component tile at a time (k_advdiff_c)
+          if (rk == 0) hipLaunchKernelGGL((k_advdiff_c<true>), G, dim3(256), 0, stream(), g, a);
+          else hipLaunchKernelGGL((k_advdiff_c<false>), G, dim3(256), 0, stream(), g, a);
+          break;
+#ifdef CUP3D_TUNING_ABLATIONS  // timing ablations with deliberately WRONG results: never in a release build (make TUNING=1)
         case 2: ADV2(2, 2); break;
         case 3: ADV2(2, 3); break;
-        case 4: ADV2(2, 4); break;
-        default: set_error("unknown advdiff_variant"); return CUP3D_EINVAL;
+#endif
+        default: set_error("unknown advdiff_variant (the ablation variants 2 and 3 need a build with -DCUP3D_TUNING_ABLATIONS)"); return CUP3D_EINVAL;
       }
 #undef ADV2
 #undef ADV

@@ -174,6 +174,22 @@ def test_golden_stencil_operators_bit_exact(golden_dir, name):
     assert np.array_equal(cu.MeshAdaptation(rt, ct).Tag(sim, "tmpV"), m.tag(w, rt, ct))
 
 
+@pytest.mark.parametrize("variant", [1, 4, 5])
+@pytest.mark.parametrize("name", FIELD_CASES)
+def test_advect_diffuse_kernel_variants_bit_exact(golden_dir, name, variant):
+    """The A/B variants of the advect-diffuse stage that are supposed to give the SAME bits as the production kernel: IEEE division
+    (1), plain stores (4) and the one-component-tile-at-a-time kernel (5) -- against the reference's golden output, every BC kind."""
+    z = load(golden_dir, name)
+    sim = make_sim(z, nu=float(z["nu"]), uinf=z["uinf"])
+    cu.capi.check(cu.lib().cup3d_debug_set_option(b"advdiff_variant", variant))
+    try:
+        sim.upload("vel", sim.grid.to_blocks(z["vel_in"]))
+        cu.AdvectionDiffusion(sim)(float(z["dt"]))
+        assert np.array_equal(sim.download("vel"), z["ad_vel"]) and np.array_equal(sim.download("tmpV"), z["ad_tmpV"])
+    finally:
+        cu.capi.check(cu.lib().cup3d_debug_set_option(b"advdiff_variant", 0))
+
+
 def test_wave_sum_on_the_matrix_pipe():
     """The wave-wide sum the production block CG uses (two v_mfma_f64_16x16x4_f64 with a ones matrix + three adds): exact on
     integers (every lane receives the total), and to rounding on random data, like the DPP form it replaces."""
