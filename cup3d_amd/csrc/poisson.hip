@@ -453,6 +453,10 @@ constexpr int kCgProduction = 0;
 int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
   GridDev g = s->gdev();
   double *sums = want_sums ? s->d_partials + (size_t)s->max_groups * 8 : nullptr;
+  if (s->block_solver == 5) {  // one multigrid V-cycle (multigrid.hip); the LHS that follows sums the blocks itself
+    s->sums_of = nullptr;
+    return mg_vcycle(s, in, out);
+  }
   if (s->block_solver == 1) {
     int rc = fdm_setup();
     if (rc) return rc;

@@ -365,6 +365,7 @@ void cup3d_sim_destroy(cup3d_sim_t *h) {
   Sim *s = reinterpret_cast<Sim *>(h);
   vcomm_unregister(s);
   hipStreamSynchronize(g_stream);
+  mg_destroy(s);
   double *ptrs[] = {s->vel, s->vel2, s->tmpV, s->pres, s->lhs, s->chi, s->pold, s->d_partials, s->d_red, s->d_stage, s->halo_recv, s->halo_send, s->d_block_dots,
                     s->d_hb, s->d_flux};
   for (double *p : ptrs) if (p) hipFree(p);

@@ -85,6 +85,7 @@ struct Sim {
   unsigned *d_counters = nullptr;  // [4] tickets of grid_sum_finish (tile.hpp), zero between launches
   int *d_cg_iters = nullptr;       // [nb] CG iterations per block of the last block-CG launch (only while profiling)
   double *d_block_dots = nullptr;  // [7][nb] per-block dot products of the fused loop + block-CG kernels (poisson.hip)
+  void *mg = nullptr;              // level hierarchy of the multigrid preconditioner (multigrid.hip), built on first use
   int max_groups = 0;
   // staging for host transfers
   double *d_stage = nullptr;
@@ -139,6 +140,9 @@ int amr_flux_fix(Sim *s, int nfc, double *out, int out_nc);
 // kernels' launchers shared across translation units
 int launch_lhs(Sim *s, const double *p, double *out, int mean_constraint);
 int launch_precond(Sim *s, const double *in, double *out, bool want_sums);
+// block_solver 5: one multigrid V-cycle from a zero guess as M^-1 (multigrid.hip; an alternative, not the reference's algorithm)
+int mg_vcycle(Sim *s, const double *in, double *out);
+void mg_destroy(Sim *s);
 // implicit diffusion (DiffusionSolver, main.cpp:6719-7147): Helmholtz operator of velocity component `direction`
 struct HelmholtzOp { int direction; double dt, nu; };
 int launch_lhs_diffusion(Sim *s, const double *p, double *out, const HelmholtzOp &op);

@@ -192,7 +192,12 @@ typedef struct {
                           1 = direct block solve by fast diagonalisation (same operator, exact to rounding);
                           2 = the block CG in the reference's association: no FMA contraction, IEEE divisions (only the ORDER of the
                               512-term sums differs from the CPU); slower, for parity checks;
-                          3 = the round-1 kernel (FMA, DPP reductions), kept for A/B timing */
+                          3 = the round-1 kernel (FMA, DPP reductions), kept for A/B timing;
+                          4 = the block CG with two blocks per wavefront (A/B timing);
+                          5 = NOT the reference's preconditioner: one geometric-multigrid V(2,2)-cycle (red-black Gauss-Seidel in LDS,
+                              summed-residual restriction, piecewise-constant prolongation) on the hierarchy of uniform block grids --
+                              same operator, same stopping rule, same converged pressure to solver tolerance, O(10) instead of O(150)
+                              iterations; uniform one-rank grids; reported by bench.py as `alt` only */
 } cup3d_poisson_params;
 typedef struct {
   int iterations; /* BiCGSTAB iterations performed (= 7-double reductions, main.cpp:14546) */

@@ -569,6 +569,46 @@ def test_baseline_256_cubed_against_the_oracle():
         restore()
 
 
+@pytest.mark.parametrize("bpd,lmax,level,bc", [
+    ((1, 1, 1), 5, 4, ("wall", "wall", "wall")),
+    ((1, 1, 1), 4, 3, ("periodic", "periodic", "periodic")),
+    ((2, 1, 1), 4, 3, ("freespace", "wall", "periodic")),
+    ((2, 2, 2), 1, 0, ("wall", "periodic", "freespace")),
+])
+def test_multigrid_preconditioner_converges_to_the_same_pressure(bpd, lmax, level, bc):
+    """block_solver = 5 replaces the reference's block-CG preconditioner by one geometric-multigrid V-cycle (NOT the reference's
+    algorithm; `alt` in bench.py): same operator, same mean constraint, same stopping rule.  Parity is on the CONVERGED pressure: with
+    tight tolerances on both sides the projection gives the oracle's pressure and velocity; at the default tolerance the iterate
+    satisfies the reference's stopping rule; and it needs several times fewer iterations than the block CG."""
+    ext = 2 * np.pi
+    o = O.OracleGrid(bpd, lmax, level, ext, bc)
+    rng = np.random.default_rng(4)
+    vel = o.taylor_green([ext * b / max(bpd) for b in bpd], 1.0) + 0.05 * rng.uniform(-1, 1, (o.nb, 8, 8, 8, 3))
+    dt = 0.3 * o.h
+    kw = dict(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=level, extent=ext, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2])
+    its = {}
+    for solver in (0, 5):
+        sim = cu.SimulationData(blockSolver=solver, **kw)
+        sim.upload("vel", vel)
+        check_rhs = o.pressure_rhs(vel, np.zeros_like(vel), np.zeros((o.nb, 8, 8, 8)), dt)
+        cu.capi.check(cu.lib().cup3d_pressure_rhs(sim.handle, dt))
+        b = sim.download("lhs")
+        assert np.array_equal(b, check_rhs)
+        sim.fill("pres", 0.0)
+        r = cu.makePoissonSolver(sim).solve()
+        its[solver] = r.iterations
+        x = sim.download("pres")
+        b0 = b.copy()
+        b0[int(np.where((o.index == 0).all(axis=1))[0][0]), 0, 0, 0] = 0.0
+        res0 = np.linalg.norm(b0.ravel())
+        assert np.linalg.norm((b0 - o.lhs(x, 1)).ravel()) <= max(1e-6, 1e-4 * res0) * (1 + 1e-6), solver
+        if solver == 5:
+            assert_tight_projection_parity(sim, o, vel, np.zeros((o.nb, 8, 8, 8)), dt, 4)
+    if level >= 3:
+        assert its[5] <= 0.5 * its[0], its
+    print(f"multigrid vs block CG, {o.ncell}: {its[5]} vs {its[0]} BiCGSTAB iterations")
+
+
 def test_medium_128_oracle_advect_diffuse_and_solver():
     """128^3 (4096 blocks) against the oracle: advect-diffuse bit-exact, one Poisson solve with a
     manufactured right-hand side within tolerance."""
