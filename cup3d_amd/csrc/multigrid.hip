@@ -178,10 +178,6 @@ static int mg_setup(Sim *s) {
         M.d_nbr = s->d_nbr;
         CUP3D_HIP(hipMalloc((void **)&M.x2, (size_t)s->nb * 512 * sizeof(double)));
         s->bytes += (size_t)s->nb * 512 * sizeof(double);
-        if (L == 0) {  // a one-level hierarchy: the coarsest-level solve edits its right-hand side (mean removal), so it needs a copy
-          CUP3D_HIP(hipMalloc((void **)&M.b, (size_t)s->nb * 512 * sizeof(double)));
-          s->bytes += (size_t)s->nb * 512 * sizeof(double);
-        }
       }
       M.nb = gl->nblocks();
       M.h = gl->h;
@@ -215,6 +211,7 @@ void mg_destroy(Sim *s) {
 static void mg_smooth(const MGLevel &M, double **xa, double **xb, const double *rhs, int launches, int sweeps, bool from_zero) {
   const GridDev g = level_gdev(M);
   const dim3 G(launch_groups(g)), B(256);
+  ProfileScope ps("mg_smooth");
   for (int i = 0; i < launches; ++i) {
     if (from_zero && i == 0) hipLaunchKernelGGL(k_mg_smooth<true>, G, B, 0, stream(), g, (const double *)nullptr, rhs, *xb, sweeps);
     else hipLaunchKernelGGL(k_mg_smooth<false>, G, B, 0, stream(), g, (const double *)*xa, rhs, *xb, sweeps);
@@ -230,7 +227,6 @@ int mg_vcycle(Sim *s, const double *in, double *out) {
   if (rc) return rc;
   Multigrid &mg = *reinterpret_cast<Multigrid *>(s->mg);
   const int L = (int)mg.lev.size() - 1;
-  ProfileScope ps("poisson_multigrid");
   const int nu = 2, sw = 2;  // smoothing launches before / after the coarse-grid correction, sweeps per launch
   std::vector<double *> xa(L + 1), xb(L + 1);  // xa[l]: where the level's iterate currently lives
   std::vector<const double *> rhs(L + 1);
@@ -239,22 +235,26 @@ int mg_vcycle(Sim *s, const double *in, double *out) {
     xb[l] = mg.lev[l].x2;
     rhs[l] = l == L ? in : mg.lev[l].b;
   }
-  if (L == 0) {
-    CUP3D_HIP(hipMemcpyAsync(mg.lev[0].b, in, (size_t)s->nb * 512 * sizeof(double), hipMemcpyDeviceToDevice, stream()));
-    rhs[0] = mg.lev[0].b;
-  }
+
   for (int l = L; l >= 1; --l) {  // downward leg
     mg_smooth(mg.lev[l], &xa[l], &xb[l], rhs[l], nu, sw, true);
     const GridDev g = level_gdev(mg.lev[l]);
+    ProfileScope ps("mg_residual_restrict");
     hipLaunchKernelGGL(k_mg_residual_restrict, dim3(launch_groups(g)), dim3(256), 0, stream(), g, (const double *)xa[l], rhs[l], (const int32_t *)mg.lev[l].d_parent,
                        mg.lev[l - 1].b);
   }
-  hipLaunchKernelGGL(k_mg_remove_mean, dim3(1), dim3(256), 0, stream(), mg.lev[0].b, (long)mg.lev[0].nb * 512);  // coarsest level
+  // coarsest level.  Its right-hand side loses its mean (the all-Neumann operator is singular) -- except in a ONE-level hierarchy, where
+  // that would make the whole M^-1 singular (it would annihilate the constant component of every input and BiCGSTAB could never
+  // reduce the residual along it); there the sweeps just carry a multiple of mean(b) along, a fixed linear map like the rest.
+  if (L > 0) hipLaunchKernelGGL(k_mg_remove_mean, dim3(1), dim3(256), 0, stream(), mg.lev[0].b, (long)mg.lev[0].nb * 512);
   if (mg.lev[0].nb == 1) mg_smooth(mg.lev[0], &xa[0], &xb[0], rhs[0], 1, 64, true);
   else mg_smooth(mg.lev[0], &xa[0], &xb[0], rhs[0], 16, 4, true);
   for (int l = 1; l <= L; ++l) {  // upward leg
-    hipLaunchKernelGGL(k_mg_prolong_add, dim3((unsigned)mg.lev[l].nb), dim3(256), 0, stream(), (int)mg.lev[l].nb, xa[l], (const int32_t *)mg.lev[l].d_parent,
-                       (const double *)xa[l - 1]);
+    {
+      ProfileScope ps("mg_prolong_add");
+      hipLaunchKernelGGL(k_mg_prolong_add, dim3((unsigned)mg.lev[l].nb), dim3(256), 0, stream(), (int)mg.lev[l].nb, xa[l], (const int32_t *)mg.lev[l].d_parent,
+                         (const double *)xa[l - 1]);
+    }
     mg_smooth(mg.lev[l], &xa[l], &xb[l], rhs[l], nu, sw, false);
   }
   if (xa[L] != out)  // an odd number of buffer swaps on the finest level cannot happen with nu + nu launches, but stay safe
