@@ -423,3 +423,65 @@ def test_adaptive_loop_on_three_ranks_equals_one_rank():
             assert np.array_equal(got[n][r][2], tab[ow == r]), (n, r)       # each rank holds its share, in the global order
             v[ow == r] = got[n][r][3]
         assert np.array_equal(v, vref), n
+
+
+@pytest.mark.parametrize("nranks", [4, 8])
+def test_adapted_mesh_of_thousands_of_blocks_over_ranks(nranks):
+    """A three-level mesh of a few thousand blocks built by the device's own adaptMesh around a compact vortex (the shape of
+    `bench.py --amr`, one size down), then spread over 4 / 8 ranks in contiguous runs of the m_vInfo order: one full step -- advect-diffuse
+    bit-exact against the one-rank device run, projection at tight tolerance to 1e-6 -- with send lists of hundreds of ghost blocks and
+    face-flux arrays per rank."""
+    ext, lmax, base = 2 * np.pi, 6, 3
+    kw = dict(bpdx=1, bpdy=1, bpdz=1, levelMax=lmax, levelStart=base, extent=ext, nu=0.002, BC_x="wall", BC_y="periodic", BC_z="freespace",
+              poissonTol=1e-12, poissonTolRel=1e-10)
+    sim = cu.SimulationData(**kw)
+    g = sim.grid
+    ax = np.arange(8) + 0.5
+    X = (g.index[:, 0, None] * 8 + ax[None, :])[:, None, None, :] * g.h
+    Y = (g.index[:, 1, None] * 8 + ax[None, :])[:, None, :, None] * g.h
+    Z = (g.index[:, 2, None] * 8 + ax[None, :])[:, :, None, None] * g.h
+    gss = np.exp(-((X - 2.6) ** 2 + (Y - 3.1) ** 2 + (Z - 3.4) ** 2) / 0.6)
+    sim.upload("vel", np.ascontiguousarray(np.stack([-(Y - 3.1) * gss, (X - 2.6) * gss, 0.3 * gss + 0 * X], axis=-1)))
+    S = cu.Simulation(sim)
+    for _ in range(2):
+        cu.ComputeVorticity(S.sim)(0)
+        w = S.sim.download("tmpV")
+        linf = np.sqrt((w ** 2).sum(axis=-1)).reshape(S.sim.nblocks, -1).max(axis=1)
+        S.adaptMesh(float(np.quantile(linf, 0.7)), -1.0)
+    one = S.sim
+    t = one.grid.tables
+    nb = one.nblocks
+    assert nb > 2000 and len(set(t[:, 0].tolist())) == 3
+    vel0, dt = one.download("vel"), 0.01
+    cu.AdvectionDiffusion(one)(dt)
+    adv_ref = one.download("vel")
+    one.step = 5
+    cu.PressureProjection(one)(dt)
+    vel_ref, pres_ref = one.download("vel"), one.download("pres")
+    corr = np.abs(vel_ref - adv_ref).max()
+    mesh = cu.operators.Grid((1, 1, 1), lmax, 0, ext, ("wall", "periodic", "freespace"), leaves=(t[:, 0].astype(np.int32), t[:, 1].copy()))
+    owner = (np.arange(nb) * nranks // nb).astype(np.int32)
+    got_adv, got_vel, got_pres = np.zeros_like(vel0), np.zeros_like(vel0), np.zeros_like(pres_ref)
+    its = [None] * nranks
+    kw.pop("levelStart")
+    with VirtualComm(nranks):
+        views = [mesh.rank_view(owner, r, nranks) for r in range(nranks)]
+        sims = [cu.SimulationData(levelStart=0, view=views[r], **kw) for r in range(nranks)]
+        assert min(v.nghost for v in views) > 100
+
+        def rank(r):
+            s, mine = sims[r], views[r].global_slot[:views[r].nlocal]
+            s.upload("vel", vel0[mine])
+            cu.AdvectionDiffusion(s)(dt)
+            got_adv[mine] = s.download("vel")
+            s.step = 5
+            res = cu.PressureProjection(s)(dt)
+            its[r] = res.iterations
+            got_vel[mine], got_pres[mine] = s.download("vel"), s.download("pres")
+
+        run_ranks(rank, nranks)
+        del sims, views
+    assert np.array_equal(got_adv, adv_ref)
+    assert len(set(its)) == 1
+    assert np.abs(got_pres - pres_ref).max() <= 1e-6 * np.abs(pres_ref).max()
+    assert np.abs(got_vel - vel_ref).max() <= 1e-6 * corr
