@@ -195,7 +195,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--size", type=int, default=512, help="cells per side (power of two >= 16)")
+    ap.add_argument("--size", type=int, default=512, help="cells per side (a multiple of 8; 512 = the BASELINE workload, 768 = the largest that leaves room on one 288 GB GPU)")
     ap.add_argument("--cpu-size", type=int, default=256, help="cells per side of the CPU-baseline sample (512 needs ~35 GB and minutes per step)")
     ap.add_argument("--cpu-steps", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=32,
@@ -251,11 +251,13 @@ def main():
         raw = (C.c_ubyte * 128)(*idbuf.cpu().tolist())
         check(lib().cup3d_comm_init(rank, world, raw))
 
-    level = int(round(np.log2(a.size // 8)))
-    assert 8 << level == a.size, "--size must be 8 * 2^k"
+    nb1 = a.size // 8
+    assert nb1 >= 2 and 8 * nb1 == a.size, "--size must be a multiple of 8"
+    level = (nb1 & -nb1).bit_length() - 1  # blocks per side = bpd * 2^level with the smallest base grid (512: 1 x 2^6; 768: 3 x 2^5)
+    bpd = nb1 >> level
     ext = 2 * np.pi
     bc = "periodic" if a.stencil_only else "wall"
-    sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=level + 1, levelStart=level, extent=ext, nu=a.nu, CFL=0.3,
+    sim = cu.SimulationData(bpdx=bpd, bpdy=bpd, bpdz=bpd, levelMax=level + 1, levelStart=level, extent=ext, nu=a.nu, CFL=0.3,
                             BC_x=bc, BC_y=bc, BC_z=bc, uMax_forced=1.0, rampup=0, rank=rank, nranks=world, blockSolver=a.block_solver,
                             implicitDiffusion=a.implicit_diffusion)
     sim.upload("vel", taylor_green_blocks(sim.grid, [ext] * 3, 1.0))
@@ -276,6 +278,7 @@ def main():
             diff_iters.append(sum(r.iterations for r in adv.last_diffusion))
 
     def fence():
+        torch.cuda.synchronize()  # the library's RCCL kernels are done before torch's communicator is used: two communicators never overlap
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
