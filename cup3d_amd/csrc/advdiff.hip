@@ -501,9 +501,11 @@ static int advdiff_stage(Sim *s, int rk, double dt, double nu, const double uinf
     a.beta = beta[rk];
     if (s->grid->multilevel) {
       a.alpha = alpha[rk];  // per-block h: divided in the kernel
-      GridDev g = s->gdev();
-      const dim3 G(launch_groups(g));
-      {
+      for (int pass = 0; pass < (split ? 2 : 1); ++pass) {  // rank views: inner blocks while the ghost blocks travel, then the rest
+        GridDev g = split ? s->gdev(pass == 1, pass == 0) : s->gdev();
+        if (pass == 1 && (rc = halo_finish(s))) return rc;
+        if (g.nblocks == 0) continue;
+        const dim3 G(launch_groups(g));
         ProfileScope ps("advdiff_stage");
         if (rk == 0) hipLaunchKernelGGL((k_advdiff<true, 2, 0, true>), G, dim3(256), 0, stream(), g, a);
         else hipLaunchKernelGGL((k_advdiff<false, 2, 0, true>), G, dim3(256), 0, stream(), g, a);

@@ -601,20 +601,21 @@ __global__ void __launch_bounds__(256) k_compress_blocks(const int32_t *__restri
 }
 
 // ---- host side
-int amr_fill_ghosts(Sim *s, const double *field, int nc, int w, double *slabs) {
-  const Grid *g = s->grid;
+int amr_fill_ghosts(Sim *s, const double *field, int nc, int w, double *slabs, int part) {
   AmrDev a{s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_nbr, s->d_index, nc == 1 ? s->scalar_bc_dir : -1};
   ProfileScope ps("amr_ghosts");
-  if (s->n_restrict) {
-    if (w == 3) hipLaunchKernelGGL(k_ghost_restrict<3>, dim3(s->n_restrict), dim3(64), 0, stream(), a, s->d_restrict_list, field, nc, slabs);
-    else hipLaunchKernelGGL(k_ghost_restrict<1>, dim3(s->n_restrict), dim3(64), 0, stream(), a, s->d_restrict_list, field, nc, slabs);
+  // both lists hold the faces of inner blocks first (sim_build): a rank view produces those while its ghost blocks travel
+  const unsigned r0 = part == 2 ? s->n_restrict_inner : 0, r1 = part == 1 ? s->n_restrict_inner : s->n_restrict;
+  const unsigned p0 = part == 2 ? s->n_prolong_inner : 0, p1 = part == 1 ? s->n_prolong_inner : s->n_prolong;
+  if (r1 > r0) {
+    if (w == 3) hipLaunchKernelGGL(k_ghost_restrict<3>, dim3(r1 - r0), dim3(64), 0, stream(), a, s->d_restrict_list + r0, field, nc, slabs);
+    else hipLaunchKernelGGL(k_ghost_restrict<1>, dim3(r1 - r0), dim3(64), 0, stream(), a, s->d_restrict_list + r0, field, nc, slabs);
   }
-  if (s->n_prolong) {
-    if (w == 3) hipLaunchKernelGGL(k_ghost_prolong<3>, dim3(s->n_prolong), dim3(64), 0, stream(), a, s->d_prolong_list, field, nc, slabs);
-    else hipLaunchKernelGGL(k_ghost_prolong<1>, dim3(s->n_prolong), dim3(64), 0, stream(), a, s->d_prolong_list, field, nc, slabs);
+  if (p1 > p0) {
+    if (w == 3) hipLaunchKernelGGL(k_ghost_prolong<3>, dim3(p1 - p0), dim3(64), 0, stream(), a, s->d_prolong_list + p0, field, nc, slabs);
+    else hipLaunchKernelGGL(k_ghost_prolong<1>, dim3(p1 - p0), dim3(64), 0, stream(), a, s->d_prolong_list + p0, field, nc, slabs);
   }
   CUP3D_HIP(hipGetLastError());
-  (void)g;
   return CUP3D_OK;
 }
 

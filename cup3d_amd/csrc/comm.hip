@@ -195,9 +195,9 @@ static int view_transfer(Sim *s, double *dst, size_t per, const std::vector<int6
   return CUP3D_OK;
 }
 
-int view_exchange_blocks(Sim *s, double *field, int nc) {
+// begin: pack + transfer enqueued (on the communication stream with RCCL; ev_h2 marks the arrival); finish: the compute stream waits
+static int view_exchange_blocks_begin(Sim *s, double *field, int nc) {
   const Grid *g = s->grid;
-  if (g->n_local < 0 || g->nranks == 1) return CUP3D_OK;
   ProfileScope ps("ghost_block_exchange");
   hipStream_t st = g_vcomm ? stream() : s->comm_stream;
   if (st != stream()) {
@@ -209,11 +209,19 @@ int view_exchange_blocks(Sim *s, double *field, int nc) {
   CUP3D_HIP(hipGetLastError());
   int rc = view_transfer(s, field + (size_t)g->n_local * nc * 512, (size_t)nc * 512, g->send_block_count, g->recv_block_count, false);
   if (rc) return rc;
-  if (st != stream()) {
-    CUP3D_HIP(hipEventRecord(s->ev_h2, st));
-    CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
-  }
+  if (st != stream()) CUP3D_HIP(hipEventRecord(s->ev_h2, st));
   return CUP3D_OK;
+}
+static int view_exchange_blocks_finish(Sim *s) {
+  if (!g_vcomm) CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
+  return CUP3D_OK;
+}
+int view_exchange_blocks(Sim *s, double *field, int nc) {
+  const Grid *g = s->grid;
+  if (g->n_local < 0 || g->nranks == 1) return CUP3D_OK;
+  int rc = view_exchange_blocks_begin(s, field, nc);
+  if (rc) return rc;
+  return view_exchange_blocks_finish(s);
 }
 
 int view_exchange_flux(Sim *s, int nfc) {
@@ -311,10 +319,14 @@ static int slab_transfer(Sim *s, size_t per_face, hipStream_t st) {
 // for the slabs before the boundary blocks are launched.
 int halo_begin(Sim *s, const double *field, int nc, int w) {
   const Grid *g = s->grid;
-  if (g->multilevel) {
-    int rc = view_exchange_blocks(s, const_cast<double *>(field), nc);  // no-op unless the mesh is spread over ranks
+  if (g->multilevel) {  // coarse/fine ghost slabs take the halo slabs' place
+    if (g->n_local < 0 || g->nranks == 1) return amr_fill_ghosts(s, field, nc, w, s->halo_recv);
+    // a rank view: the ghost blocks travel on the communication stream while the slabs of the inner blocks' faces are produced and
+    // the caller launches its kernel on the inner blocks (gdev(inner_only)); halo_finish() waits and produces the rest
+    int rc = view_exchange_blocks_begin(s, const_cast<double *>(field), nc);
     if (rc) return rc;
-    return amr_fill_ghosts(s, field, nc, w, s->halo_recv);  // coarse/fine ghost slabs take the halo slabs' place
+    s->pending_fill.field = field; s->pending_fill.nc = nc; s->pending_fill.w = w; s->pending_fill.slabs = s->halo_recv; s->pending_fill.bc_dir = s->scalar_bc_dir; s->pending_fill.open = true;
+    return amr_fill_ghosts(s, field, nc, w, s->halo_recv, 1);
   }
   if (g->nranks == 1 || (g_virtual_ranks && !g_vcomm)) return CUP3D_OK;
   const size_t per_face = (size_t)nc * w * 64;
@@ -334,7 +346,18 @@ int halo_begin(Sim *s, const double *field, int nc, int w) {
   return CUP3D_OK;
 }
 int halo_finish(Sim *s) {
-  if (s->grid->multilevel || s->grid->nranks == 1 || g_virtual_ranks || g_vcomm) return CUP3D_OK;
+  if (s->grid->multilevel) {
+    if (!s->pending_fill.open) return CUP3D_OK;
+    s->pending_fill.open = false;
+    int rc = view_exchange_blocks_finish(s);
+    if (rc) return rc;
+    const int dir = s->scalar_bc_dir;
+    s->scalar_bc_dir = s->pending_fill.bc_dir;  // the Helmholtz operators set it around halo_begin only
+    rc = amr_fill_ghosts(s, s->pending_fill.field, s->pending_fill.nc, s->pending_fill.w, s->pending_fill.slabs, 2);
+    s->scalar_bc_dir = dir;
+    return rc;
+  }
+  if (s->grid->nranks == 1 || g_virtual_ranks || g_vcomm) return CUP3D_OK;
   CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
   return CUP3D_OK;
 }

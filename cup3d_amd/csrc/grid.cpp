@@ -375,9 +375,28 @@ std::unique_ptr<Grid> Grid::rank_view(const int32_t *owner, int rank_, int nrank
       V.nbr[6 * i + f] = x >= kNbrHalo ? kNbrHalo + face_to_view[x - kNbrHalo] : (x >= 0 ? to_view[x] : x);
     }
   }
-  V.inner.resize(V.n_local);
-  for (int64_t i = 0; i < V.n_local; ++i) V.inner[i] = (int32_t)i;
-  V.boundary.clear();
+  // inner / boundary split (the reference's inner_blocks / halo_blocks, main.cpp:2196-2199): a local block is a boundary block when
+  // anything its tables lead to lives in a ghost slot -- a same-level or coarser neighbour in one of the 27 directions, or a finer
+  // leaf behind one of its faces (its ghost slab is restricted from that leaf) -- and only those wait for the exchange
+  {
+    std::vector<char> remote((size_t)V.n_local, 0);
+    for (int64_t i = 0; i < V.n_local; ++i)
+      for (int c = 0; c < 27 && !remote[i]; ++c) {
+        const int32_t x = V.nbr27[27 * i + c];
+        const int32_t sl = x >= kNbrCoarser ? x - kNbrCoarser : x;
+        if (sl >= V.n_local) remote[i] = 1;
+      }
+    for (int64_t e = 0; e < V.n_local_faces; ++e) {
+      if (V.amr_faces[2 * e + 1] != 1) continue;
+      for (int B = 0; B < 4; ++B) {
+        const int32_t fe = V.amr_fine[4 * e + B];
+        if (fe >= V.n_local_faces || (fe >= 0 && V.amr_faces[2 * fe] / 6 >= V.n_local)) remote[V.amr_faces[2 * e] / 6] = 1;
+      }
+    }
+    V.inner.clear();
+    V.boundary.clear();
+    for (int64_t i = 0; i < V.n_local; ++i) (remote[i] ? V.boundary : V.inner).push_back((int32_t)i);
+  }
   V.total_blocks = nb;
   // exchange plans: what I receive from p is the (p-owned) part of my ghost list; what I send to p is the (me-owned) part of p's
   V.recv_block_count.assign(nranks_, 0);

@@ -304,7 +304,14 @@ static int sim_build(Sim *s, const Grid *g) {
     // flux arrays arrive from their owners)
     const int64_t nlf = view ? g->n_local_faces : g->n_amr_faces();
     std::vector<int32_t> lr, lp;
-    for (int64_t e = 0; e < nlf; ++e) (g->amr_faces[2 * e + 1] ? lr : lp).push_back((int32_t)e);
+    // the faces of inner blocks first: their slabs are produced while the ghost blocks of a view are still travelling (halo_begin)
+    std::vector<char> waits(std::max<size_t>(nb, 1), 0);
+    if (view) for (int32_t b : g->boundary) waits[(size_t)b] = 1;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int64_t e = 0; e < nlf; ++e)
+        if (waits[(size_t)(g->amr_faces[2 * e] / 6)] == pass) (g->amr_faces[2 * e + 1] ? lr : lp).push_back((int32_t)e);
+      if (pass == 0) { s->n_restrict_inner = (unsigned)lr.size(); s->n_prolong_inner = (unsigned)lp.size(); }
+    }
     s->n_restrict = (unsigned)lr.size();
     s->n_prolong = (unsigned)lp.size();
     if ((rc = up(&s->d_amr_faces, g->amr_faces)) || (rc = up(&s->d_amr_fine, g->amr_fine)) || (rc = up(&s->d_nbr27, g->nbr27)) ||

@@ -97,6 +97,8 @@ struct Sim {
   int32_t *d_amr_faces = nullptr, *d_amr_fine = nullptr, *d_nbr27 = nullptr, *d_index = nullptr;
   int32_t *d_restrict_list = nullptr, *d_prolong_list = nullptr, *d_fix_list[3] = {nullptr, nullptr, nullptr};
   unsigned n_restrict = 0, n_prolong = 0;
+  unsigned n_restrict_inner = 0, n_prolong_inner = 0;  // leading entries of the two lists that belong to inner blocks (rank views)
+  struct { const double *field = nullptr; int nc = 0, w = 0, bc_dir = -1; double *slabs = nullptr; bool open = false; } pending_fill;  // halo_begin -> halo_finish
   int32_t *d_send_blocks = nullptr, *d_send_flux = nullptr;  // rank views: exchange plans (comm.hip)
   unsigned char *d_raw_mask = nullptr;  // [nb], see GridDev::raw
   int32_t *d_raw_list = nullptr;        // the blocks with raw_mask set
@@ -134,7 +136,7 @@ void vcomm_unregister(Sim *s);
 
 // multi-level meshes: ghost slabs of every interface face of `field` for a w-deep star stencil -> slabs;
 // flux correction of `out` (out_nc components per block, the first nfc corrected) from s->d_flux
-int amr_fill_ghosts(Sim *s, const double *field, int ncomp, int w, double *slabs);
+int amr_fill_ghosts(Sim *s, const double *field, int ncomp, int w, double *slabs, int part = 0);  // part 0: every face, 1: inner blocks' faces, 2: boundary blocks' faces
 int amr_flux_fix(Sim *s, int nfc, double *out, int out_nc);
 
 // kernels' launchers shared across translation units

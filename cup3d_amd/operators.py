@@ -140,6 +140,7 @@ class RankView:
         check(lib().cup3d_grid_tables(h, self.tables, self.geom))
         self.index = self.tables[:, 2:5]
         self.h = mesh.h
+        self.ninner = int(lib().cup3d_grid_ninner(h))  # local blocks whose tables lead to no ghost: computed while the ghost blocks travel
         sz = (C.c_long * 6)()
         check(lib().cup3d_grid_view_sizes(h, sz))
         self.nlocal, self.nghost, self.nfaces_local, self.nfaces_ghost, nsb, nsf = (int(v) for v in sz)

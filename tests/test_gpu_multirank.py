@@ -468,6 +468,7 @@ def test_adapted_mesh_of_thousands_of_blocks_over_ranks(nranks):
         views = [mesh.rank_view(owner, r, nranks) for r in range(nranks)]
         sims = [cu.SimulationData(levelStart=0, view=views[r], **kw) for r in range(nranks)]
         assert min(v.nghost for v in views) > 100
+        assert all(0 < v.ninner < v.nlocal for v in views)   # both passes of every stencil launch run: inner blocks, then the ones that wait
 
         def rank(r):
             s, mine = sims[r], views[r].global_slot[:views[r].nlocal]

@@ -422,6 +422,15 @@ def test_rank_views_of_a_multilevel_mesh(golden_dir, nranks):
                         used_slots.update(int(v.faces[x, 0]) // 6 for x in v.fine[e])
                 else:
                     assert slot >= v.nlocal and v.faces[e, 1] == 0
+            # inner blocks (computed while the ghost blocks travel): nothing their tables lead to is a ghost
+            waits = np.zeros(v.nlocal, dtype=bool)
+            for i in range(v.nlocal):
+                sl = np.where(v.nbr27[i] >= cu.capi.NBR_COARSER, v.nbr27[i] - cu.capi.NBR_COARSER, v.nbr27[i])
+                waits[i] = (sl >= v.nlocal).any()
+            for e in range(v.nfaces_local):
+                if v.faces[e, 1] == 1 and any(x >= v.nfaces_local or v.faces[x, 0] // 6 >= v.nlocal for x in v.fine[e]):
+                    waits[int(v.faces[e, 0]) // 6] = True
+            assert v.ninner == int((~waits).sum()) and 0 <= v.ninner < v.nlocal
             assert set(range(v.nlocal, v.nlocal + v.nghost)) <= used_slots            # no superfluous ghost block
             assert set(range(v.nfaces_local, len(v.faces))) <= used_faces             # ... or ghost face
             assert max(used_slots) < v.nlocal + v.nghost
