@@ -15,6 +15,7 @@
 // Elementwise updates keep the reference's association (no FMA contraction); only the
 // summation ORDER of the dot products and of the block-CG inner products differs
 // from the CPU, so pressure agrees to solver tolerance, not bitwise.
+#include <atomic>
 #include <cmath>
 
 #include "sim.hpp"
@@ -664,17 +665,25 @@ __global__ void __launch_bounds__(64) k_loop2_cg(GridDev g, Vecs V, Loop2Args a,
   cg_block<FMA, false, EV>(g, slot, r, V.v[WHAT], block_sums, 0.0, 0.0, iters_out, P);  // what = M^-1 w, 14548
 }
 
-// K sums of nb per-block values each ([K][nb]) finished in one launch: 64 workgroups, the last one to arrive totals the partials
-template <int K>
-__global__ void __launch_bounds__(256) k_sums_finish(const double *__restrict__ v, long nb, RedOut ro) {
-  double acc[K];
+// K sums of nb per-block values each ([K][nb]) finished in one launch: 64 workgroups, the last one to arrive totals the partials.
+// MEAN: one more sum rides along -- the per-block sums of zhat h^3 / what h^3 the fused kernel left in mean_src; the total lands in
+// ro.out[K], where the LHS application that follows takes its mean-constraint row from (no k_mean_finish launch, and over ranks no
+// second all-reduce: the total travels with the dot products)
+template <int K, bool MEAN>
+__global__ void __launch_bounds__(256) k_sums_finish(const double *__restrict__ v, long nb, RedOut ro, const double *__restrict__ mean_src) {
+  double acc[K + (MEAN ? 1 : 0)];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     double t = 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (long)gridDim.x * 256) t += v[(size_t)k * nb + i];
     acc[k] = t;
   }
-  grid_sum_finish<K>(acc, ro);
+  if (MEAN) {
+    double t = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (long)gridDim.x * 256) t += mean_src[i];
+    acc[K] = t;
+  }
+  grid_sum_finish<K + (MEAN ? 1 : 0)>(acc, ro);
 }
 
 // b = r = rhs, x = pres   (main.cpp:14408-14415)
@@ -809,7 +818,13 @@ struct Reducer {
   // where the kernel that ends with grid_sum_finish puts its totals: d_red always; the pinned host mirror directly when no
   // all-reduce has to run in between
   bool direct() const { return !(s->grid->nranks > 1 || (debug_option("force_allreduce") && comm())); }
-  RedOut out() const { return RedOut{s->d_partials, s->d_counters, s->d_red, direct() ? s->h_red_dev : nullptr}; }
+  // direct: the kernel also raises a pinned sequence word after the totals, and wait() spins on it -- a few microseconds instead of
+  // the wake-up latency of hipEventSynchronize, which at <= 256^3 per GPU (the 8-GPU share of the 512^3 workload) is what the LHS
+  // enqueued behind the reduction no longer hides
+  RedOut out() {
+    if (!direct()) return RedOut{s->d_partials, s->d_counters, s->d_red, nullptr, nullptr, 0u};
+    return RedOut{s->d_partials, s->d_counters, s->d_red, s->h_red_dev, reinterpret_cast<unsigned *>(s->h_red_dev + 16), ++s->red_seq};
+  }
   // the k totals are in d_red when the work enqueued so far completes: all-reduce (communication stream), start the read-back
   int begin(int k) {
     if (direct()) {
@@ -830,6 +845,20 @@ struct Reducer {
     return CUP3D_OK;
   }
   int wait() {
+    if (direct()) {
+      const volatile unsigned *flag = reinterpret_cast<const volatile unsigned *>(s->h_red + 16);
+      const unsigned want = s->red_seq;
+      for (unsigned spin = 1; *flag != want; ++spin) {
+        __builtin_ia32_pause();
+        if ((spin & 0x3fff) == 0) {  // every ~16k polls: has the stream finished (or failed) without raising the flag?
+          const hipError_t e = hipEventQuery(s->ev_a);
+          if (e == hipSuccess) break;  // completed: the totals are in place (an event wait makes them visible as well)
+          if (e != hipErrorNotReady) return hip_fail(e, "hipEventQuery", __FILE__, __LINE__);
+        }
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return CUP3D_OK;
+    }
     CUP3D_HIP(hipEventSynchronize(s->ev_a));
     return CUP3D_OK;
   }
@@ -906,7 +935,13 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       }
       s->sums_of = want_sums ? V.v[ZHAT] : nullptr;
       ProfileScope ps("bicgstab_dots_finish");
-      hipLaunchKernelGGL(k_sums_finish<2>, dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, red.out());
+      if (want_sums) {
+        hipLaunchKernelGGL((k_sums_finish<2, true>), dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, red.out(), sums);
+        s->mean_total_of = V.v[ZHAT];
+        s->mean_total = s->d_red + 2;
+      } else {
+        hipLaunchKernelGGL((k_sums_finish<2, false>), dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, red.out(), nullptr);
+      }
     } else if (k % 50 != 0) {
       ProfileScope ps("bicgstab_loop1");
       if (!debug_option("loops_no_nt")) LAUNCH_VEC(k_loop1<true>, V, N, alpha, beta, omega, red.out());
@@ -916,7 +951,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       TRY(LHS(PHAT, S_)); TRY(PRE(S_, SHAT)); TRY(LHS(SHAT, Z_));
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_loop1_tail, V, N, alpha, red.out()); }
     }
-    TRY(red.begin(2));                       // MPI_Iallreduce(2), 14486
+    TRY(red.begin(fused_now && want_sums ? 3 : 2));  // MPI_Iallreduce(2), 14486 (+ the mean-constraint sum of zhat, 9295)
     if (!fused_now) TRY(PRE(Z_, ZHAT));      // overlapped with the reduction read-back, 14488-14489
     TRY(LHS(ZHAT, V_));
     TRY(red.wait());
@@ -930,7 +965,13 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       }
       s->sums_of = want_sums ? V.v[WHAT] : nullptr;
       ProfileScope ps("bicgstab_dots_finish");
-      hipLaunchKernelGGL(k_sums_finish<7>, dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, red.out());
+      if (want_sums) {
+        hipLaunchKernelGGL((k_sums_finish<7, true>), dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, red.out(), sums);
+        s->mean_total_of = V.v[WHAT];
+        s->mean_total = s->d_red + 7;
+      } else {
+        hipLaunchKernelGGL((k_sums_finish<7, false>), dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, red.out(), nullptr);
+      }
     } else if (k % 50 != 0) {
       ProfileScope ps("bicgstab_loop2");
       if (!debug_option("loops_no_nt")) LAUNCH_VEC(k_loop2<true>, V, N, alpha, omega, red.out());
@@ -945,7 +986,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       TRY(PRE(R_, RHAT)); TRY(LHS(RHAT, W_));
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots7, V, N, red.out()); }
     }
-    TRY(red.begin(7));                       // MPI_Iallreduce(7), 14546
+    TRY(red.begin(fused_now && want_sums ? 8 : 7));  // MPI_Iallreduce(7), 14546 (+ the mean-constraint sum of what)
     if (!fused_now) TRY(PRE(W_, WHAT));      // 14548-14549
     TRY(LHS(WHAT, T_));
     TRY(red.wait());

@@ -33,6 +33,12 @@ static std::vector<std::string> g_prof_names;
 static std::vector<long> g_prof_launches;
 static std::vector<double> g_prof_ms;
 static std::vector<ProfileRec> g_prof_open;
+static std::vector<hipEvent_t> g_event_pool;  // events are reused: creating two per launch costs more host time than the launch
+static hipEvent_t pooled_event() {
+  if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
 
 static void profile_drain() {
   for (auto &r : g_prof_open) {
@@ -41,8 +47,8 @@ static void profile_drain() {
       g_prof_ms[r.idx] += ms;
       g_prof_launches[r.idx] += 1;
     }
-    hipEventDestroy(r.a);
-    hipEventDestroy(r.b);
+    g_event_pool.push_back(r.a);
+    g_event_pool.push_back(r.b);
   }
   g_prof_open.clear();
 }
@@ -56,13 +62,13 @@ ProfileScope::ProfileScope(const char *name) : idx(-1), start(nullptr) {
     g_prof_launches.push_back(0);
     g_prof_ms.push_back(0);
   }
-  if (hipEventCreate(&start) != hipSuccess) { idx = -1; return; }
+  if (!(start = pooled_event())) { idx = -1; return; }
   hipEventRecord(start, g_stream);
 }
 ProfileScope::~ProfileScope() {
   if (idx < 0) return;
-  hipEvent_t stop;
-  if (hipEventCreate(&stop) != hipSuccess) return;
+  hipEvent_t stop = pooled_event();
+  if (!stop) { g_event_pool.push_back(start); return; }
   hipEventRecord(stop, g_stream);
   g_prof_open.push_back({idx, start, stop});
   if (g_prof_open.size() > 4096) profile_drain();
@@ -285,7 +291,8 @@ static int sim_build(Sim *s, const Grid *g) {
   A(s->pres, nv * 512) A(s->lhs, nv * 512) A(s->chi, nv * 512) A(s->pold, nv * 512)
   s->max_groups = 4096;
   A(s->d_partials, (size_t)s->max_groups * 8 + nb) A(s->d_red, 16)
-  CUP3D_HIP(hipHostMalloc((void **)&s->h_red, 16 * sizeof(double), hipHostMallocDefault));
+  CUP3D_HIP(hipHostMalloc((void **)&s->h_red, 17 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));  // 16 totals + the sequence word of Reducer
+  memset(s->h_red, 0, 17 * sizeof(double));
   CUP3D_HIP(hipHostGetDevicePointer((void **)&s->h_red_dev, s->h_red, 0));
   CUP3D_HIP(hipMalloc((void **)&s->d_counters, 4 * sizeof(unsigned)));
   CUP3D_HIP(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned), g_stream));

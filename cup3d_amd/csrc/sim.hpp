@@ -96,6 +96,8 @@ struct Sim {
   // multi-level mesh tables (amr.hip); all nullptr / 0 on uniform grids
   int32_t *d_amr_faces = nullptr, *d_amr_fine = nullptr, *d_nbr27 = nullptr, *d_index = nullptr;
   int32_t *d_restrict_list = nullptr, *d_prolong_list = nullptr, *d_fix_list[3] = {nullptr, nullptr, nullptr};
+  const double *mean_total_of = nullptr, *mean_total = nullptr;  // the vector whose sum(p h^3) total is already in *mean_total (device)
+  unsigned red_seq = 0;  // last sequence number handed to a reduction kernel (Reducer, poisson.hip)
   unsigned n_restrict = 0, n_prolong = 0;
   unsigned n_restrict_inner = 0, n_prolong_inner = 0;  // leading entries of the two lists that belong to inner blocks (rank views)
   struct { const double *field = nullptr; int nc = 0, w = 0, bc_dir = -1; double *slabs = nullptr; bool open = false; } pending_fill;  // halo_begin -> halo_finish

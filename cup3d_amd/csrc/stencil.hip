@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256) k_vorticity(GridDev g, const double *__re
 // ---- KernelLHSPoisson (main.cpp:9205-9215) + the per-block partial of sum(p*h^3) that
 // ComputeLHS needs for the mean constraint (9283-9294)
 __global__ void __launch_bounds__(256) k_lhs(GridDev g, const double *__restrict__ p, const double *__restrict__ halo, double *__restrict__ out,
-                                             double *__restrict__ block_sums) {
+                                             double *__restrict__ block_sums, const double *__restrict__ avg, int corner_slot) {
   __shared__ double tile[kT];
   __shared__ double red[4];
   const int slot = block_slot(g);
@@ -123,6 +123,7 @@ __global__ void __launch_bounds__(256) k_lhs(GridDev g, const double *__restrict
     out[(size_t)slot * 512 + k * 256 + cell0] =
         h * (tile[b - 1] + tile[b + 1] + tile[b - 10] + tile[b + 10] + tile[b - kTP] + tile[b + kTP] - 6.0 * c[k]);
   }
+  if (avg && slot == corner_slot && cell0 == 0) out[(size_t)slot * 512] = avg[0];  // LHS(0,0,0) = avgP, 9299-9304 (the total is known already)
   if (g.flux) write_face_fluxes<1>(g, slot, [&](int, int in, int gh, int, int) { return h * (tile[in] - tile[gh]); });
   if (block_sums) {
     const double h3 = h * h * h;
@@ -365,20 +366,35 @@ int launch_lhs(Sim *s, const double *p, double *out, int mc) {
   double *block_sums = s->d_partials + (size_t)s->max_groups * 8;
   const bool have_sums = need_sum && s->sums_of == p;  // the block solve that produced p already summed it
   s->sums_of = nullptr;
+  // ... and the fused solver loop has even totalled those sums (k_sums_finish<K, true>) and, over ranks, all-reduced the total
+  // together with its dot products (Reducer::begin; ev_a marks the arrival)
+  const bool have_total = need_sum && s->mean_total_of == p;
+  const double *total = have_total ? s->mean_total : s->d_red + 8;
+  s->mean_total_of = nullptr;
+  const bool across = scalars_cross_ranks(s);
+  const int corner = s->grid->corner_slot;
+  // one rank, uniform grid: the kernel writes the constraint row itself (on a multi-level mesh the flux correction runs in between)
+  const bool row_in_kernel = have_total && !across && mc == 1 && corner >= 0 && !s->grid->multilevel;
   for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
     GridDev g = split ? s->gdev(pass == 1, pass == 0) : s->gdev();
     if (pass == 1 && (rc = halo_finish(s))) return rc;
     if (g.nblocks == 0) continue;
     ProfileScope ps("poisson_lhs");
-    hipLaunchKernelGGL(k_lhs, dim3(launch_groups(g)), dim3(256), 0, stream(), g, p, s->halo_recv, out, (need_sum && !have_sums) ? block_sums : nullptr);
+    hipLaunchKernelGGL(k_lhs, dim3(launch_groups(g)), dim3(256), 0, stream(), g, p, s->halo_recv, out, (need_sum && !have_sums && !have_total) ? block_sums : nullptr,
+                       row_in_kernel ? total : nullptr, corner);
   }
   CUP3D_HIP(hipGetLastError());
   if (s->grid->multilevel && (rc = amr_flux_fix(s, 1, out, 1))) return rc;  // compute(..., lhs) corrector, main.cpp:9298
   if (mc == 0) return CUP3D_OK;
-  const int corner = s->grid->corner_slot;
-  if (need_sum) {
+  if (need_sum && have_total) {
+    if (across) CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_a, 0));  // the all-reduced total (communication stream)
+    if (mc == 1 && corner >= 0 && !row_in_kernel) hipLaunchKernelGGL(k_lhs_corner, dim3(1), dim3(1), 0, stream(), out, p, total, corner, 1);
+    if (mc == 2) {
+      const double h = s->grid->h;
+      hipLaunchKernelGGL(k_lhs_add_mean, dim3(2048), dim3(256), 0, stream(), out, s->nb * 512L, total, h * h * h, s->d_hb);
+    }
+  } else if (need_sum) {
     ProfileScope ps("poisson_mean_sum");
-    const bool across = scalars_cross_ranks(s);
     double *corner_out = (!across && mc == 1 && corner >= 0) ? out + (size_t)corner * 512 : nullptr;
     hipLaunchKernelGGL(k_mean_finish, dim3(64), dim3(256), 0, stream(), block_sums, (int)s->nb, s->d_partials, s->d_counters + 1, s->d_red + 8, corner_out);
     if (across) {  // MPI_Iallreduce, main.cpp:9295 -- on the communication stream like every RCCL call; the fix-up below waits for it

@@ -85,6 +85,8 @@ struct RedOut {
   unsigned *counter;  // zero before the launch; reset by the last workgroup
   double *out;        // [K] device
   double *host;       // [K] pinned host memory mapped into the device, or nullptr
+  unsigned *flag;     // with `host`: pinned word that receives `seq` once the K totals are visible to the host (it spins on it)
+  unsigned seq;
 };
 template <int K>
 __device__ __forceinline__ void grid_sum_finish(double (&acc)[K], const RedOut &ro) {
@@ -113,7 +115,10 @@ __device__ __forceinline__ void grid_sum_finish(double (&acc)[K], const RedOut &
   }
   if (threadIdx.x == 0) {
     *ro.counter = 0;
-    if (ro.host) __threadfence_system();
+    if (ro.host) {
+      __threadfence_system();  // the totals (this thread's own stores) before the flag
+      if (ro.flag) __hip_atomic_store(ro.flag, ro.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
