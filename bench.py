@@ -411,8 +411,8 @@ def report(a, sim, prof, sec, iters, world, alt=None):
             e.update({"bound": "fp64", "achieved": round(tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_PEAK_TFLOPS, 4),
                       "hbm_frac": e["frac"], "cg_iterations_per_block": round(a.cg_iters_per_block, 2),
                       "note": ("one wavefront per 8^3 block, <= 100 CG iterations in registers; flops = 17/cell/CG-iteration x counted iterations "
-                               "(6 FMA + 5 add: 11 issue slots, so 17/22 = 0.77 of peak is the ceiling of this instruction mix); wave sums on the "
-                               "FP64 matrix pipe; HBM traffic = the algorithmic 16 B/cell (hbm_frac)")})
+                               "(6 FMA + 5 add: 11 issue slots, so 17/22 = 0.77 of peak is the ceiling of this instruction mix); wave sums by DPP row "
+                               "reductions (the FP64 matrix pipe was measured 12-20 % slower); HBM traffic = the algorithmic 16 B/cell (hbm_frac)")})
         kernels.append(e)
     with_roof = [k for k in kernels if "achieved" in k]
     dominant = with_roof[0] if with_roof else None
