@@ -205,6 +205,7 @@ def main():
     ap.add_argument("--block-solver", type=int, default=0, help="0: block CG as in the reference, 1: direct block solve, 5: multigrid V-cycle")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed region with the other block solver")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host<->device transfer measurement behind `pcie_inclusive`")
+    ap.add_argument("--no-profile", action="store_true", help="A/B: no per-kernel HIP events in the timed region (no roofline in the output)")
     ap.add_argument("--no-fuse", action="store_true", help="A/B: vector loops and block CG as separate launches (round-1 structure)")
     ap.add_argument("--implicit-diffusion", action="store_true",
                     help="-implicitDiffusion 1: AdvectionDiffusionImplicit (upwind advection + three Helmholtz solves) instead of the explicit RK3")
@@ -286,7 +287,7 @@ def main():
     for _ in range(a.warmup):
         one_step()
     iters.clear()
-    lib().cup3d_profile_enable(1)
+    lib().cup3d_profile_enable(0 if a.no_profile else 1)
     lib().cup3d_profile_reset()
     fence()
     t0 = time.perf_counter()
@@ -341,8 +342,9 @@ def main():
     if not a.stencil_only and not a.no_alt and not a.implicit_diffusion:
         # the same workload once more with the preconditioner M^-1 evaluated / chosen differently (cup3d_poisson_params.block_solver),
         # reported NEXT to the headline, never instead of it: the direct block solve (the reference's M, exact instead of by CG) and,
-        # on one GPU, a multigrid V-cycle in M's place (what BASELINE.json's north_star wording describes; the reference has none)
-        for solver in ([1, 5] if (a.block_solver == 0 and world == 1) else [1 - a.block_solver] if a.block_solver in (0, 1) else []):
+        # a multigrid V-cycle in M's place (what BASELINE.json's north_star wording describes; the reference has none; over several
+        # GPUs every rank cycles on its own blocks -- additive Schwarz, no message inside the preconditioner)
+        for solver in ([1, 5] if a.block_solver == 0 else [1 - a.block_solver] if a.block_solver in (0, 1) else []):
             sim.blockSolver = solver
             sim.upload("vel", taylor_green_blocks(sim.grid, [ext] * 3, 1.0))
             sim.fill("pres", 0.0)

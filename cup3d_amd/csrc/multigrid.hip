@@ -4,7 +4,8 @@
 // smoother / restrict / prolong ... red-black Gauss-Seidel smoother"; this file is that wording taken literally, behind the same
 // BiCGSTAB driver, the same operator A = h (sum6 - 6 p) (KernelLHSPoisson, 9205-9215), the same mean constraint and the same
 // stopping rule -- so the CONVERGED pressure is the reference's to solver tolerance (tests), while the iteration count drops
-// from O(150) to O(10) at 512^3.  bench.py reports it under `alt`, never as `value`.  Uniform one-rank grids.
+// from O(150) to O(10) at 512^3.  bench.py reports it under `alt_multigrid`, never as `value`.  Uniform grids; over several ranks each
+// rank cycles on its own blocks (additive Schwarz, see mg_setup).
 //
 // One application M^-1 r = one V(2,2)-cycle from a zero guess on the hierarchy of uniform block grids, level L (the solver's grid)
 // down to level 0 (the bpd[0] x bpd[1] x bpd[2] box of 8^3 blocks):
@@ -35,7 +36,10 @@ struct MGLevel {
 };
 struct Multigrid {
   std::vector<MGLevel> lev;  // [0] coarsest ... [L] finest
+  double *zeros = nullptr;   // ghost values behind faces owned by other ranks (see mg_setup); the x pointer itself on one rank
+  bool local = false;        // a rank-local hierarchy (several ranks)
   ~Multigrid() {
+    if (zeros) hipFree(zeros);
     for (size_t i = 0; i < lev.size(); ++i) {
       MGLevel &l = lev[i];
       if (l.grid && l.d_nbr) hipFree(l.d_nbr);
@@ -50,7 +54,8 @@ struct Multigrid {
 // `sweeps` red-black Gauss-Seidel sweeps of h (sum6 - 6 x) = b on one block, ghosts from the neighbours' xin (frozen);
 // ZERO: the incoming iterate is zero everywhere (first smoothing of a cycle): nothing is loaded but b
 template <bool ZERO>
-__global__ void __launch_bounds__(256) k_mg_smooth(GridDev g, const double *__restrict__ xin, const double *__restrict__ b, double *__restrict__ xout, int sweeps) {
+__global__ void __launch_bounds__(256) k_mg_smooth(GridDev g, const double *__restrict__ xin, const double *__restrict__ halo, const double *__restrict__ b,
+                                                   double *__restrict__ xout, int sweeps) {
   __shared__ double tile[kT];
   const int slot = block_slot(g);
   if (slot < 0) return;
@@ -61,7 +66,7 @@ __global__ void __launch_bounds__(256) k_mg_smooth(GridDev g, const double *__re
     for (int i = t; i < kT; i += 256) tile[i] = 0.0;
   } else {
     double c[2];
-    load_scalar_tile(g, slot, xin, xin, tile, c);  // (no halo slabs on a one-rank uniform grid; a literal nullptr here crashes clang 22's inliner)
+    load_scalar_tile(g, slot, xin, halo, tile, c);  // halo: zeros behind the faces other ranks own (never a literal nullptr: clang 22's inliner crashes on it)
   }
   const double invh = 1.0 / g.h;
   const double r0 = invh * b[(size_t)slot * 512 + cell0], r1 = invh * b[(size_t)slot * 512 + 256 + cell0];
@@ -83,7 +88,7 @@ __global__ void __launch_bounds__(256) k_mg_smooth(GridDev g, const double *__re
 }
 
 // coarse b (parent block, this block's octant) <- sum over 2x2x2 of the fine residual b - A x
-__global__ void __launch_bounds__(256) k_mg_residual_restrict(GridDev g, const double *__restrict__ x, const double *__restrict__ b,
+__global__ void __launch_bounds__(256) k_mg_residual_restrict(GridDev g, const double *__restrict__ x, const double *__restrict__ halo, const double *__restrict__ b,
                                                               const int32_t *__restrict__ parent, double *__restrict__ bc) {
   __shared__ double tile[kT];
   __shared__ double r[512];
@@ -91,7 +96,7 @@ __global__ void __launch_bounds__(256) k_mg_residual_restrict(GridDev g, const d
   if (slot < 0) return;
   const int t = threadIdx.x;
   double c[2];
-  load_scalar_tile(g, slot, x, x, tile, c);
+  load_scalar_tile(g, slot, x, halo, tile, c);
   __syncthreads();
   int x_, y, z0, cell0;
   thread_cells(t, x_, y, z0, cell0);
@@ -151,10 +156,21 @@ static GridDev level_gdev(const MGLevel &L) {
 static int mg_setup(Sim *s) {
   if (s->mg) return CUP3D_OK;
   const Grid *g = s->grid;
-  if (g->multilevel || g->nranks != 1) { set_error("the multigrid preconditioner (block_solver 5) runs on uniform one-rank grids"); return CUP3D_EINVAL; }
+  if (g->multilevel) { set_error("the multigrid preconditioner (block_solver 5) runs on uniform grids"); return CUP3D_EINVAL; }
   std::unique_ptr<Multigrid> mg(new Multigrid());
-  const int L = g->level;
-  mg->lev.resize(L + 1);
+  const int L = g->level, N = g->nranks;
+  // Several ranks: every rank runs the V-cycle on ITS blocks only, with zero ghost values behind the faces other ranks own -- an
+  // additive-Schwarz preconditioner whose subdomain solves are multigrid cycles, the reference's block-local preconditioner
+  // (zero ghosts around every 8^3 block) scaled up from a block to a rank.  No message is exchanged inside M^-1; BiCGSTAB's own
+  // LHS applications and dot products couple the ranks.  The hierarchy goes down as far as the Hilbert-range partition of the
+  // coarser grid still nests in this one (every rank's share a whole number of parent blocks): level 1 for 2, 4 or 8 ranks of a
+  // cubic base grid of one block.
+  mg->local = N > 1;
+  auto nblocks_at = [&](int l) { return (int64_t)g->bpd[0] * g->bpd[1] * g->bpd[2] << (3 * l); };
+  int lmin = L;
+  while (lmin > 0 && (N == 1 || (nblocks_at(lmin - 1) % N == 0 && nblocks_at(lmin) % N == 0))) --lmin;
+  const int nlev = L - lmin + 1;
+  mg->lev.resize(nlev);
   auto up = [&](int32_t **d, const std::vector<int32_t> &v) -> int {
     CUP3D_HIP(hipMalloc((void **)d, std::max<size_t>(v.size(), 1) * sizeof(int32_t)));
     CUP3D_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -162,11 +178,12 @@ static int mg_setup(Sim *s) {
   };
   int rc;
   try {
-    for (int l = L; l >= 0; --l) {
-      MGLevel &M = mg->lev[l];
+    int64_t max_halo_faces = 0;
+    for (int i = nlev - 1; i >= 0; --i) {
+      MGLevel &M = mg->lev[i];
       const Grid *gl = g;
-      if (l < L) {
-        M.grid.reset(new Grid(g->bpd, g->level_max, l, g->maxextent, g->bc, 0, 1));
+      if (i < nlev - 1) {
+        M.grid.reset(new Grid(g->bpd, g->level_max, lmin + i, g->maxextent, g->bc, g->rank, N));
         gl = M.grid.get();
         if ((rc = up(&M.d_nbr, gl->nbr))) return rc;
         const size_t bytes = (size_t)gl->nblocks() * 512 * sizeof(double);
@@ -181,18 +198,24 @@ static int mg_setup(Sim *s) {
       }
       M.nb = gl->nblocks();
       M.h = gl->h;
+      max_halo_faces = std::max<int64_t>(max_halo_faces, gl->n_recv_faces);
     }
-    for (int l = L; l >= 1; --l) {  // parent tables
-      const Grid *gf = l == L ? g : mg->lev[l].grid.get(), *gc = mg->lev[l - 1].grid.get();
+    if (N > 1) {
+      const size_t bytes = (size_t)std::max<int64_t>(max_halo_faces, 1) * 64 * sizeof(double);
+      CUP3D_HIP(hipMalloc((void **)&mg->zeros, bytes));
+      CUP3D_HIP(hipMemset(mg->zeros, 0, bytes));
+    }
+    for (int i = nlev - 1; i >= 1; --i) {  // parent tables
+      const Grid *gf = i == nlev - 1 ? g : mg->lev[i].grid.get(), *gc = mg->lev[i - 1].grid.get();
       std::vector<int32_t> par(2 * (size_t)gf->nblocks());
       for (int64_t b = 0; b < gf->nblocks(); ++b) {
-        const int i = gf->index[3 * b], j = gf->index[3 * b + 1], k = gf->index[3 * b + 2];
-        const int32_t ps = gc->slot_of_index(i >> 1, j >> 1, k >> 1);
-        if (ps < 0) throw std::logic_error("multigrid: parent block not found");
+        const int ii = gf->index[3 * b], j = gf->index[3 * b + 1], k = gf->index[3 * b + 2];
+        const int32_t ps = gc->slot_of_index(ii >> 1, j >> 1, k >> 1);
+        if (ps < 0) throw std::logic_error("multigrid: the parent of a local block is not local (partition does not nest)");
         par[2 * b] = ps;
-        par[2 * b + 1] = (i & 1) + 2 * (j & 1) + 4 * (k & 1);
+        par[2 * b + 1] = (ii & 1) + 2 * (j & 1) + 4 * (k & 1);
       }
-      if ((rc = up(&mg->lev[l].d_parent, par))) return rc;
+      if ((rc = up(&mg->lev[i].d_parent, par))) return rc;
     }
   } catch (const std::exception &e) {
     set_error("multigrid setup: %s", e.what());
@@ -208,13 +231,14 @@ void mg_destroy(Sim *s) {
 }
 
 // `launches` smoothing launches of `sweeps` sweeps each on one level; the iterate alternates between *xa and *xb and ends in *xa
-static void mg_smooth(const MGLevel &M, double **xa, double **xb, const double *rhs, int launches, int sweeps, bool from_zero) {
+static void mg_smooth(const MGLevel &M, const double *zeros, double **xa, double **xb, const double *rhs, int launches, int sweeps, bool from_zero) {
   const GridDev g = level_gdev(M);
   const dim3 G(launch_groups(g)), B(256);
   ProfileScope ps("mg_smooth");
   for (int i = 0; i < launches; ++i) {
-    if (from_zero && i == 0) hipLaunchKernelGGL(k_mg_smooth<true>, G, B, 0, stream(), g, (const double *)nullptr, rhs, *xb, sweeps);
-    else hipLaunchKernelGGL(k_mg_smooth<false>, G, B, 0, stream(), g, (const double *)*xa, rhs, *xb, sweeps);
+    const double *halo = zeros ? zeros : (const double *)*xa;
+    if (from_zero && i == 0) hipLaunchKernelGGL(k_mg_smooth<true>, G, B, 0, stream(), g, (const double *)nullptr, halo, rhs, *xb, sweeps);
+    else hipLaunchKernelGGL(k_mg_smooth<false>, G, B, 0, stream(), g, (const double *)*xa, halo, rhs, *xb, sweeps);
     double *t = *xa;
     *xa = *xb;
     *xb = t;
@@ -237,25 +261,25 @@ int mg_vcycle(Sim *s, const double *in, double *out) {
   }
 
   for (int l = L; l >= 1; --l) {  // downward leg
-    mg_smooth(mg.lev[l], &xa[l], &xb[l], rhs[l], nu, sw, true);
+    mg_smooth(mg.lev[l], mg.zeros, &xa[l], &xb[l], rhs[l], nu, sw, true);
     const GridDev g = level_gdev(mg.lev[l]);
     ProfileScope ps("mg_residual_restrict");
-    hipLaunchKernelGGL(k_mg_residual_restrict, dim3(launch_groups(g)), dim3(256), 0, stream(), g, (const double *)xa[l], rhs[l], (const int32_t *)mg.lev[l].d_parent,
+    hipLaunchKernelGGL(k_mg_residual_restrict, dim3(launch_groups(g)), dim3(256), 0, stream(), g, (const double *)xa[l], mg.zeros ? (const double *)mg.zeros : (const double *)xa[l], rhs[l], (const int32_t *)mg.lev[l].d_parent,
                        mg.lev[l - 1].b);
   }
   // coarsest level.  Its right-hand side loses its mean (the all-Neumann operator is singular) -- except in a ONE-level hierarchy, where
   // that would make the whole M^-1 singular (it would annihilate the constant component of every input and BiCGSTAB could never
   // reduce the residual along it); there the sweeps just carry a multiple of mean(b) along, a fixed linear map like the rest.
-  if (L > 0) hipLaunchKernelGGL(k_mg_remove_mean, dim3(1), dim3(256), 0, stream(), mg.lev[0].b, (long)mg.lev[0].nb * 512);
-  if (mg.lev[0].nb == 1) mg_smooth(mg.lev[0], &xa[0], &xb[0], rhs[0], 1, 64, true);
-  else mg_smooth(mg.lev[0], &xa[0], &xb[0], rhs[0], 16, 4, true);
+  if (L > 0 && !mg.local) hipLaunchKernelGGL(k_mg_remove_mean, dim3(1), dim3(256), 0, stream(), mg.lev[0].b, (long)mg.lev[0].nb * 512);
+  if (mg.lev[0].nb == 1) mg_smooth(mg.lev[0], mg.zeros, &xa[0], &xb[0], rhs[0], 1, 64, true);
+  else mg_smooth(mg.lev[0], mg.zeros, &xa[0], &xb[0], rhs[0], 16, 4, true);
   for (int l = 1; l <= L; ++l) {  // upward leg
     {
       ProfileScope ps("mg_prolong_add");
       hipLaunchKernelGGL(k_mg_prolong_add, dim3((unsigned)mg.lev[l].nb), dim3(256), 0, stream(), (int)mg.lev[l].nb, xa[l], (const int32_t *)mg.lev[l].d_parent,
                          (const double *)xa[l - 1]);
     }
-    mg_smooth(mg.lev[l], &xa[l], &xb[l], rhs[l], nu, sw, false);
+    mg_smooth(mg.lev[l], mg.zeros, &xa[l], &xb[l], rhs[l], nu, sw, false);
   }
   if (xa[L] != out)  // an odd number of buffer swaps on the finest level cannot happen with nu + nu launches, but stay safe
     CUP3D_HIP(hipMemcpyAsync(out, xa[L], (size_t)s->nb * 512 * sizeof(double), hipMemcpyDeviceToDevice, stream()));

@@ -197,7 +197,8 @@ typedef struct {
                           5 = NOT the reference's preconditioner: one geometric-multigrid V(2,2)-cycle (red-black Gauss-Seidel in LDS,
                               summed-residual restriction, piecewise-constant prolongation) on the hierarchy of uniform block grids --
                               same operator, same stopping rule, same converged pressure to solver tolerance, O(10) instead of O(150)
-                              iterations; uniform one-rank grids; reported by bench.py as `alt` only */
+                              iterations; uniform grids (over several ranks each rank cycles on its own blocks with zero ghosts behind
+                              the faces other ranks own: additive Schwarz, no message inside M^-1); bench.py: `alt_multigrid` only */
 } cup3d_poisson_params;
 typedef struct {
   int iterations; /* BiCGSTAB iterations performed (= 7-double reductions, main.cpp:14546) */

@@ -486,3 +486,52 @@ def test_adapted_mesh_of_thousands_of_blocks_over_ranks(nranks):
     assert len(set(its)) == 1
     assert np.abs(got_pres - pres_ref).max() <= 1e-6 * np.abs(pres_ref).max()
     assert np.abs(got_vel - vel_ref).max() <= 1e-6 * corr
+
+
+@pytest.mark.parametrize("nranks,level", [(2, 3), (8, 3), (4, 4)])
+def test_rank_local_multigrid_preconditioner_over_ranks(nranks, level):
+    """block_solver 5 over ranks: every rank runs the V-cycle on its own blocks with zero ghosts behind the faces other ranks own (an
+    additive-Schwarz preconditioner, no message inside M^-1).  Same operator, same stopping rule: the converged pressure equals the
+    one-rank block-CG run's to solver tolerance, every rank takes the same path, and the iteration count stays far below block CG's."""
+    bpd, lmax, bc = (1, 1, 1), level + 1, ("wall", "wall", "wall")
+    kw = dict(bpdx=1, bpdy=1, bpdz=1, levelMax=lmax, levelStart=level, extent=EXT, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], nu=0.01,
+              poissonTol=1e-11, poissonTolRel=1e-9)
+    one = cu.SimulationData(**kw)
+    g = one.grid
+    n = 8 << level
+    from bench import taylor_green_blocks
+    vel = taylor_green_blocks(g, [EXT] * 3, 1.0)
+    one.upload("vel", vel)
+    dt = 0.3 * g.h
+    one.step = 5
+    r1 = cu.PressureProjection(one)(dt)
+    pres_one, vel_one = np.zeros((n, n, n)), np.zeros((n, n, n, 3))
+    g.scatter_to_global(one.download("pres"), pres_one)
+    g.scatter_to_global(one.download("vel"), vel_one)
+    velg = np.zeros((n, n, n, 3))
+    g.scatter_to_global(vel, velg)
+    out = {}
+    with VirtualComm(nranks):
+        sims = [cu.SimulationData(rank=r, nranks=nranks, blockSolver=5, **kw) for r in range(nranks)]
+
+        def rank(r):
+            s = sims[r]
+            s.upload("vel", s.grid.to_blocks(velg))
+            s.step = 5
+            res = cu.PressureProjection(s)(dt)
+            out[r] = (s.download("vel"), s.download("pres"), res.iterations)
+
+        run_ranks(rank, nranks)
+        got_vel, got_pres = np.zeros_like(velg), np.zeros_like(pres_one)
+        for r, s in enumerate(sims):
+            s.grid.scatter_to_global(out[r][0], got_vel)
+            s.grid.scatter_to_global(out[r][1], got_pres)
+        del sims
+    its = {out[r][2] for r in range(nranks)}
+    assert len(its) == 1
+    it = its.pop()
+    print(f"rank-local multigrid on {nranks} ranks, {n}^3: {it} BiCGSTAB iterations (block CG on one rank: {r1.iterations})")
+    assert it < r1.iterations // 2
+    corr = np.abs(vel_one - velg).max()
+    assert np.abs(got_pres - pres_one).max() <= 1e-6 * np.abs(pres_one).max()
+    assert np.abs(got_vel - vel_one).max() <= 1e-6 * corr
