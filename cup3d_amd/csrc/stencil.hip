@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(256) k_vorticity(GridDev g, const double *__re
 
 // ---- KernelLHSPoisson (main.cpp:9205-9215) + the per-block partial of sum(p*h^3) that
 // ComputeLHS needs for the mean constraint (9283-9294)
+template <bool SKIPX = false>
 __global__ void __launch_bounds__(256) k_lhs(GridDev g, const double *__restrict__ p, const double *__restrict__ halo, double *__restrict__ out,
                                              double *__restrict__ block_sums, const double *__restrict__ avg, int corner_slot) {
   __shared__ double tile[kT];
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(256) k_lhs(GridDev g, const double *__restrict
   const int slot = block_slot(g);
   if (slot < 0) return;
   double c[2];
-  load_scalar_tile(g, slot, p, halo, tile, c);
+  load_scalar_tile<SKIPX>(g, slot, p, halo, tile, c);
   __syncthreads();
   const int t = threadIdx.x;
   int x, y, z0, cell0;
@@ -380,7 +381,13 @@ int launch_lhs(Sim *s, const double *p, double *out, int mc) {
     if (pass == 1 && (rc = halo_finish(s))) return rc;
     if (g.nblocks == 0) continue;
     ProfileScope ps("poisson_lhs");
-    hipLaunchKernelGGL(k_lhs, dim3(launch_groups(g)), dim3(256), 0, stream(), g, p, s->halo_recv, out, (need_sum && !have_sums && !have_total) ? block_sums : nullptr,
+#ifdef CUP3D_TUNING_ABLATIONS  // timing ablation with deliberately WRONG results (no x-face ghosts): never in a release build
+    if (debug_option("lhs_variant") == 1) {
+      hipLaunchKernelGGL(k_lhs<true>, dim3(launch_groups(g)), dim3(256), 0, stream(), g, p, s->halo_recv, out, (double *)nullptr, (const double *)nullptr, corner);
+      continue;
+    }
+#endif
+    hipLaunchKernelGGL(k_lhs<false>, dim3(launch_groups(g)), dim3(256), 0, stream(), g, p, s->halo_recv, out, (need_sum && !have_sums && !have_total) ? block_sums : nullptr,
                        row_in_kernel ? total : nullptr, corner);
   }
   CUP3D_HIP(hipGetLastError());

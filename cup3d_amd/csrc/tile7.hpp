@@ -32,6 +32,8 @@ __device__ __forceinline__ void face1(int f, int lane, int &nb_cell, int &own_ce
 // scalar tile with zero-gradient domain faces (BlockLabNeumann3D, main.cpp:6561-6581); bc_comp >= 0: the scalar element of
 // BlockLabBC<ScalarGrid, .., direction = bc_comp> instead (wall: negated; freespace: negated behind the faces normal to
 // bc_comp, main.cpp:6120, 6384-6394) -- the tiles of DiffusionSolver::_lhs (6853-6862)
+// SKIPX (timing ablation only, wrong results): the two x faces are not fetched from the neighbours
+template <bool SKIPX = false>
 __device__ __forceinline__ void load_scalar_tile(const GridDev &g, int slot, const double *__restrict__ f, const double *__restrict__ halo,
                                                  double *tile, double c[2], int bc_comp = -1) {
   const int t = threadIdx.x, lane = t & 63;
@@ -50,7 +52,7 @@ __device__ __forceinline__ void load_scalar_tile(const GridDev &g, int slot, con
     const int face = wave + 4 * i;
     gon[i] = face < 6;
     if (gon[i]) {
-      const int n = g.nbr[slot * 6 + face];
+      const int n = (SKIPX && face < 2) ? -1 : g.nbr[slot * 6 + face];
       int nb_cell, own_cell, lds;
       face1(face, lane, nb_cell, own_cell, lds);
       const double *__restrict__ base = n >= kNbrHalo ? halo + (size_t)(n - kNbrHalo) * 64 : (n >= 0 ? f + (size_t)n * 512 : own);

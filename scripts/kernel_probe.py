@@ -37,7 +37,7 @@ def make(size, bc="periodic"):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["adv", "pre", "one", "loops", "pcie", "cgvar"])
+    ap.add_argument("what", choices=["adv", "pre", "one", "loops", "pcie", "cgvar", "lhs"])
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--variants", default="0,1,2,3")
     ap.add_argument("--kernel", default="adv")
@@ -65,6 +65,23 @@ def main():
             print(json.dumps({"probe": "advdiff", "size": a.size, "variant": v, "avg_ms": round(avg, 4),
                               "GBps_algorithmic": round(96 * cells / avg / 1e6, 1), "frac_8TBs": round(96 * cells / avg / 1e6 / 8000, 4)}))
         check(lib().cup3d_debug_set_option(b"advdiff_variant", 0))
+    elif a.what == "lhs":
+        # KernelLHSPoisson alone (no mean constraint); variant 1 (TUNING builds only, wrong results): no x-face ghost gathers
+        sim = make(a.size, "wall")
+        sim.upload("pres", np.random.default_rng(1).uniform(-1, 1, (sim.nblocks, 8, 8, 8)))
+        for v in [int(x) for x in a.variants.split(",")]:
+            if lib().cup3d_debug_set_option(b"lhs_variant", v) != 0:
+                continue
+            check(lib().cup3d_compute_lhs(sim.handle, 0))
+            lib().cup3d_device_synchronize()
+            lib().cup3d_profile_reset()
+            for _ in range(a.reps * 5):
+                check(lib().cup3d_compute_lhs(sim.handle, 0))
+            n, ms = profile()["poisson_lhs"]
+            avg = ms / n
+            print(json.dumps({"probe": "poisson_lhs", "size": a.size, "variant": v, "avg_ms": round(avg, 4), "GBps_algorithmic": round(16 * cells / avg / 1e6, 1),
+                              "frac_8TBs": round(16 * cells / avg / 1e6 / 8000, 4)}))
+        lib().cup3d_debug_set_option(b"lhs_variant", 0)
     elif a.what == "pcie":
         # host <-> device rate of the boundary's block transfers (reference layout AoS on the host, SoA slab on the device)
         import time
