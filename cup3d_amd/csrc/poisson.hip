@@ -813,14 +813,23 @@ static unsigned vec_groups(long n) {
   return (unsigned)(g > cap ? cap : g);
 }
 
+// several ranks: the all-reduced totals (device) -> the pinned host mirror, then the sequence word the host spins on
+__global__ void k_publish_totals(const double *__restrict__ d, int k, double *__restrict__ host, unsigned *flag, unsigned seq) {
+  if ((int)threadIdx.x < k) host[threadIdx.x] = d[threadIdx.x];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct Reducer {
   Sim *s;
   // where the kernel that ends with grid_sum_finish puts its totals: d_red always; the pinned host mirror directly when no
   // all-reduce has to run in between
   bool direct() const { return !(s->grid->nranks > 1 || (debug_option("force_allreduce") && comm())); }
-  // direct: the kernel also raises a pinned sequence word after the totals, and wait() spins on it -- a few microseconds instead of
-  // the wake-up latency of hipEventSynchronize, which at <= 256^3 per GPU (the 8-GPU share of the 512^3 workload) is what the LHS
-  // enqueued behind the reduction no longer hides
+  // The totals reach the host through pinned memory followed by a sequence word that wait() spins on -- a few microseconds instead
+  // of the wake-up latency of hipEventSynchronize, which at <= 256^3 per GPU (the 8-GPU share of the 512^3 workload) is what the LHS
+  // enqueued behind the reduction no longer hides.  direct: written by the reducing kernel itself; several ranks: by
+  // k_publish_totals behind the all-reduce on the communication stream
   RedOut out() {
     if (!direct()) return RedOut{s->d_partials, s->d_counters, s->d_red, nullptr, nullptr, 0u};
     return RedOut{s->d_partials, s->d_counters, s->d_red, s->h_red_dev, reinterpret_cast<unsigned *>(s->h_red_dev + 16), ++s->red_seq};
@@ -840,26 +849,23 @@ struct Reducer {
     }
     int rc = allreduce(s, s->d_red, k, false, cs);
     if (rc) return rc;
-    CUP3D_HIP(hipMemcpyAsync(s->h_red, s->d_red, k * sizeof(double), hipMemcpyDeviceToHost, cs));
+    hipLaunchKernelGGL(k_publish_totals, dim3(1), dim3(64), 0, cs, (const double *)s->d_red, k, s->h_red_dev, reinterpret_cast<unsigned *>(s->h_red_dev + 16), ++s->red_seq);
+    CUP3D_HIP(hipGetLastError());
     CUP3D_HIP(hipEventRecord(s->ev_a, cs));
     return CUP3D_OK;
   }
   int wait() {
-    if (direct()) {
-      const volatile unsigned *flag = reinterpret_cast<const volatile unsigned *>(s->h_red + 16);
-      const unsigned want = s->red_seq;
-      for (unsigned spin = 1; *flag != want; ++spin) {
-        __builtin_ia32_pause();
-        if ((spin & 0x3fff) == 0) {  // every ~16k polls: has the stream finished (or failed) without raising the flag?
-          const hipError_t e = hipEventQuery(s->ev_a);
-          if (e == hipSuccess) break;  // completed: the totals are in place (an event wait makes them visible as well)
-          if (e != hipErrorNotReady) return hip_fail(e, "hipEventQuery", __FILE__, __LINE__);
-        }
+    const volatile unsigned *flag = reinterpret_cast<const volatile unsigned *>(s->h_red + 16);
+    const unsigned want = s->red_seq;
+    for (unsigned spin = 1; *flag != want; ++spin) {
+      __builtin_ia32_pause();
+      if ((spin & 0x3fff) == 0) {  // every ~16k polls: has the stream finished (or failed) without raising the flag?
+        const hipError_t e = hipEventQuery(s->ev_a);
+        if (e == hipSuccess) break;  // completed: the totals are in place (an event wait makes them visible as well)
+        if (e != hipErrorNotReady) return hip_fail(e, "hipEventQuery", __FILE__, __LINE__);
       }
-      std::atomic_thread_fence(std::memory_order_acquire);
-      return CUP3D_OK;
     }
-    CUP3D_HIP(hipEventSynchronize(s->ev_a));
+    std::atomic_thread_fence(std::memory_order_acquire);
     return CUP3D_OK;
   }
 };
