@@ -119,6 +119,15 @@ __global__ void k_vreduce(VPtrs v, int nranks, int n, int is_max, double *__rest
   out[i] = a;
 }
 
+// The stream exchanges are enqueued on.  RCCL: the rank's communication stream.  Virtual communicator: the same by default, so that
+// the event hand-offs between a rank's compute stream and its communication stream are executed (and can fail) in the tests exactly
+// as under RCCL; cup3d_debug_set_option("vcomm_one_stream", 1) puts everything on the compute stream instead.
+static bool vcomm_two_streams(const Sim *s) { return g_vcomm && s->comm_stream && !debug_option("vcomm_one_stream"); }
+static hipStream_t exchange_stream(const Sim *s) {
+  if (g_vcomm) return vcomm_two_streams(s) ? s->comm_stream : stream();
+  return s->comm_stream;
+}
+
 bool scalars_cross_ranks(const Sim *s) {
   if (g_vcomm) return s->grid->nranks > 1;
   if (g_virtual_ranks) return false;
@@ -127,16 +136,19 @@ bool scalars_cross_ranks(const Sim *s) {
 // the stream the scalar all-reduces are enqueued on: the communication stream where there is one (every RCCL call of the library is
 // issued from that stream, in the same order on all ranks), else the compute stream
 hipStream_t scalar_stream(const Sim *s) {
-  if (g_vcomm || g_virtual_ranks || !s->comm_stream) return stream();
+  if (g_virtual_ranks && !g_vcomm) return stream();
+  if (!s->comm_stream || (g_vcomm && !vcomm_two_streams(s))) return stream();
   return s->comm_stream;
 }
 
 // copy `count[p]` items of `per` doubles from every peer's send buffer (peer-major, so my share of p's buffer starts after what p
 // sends to the ranks before me) to dst, in rank order
 template <class CountOf>
-static int vcomm_pull(Sim *s, double *dst, size_t per, const std::vector<int64_t> &recv_count, CountOf send_count_of) {
+static int vcomm_pull(Sim *s, double *dst, size_t per, const std::vector<int64_t> &recv_count, CountOf send_count_of, hipStream_t st) {
   VComm *vc = g_vcomm;
   const Grid *g = s->grid;
+  // my pack is enqueued on st: the event lets the receivers' streams wait for it (what a matched ncclSend / ncclRecv does)
+  CUP3D_HIP(hipEventRecord(s->ev_vc_pack, st));
   if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the exchange"); return CUP3D_ECOMM; }  // every rank has enqueued its pack
   size_t ro = 0;
   for (int p = 0; p < g->nranks; ++p) {
@@ -148,10 +160,16 @@ static int vcomm_pull(Sim *s, double *dst, size_t per, const std::vector<int64_t
     size_t so = 0;
     for (int q = 0; q < g->rank; ++q) so += (size_t)sc[q] * per;
     if ((size_t)sc[g->rank] * per != nr) { set_error("plan mismatch between ranks %d and %d", p, g->rank); return CUP3D_ESTATE; }
-    CUP3D_HIP(hipMemcpyAsync(dst + ro, src->halo_send + so, nr * sizeof(double), hipMemcpyDeviceToDevice, stream()));
+    CUP3D_HIP(hipStreamWaitEvent(st, src->ev_vc_pack, 0));
+    CUP3D_HIP(hipMemcpyAsync(dst + ro, src->halo_send + so, nr * sizeof(double), hipMemcpyDeviceToDevice, st));
     ro += nr;
   }
-  if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the exchange"); return CUP3D_ECOMM; }  // nobody packs again before every copy is enqueued
+  CUP3D_HIP(hipEventRecord(s->ev_vc_done, st));
+  if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the exchange"); return CUP3D_ECOMM; }  // every copy is enqueued
+  // a send completes when the data has left: my stream (hence my next pack into halo_send) waits for the copies of my receivers
+  const std::vector<int64_t> &mine = send_count_of(g);
+  for (int p = 0; p < g->nranks; ++p)
+    if (mine[p] && vc->sims[p]) CUP3D_HIP(hipStreamWaitEvent(st, vc->sims[p]->ev_vc_done, 0));
   return CUP3D_OK;
 }
 
@@ -177,8 +195,8 @@ __global__ void __launch_bounds__(64) k_pack_flux(const double *__restrict__ flu
 static int view_transfer(Sim *s, double *dst, size_t per, const std::vector<int64_t> &send_count, const std::vector<int64_t> &recv_count, bool flux) {
   const Grid *g = s->grid;
   if (g_vcomm) {
-    if (flux) return vcomm_pull(s, dst, per, recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_flux_count; });
-    return vcomm_pull(s, dst, per, recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_block_count; });
+    if (flux) return vcomm_pull(s, dst, per, recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_flux_count; }, exchange_stream(s));
+    return vcomm_pull(s, dst, per, recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_block_count; }, exchange_stream(s));
   }
   Comm *c = comm();
   if (!c) { set_error("multi-rank mesh without cup3d_comm_init"); return CUP3D_ESTATE; }
@@ -199,7 +217,7 @@ static int view_transfer(Sim *s, double *dst, size_t per, const std::vector<int6
 static int view_exchange_blocks_begin(Sim *s, double *field, int nc) {
   const Grid *g = s->grid;
   ProfileScope ps("ghost_block_exchange");
-  hipStream_t st = g_vcomm ? stream() : s->comm_stream;
+  hipStream_t st = exchange_stream(s);
   if (st != stream()) {
     CUP3D_HIP(hipEventRecord(s->ev_h1, stream()));
     CUP3D_HIP(hipStreamWaitEvent(st, s->ev_h1, 0));
@@ -213,7 +231,7 @@ static int view_exchange_blocks_begin(Sim *s, double *field, int nc) {
   return CUP3D_OK;
 }
 static int view_exchange_blocks_finish(Sim *s) {
-  if (!g_vcomm) CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
+  if (exchange_stream(s) != stream()) CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
   return CUP3D_OK;
 }
 int view_exchange_blocks(Sim *s, double *field, int nc) {
@@ -228,7 +246,7 @@ int view_exchange_flux(Sim *s, int nfc) {
   const Grid *g = s->grid;
   if (g->n_local < 0 || g->nranks == 1) return CUP3D_OK;
   ProfileScope ps("face_flux_exchange");
-  hipStream_t st = g_vcomm ? stream() : s->comm_stream;
+  hipStream_t st = exchange_stream(s);
   if (st != stream()) {
     CUP3D_HIP(hipEventRecord(s->ev_h1, stream()));
     CUP3D_HIP(hipStreamWaitEvent(st, s->ev_h1, 0));
@@ -297,7 +315,7 @@ int exchange_items(Sim *s, const double *sendbuf, const std::vector<int64_t> &se
 // ------------------------------------------------------------------ face-slab halo exchange of uniform grids
 static int slab_transfer(Sim *s, size_t per_face, hipStream_t st) {
   const Grid *g = s->grid;
-  if (g_vcomm) return vcomm_pull(s, s->halo_recv, per_face, g->recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_count; });
+  if (g_vcomm) return vcomm_pull(s, s->halo_recv, per_face, g->recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_count; }, st);
   Comm *c = comm();
   if (!c) { set_error("multi-rank grid without cup3d_comm_init"); return CUP3D_ESTATE; }
   CUP3D_NCCL(c->GroupStart());
@@ -330,7 +348,7 @@ int halo_begin(Sim *s, const double *field, int nc, int w) {
   }
   if (g->nranks == 1 || (g_virtual_ranks && !g_vcomm)) return CUP3D_OK;
   const size_t per_face = (size_t)nc * w * 64;
-  hipStream_t st = g_vcomm ? stream() : s->comm_stream;
+  hipStream_t st = exchange_stream(s);
   // the field (and the previous consumers of the slab buffers) live on the compute stream
   if (st != stream()) {
     CUP3D_HIP(hipEventRecord(s->ev_h1, stream()));
@@ -357,8 +375,8 @@ int halo_finish(Sim *s) {
     s->scalar_bc_dir = dir;
     return rc;
   }
-  if (s->grid->nranks == 1 || g_virtual_ranks || g_vcomm) return CUP3D_OK;
-  CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
+  if (s->grid->nranks == 1 || (g_virtual_ranks && !g_vcomm)) return CUP3D_OK;
+  if (exchange_stream(s) != stream()) CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
   return CUP3D_OK;
 }
 int halo_exchange(Sim *s, const double *field, int nc, int w) {
@@ -374,13 +392,20 @@ int allreduce(Sim *s, double *d_buf, int n, bool is_max, hipStream_t st) {
     const int r = s->grid->rank;
     if (n > 16 || vc->n > 16) { set_error("virtual communicator: at most 16 ranks / 16 values"); return CUP3D_EINVAL; }
     vc->ptr[r] = d_buf;
+    CUP3D_HIP(hipEventRecord(s->ev_vc_pack, st));  // my operand is final at this point of st
     if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the all-reduce"); return CUP3D_ECOMM; }  // every rank's operand is enqueued
     VPtrs v;
-    for (int q = 0; q < vc->n; ++q) v.p[q] = vc->ptr[q];
-    hipLaunchKernelGGL(k_vreduce, dim3(1), dim3(64), 0, stream(), v, vc->n, n, is_max ? 1 : 0, vc->d_tmp + 16 * r);
+    for (int q = 0; q < vc->n; ++q) {
+      v.p[q] = vc->ptr[q];
+      if (q != r && vc->sims[q]) CUP3D_HIP(hipStreamWaitEvent(st, vc->sims[q]->ev_vc_pack, 0));
+    }
+    hipLaunchKernelGGL(k_vreduce, dim3(1), dim3(64), 0, st, v, vc->n, n, is_max ? 1 : 0, vc->d_tmp + 16 * r);
     CUP3D_HIP(hipGetLastError());
-    if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the all-reduce"); return CUP3D_ECOMM; }  // every rank has read the operands
-    CUP3D_HIP(hipMemcpyAsync(d_buf, vc->d_tmp + 16 * r, n * sizeof(double), hipMemcpyDeviceToDevice, stream()));
+    CUP3D_HIP(hipEventRecord(s->ev_vc_done, st));
+    if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the all-reduce"); return CUP3D_ECOMM; }  // every rank has enqueued its read
+    for (int q = 0; q < vc->n; ++q)
+      if (q != r && vc->sims[q]) CUP3D_HIP(hipStreamWaitEvent(st, vc->sims[q]->ev_vc_done, 0));  // ... and has read my operand before I overwrite it
+    CUP3D_HIP(hipMemcpyAsync(d_buf, vc->d_tmp + 16 * r, n * sizeof(double), hipMemcpyDeviceToDevice, st));
     return CUP3D_OK;
   }
   Comm *c = comm();

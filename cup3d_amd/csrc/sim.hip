@@ -353,6 +353,10 @@ static int sim_build(Sim *s, const Grid *g) {
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_b, hipEventDisableTiming));
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_h1, hipEventDisableTiming));
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_h2, hipEventDisableTiming));
+  if (g->nranks > 1) {
+    CUP3D_HIP(hipEventCreateWithFlags(&s->ev_vc_pack, hipEventDisableTiming));
+    CUP3D_HIP(hipEventCreateWithFlags(&s->ev_vc_done, hipEventDisableTiming));
+  }
   CUP3D_HIP(hipStreamSynchronize(g_stream));
   return CUP3D_OK;
 }
@@ -400,6 +404,8 @@ void cup3d_sim_destroy(cup3d_sim_t *h) {
   if (s->ev_b) hipEventDestroy(s->ev_b);
   if (s->ev_h1) hipEventDestroy(s->ev_h1);
   if (s->ev_h2) hipEventDestroy(s->ev_h2);
+  if (s->ev_vc_pack) hipEventDestroy(s->ev_vc_pack);
+  if (s->ev_vc_done) hipEventDestroy(s->ev_vc_done);
   delete s;
 }
 size_t cup3d_sim_device_bytes(const cup3d_sim_t *h) { return h ? reinterpret_cast<const Sim *>(h)->bytes : 0; }

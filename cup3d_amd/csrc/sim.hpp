@@ -111,6 +111,7 @@ struct Sim {
   size_t bytes = 0;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_h1 = nullptr, ev_h2 = nullptr;
+  hipEvent_t ev_vc_pack = nullptr, ev_vc_done = nullptr;  // virtual communicator (tests): "my send buffer is packed" / "my copies are enqueued"
 
   GridDev gdev(bool boundary_only = false, bool inner_only = false) const;
   double *field(int id, int *ncomp) const;
