@@ -109,6 +109,7 @@ SIGNATURES = {
     "cup3d_tag_blocks": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]),
     "cup3d_compute_vorticity": (C.c_int, [_vp]),
     "cup3d_grad_chi_on_tmp": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int]),
+    "cup3d_grad_chi_on_tmp_over_ranks": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_int]),
     "cup3d_grid_adapted_owners": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "cup3d_grid_rank_view": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "cup3d_grid_view_sizes": (C.c_int, [_vp, _vp]),

@@ -863,19 +863,13 @@ extern "C" int cup3d_adapt_migrate(const cup3d_grid_t *old_mesh_h, const int32_t
 
 // compute<ScalarLab>(GradChiOnTmp(sim), sim.chi) (main.cpp:15182, 8540-8600): edits tmpV (= the vorticity of ComputeVorticity) from
 // the resident chi; with cup3d_compute_vorticity before and cup3d_tag_blocks after it, adaptMesh's decision input is complete for
-// runs with obstacles.  One rank (uniform grid or multi-level mesh).
-extern "C" int cup3d_grad_chi_on_tmp(cup3d_sim_t *h, double Rtol, double Ctol, int level_max_vorticity) {
-  if (!h) return CUP3D_EINVAL;
-  Sim *s = reinterpret_cast<Sim *>(h);
-  if (s->grid->nranks > 1) { set_error("cup3d_grad_chi_on_tmp: meshes spread over ranks are not supported yet (the tensorial chi tile needs edge / corner ghosts)"); return CUP3D_ESTATE; }
-  std::unique_ptr<Grid> tmp;
-  const Grid *mo = s->grid;
+// runs with obstacles.  `mo`: a multi-level mesh object whose first `nloc` slots are the blocks of `tmpV` (the mesh itself on one
+// rank, the rank's TENSORIAL view over ranks -- the tensorial chi tile reaches edge / corner neighbours); `chi` lives on mo's slots.
+static int grad_chi_run(const Grid *mo, int64_t nloc, const double *chi, double *tmpV, double Rtol, double Ctol, int level_max_vorticity) {
   std::vector<int32_t> finer_row, finer;
   try {
-    if (!mo->multilevel) { tmp = mo->as_mesh(); mo = tmp.get(); }
-    const int64_t nb = mo->nblocks();
-    finer_row.assign((size_t)nb, -1);
-    for (int64_t b = 0; b < nb; ++b) {
+    finer_row.assign((size_t)nloc, -1);
+    for (int64_t b = 0; b < nloc; ++b) {
       bool any = false;
       for (int c = 0; c < 27; ++c) any = any || mo->nbr27[27 * (size_t)b + c] == kNbrFiner;
       if (!any) continue;
@@ -911,12 +905,60 @@ extern "C" int cup3d_grad_chi_on_tmp(cup3d_sim_t *h, double Rtol, double Ctol, i
   AmrDev a{nullptr, nullptr, d_n27.p, d_nbr.p, d_index.p, -1};
   {
     ProfileScope ps("grad_chi_on_tmp");
-    hipLaunchKernelGGL(k_grad_chi, dim3((unsigned)mo->nblocks()), dim3(256), 0, stream(), a, d_row.p, d_finer.p, d_level.p, mo->level_max, level_max_vorticity, Rtol,
-                       Ctol, (const double *)s->chi, s->tmpV);
+    hipLaunchKernelGGL(k_grad_chi, dim3((unsigned)nloc), dim3(256), 0, stream(), a, d_row.p, d_finer.p, d_level.p, mo->level_max, level_max_vorticity, Rtol, Ctol, chi,
+                       tmpV);
   }
   CUP3D_HIP(hipGetLastError());
   CUP3D_HIP(hipStreamSynchronize(stream()));  // the tables above are freed on return
   return CUP3D_OK;
+}
+
+extern "C" int cup3d_grad_chi_on_tmp(cup3d_sim_t *h, double Rtol, double Ctol, int level_max_vorticity) {
+  if (!h) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  if (s->grid->nranks > 1) { set_error("cup3d_grad_chi_on_tmp: a mesh spread over ranks goes through cup3d_grad_chi_on_tmp_over_ranks (its chi tile needs edge / corner ghost blocks)"); return CUP3D_ESTATE; }
+  std::unique_ptr<Grid> tmp;
+  const Grid *mo = s->grid;
+  try {
+    if (!mo->multilevel) { tmp = mo->as_mesh(); mo = tmp.get(); }
+  } catch (const std::exception &e) {
+    set_error("cup3d_grad_chi_on_tmp: %s", e.what());
+    return CUP3D_EINVAL;
+  }
+  return grad_chi_run(mo, mo->nblocks(), s->chi, s->tmpV, Rtol, Ctol, level_max_vorticity);
+}
+
+// The same on a mesh spread over ranks: `mesh` / `owner` are the global mesh object and the rank of every leaf (as for
+// cup3d_adapt_migrate); chi of the edge / corner / finer neighbours other ranks own arrives first (the plan of the rank's tensorial view),
+// then the one-rank kernel runs on the rank's blocks.  Collective: every rank calls it.
+extern "C" int cup3d_grad_chi_on_tmp_over_ranks(cup3d_sim_t *h, const cup3d_grid_t *mesh_h, const int32_t *owner, double Rtol, double Ctol, int level_max_vorticity) {
+  if (!h || !mesh_h || !owner) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  const Grid *gm = reinterpret_cast<const Grid *>(mesh_h);
+  if (!gm->multilevel || gm->n_local >= 0) { set_error("cup3d_grad_chi_on_tmp_over_ranks needs the GLOBAL mesh object"); return CUP3D_EINVAL; }
+  const int me = s->grid->rank, nranks = s->grid->nranks;
+  std::unique_ptr<Grid> tv;
+  try {
+    tv = gm->rank_view(owner, me, nranks, /*tensorial=*/true);
+    if (tv->n_local != s->nb) throw std::invalid_argument("the sim does not hold this rank's blocks of the mesh");
+  } catch (const std::exception &e) {
+    set_error("cup3d_grad_chi_on_tmp_over_ranks: %s", e.what());
+    return CUP3D_EINVAL;
+  }
+  const size_t nvis = tv->Z.size();
+  DevBuf F, pack;
+  DevInts d_send;
+  int rc;
+  if ((rc = F.alloc(nvis * 512 * sizeof(double))) || (rc = pack.alloc(std::max<size_t>(tv->send_blocks.size(), 1) * 512 * sizeof(double))) ||
+      (rc = d_send.upload(tv->send_blocks)))
+    return rc;
+  CUP3D_HIP(hipMemcpyAsync(F.p, s->chi, (size_t)s->nb * 512 * sizeof(double), hipMemcpyDeviceToDevice, stream()));
+  if (!tv->send_blocks.empty())
+    hipLaunchKernelGGL(k_pack_blocks, dim3((unsigned)tv->send_blocks.size()), dim3(256), 0, stream(), (const double *)F.p, d_send.p, 1, (double *)pack.p);
+  CUP3D_HIP(hipGetLastError());
+  if ((rc = exchange_items(s, (const double *)pack.p, tv->send_block_count, (double *)F.p + (size_t)tv->n_local * 512, tv->recv_block_count, 512))) return rc;
+  CUP3D_HIP(hipStreamSynchronize(stream()));
+  return grad_chi_run(tv.get(), tv->n_local, (const double *)F.p, s->tmpV, Rtol, Ctol, level_max_vorticity);
 }
 
 // TEST SUPPORT: the ghost slabs of every interface face for `field` and a w-deep stencil, [(e*nc + c)*w + gl][64]

@@ -386,9 +386,15 @@ class GradChiOnTmp(Operator):
     """compute<ScalarLab>(GradChiOnTmp(sim), sim.chi), main.cpp:15182 / 8540-8600: the chi-driven edit of the vorticity in tmpV that
     precedes the tagging in adaptMesh (needs sim.Rtol, sim.Ctol, sim.levelMaxVorticity; chi resident)."""
 
-    def __call__(self, dt=0):
+    def __call__(self, dt=0, mesh=None, owner=None):
+        """mesh / owner (the global mesh object and the rank of every leaf): the mesh is spread over ranks and this is a collective."""
         s = self.sim
-        check(lib().cup3d_grad_chi_on_tmp(s.handle, float(s.Rtol), float(s.Ctol), int(getattr(s, "levelMaxVorticity", s.levelMax))))
+        lmv = int(getattr(s, "levelMaxVorticity", s.levelMax))
+        if mesh is None:
+            check(lib().cup3d_grad_chi_on_tmp(s.handle, float(s.Rtol), float(s.Ctol), lmv))
+        else:
+            ow = np.ascontiguousarray(owner, dtype=np.int32)
+            check(lib().cup3d_grad_chi_on_tmp_over_ranks(s.handle, mesh.handle, ow.ctypes.data_as(C.c_void_p), float(s.Rtol), float(s.Ctol), lmv))
 
 
 class ObstacleData:
@@ -562,6 +568,9 @@ class Simulation:
         new ones when the mesh changed; self.sim is then this rank's SimulationData on the adapted mesh."""
         s = self.sim
         ComputeVorticity(s)(0)
+        if s.obstacles or getattr(s, "chi_resident", False):   # compute<ScalarLab>(GradChiOnTmp(sim), sim.chi), 15182
+            s.Rtol, s.Ctol = Rtol, Ctol
+            GradChiOnTmp(s)(0, mesh=mesh, owner=owner)
         parts = allgather(MeshAdaptation(Rtol, Ctol).Tag(s, "tmpV"))
         tags = np.zeros(mesh.nblocks, dtype=np.int8)
         ow = np.asarray(owner)

@@ -300,6 +300,9 @@ int cup3d_compute_vorticity(cup3d_sim_t *);
  * inside a body cleared, vorticity capped on level levelMaxVorticity - 1.  With cup3d_compute_vorticity before and cup3d_tag_blocks
  * after, this is the decision input of Simulation::adaptMesh (15180-15183) for runs with obstacles.  One rank. */
 int cup3d_grad_chi_on_tmp(cup3d_sim_t *, double Rtol, double Ctol, int level_max_vorticity);
+/* ... on a mesh spread over ranks (collective; mesh / owner as for cup3d_adapt_migrate): the chi blocks behind edges, corners and finer
+ * neighbours that other ranks own arrive first, by the plan of the rank's tensorial view (SynchronizerMPI_AMR with a tensorial stencil) */
+int cup3d_grad_chi_on_tmp_over_ranks(cup3d_sim_t *, const cup3d_grid_t *mesh, const int32_t *owner, double Rtol, double Ctol, int level_max_vorticity);
 
 /* per-kernel device time accounting (hipEvents on the compute stream) */
 int cup3d_profile_enable(int on);

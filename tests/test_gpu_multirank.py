@@ -535,3 +535,42 @@ def test_rank_local_multigrid_preconditioner_over_ranks(nranks, level):
     corr = np.abs(vel_one - velg).max()
     assert np.abs(got_pres - pres_one).max() <= 1e-6 * np.abs(pres_one).max()
     assert np.abs(got_vel - vel_one).max() <= 1e-6 * corr
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+@pytest.mark.parametrize("name", ["amr_periodic_l01", "amr_mixed_l12"])
+def test_grad_chi_on_tmp_over_ranks_equals_the_reference(golden_dir, name, nranks):
+    """compute<ScalarLab>(GradChiOnTmp(sim), sim.chi) on a multi-level mesh spread over ranks: chi of the edge / corner / finer neighbours
+    other ranks own arrives by the plan of the rank's tensorial view; the gathered tmpV equals the REFERENCE's output bit for bit
+    (tests/golden/grad_chi.npz, the one-rank pin of tests/test_gpu_amr.py), with and without the levelMaxVorticity cap."""
+    BCN = {0: "periodic", 1: "wall", 2: "freespace"}
+    z, vz = np.load(os.path.join(golden_dir, "grad_chi.npz")), np.load(os.path.join(golden_dir, "vorticity.npz"))
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    t = g["tables"]
+    bpd, lmax, bc = tuple(int(b) for b in g["bpd"]), int(g["level_max"]), tuple(BCN[int(b)] for b in g["bc"])
+    ext = float(g["extent"])
+    kw = dict(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=0, extent=ext, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2])
+    mesh = cu.operators.Grid(bpd, lmax, 0, ext, bc, leaves=(t[:, 0].astype(np.int32), t[:, 1].copy()))
+    nb = len(t)
+    owner = (np.arange(nb) * nranks // nb).astype(np.int32)
+    rt, ct = (float(v) for v in vz[name + "_tol"])
+    chi, vort = z[name + "_chi"], vz[name + "_vort"]
+    got = {tag: np.zeros_like(vort) for tag in ("", "_capped")}
+    with VirtualComm(nranks):
+        views = [mesh.rank_view(owner, r, nranks) for r in range(nranks)]
+        sims = [cu.SimulationData(view=views[r], **kw) for r in range(nranks)]
+
+        def rank(r):
+            s, mine = sims[r], views[r].global_slot[:views[r].nlocal]
+            s.Rtol, s.Ctol = rt, ct
+            s.upload("chi", chi[mine])
+            for tag, lmv in (("", lmax), ("_capped", lmax - 1)):
+                s.levelMaxVorticity = lmv
+                s.upload("tmpV", vort[mine])
+                cu.GradChiOnTmp(s)(0, mesh=mesh, owner=owner)
+                got[tag][mine] = s.download("tmpV")
+
+        run_ranks(rank, nranks)
+        del sims, views
+    for tag in ("", "_capped"):
+        assert np.array_equal(got[tag], z[name + "_tmpV" + tag]), (name, tag)
