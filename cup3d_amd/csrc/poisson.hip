@@ -572,8 +572,8 @@ struct Loop2Args { double alpha, omega; const double *xin; };
 #define NTS(v, j, val) __builtin_nontemporal_store((val), &(v)[j])
 
 template <bool FMA, int EV>
-__global__ void __launch_bounds__(64) k_loop1_cg(GridDev g, Vecs V, Loop1Args a, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
-                                                 int *__restrict__ iters_out) {
+__device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, const Loop1Args &a, double *__restrict__ block_dots, long nb,
+                                              double *__restrict__ block_sums, int *__restrict__ iters_out) {
   __shared__ double P[8 * 80];
   const int slot = block_slot(g);
   if (slot < 0) return;
@@ -617,10 +617,15 @@ __global__ void __launch_bounds__(64) k_loop1_cg(GridDev g, Vecs V, Loop1Args a,
   if (l == 0) { block_dots[slot] = d0; block_dots[nb + slot] = d1; }
   cg_block<FMA, false, EV>(g, slot, r, V.v[ZHAT], block_sums, 0.0, 0.0, iters_out, P);  // zhat = M^-1 z, 14488
 }
+template <bool FMA, int EV>
+__global__ void __launch_bounds__(64) k_loop1_cg(GridDev g, Vecs V, Loop1Args a, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
+                                                 int *__restrict__ iters_out) {
+  loop1_cg_body<FMA, EV>(g, V, a, block_dots, nb, block_sums, iters_out);
+}
 
 template <bool FMA, int EV>
-__global__ void __launch_bounds__(64) k_loop2_cg(GridDev g, Vecs V, Loop2Args a, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
-                                                 int *__restrict__ iters_out) {
+__device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, const Loop2Args &a, double *__restrict__ block_dots, long nb,
+                                              double *__restrict__ block_sums, int *__restrict__ iters_out) {
   __shared__ double P[8 * 80];
   const int slot = block_slot(g);
   if (slot < 0) return;
@@ -663,6 +668,21 @@ __global__ void __launch_bounds__(64) k_loop2_cg(GridDev g, Vecs V, Loop2Args a,
     if (i == 4 && l == 0) block_dots[(size_t)6 * nb + slot] = t;  // norm = the same sum as norm_1 (14512-14514)
   }
   cg_block<FMA, false, EV>(g, slot, r, V.v[WHAT], block_sums, 0.0, 0.0, iters_out, P);  // what = M^-1 w, 14548
+}
+// Production: held to 96 registers (2 of the 122 the body asks for are spilled, outside the CG loop) -> 5 wavefronts per SIMD like the
+// first fused kernel: 3.63-3.70 ms instead of 3.75 at 512^3, 0.457-0.461 instead of 0.497 at 256^3
+// (profiles/r02/probe_fused_kernel_occupancy.jsonl).  The same test on the other side -- the first kernel or the stand-alone block
+// CG held to 80 registers for 6 wavefronts -- loses (12-14 spills inside the loops: 5.3 ms instead of 3.88; CG 0.43 instead of 0.40).
+template <bool FMA, int EV>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
+k_loop2_cg(GridDev g, Vecs V, Loop2Args a, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums, int *__restrict__ iters_out) {
+  loop2_cg_body<FMA, EV>(g, V, a, block_dots, nb, block_sums, iters_out);
+}
+// A/B (debug option "loop2_four_waves"): the register allocation the compiler picks on its own, 122 -> 4 wavefronts per SIMD
+template <bool FMA, int EV>
+__global__ void __launch_bounds__(64) k_loop2_cg_w4(GridDev g, Vecs V, Loop2Args a, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
+                                                    int *__restrict__ iters_out) {
+  loop2_cg_body<FMA, EV>(g, V, a, block_dots, nb, block_sums, iters_out);
 }
 
 // K sums of nb per-block values each ([K][nb]) finished in one launch: 64 workgroups, the last one to arrive totals the partials.
@@ -911,6 +931,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   // vector loop + block CG in one launch (k_loop1_cg / k_loop2_cg): the production path of the pressure solver with the block CG
   const bool fuse = !helm && (P.block_solver == 0 || P.block_solver == 2) && !debug_option("no_fuse");
   const bool want_sums = mc > 0 && mc <= 2;
+  const bool four_waves = debug_option("loop2_four_waves") != 0;  // A/B of the second fused kernel's occupancy
   double *const sums = want_sums ? s->d_partials + (size_t)s->max_groups * 8 : nullptr;
   int *const cg_it = profile_on() ? cg_iters_buffer(s) : nullptr;
   const GridDev gd = s->gdev();
@@ -966,7 +987,8 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       {
         ProfileScope ps("bicgstab_loop2_cg");
         const Loop2Args la{alpha, omega, V.xin};
-        if (P.block_solver == 0) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, la, s->d_block_dots, (long)s->nb, sums, cg_it);
+        if (P.block_solver == 0 && four_waves) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, la, s->d_block_dots, (long)s->nb, sums, cg_it);
+        else if (P.block_solver == 0) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, la, s->d_block_dots, (long)s->nb, sums, cg_it);
         else hipLaunchKernelGGL((k_loop2_cg<false, 0>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, la, s->d_block_dots, (long)s->nb, sums, cg_it);
       }
       s->sums_of = want_sums ? V.v[WHAT] : nullptr;

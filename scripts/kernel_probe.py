@@ -37,7 +37,7 @@ def make(size, bc="periodic"):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["adv", "pre", "one", "loops", "pcie", "cgvar", "lhs"])
+    ap.add_argument("what", choices=["adv", "pre", "one", "loops", "pcie", "cgvar", "lhs", "fusedwaves"])
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--variants", default="0,1,2,3")
     ap.add_argument("--kernel", default="adv")
@@ -82,6 +82,24 @@ def main():
             print(json.dumps({"probe": "poisson_lhs", "size": a.size, "variant": v, "avg_ms": round(avg, 4), "GBps_algorithmic": round(16 * cells / avg / 1e6, 1),
                               "frac_8TBs": round(16 * cells / avg / 1e6 / 8000, 4)}))
         lib().cup3d_debug_set_option(b"lhs_variant", 0)
+    elif a.what == "fusedwaves":
+        # occupancy A/B of the second fused solver kernel (debug option "loop2_four_waves": variant 1 = 122 registers, 4 waves / SIMD;
+        # 0 = production, 96 registers, 5 waves): one pressure projection per variant, same input
+        sim = make(a.size, "wall")
+        sim.step = 21
+        dt = 0.3 * sim.grid.h
+        vel0 = sim.download("vel")
+        for v in [int(x) for x in a.variants.split(",")]:
+            check(lib().cup3d_debug_set_option(b"loop2_four_waves", v))
+            sim.upload("vel", vel0); sim.fill("pres", 0.0)
+            lib().cup3d_device_synchronize()
+            lib().cup3d_profile_reset()
+            r = cu.PressureProjection(sim)(dt)
+            p = profile()
+            print(json.dumps({"probe": "loop2_four_waves", "size": a.size, "variant": v, "iterations": r.iterations,
+                              "loop1_cg_ms": round(p["bicgstab_loop1_cg"][1] / p["bicgstab_loop1_cg"][0], 4),
+                              "loop2_cg_ms": round(p["bicgstab_loop2_cg"][1] / p["bicgstab_loop2_cg"][0], 4)}))
+        check(lib().cup3d_debug_set_option(b"loop2_four_waves", 0))
     elif a.what == "pcie":
         # host <-> device rate of the boundary's block transfers (reference layout AoS on the host, SoA slab on the device)
         import time
@@ -135,7 +153,8 @@ def main():
         sim.upload("pres", rhs)
         check(lib().cup3d_preconditioner(sim.handle, 2))
         ref = sim.download("pres")
-        for bits in list(range(16)) + ["pair"]:
+        todo = [int(x) for x in a.variants.split(",")] if a.variants != "0,1,2,3" else list(range(16)) + ["pair"]
+        for bits in todo:
             solver = 4 if bits == "pair" else 0
             if solver == 0:
                 check(lib().cup3d_debug_set_option(b"cg_variant", 8 + bits))
