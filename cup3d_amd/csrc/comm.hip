@@ -274,10 +274,18 @@ int exchange_items(Sim *s, const double *sendbuf, const std::vector<int64_t> &se
   if (send_count[me] != recv_count[me]) { set_error("exchange_items: inconsistent self count"); return CUP3D_EINVAL; }
   if (send_count[me]) CUP3D_HIP(hipMemcpyAsync(recvbuf + ro[me], sendbuf + so[me], (size_t)send_count[me] * per * sizeof(double), hipMemcpyDeviceToDevice, stream()));
   if (n == 1) return CUP3D_OK;
-  if (g_vcomm) {
+  Comm *c = g_vcomm ? nullptr : comm();
+  if (!g_vcomm && !c) { set_error("multi-rank mesh without cup3d_comm_init"); return CUP3D_ESTATE; }
+  hipStream_t st = g_vcomm ? exchange_stream(s) : (s->comm_stream ? s->comm_stream : stream());
+  if (st != stream()) {
+    CUP3D_HIP(hipEventRecord(s->ev_h1, stream()));
+    CUP3D_HIP(hipStreamWaitEvent(st, s->ev_h1, 0));
+  }
+  if (g_vcomm) {  // the in-process transport, on the same stream and behind the same hand-offs as the RCCL calls below
     VComm *vc = g_vcomm;
     vc->ptr[me] = const_cast<double *>(sendbuf);
     vc->counts[me] = &send_count;
+    CUP3D_HIP(hipEventRecord(s->ev_vc_pack, st));
     if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the block exchange"); return CUP3D_ECOMM; }
     for (int p = 0; p < n; ++p) {
       if (p == me || !recv_count[p]) continue;
@@ -285,26 +293,22 @@ int exchange_items(Sim *s, const double *sendbuf, const std::vector<int64_t> &se
       size_t off = 0;
       for (int q = 0; q < me; ++q) off += (size_t)sc[q] * per;
       if (sc[me] != recv_count[p]) { set_error("exchange_items: rank %d sends %ld items, rank %d expects %ld", p, (long)sc[me], me, (long)recv_count[p]); return CUP3D_ESTATE; }
-      CUP3D_HIP(hipMemcpyAsync(recvbuf + ro[p], vc->ptr[p] + off, (size_t)recv_count[p] * per * sizeof(double), hipMemcpyDeviceToDevice, stream()));
+      if (vc->sims[p]) CUP3D_HIP(hipStreamWaitEvent(st, vc->sims[p]->ev_vc_pack, 0));
+      CUP3D_HIP(hipMemcpyAsync(recvbuf + ro[p], vc->ptr[p] + off, (size_t)recv_count[p] * per * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
-    CUP3D_HIP(hipStreamSynchronize(stream()));  // the peers may free their send buffers after the next barrier
+    CUP3D_HIP(hipEventRecord(s->ev_vc_done, st));
     if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the block exchange"); return CUP3D_ECOMM; }
-    return CUP3D_OK;
+    for (int p = 0; p < n; ++p)  // a send completes when the data has left: the callers free their send buffers after the compute stream drains
+      if (p != me && send_count[p] && vc->sims[p]) CUP3D_HIP(hipStreamWaitEvent(st, vc->sims[p]->ev_vc_done, 0));
+  } else {
+    CUP3D_NCCL(c->GroupStart());
+    for (int p = 0; p < n; ++p) {
+      if (p == me) continue;
+      if (send_count[p]) CUP3D_NCCL(c->Send(sendbuf + so[p], (size_t)send_count[p] * per, ncclDouble, p, c->comm, st));
+      if (recv_count[p]) CUP3D_NCCL(c->Recv(recvbuf + ro[p], (size_t)recv_count[p] * per, ncclDouble, p, c->comm, st));
+    }
+    CUP3D_NCCL(c->GroupEnd());
   }
-  Comm *c = comm();
-  if (!c) { set_error("multi-rank mesh without cup3d_comm_init"); return CUP3D_ESTATE; }
-  hipStream_t st = s->comm_stream ? s->comm_stream : stream();
-  if (st != stream()) {
-    CUP3D_HIP(hipEventRecord(s->ev_h1, stream()));
-    CUP3D_HIP(hipStreamWaitEvent(st, s->ev_h1, 0));
-  }
-  CUP3D_NCCL(c->GroupStart());
-  for (int p = 0; p < n; ++p) {
-    if (p == me) continue;
-    if (send_count[p]) CUP3D_NCCL(c->Send(sendbuf + so[p], (size_t)send_count[p] * per, ncclDouble, p, c->comm, st));
-    if (recv_count[p]) CUP3D_NCCL(c->Recv(recvbuf + ro[p], (size_t)recv_count[p] * per, ncclDouble, p, c->comm, st));
-  }
-  CUP3D_NCCL(c->GroupEnd());
   if (st != stream()) {
     CUP3D_HIP(hipEventRecord(s->ev_h2, st));
     CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
