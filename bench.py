@@ -205,6 +205,7 @@ def main():
     ap.add_argument("--block-solver", type=int, default=0, help="0: block CG as in the reference, 1: direct block solve, 5: multigrid V-cycle")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed region with the other block solver")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host<->device transfer measurement behind `pcie_inclusive`")
+    ap.add_argument("--debug-option", action="append", help="name=value for cup3d_debug_set_option (tuning scans)")
     ap.add_argument("--no-profile", action="store_true", help="A/B: no per-kernel HIP events in the timed region (no roofline in the output)")
     ap.add_argument("--no-fuse", action="store_true", help="A/B: vector loops and block CG as separate launches (round-1 structure)")
     ap.add_argument("--implicit-diffusion", action="store_true",
@@ -236,6 +237,9 @@ def main():
     cu.device_init(local_rank)
     if a.no_fuse:
         check(lib().cup3d_debug_set_option(b"no_fuse", 1))
+    for opt in (a.debug_option or []):   # tuning scans: --debug-option name=value (cup3d_debug_set_option)
+        name, val = opt.split("=")
+        check(lib().cup3d_debug_set_option(name.encode(), int(val)))
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -251,7 +251,9 @@ int mg_vcycle(Sim *s, const double *in, double *out) {
   if (rc) return rc;
   Multigrid &mg = *reinterpret_cast<Multigrid *>(s->mg);
   const int L = (int)mg.lev.size() - 1;
-  const int nu = 2, sw = 2;  // smoothing launches before / after the coarse-grid correction, sweeps per launch
+  // smoothing launches before / after the coarse-grid correction, sweeps per launch (ghosts are frozen within a launch);
+  // cup3d_debug_set_option("mg_launches" / "mg_sweeps") for tuning scans
+  const int nu = debug_option("mg_launches") > 0 ? debug_option("mg_launches") : 2, sw = debug_option("mg_sweeps") > 0 ? debug_option("mg_sweeps") : 2;
   std::vector<double *> xa(L + 1), xb(L + 1);  // xa[l]: where the level's iterate currently lives
   std::vector<const double *> rhs(L + 1);
   for (int l = 0; l <= L; ++l) {
