@@ -51,6 +51,15 @@ public:
   // velocity stays in HBM (no download / upload), see install()
   bool resident = false;      // allowed at all: decided by install() from the pipeline
   bool vel_on_device = false; // the device copy of vel is newer than the host's
+  // resident ACROSS steps (install(sim, 2) / CUP3D_HIP_RESIDENT=2): after PressureProjectionHIP the host holds a copy of the
+  // device's vel and pres; as long as nobody but the intercepted operators writes those two fields on the host, the next step need
+  // not send them up again (3.2 + 1.1 GB per step at 512^3).  That "as long as" is a CONTRACT with the host code: the reference's own
+  // step writes vel / pres only inside the operators this header replaces or wraps and in adaptMesh (which changes the block list:
+  // ensure() notices and drops the flags); any other writer -- an initial condition, a restart, a test harness loading a field --
+  // must call invalidate().  Off by default for that reason.
+  bool across_steps = false;
+  bool host_vel_clean = false, host_pres_clean = false;  // host copy == device copy
+  void invalidate() { host_vel_clean = host_pres_clean = false; }
   void upload(int field) {
     ensure();
     const std::vector<Info> &I = infos(field);
@@ -120,6 +129,7 @@ private:
     for (size_t i = 0; same && i < I.size(); ++i) same = signature[2 * i] == I[i].level && signature[2 * i + 1] == I[i].Z;
     if (same) return;
     release();
+    invalidate();  // a new block list: nothing of the old mirror is current
     int rank = 0, size = 1;
     MPI_Comm_rank(sim.comm, &rank);
     MPI_Comm_size(sim.comm, &size);
@@ -232,7 +242,9 @@ public:
   AdvectionDiffusionHIP(SimulationData &s, std::shared_ptr<DeviceMirror> d) : Operator(s), devp(d), dev(*d) {}
   void operator()(const Real dt) override {
     (void)dt;  // KernelAdvectDiffuse reads sim.dt (9465), which advance() passes as dt
-    dev.upload(CUP3D_FIELD_VEL);
+    dev.handle();  // (re)builds the mirror when the block list changed, which drops the clean flags
+    if (!(dev.across_steps && dev.host_vel_clean)) dev.upload(CUP3D_FIELD_VEL);
+    dev.host_vel_clean = false;  // the device is about to move on
     const double uinf[3] = {sim.uinf[0], sim.uinf[1], sim.uinf[2]};
     CUP3D_HIP_CALL(cup3d_advect_diffuse(dev.handle(), sim.dt, sim.nu, uinf));
     if (dev.resident) {
@@ -260,7 +272,9 @@ public:
   AdvectionDiffusionImplicitHIP(SimulationData &s, std::shared_ptr<DeviceMirror> d) : Operator(s), devp(d), dev(*d) {}
   void operator()(const Real dt) override {
     (void)dt;  // euler(sim.dt), 10119
-    dev.upload(CUP3D_FIELD_VEL);
+    dev.handle();
+    if (!(dev.across_steps && dev.host_vel_clean)) dev.upload(CUP3D_FIELD_VEL);
+    dev.host_vel_clean = false;
     const double uinf[3] = {sim.uinf[0], sim.uinf[1], sim.uinf[2]};
     cup3d_poisson_params p;
     cup3d_poisson_default_params(&p);
@@ -323,6 +337,7 @@ public:
     const cup3d_poisson_params p = poisson_params(sim);
     CUP3D_HIP_CALL(cup3d_poisson_solve(dev.handle(), &p, &last));
     dev.download(CUP3D_FIELD_PRES);
+    dev.host_pres_clean = true;
   }
 };
 
@@ -353,15 +368,20 @@ public:
       CUP3D_HIP_CALL(cup3d_sim_fill(dev.handle(), CUP3D_FIELD_CHI, 0.0));
       had_obstacles = false;
     }
+    dev.handle();
     if (!dev.vel_on_device) dev.upload(CUP3D_FIELD_VEL);
     else if (obstacles) dev.upload_obstacle_blocks(CUP3D_FIELD_VEL);  // what UpdateObstacles / Penalization changed on the host
     dev.vel_on_device = false;
-    dev.upload(CUP3D_FIELD_PRES);
+    if (!(dev.across_steps && dev.host_pres_clean)) dev.upload(CUP3D_FIELD_PRES);
     const cup3d_poisson_params p = poisson_params(sim);
     CUP3D_HIP_CALL(cup3d_pressure_project(dev.handle(), dt, sim.step, &p, &last));
     dev.download(CUP3D_FIELD_VEL);
     dev.download(CUP3D_FIELD_PRES);
-    dev.download(CUP3D_FIELD_TMPV);  // gradP scratch, as the reference leaves it (15146)
+    dev.host_vel_clean = dev.host_pres_clean = true;
+    // gradP scratch, as the reference leaves it (15146).  Nothing reads it on the host before it is overwritten (AdvectionDiffusion
+    // clears tmpV first, 9702-9706; adaptMesh's ComputeVorticity and the projection's own prologue fill it) -- the resident modes
+    // leave the host copy stale (3.2 GB per step at 512^3)
+    if (!dev.resident) dev.download(CUP3D_FIELD_TMPV);
   }
 };
 
@@ -390,8 +410,9 @@ struct Installed {
 };
 
 // Swap the hot-path operators of an initialised Simulation for the HIP-backed ones.
-// resident (default: environment CUP3D_HIP_RESIDENT=1): keep the velocity in HBM between AdvectionDiffusion and
-// PressureProjection.  Allowed only if every operator the reference put between the two (setupOperators 15229-15246) is
+// resident (default: environment CUP3D_HIP_RESIDENT, 0 / 1 / 2): 1 = keep the velocity in HBM between AdvectionDiffusion and
+// PressureProjection; 2 = also skip the uploads of vel and pres at the next step while the host copies are known to be current
+// (DeviceMirror::across_steps: read its contract).  Allowed only if every operator the reference put between the two (setupOperators 15229-15246) is
 // ExternalForcing (then run on the device too) or one of the obstacle operators: UpdateObstacles and Penalization touch the
 // velocity only in the blocks an obstacle covers, so those blocks alone make the round trip (UpdateObstaclesHIP fetches them,
 // PressureProjectionHIP sends them back); without obstacles both return immediately (13813-13814, 14327-14328).  With
@@ -412,6 +433,7 @@ inline Installed install(SimulationData &sim, int resident = -1) {
       safe = false;
   }
   r.mirror->resident = resident != 0 && safe;
+  r.mirror->across_steps = resident >= 2 && safe;
   for (auto &op : sim.pipeline) {
     if (std::dynamic_pointer_cast<AdvectionDiffusion>(op)) {
       r.advdiff = std::make_shared<AdvectionDiffusionHIP>(sim, r.mirror);

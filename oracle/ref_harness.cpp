@@ -163,6 +163,12 @@ int main(int argc, char **argv) {
   for (auto &op : sd.pipeline)
     if (auto p = std::dynamic_pointer_cast<PressureProjection>(op)) proj = p;
   std::shared_ptr<Operator> hip_adv, hip_proj;
+#ifdef CUP3D_WITH_HIP
+  std::shared_ptr<cup3d_hip::DeviceMirror> hip_mirror;
+#define HIP_INVALIDATE() do { if (hip_mirror) hip_mirror->invalidate(); } while (0)
+#else
+#define HIP_INVALIDATE() do { } while (0)
+#endif
   std::ifstream script(argv[1]);
   std::string cmd;
   int rep = 1;
@@ -207,6 +213,7 @@ int main(int argc, char **argv) {
       write_file(path, out.data(), out.size() * 8);
     } else if (cmd == "loadg") {
       std::string fname, path; script >> fname >> path;
+      HIP_INVALIDATE();  /* the script writes a host field behind the operators' back */
       Field F = field_of(sd, fname);
       auto buf = read_file(path);
       const double *g = (const double *)buf.data();
@@ -230,6 +237,7 @@ int main(int argc, char **argv) {
       std::string fname; script >> fname;
       Field F = field_of(sd, fname);
       for (auto &inf : *F.infos) memset(inf.block, 0, 512 * F.ncomp * 8);
+      HIP_INVALIDATE();  /* the script writes a host field behind the operators' back */
     } else if (cmd == "dump") {
       std::string fname, path; script >> fname >> path;
       Field F = field_of(sd, fname);
@@ -257,13 +265,15 @@ int main(int argc, char **argv) {
       else if (k == "difftolrel") sd.DiffusionErrorTolRel = v;
       else { fprintf(stderr, "ref_tool: unknown set key %s\n", k.c_str()); exit(2); }
     } else if (cmd == "hip") {
-      /* `hip on` | `hip resident`: swap AdvectionDiffusion / PressureProjection in sim.pipeline for the HIP-backed
+      /* `hip on` | `hip resident` | `hip resident2`: swap AdvectionDiffusion / PressureProjection in sim.pipeline for the HIP-backed
          operators (cup3d_hip::install); every later op/steps command runs through them */
       std::string v; script >> v;
 #ifdef CUP3D_WITH_HIP
       static cup3d_hip::Installed inst;
-      inst = cup3d_hip::install(sd, v == "resident" ? 1 : -1);  /* `hip resident`: vel stays in HBM between the two operators */
+      /* `hip resident`: vel stays in HBM between the two operators; `hip resident2`: also across steps (DeviceMirror::across_steps) */
+      inst = cup3d_hip::install(sd, v == "resident2" ? 2 : (v == "resident" ? 1 : -1));
       hip_adv = inst.advdiff; hip_proj = inst.projection;
+      hip_mirror = inst.mirror;
 #else
       fprintf(stderr, "ref_tool: built without CUP3D_WITH_HIP\n"); exit(2);
 #endif
@@ -303,6 +313,7 @@ int main(int argc, char **argv) {
     } else if (cmd == "loadb") {
       /* `loadb <field> <file>`: block-order load [nb][8][8][8][nc] (works on multi-level meshes) */
       std::string fname, path; script >> fname >> path;
+      HIP_INVALIDATE();  /* the script writes a host field behind the operators' back */
       Field F = field_of(sd, fname);
       auto buf = read_file(path);
       const size_t per = 512 * F.ncomp;

@@ -26,7 +26,7 @@ def run(tool, script, args, wd):
             for l in out.splitlines() if l.startswith("REF ")]
 
 
-@pytest.mark.parametrize("mode", ["hip on", "hip resident"])
+@pytest.mark.parametrize("mode", ["hip on", "hip resident", "hip resident2"])
 @pytest.mark.parametrize("bc", [("periodic", "periodic", "periodic"), ("wall", "wall", "wall"), ("freespace", "periodic", "wall")])
 def test_reference_time_loop_with_hip_operators(tmp_path, bc, mode):
     bpd, lmax, lstart, nsteps = (1, 1, 1), 3, 2, 5
@@ -74,13 +74,14 @@ FISH_ARGS = ["-bMeanConstraint", "2", "-bpdx", "2", "-bpdy", "2", "-bpdz", "2", 
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode", ["hip on", "hip resident"])
+@pytest.mark.parametrize("mode", ["hip on", "hip resident", "hip resident2"])
 def test_fish_plumbing_run(tmp_path, mode):
     """BASELINE configs[0]: a single carling-fish swimmer (StefanFish, the parameters of the reference's run.sh / fish.ipynb, one fish),
     coarse 2-level AMR (levels 1 and 2 of a 2^3-block box, 148 blocks), one rank, 30 steps of the reference's own time loop --
     CreateObstacles, adaptMesh (steps < 10 and every 20th, 15314), AdvectionDiffusion, UpdateObstacles, Penalization,
     PressureProjection with chi / udef, ComputeForces -- once with the reference's CPU operators and once with the two hot-path
-    operators swapped for the HIP ones (default round-trip mode and resident mode).  Same binary otherwise, including the stand-ins
+    operators swapped for the HIP ones (default round-trip mode, resident mode, and resident across steps: vel / pres go up only
+    when the mirror is rebuilt after an adaptation).  Same binary otherwise, including the stand-ins
     for the two GSL entry points (oracle/refbuild/gsl: nothing is claimed about GSL itself).  Block lists identical at both
     check points; velocity, pressure and chi to solver round-off (Poisson tolerance 1e-9 / 1e-8 on both sides)."""
     res = {}
