@@ -384,8 +384,12 @@ def ref_iters(a):
     if a.stencil_only or a.implicit_diffusion or not os.path.exists(f):
         return None
     rec = json.load(open(f))
-    return {"value": rec["ref_iters_per_step"], "device_in_the_same_run": rec["device_iters_per_step"], "steps": len(rec["steps"]),
-            "source": f"profiles/r02/reference_step_{a.size}.json (compiled reference, one step from step 21)"}
+    out = {"value": rec["ref_iters_per_step"], "device_in_the_same_run": rec["device_iters_per_step"], "steps": len(rec["steps"]),
+           "source": f"profiles/r02/reference_step_{a.size}.json (compiled reference, one step from step 21)"}
+    f1 = os.path.join(ROOT, "profiles", "r02", f"reference_step_{a.size}_first_run.json")
+    if os.path.exists(f1):  # the reference's count is not reproducible (OpenMP reduction order): an earlier run of the same campaign
+        out["value_in_an_earlier_run"] = json.load(open(f1))["ref_iters_per_step"]
+    return out
 
 
 def report(a, sim, prof, sec, iters, world, alt=None):
