@@ -221,6 +221,10 @@ def main():
             sys.exit("bench.py --amr runs on one GPU (multi-level meshes are single-rank this round)")
         return run_amr(a)
 
+    # RCCL prints a version banner to STDOUT under NCCL_DEBUG=VERSION (the image's default), once per process and communicator
+    # library: stdout carries the one JSON line of rank 0 and nothing else
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
