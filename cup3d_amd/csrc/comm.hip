@@ -76,7 +76,8 @@ static int load_rccl() {
 // multi-rank control flow is executed before it meets RCCL.
 struct VComm {
   int n = 0;
-  std::vector<Sim *> sims;
+  std::vector<Sim *> sims;   // registry: the sim each rank created last
+  std::vector<Sim *> cur;    // the sim each rank entered the CURRENT collective with (a rank can hold two: old and adapted mesh)
   std::vector<double *> ptr;
   std::vector<const std::vector<int64_t> *> counts;
   double *d_tmp = nullptr;  // [n][16]
@@ -108,6 +109,7 @@ void vcomm_register(Sim *s) {
 void vcomm_unregister(Sim *s) {
   if (!g_vcomm) return;
   for (auto &p : g_vcomm->sims) if (p == s) p = nullptr;
+  for (auto &p : g_vcomm->cur) if (p == s) p = nullptr;
 }
 
 struct VPtrs { const double *p[16]; };
@@ -148,13 +150,14 @@ static int vcomm_pull(Sim *s, double *dst, size_t per, const std::vector<int64_t
   VComm *vc = g_vcomm;
   const Grid *g = s->grid;
   // my pack is enqueued on st: the event lets the receivers' streams wait for it (what a matched ncclSend / ncclRecv does)
+  vc->cur[g->rank] = s;
   CUP3D_HIP(hipEventRecord(s->ev_vc_pack, st));
   if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the exchange"); return CUP3D_ECOMM; }  // every rank has enqueued its pack
   size_t ro = 0;
   for (int p = 0; p < g->nranks; ++p) {
     const size_t nr = (size_t)recv_count[p] * per;
     if (!nr) continue;
-    Sim *src = vc->sims[p];
+    Sim *src = vc->cur[p];
     if (!src) { set_error("virtual communicator: rank %d has no sim", p); return CUP3D_ESTATE; }
     const std::vector<int64_t> &sc = send_count_of(src->grid);
     size_t so = 0;
@@ -169,7 +172,7 @@ static int vcomm_pull(Sim *s, double *dst, size_t per, const std::vector<int64_t
   // a send completes when the data has left: my stream (hence my next pack into halo_send) waits for the copies of my receivers
   const std::vector<int64_t> &mine = send_count_of(g);
   for (int p = 0; p < g->nranks; ++p)
-    if (mine[p] && vc->sims[p]) CUP3D_HIP(hipStreamWaitEvent(st, vc->sims[p]->ev_vc_done, 0));
+    if (mine[p] && vc->cur[p]) CUP3D_HIP(hipStreamWaitEvent(st, vc->cur[p]->ev_vc_done, 0));
   return CUP3D_OK;
 }
 
@@ -283,6 +286,7 @@ int exchange_items(Sim *s, const double *sendbuf, const std::vector<int64_t> &se
   }
   if (g_vcomm) {  // the in-process transport, on the same stream and behind the same hand-offs as the RCCL calls below
     VComm *vc = g_vcomm;
+    vc->cur[me] = s;
     vc->ptr[me] = const_cast<double *>(sendbuf);
     vc->counts[me] = &send_count;
     CUP3D_HIP(hipEventRecord(s->ev_vc_pack, st));
@@ -293,13 +297,13 @@ int exchange_items(Sim *s, const double *sendbuf, const std::vector<int64_t> &se
       size_t off = 0;
       for (int q = 0; q < me; ++q) off += (size_t)sc[q] * per;
       if (sc[me] != recv_count[p]) { set_error("exchange_items: rank %d sends %ld items, rank %d expects %ld", p, (long)sc[me], me, (long)recv_count[p]); return CUP3D_ESTATE; }
-      if (vc->sims[p]) CUP3D_HIP(hipStreamWaitEvent(st, vc->sims[p]->ev_vc_pack, 0));
+      if (vc->cur[p]) CUP3D_HIP(hipStreamWaitEvent(st, vc->cur[p]->ev_vc_pack, 0));
       CUP3D_HIP(hipMemcpyAsync(recvbuf + ro[p], vc->ptr[p] + off, (size_t)recv_count[p] * per * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
     CUP3D_HIP(hipEventRecord(s->ev_vc_done, st));
     if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the block exchange"); return CUP3D_ECOMM; }
     for (int p = 0; p < n; ++p)  // a send completes when the data has left: the callers free their send buffers after the compute stream drains
-      if (p != me && send_count[p] && vc->sims[p]) CUP3D_HIP(hipStreamWaitEvent(st, vc->sims[p]->ev_vc_done, 0));
+      if (p != me && send_count[p] && vc->cur[p]) CUP3D_HIP(hipStreamWaitEvent(st, vc->cur[p]->ev_vc_done, 0));
   } else {
     CUP3D_NCCL(c->GroupStart());
     for (int p = 0; p < n; ++p) {
@@ -395,20 +399,21 @@ int allreduce(Sim *s, double *d_buf, int n, bool is_max, hipStream_t st) {
     VComm *vc = g_vcomm;
     const int r = s->grid->rank;
     if (n > 16 || vc->n > 16) { set_error("virtual communicator: at most 16 ranks / 16 values"); return CUP3D_EINVAL; }
+    vc->cur[r] = s;
     vc->ptr[r] = d_buf;
     CUP3D_HIP(hipEventRecord(s->ev_vc_pack, st));  // my operand is final at this point of st
     if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the all-reduce"); return CUP3D_ECOMM; }  // every rank's operand is enqueued
     VPtrs v;
     for (int q = 0; q < vc->n; ++q) {
       v.p[q] = vc->ptr[q];
-      if (q != r && vc->sims[q]) CUP3D_HIP(hipStreamWaitEvent(st, vc->sims[q]->ev_vc_pack, 0));
+      if (q != r && vc->cur[q]) CUP3D_HIP(hipStreamWaitEvent(st, vc->cur[q]->ev_vc_pack, 0));
     }
     hipLaunchKernelGGL(k_vreduce, dim3(1), dim3(64), 0, st, v, vc->n, n, is_max ? 1 : 0, vc->d_tmp + 16 * r);
     CUP3D_HIP(hipGetLastError());
     CUP3D_HIP(hipEventRecord(s->ev_vc_done, st));
     if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the all-reduce"); return CUP3D_ECOMM; }  // every rank has enqueued its read
     for (int q = 0; q < vc->n; ++q)
-      if (q != r && vc->sims[q]) CUP3D_HIP(hipStreamWaitEvent(st, vc->sims[q]->ev_vc_done, 0));  // ... and has read my operand before I overwrite it
+      if (q != r && vc->cur[q]) CUP3D_HIP(hipStreamWaitEvent(st, vc->cur[q]->ev_vc_done, 0));  // ... and has read my operand before I overwrite it
     CUP3D_HIP(hipMemcpyAsync(d_buf, vc->d_tmp + 16 * r, n * sizeof(double), hipMemcpyDeviceToDevice, st));
     return CUP3D_OK;
   }
@@ -476,6 +481,7 @@ int cup3d_debug_virtual_comm(int nranks) {
   VComm *vc = new VComm();
   vc->n = nranks;
   vc->sims.assign(nranks, nullptr);
+  vc->cur.assign(nranks, nullptr);
   vc->ptr.assign(nranks, nullptr);
   vc->counts.assign(nranks, nullptr);
   if (hipMalloc((void **)&vc->d_tmp, (size_t)nranks * 16 * sizeof(double)) != hipSuccess) { delete vc; set_error("virtual communicator: hipMalloc failed"); return CUP3D_EDEVICE; }

@@ -83,9 +83,32 @@ __device__ __forceinline__ double fast_div(double n, double d) {
   const double q = n * y;
   return __builtin_fma(__builtin_fma(-d, q, n), y, q);
 }
-template <bool MFMA>
-__device__ __forceinline__ double cg_sum(double v) {
+// LDS of one block CG: the padded copy of p ([z][10 rows][8], see below) + 4 doubles for the row totals of wave_sum_rows
+constexpr int kCgLds = 8 * 80 + 8;
+// The wave sum with its last two steps through LDS: after the four in-row DPP steps every lane of a 16-lane row holds the row total;
+// the rows park their totals in LDS and every lane adds the four of them -- (R3 + R2) + (R1 + R0), the association of the two
+// row_bcast steps of wave_sum, so the result is BIT-IDENTICAL -- then the value goes through the scalar unit like there (the loop
+// stays uniform).  15 + 2 vector instructions instead of 24 + 2 hazard nops.  MEASURED SLOWER (the LDS round trip sits on the
+// iteration's dependency chain: reduction -> division -> update): the kernel is bound by that chain more than by instruction issue,
+// whatever SQ_ACTIVE_INST_VALU suggests (profiles/r02/pmc_fused_kernels_sq_256cubed.txt).  A/B variant, not production.
+__device__ __forceinline__ double wave_sum_rows(double v, double *P) {
+  typedef volatile __attribute__((address_space(3))) double lds_vd;
+  lds_vd *R = (lds_vd *)(P + 8 * 80);
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x141>(v);
+  v += dpp_move<0x140>(v);
+  R[threadIdx.x >> 4] = v;
+  const double r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3];
+  const double t = (r3 + r2) + (r1 + r0);
+  const long long b = __builtin_bit_cast(long long, t);
+  const int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <bool MFMA, bool ROWS = false>
+__device__ __forceinline__ double cg_sum(double v, double *P = nullptr) {
   if constexpr (MFMA) return wave_sum_mfma(v);
+  else if constexpr (ROWS) return wave_sum_rows(v, P);
   else return wave_sum(v);
 }
 template <bool FAST>
@@ -95,7 +118,9 @@ __device__ __forceinline__ double cg_div(double n, double d) {
 }
 
 // EV = how the iteration is evaluated, a bit set: 1 = wave sums on the matrix pipe, 2 = single-width volatile LDS reads,
-// 4 = reciprocal divisions (FMA variants only), 8 = three-operand FMA for the p update (p_update above)
+// 4 = reciprocal divisions (FMA variants only), 8 = three-operand FMA for the p update (p_update above), 16 = the last two steps of
+// the wave sums through LDS (wave_sum_rows: bit-identical sums, 168 instead of 182 vector instructions per iteration -- and SLOWER:
+// block CG 3.18 instead of 2.88 ms, fused kernels 4.1 instead of 3.8 ms at 512^3; kept for A/B only)
 // cg_block: the iteration itself, entered with r = the block's right-hand side / h already in registers (lane = (x, y), 8 z per lane) --
 // shared by the stand-alone preconditioner kernel and the kernels that produce that right-hand side on the fly (k_loop1_cg / k_loop2_cg)
 template <bool FMA, bool HELM, int EV>
@@ -103,7 +128,7 @@ __device__ __forceinline__ void cg_block(const GridDev &g, int slot, double (&r)
                                          int *__restrict__ iters_out, double *P) {
   // (r01 kernel: 86 VGPRs -> 5 waves/SIMD.  Forcing 6 with amdgpu_waves_per_eu spills five values that are reloaded every iteration:
   //  0.476 vs 0.431 ms at 256^3, so the natural allocation stays.)
-  constexpr bool V2 = (EV & 1) != 0, LDSV = (EV & 2) != 0, FDIV = (EV & 4) != 0 && FMA;
+  constexpr bool V2 = (EV & 1) != 0, LDSV = (EV & 2) != 0, FDIV = (EV & 4) != 0 && FMA, ROWS = (EV & 16) != 0;
   const int l = threadIdx.x;
   const int base = ((l >> 3) + 1) * 8 + (l & 7);
   for (int i = l; i < 640; i += 64) P[i] = 0.0;
@@ -123,13 +148,13 @@ __device__ __forceinline__ void cg_block(const GridDev &g, int slot, double (&r)
     p[z] = r[z];
     x[z] = 0;
   }
-  rr = cg_sum<V2>(rr);
+  rr = cg_sum<V2, ROWS>(rr, P);
   const double kRel = 1e-7 * 1e-7, kAbs = 1e-16 * 1e-16;  // kSqrNorm{Rel,Abs}Criterion, 14619-14624
   const double sqrNorm0 = (double)1 / (512 * 512) * rr;    // 14734
   int kdone = 0;
   if (sqrNorm0 >= 1e-32) {                                  // else: block stays 0 (14735-14736)
     __syncthreads();
-    for (int k = 0; k < 100; ++k) {                         // 14739
+    auto iteration = [&](int k) -> bool {                     // one trip of the loop at 14739; false = leave it
       kdone = k + 1;
 #pragma unroll
       for (int z = 0; z < 8; ++z) P[z * 80 + base] = p[z];
@@ -153,7 +178,7 @@ __device__ __forceinline__ void cg_block(const GridDev &g, int slot, double (&r)
         a2 = mad<FMA>(p[z], t, a2);
       }
       __syncthreads();
-      a2 = cg_sum<V2>(a2);
+      a2 = cg_sum<V2, ROWS>(a2, P);
       const double a = cg_div<FDIV>(rr, a2 + 1e-55);        // 14684
       double ss = 0;
 #pragma unroll
@@ -162,15 +187,20 @@ __device__ __forceinline__ void cg_block(const GridDev &g, int slot, double (&r)
         r[z] = mad<FMA>(-a, Ax[z], r[z]);                   // subAndSumSqr, 14636-14638
         ss = mad<FMA>(r[z], r[z], ss);
       }
-      ss = cg_sum<V2>(ss);
+      ss = cg_sum<V2, ROWS>(ss, P);
       const double beta = cg_div<FDIV>(ss, rr + 1e-55);       // 14690
       const double sqrNorm = (double)1 / (512 * 512) * ss;  // 14691
-      if (sqrNorm < kRel * sqrNorm0 || sqrNorm < kAbs) break;  // 14692-14694 (returns -1)
+      if (sqrNorm < kRel * sqrNorm0 || sqrNorm < kAbs) return false;  // 14692-14694 (returns -1)
 #pragma unroll
       for (int z = 0; z < 8; ++z) p[z] = (EV & 8) ? p_update<FMA>(beta, p[z], r[z]) : mad<FMA>(beta, p[z], r[z]);   // 14698-14699
       rr = ss;
-      if (rr <= 0) break;                                   // 14741
-    }
+      if (rr <= 0) return false;                                   // 14741
+      return true;
+    };
+    // (two iterations per trip, to pay the register rotation of p at the back edge -- 8 v_mov_b64 -- every other iteration, costs
+    //  101-119 registers instead of 88-94: below 5 wavefronts per SIMD, not kept)
+    for (int k = 0; k < 100; ++k)
+      if (!iteration(k)) break;
   }
   double sx = 0;
 #pragma unroll
@@ -181,7 +211,7 @@ __device__ __forceinline__ void cg_block(const GridDev &g, int slot, double (&r)
   if (iters_out && l == 0) iters_out[slot] = kdone;  // measurement only (cup3d_profile_enable): CG iterations this block took
   if (block_sums) {  // sum(z*h^3) of this block for the mean constraint of the LHS that follows (9283-9294)
     const double hq = block_h(g, slot), h3 = hq * hq * hq;
-    sx = cg_sum<V2>(sx * h3);
+    sx = cg_sum<V2, ROWS>(sx * h3, P);
     if (l == 0) block_sums[slot] = sx;
   }
 }
@@ -189,7 +219,7 @@ __device__ __forceinline__ void cg_block(const GridDev &g, int slot, double (&r)
 template <bool FMA, bool HELM = false, int EV = 0>
 __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, double *out, double *__restrict__ block_sums, double nu, double dt,
                                                 int *__restrict__ iters_out) {
-  __shared__ double P[8 * 80];
+  __shared__ double P[kCgLds];
   const int slot = block_slot(g);
   if (slot < 0) return;
   const double invh = 1 / block_h(g, slot);  // main.cpp:14723
@@ -494,6 +524,10 @@ int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
         case 13: CG(true, 13); break;
         case 14: CG(true, 14); break;
         case 15: CG(true, 15); break;
+        case 16: CG(true, 16); break;   // row totals through LDS (wave_sum_rows)
+        case 18: CG(true, 18); break;
+        case 22: CG(true, 22); break;
+        case 30: CG(true, 30); break;
         default: set_error("unknown cg_variant"); return CUP3D_EINVAL;
       }
       break;
@@ -574,7 +608,7 @@ struct Loop2Args { double alpha, omega; const double *xin; };
 template <bool FMA, int EV>
 __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, const Loop1Args &a, double *__restrict__ block_dots, long nb,
                                               double *__restrict__ block_sums, int *__restrict__ iters_out) {
-  __shared__ double P[8 * 80];
+  __shared__ double P[kCgLds];
   const int slot = block_slot(g);
   if (slot < 0) return;
   const int l = threadIdx.x;
@@ -626,7 +660,7 @@ __global__ void __launch_bounds__(64) k_loop1_cg(GridDev g, Vecs V, Loop1Args a,
 template <bool FMA, int EV>
 __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, const Loop2Args &a, double *__restrict__ block_dots, long nb,
                                               double *__restrict__ block_sums, int *__restrict__ iters_out) {
-  __shared__ double P[8 * 80];
+  __shared__ double P[kCgLds];
   const int slot = block_slot(g);
   if (slot < 0) return;
   const int l = threadIdx.x;

@@ -86,6 +86,25 @@ PY
     tail -5 $OUT/pmc3_$TAGC.log
     rm -rf $OUT/pmc3_$TAGC
   done; fi
+if has pmcsq2; then echo "== rocprofv3 SQ counters of the fused solver kernels (one pressure projection at 256^3)"
+  for SET in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+    TAGC=$(echo $SET | cut -d" " -f1)
+    ( cd /tmp && timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $ROOT/$OUT/pmc4_$TAGC -o p -- python $ROOT/scripts/kernel_probe.py one --size 256 --kernel solve > $ROOT/$OUT/pmc4_$TAGC.log 2>&1 )
+    for f in $(find $OUT/pmc4_$TAGC -name "*counter_collection.csv" | head -1); do python - "$f" <<'PY' | tee -a $OUT/pmc_fused_kernels_sq.txt
+import csv, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"][:48]
+    if "k_loop1_cg" in k or "k_loop2_cg" in k or "k_precond<" in k or "k_lhs" in k:
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in sorted(acc.items()):
+    for c, v in sorted(d.items()):
+        print(k, c, "launches", len(v), "mean", round(sum(v) / len(v), 1))
+PY
+    done
+    tail -3 $OUT/pmc4_$TAGC.log
+    rm -rf $OUT/pmc4_$TAGC
+  done; fi
 if has campaign256; then echo "== campaign: 256^3 periodic, 3 default-tolerance steps + tight projection, device vs compiled reference"
   timeout 1500 python scripts/campaigns/baseline_sizes_vs_reference.py --size 256 --bc periodic --steps 3 --tight --threads ${REF_THREADS:-64} --out profiles/r02/reference_steps_256_periodic.json > $OUT/campaign256.json 2> $OUT/campaign256.err ; echo "rc=$?"; tail -c 3000 $OUT/campaign256.json; tail -3 $OUT/campaign256.err
   cp profiles/r02/reference_steps_256_periodic.json $OUT/ 2>/dev/null; fi
