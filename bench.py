@@ -4,6 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no launcher environment re-executes itself under torch.distributed.run (one process per GPU,
+127.0.0.1 rendezvous) and still prints ONE JSON line; with fewer than N visible devices it says so and exits 2.
+
 One "step" = one reference time step of the hot path on a synthetic uniform grid:
 calcMaxTimestep (findMaxU) + AdvectionDiffusion (fused RK3) + ExternalForcing +
 PressureProjection (pressure RHS, pipelined BiCGSTAB with block-CG preconditioner,
@@ -71,6 +74,77 @@ def taylor_green_blocks(grid, ext, umax):
     vel[..., 0] = (A * np.cos(a * px))[:, None, None, :] * np.sin(b * py)[:, None, :, None] * sz
     vel[..., 1] = (B * np.sin(a * px))[:, None, None, :] * np.cos(b * py)[:, None, :, None] * sz
     return vel
+
+
+def exact_test_field_blocks(grid, size):
+    """Velocity field of the partition-independent checksum (config.checksum): polynomials of the cell-centre coordinates evaluated
+    with correctly rounded +, -, *, / only -- no libm, so the input bits are the same on every machine and the constant in
+    tests/golden/advdiff_checksums.json (the CPU oracle's result, tests/golden/make_checksums.py) is portable.  Both signs of every
+    component occur (both upwind branches of KernelAdvectDiffuse, main.cpp:9474-9483); zero at no wall in particular."""
+    n = float(size)
+    idx = grid.index.astype(np.float64)
+    cell = np.arange(8) + 0.5
+    x = ((idx[:, 0:1] * 8 + cell[None, :]) / n)[:, None, None, :]
+    y = ((idx[:, 1:2] * 8 + cell[None, :]) / n)[:, None, :, None]
+    z = ((idx[:, 2:3] * 8 + cell[None, :]) / n)[:, :, None, None]
+    vel = np.empty((grid.nblocks, 8, 8, 8, 3))
+    vel[..., 0] = ((4.0 * x) * (1.0 - x)) * (y - 0.5) * (0.25 + z * z)
+    vel[..., 1] = (0.5 - x) * ((4.0 * y) * (1.0 - y)) * (z + 0.125)
+    vel[..., 2] = (x * y - 0.25) * ((4.0 * z) * (1.0 - z))
+    return vel
+
+
+def checksum_dt(size):
+    return 0.3 * (2 * np.pi / size)
+
+
+def advdiff_checksums(sim, a, dist, world):
+    """config.checksum: one AdvectionDiffusion::operator() (fixed dt = 0.3 h, nu = 0.01) applied to (a) the exact test field, (b) the
+    Taylor-Green field of the run; the wrapping 64-bit sums of the bit patterns of `vel` afterwards, added over the ranks mod 2^64.
+    The stencil path is bit-exact with the CPU oracle under any sharding of the blocks, so both values must equal the oracle's
+    constants at every N (the reference's own multi-rank run equals its one-rank run the same way: tests/test_oracle_vs_ref.py)."""
+    import torch
+    import cup3d_amd as cu
+    ext = 2 * np.pi
+    golden = os.path.join(ROOT, "tests", "golden", "advdiff_checksums.json")
+    expected = json.load(open(golden)).get(str(a.size), {}) if os.path.exists(golden) else {}
+    out = {"what": "wrapping uint64 sum of the bit patterns of vel after ONE AdvectionDiffusion (dt = 0.3 h, nu = 0.01) on this workload's grid, "
+                   "summed over ranks mod 2^64; `expected` = the CPU oracle's value (tests/golden/advdiff_checksums.json)", "dt": checksum_dt(a.size)}
+    adv = cu.AdvectionDiffusion(sim)
+    nu0, sim.nu = sim.nu, 0.01
+    for key, field in (("exact_field", exact_test_field_blocks(sim.grid, a.size)), ("taylor_green", taylor_green_blocks(sim.grid, [ext] * 3, 1.0))):
+        sim.upload("vel", field)
+        adv(checksum_dt(a.size))
+        mine = sim.checksum("vel")
+        if dist is not None:
+            parts = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
+            dist.all_gather(parts, torch.tensor([mine - (1 << 64) if mine >= (1 << 63) else mine], dtype=torch.int64, device="cuda"))
+            mine = sum(int(p.item()) for p in parts) % (1 << 64)
+        exp = expected.get(key)
+        out[key] = {"value": mine, "expected": exp, "ok": (mine == exp) if exp is not None else None}
+    sim.nu = nu0
+    out["ok"] = all(out[k]["ok"] is not False for k in ("exact_field", "taylor_green")) and out["exact_field"]["ok"] is not None
+    return out
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` (N > 1) as the driver types it: one process per GPU via torch.distributed.run, rendezvous on
+    127.0.0.1; rank 0's JSON line is the only thing on stdout."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write(f"bench.py --gpus {n} needs {n} devices; {have} visible on this host\n")
+        sys.exit(2)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def cpu_baseline(size_cpu, steps, threads):
@@ -204,6 +278,7 @@ def main():
     ap.add_argument("--stencil-only", action="store_true", help="BASELINE configs[1]: periodic, advect-diffuse only")
     ap.add_argument("--block-solver", type=int, default=0, help="0: block CG as in the reference, 1: direct block solve, 5: multigrid V-cycle")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed region with the other block solver")
+    ap.add_argument("--no-checksum", action="store_true", help="skip config.checksum (one extra AdvectionDiffusion on two fields before the timed region)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host<->device transfer measurement behind `pcie_inclusive`")
     ap.add_argument("--debug-option", action="append", help="name=value for cup3d_debug_set_option (tuning scans)")
     ap.add_argument("--no-profile", action="store_true", help="A/B: no per-kernel HIP events in the timed region (no roofline in the output)")
@@ -216,6 +291,8 @@ def main():
     ap.add_argument("--amr-levels", type=int, default=3, help="--amr: number of levels of the final mesh")
     ap.add_argument("--amr-fraction", type=float, default=0.3, help="--amr: fraction of the blocks refined per pass")
     a = ap.parse_args()
+    if a.no_fuse or a.debug_option or a.block_solver in (3, 4):
+        os.environ["CUP3D_HIP_FLAVOUR"] = "testing"   # A/B switches live in libcup3d_hip_testing.so only; everything else times the release build
     if a.amr:
         if int(os.environ.get("WORLD_SIZE", "1")) > 1:
             sys.exit("bench.py --amr runs on one GPU (multi-level meshes are single-rank this round)")
@@ -230,12 +307,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+            return relaunch_under_torchrun(a.gpus)
         a.gpus = world
 
     import torch
     import cup3d_amd as cu
-    from cup3d_amd.capi import ProfileEntry, check, lib
+    from cup3d_amd.capi import ProfileEntry, RunStats, check, lib
 
     torch.cuda.set_device(local_rank)
     cu.device_init(local_rank)
@@ -269,6 +346,10 @@ def main():
     sim = cu.SimulationData(bpdx=bpd, bpdy=bpd, bpdz=bpd, levelMax=level + 1, levelStart=level, extent=ext, nu=a.nu, CFL=0.3,
                             BC_x=bc, BC_y=bc, BC_z=bc, uMax_forced=1.0, rampup=0, rank=rank, nranks=world, blockSolver=a.block_solver,
                             implicitDiffusion=a.implicit_diffusion)
+    a.checksum = None
+    if not a.stencil_only and not a.implicit_diffusion and not a.no_checksum:
+        a.checksum = advdiff_checksums(sim, a, dist, world)  # the run's correctness signal at every N (before anything is timed)
+        sim.dt = 0.0
     sim.upload("vel", taylor_green_blocks(sim.grid, [ext] * 3, 1.0))
     sim.step = 21
     S = cu.Simulation(sim)
@@ -297,6 +378,7 @@ def main():
     iters.clear()
     lib().cup3d_profile_enable(0 if a.no_profile else 1)
     lib().cup3d_profile_reset()
+    lib().cup3d_stats_reset()
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -304,6 +386,13 @@ def main():
     fence()
     sec = time.perf_counter() - t0
     main_iters = list(iters)
+    st = RunStats()
+    lib().cup3d_stats_read(C.byref(st))
+    nit = max(1, st.solver_iterations)
+    a.comm = {"rccl_ranks": world, "halo_exchanges_per_iteration": round(st.halo_exchanges / nit, 2), "halo_bytes_sent_per_iteration (rank 0)": round(st.halo_bytes_sent / nit, 1),
+              "allreduces_per_iteration": round(st.allreduces / nit, 2), "host_waits_per_iteration": round(st.host_waits / nit, 3),
+              "host_wait_ms_per_step (spinning on the device's status, overlapped with queued kernels)": round(st.host_wait_seconds / a.steps * 1e3, 3),
+              "host_wait_fraction": round(st.host_wait_seconds / sec, 4)}
     a.diffusion_iters = round(float(np.mean(diff_iters[-a.steps:])), 2) if diff_iters else None
     if dist is not None:
         t = torch.tensor([sec], dtype=torch.float64, device="cuda")
@@ -347,7 +436,7 @@ def main():
     SOLVERS = {0: "block CG (reference algorithm)", 1: "direct block solve (fast diagonalisation)", 2: "block CG, reference association (no FMA)",
                5: "geometric multigrid V(2,2)-cycle (NOT the reference's preconditioner; same operator, stopping rule and converged pressure)"}
     alt, alts = None, {}
-    if not a.stencil_only and not a.no_alt and not a.implicit_diffusion:
+    if not a.stencil_only and not a.no_alt and not a.implicit_diffusion and world == 1:
         # the same workload once more with the preconditioner M^-1 evaluated / chosen differently (cup3d_poisson_params.block_solver),
         # reported NEXT to the headline, never instead of it: the direct block solve (the reference's M, exact instead of by CG) and,
         # a multigrid V-cycle in M's place (what BASELINE.json's north_star wording describes; the reference has none; over several
@@ -374,11 +463,14 @@ def main():
                             "ms_per_step": round(sec2 / a.steps * 1e3, 3), "bicgstab_iters_per_step": round(float(np.mean(iters)), 2), "warmup": 1, "steps": a.steps}
         alt = alts.get(1, alts.get(0))
         a.alt_multigrid = alts.get(5)
+    invalid = a.checksum is not None and not a.checksum["ok"]  # the same on every rank (all-gathered)
     if rank == 0:
         report(a, sim, prof, sec, main_iters, world, alt)
     if dist is not None:
         lib().cup3d_comm_finalize()
         dist.destroy_process_group()
+    if invalid:
+        sys.exit(3)
 
 
 def ref_iters(a):
@@ -442,11 +534,15 @@ def report(a, sim, prof, sec, iters, world, alt=None):
                    else f"taylor-green {a.size}^3 uniform periodic, advect-diffuse RK3 only",
                    "cells": int(cells), "blocks": int(cells // 512), "block": "8^3", "partition": f"hilbert-range x{world}",
                    "bicgstab_iters_per_step": round(float(np.mean(iters)), 2) if iters else None,
+                   "bicgstab_iters_by_step": [int(i) for i in iters] if iters else None,
                    "ref_iters_per_step": ref_iters(a),
+                   "checksum": getattr(a, "checksum", None),
+                   "communication": getattr(a, "comm", None),
                    "nu": a.nu, "implicit_diffusion": bool(a.implicit_diffusion),
                    "helmholtz_iters_per_step (3 solves)": getattr(a, "diffusion_iters", None),
                    "block_preconditioner": {0: "block CG (reference algorithm)", 1: "direct block solve (fast diagonalisation)",
-                                            5: "geometric multigrid V-cycle (not the reference's)"}.get(a.block_solver, str(a.block_solver))},
+                                            5: "geometric multigrid V-cycle (not the reference's)"}.get(a.block_solver, str(a.block_solver)),
+                   "library": os.path.basename(getattr(sys.modules.get("cup3d_amd.capi"), "LIB_PATH", "libcup3d_hip.so"))},
         "roofline": ({k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]})
         if dominant else None,
         "kernels": kernels,
@@ -469,8 +565,14 @@ def report(a, sim, prof, sec, iters, world, alt=None):
         out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         if a.cpu_size != 128:
             out["cpu_baseline_128"] = cpu_baseline(128, 10, min(32, os.cpu_count() or 1))
+    ck = getattr(a, "checksum", None)
+    if ck is not None and not ck["ok"]:
+        out["valid"] = False  # the stencil path did not reproduce the oracle's bits on this partition: the rate above measures a wrong program
     print(json.dumps(out))
     sys.stdout.flush()
+    if out.get("valid") is False:
+        sys.stderr.write("bench: config.checksum does not match the oracle's constant -- results INVALID\n")
+    return out
 
 
 if __name__ == "__main__":

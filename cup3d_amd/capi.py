@@ -9,7 +9,13 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcup3d_hip.so")
+# Two flavours are built from the same sources (csrc/Makefile): the release library, and libcup3d_hip_testing.so (-DCUP3D_TESTING) with
+# the debug-option map, the in-process "virtual" communicator and the A/B kernel variants.  The test-suite and the tuning scans ask
+# for the second one (tests/conftest.py sets CUP3D_HIP_FLAVOUR=testing); bench.py and __graft_entry__.smoke() run the release build.
+FLAVOUR = os.environ.get("CUP3D_HIP_FLAVOUR", "release")
+if FLAVOUR not in ("release", "testing"):
+    raise ImportError(f"CUP3D_HIP_FLAVOUR={FLAVOUR!r}: expected 'release' or 'testing'")
+LIB_PATH = os.path.join(HERE, "libcup3d_hip.so" if FLAVOUR == "release" else "libcup3d_hip_testing.so")
 
 FIELD_CHI, FIELD_PRES, FIELD_VEL, FIELD_TMPV, FIELD_LHS = 0, 1, 2, 3, 4
 FIELD_NCOMP = {FIELD_CHI: 1, FIELD_PRES: 1, FIELD_VEL: 3, FIELD_TMPV: 3, FIELD_LHS: 1}
@@ -30,6 +36,12 @@ class PoissonParams(C.Structure):
 class PoissonResult(C.Structure):
     _fields_ = [("iterations", C.c_int), ("restarts", C.c_int), ("norm0", C.c_double), ("norm", C.c_double),
                 ("used_xopt", C.c_int)]
+
+
+class RunStats(C.Structure):
+    """cup3d_run_stats"""
+    _fields_ = [("halo_exchanges", C.c_long), ("halo_bytes_sent", C.c_double), ("allreduces", C.c_long), ("host_waits", C.c_long),
+                ("host_wait_seconds", C.c_double), ("solver_iterations", C.c_long)]
 
 
 class ProfileEntry(C.Structure):
@@ -93,6 +105,10 @@ SIGNATURES = {
     "cup3d_sim_download": (C.c_int, [_vp, C.c_int, _dp]),
     "cup3d_sim_fill": (C.c_int, [_vp, C.c_int, C.c_double]),
     "cup3d_sim_device_ptr": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "cup3d_sim_mark_written": (C.c_int, [_vp, C.c_int]),
+    "cup3d_sim_checksum": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_ulonglong)]),
+    "cup3d_stats_reset": (C.c_int, []),
+    "cup3d_stats_read": (C.c_int, [C.POINTER(RunStats)]),
     "cup3d_advect_diffuse": (C.c_int, [_vp, C.c_double, C.c_double, _dp]),
     "cup3d_max_u": (C.c_int, [_vp, _dp, C.POINTER(C.c_double)]),
     "cup3d_external_forcing": (C.c_int, [_vp] + [C.c_double] * 4),

@@ -526,6 +526,9 @@ static int advdiff_stage(Sim *s, int rk, double dt, double nu, const double uinf
       const dim3 G(launch_groups(g));
 #define ADV(FIRST, CPT, VAR) hipLaunchKernelGGL((k_advdiff<FIRST, CPT, VAR>), G, dim3(512 / CPT), 0, stream(), g, a)
 #define ADV2(CPT, VAR) do { if (rk == 0) ADV(true, CPT, VAR); else ADV(false, CPT, VAR); } while (0)
+#ifndef CUP3D_TESTING
+      ADV2(2, 0);  // release build: the production kernel only
+#else
       switch (debug_option("advdiff_variant")) {  // 0 = production; 1 and 4 are A/B variants with the SAME results
         case 0: ADV2(2, 0); break;
         case 1: ADV2(2, 1); break;
@@ -540,6 +543,7 @@ static int advdiff_stage(Sim *s, int rk, double dt, double nu, const double uinf
 #endif
         default: set_error("unknown advdiff_variant (the ablation variants 2 and 3 need a build with -DCUP3D_TUNING_ABLATIONS)"); return CUP3D_EINVAL;
       }
+#endif
 #undef ADV2
 #undef ADV
     }

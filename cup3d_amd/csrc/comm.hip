@@ -22,7 +22,11 @@
 namespace cup3d {
 
 int launch_pack(Sim *src, const double *field, int nc, int w, hipStream_t st);  // advdiff.hip
+#ifdef CUP3D_TESTING
 static bool g_virtual_ranks = false;  // test mode: halos are pre-filled by cup3d_debug_halo_pull
+#else
+static constexpr bool g_virtual_ranks = false;  // release build: no test transport, every `if (g_vcomm)` / `g_virtual_ranks` branch folds away
+#endif
 bool virtual_ranks() { return g_virtual_ranks; }
 
 struct Comm {
@@ -101,7 +105,11 @@ struct VComm {
     return true;
   }
 };
+#ifdef CUP3D_TESTING
 static VComm *g_vcomm = nullptr;
+#else
+static constexpr VComm *g_vcomm = nullptr;
+#endif
 VComm *vcomm() { return g_vcomm; }
 void vcomm_register(Sim *s) {
   if (g_vcomm && s->grid->nranks == g_vcomm->n) g_vcomm->sims[s->grid->rank] = s;
@@ -195,8 +203,14 @@ __global__ void __launch_bounds__(64) k_pack_flux(const double *__restrict__ flu
 
 // items of `per` doubles: packed send buffer -> peers; received runs land contiguously at dst.  RCCL on the communication stream
 // (compute stream <-> communication stream hand-off by events), or the in-process transport.
+static size_t sent_bytes(const std::vector<int64_t> &send_count, size_t per, int skip = -1) {
+  size_t n = 0;
+  for (size_t p = 0; p < send_count.size(); ++p) if ((int)p != skip) n += (size_t)send_count[p];
+  return n * per * sizeof(double);
+}
 static int view_transfer(Sim *s, double *dst, size_t per, const std::vector<int64_t> &send_count, const std::vector<int64_t> &recv_count, bool flux) {
   const Grid *g = s->grid;
+  stats_halo(sent_bytes(send_count, per));
   if (g_vcomm) {
     if (flux) return vcomm_pull(s, dst, per, recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_flux_count; }, exchange_stream(s));
     return vcomm_pull(s, dst, per, recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_block_count; }, exchange_stream(s));
@@ -277,6 +291,7 @@ int exchange_items(Sim *s, const double *sendbuf, const std::vector<int64_t> &se
   if (send_count[me] != recv_count[me]) { set_error("exchange_items: inconsistent self count"); return CUP3D_EINVAL; }
   if (send_count[me]) CUP3D_HIP(hipMemcpyAsync(recvbuf + ro[me], sendbuf + so[me], (size_t)send_count[me] * per * sizeof(double), hipMemcpyDeviceToDevice, stream()));
   if (n == 1) return CUP3D_OK;
+  stats_halo(sent_bytes(send_count, per, me));
   Comm *c = g_vcomm ? nullptr : comm();
   if (!g_vcomm && !c) { set_error("multi-rank mesh without cup3d_comm_init"); return CUP3D_ESTATE; }
   hipStream_t st = g_vcomm ? exchange_stream(s) : (s->comm_stream ? s->comm_stream : stream());
@@ -323,6 +338,7 @@ int exchange_items(Sim *s, const double *sendbuf, const std::vector<int64_t> &se
 // ------------------------------------------------------------------ face-slab halo exchange of uniform grids
 static int slab_transfer(Sim *s, size_t per_face, hipStream_t st) {
   const Grid *g = s->grid;
+  stats_halo(sent_bytes(g->send_count, per_face));
   if (g_vcomm) return vcomm_pull(s, s->halo_recv, per_face, g->recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_count; }, st);
   Comm *c = comm();
   if (!c) { set_error("multi-rank grid without cup3d_comm_init"); return CUP3D_ESTATE; }
@@ -395,6 +411,7 @@ int halo_exchange(Sim *s, const double *field, int nc, int w) {
 
 int allreduce(Sim *s, double *d_buf, int n, bool is_max, hipStream_t st) {
   if (!scalars_cross_ranks(s)) return CUP3D_OK;
+  stats_allreduce();
   if (g_vcomm) {
     VComm *vc = g_vcomm;
     const int r = s->grid->rank;
@@ -465,11 +482,21 @@ int cup3d_comm_finalize(void) {
 }
 
 // TEST SUPPORT: several ranks' sims in one process on one GPU; exchanges become no-ops
-int cup3d_debug_virtual_ranks(int on) { g_virtual_ranks = on != 0; return CUP3D_OK; }
+int cup3d_debug_virtual_ranks(int on) {
+#ifdef CUP3D_TESTING
+  g_virtual_ranks = on != 0;
+  return CUP3D_OK;
+#else
+  return on ? not_in_release("cup3d_debug_virtual_ranks") : CUP3D_OK;
+#endif
+}
 
 // TEST SUPPORT: in-process communicator over `nranks` host threads (see VComm above); nranks = 0 tears it down.  Create it before
 // the sims of the run (they register themselves by rank), then call the ordinary entry points from one thread per rank.
 int cup3d_debug_virtual_comm(int nranks) {
+#ifndef CUP3D_TESTING
+  return nranks ? not_in_release("cup3d_debug_virtual_comm") : CUP3D_OK;
+#else
   if (nranks < 0 || nranks > 16) return CUP3D_EINVAL;
   if (g_vcomm) {
     if (g_vcomm->d_tmp) hipFree(g_vcomm->d_tmp);
@@ -488,6 +515,7 @@ int cup3d_debug_virtual_comm(int nranks) {
   g_vcomm = vc;
   g_virtual_ranks = true;
   return CUP3D_OK;
+#endif
 }
 
 // TEST SUPPORT: fill `dst`'s halo slabs for (field, nc, w) by packing directly from peer
@@ -495,6 +523,9 @@ int cup3d_debug_virtual_comm(int nranks) {
 // ordering, the pack kernel and the kernels' halo-read path on one GPU; the RCCL call
 // sequence itself is what halo_exchange() adds on top.
 int cup3d_debug_halo_pull(cup3d_sim_t *dst_h, cup3d_sim_t *const *peers, int npeers, int field, int nc, int w) {
+#ifndef CUP3D_TESTING
+  return not_in_release("cup3d_debug_halo_pull");
+#endif
   if (!dst_h || !peers) return CUP3D_EINVAL;
   Sim *dst = reinterpret_cast<Sim *>(dst_h);
   const Grid *g = dst->grid;

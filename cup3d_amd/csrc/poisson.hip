@@ -16,7 +16,9 @@
 // summation ORDER of the dot products and of the block-CG inner products differs
 // from the CPU, so pressure agrees to solver tolerance, not bitwise.
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstring>
 
 #include "sim.hpp"
 #include "tile.hpp"
@@ -229,6 +231,7 @@ __global__ void __launch_bounds__(64) k_precond(GridDev g, const double *in, dou
   cg_block<FMA, HELM, EV>(g, slot, r, out, block_sums, nu, dt, iters_out, P);
 }
 
+#ifdef CUP3D_TESTING
 // ------------------------------------------------------------------ block CG, two blocks per wavefront
 // The full-wave kernel above spends more than half of its FP64 issue slots on work that does not scale with the cells: two
 // wave-wide sums (12 DPP moves + 6 adds + read-lanes + hazard nops each), two divisions, loop control.  Here a HALF-wave owns a
@@ -360,6 +363,8 @@ __global__ void __launch_bounds__(64) k_precond_pair(GridDev g, int pchunk, cons
   }
 }
 
+#endif  // CUP3D_TESTING
+
 // ------------------------------------------------------------------ direct block solve
 // The block preconditioner M^-1 is "solve sum6(z) - 6z = r/h on one 8^3 block with zero
 // ghosts".  The reference evaluates it by CG to a 1e-7 relative residual (14704-14745);
@@ -449,12 +454,14 @@ __global__ void __launch_bounds__(64) k_precond_fdm(GridDev g, const double *in,
   }
 }
 
+#ifdef CUP3D_TESTING
 // TEST SUPPORT: the two wave-wide sums of one 64-value vector: out[0..63] = MFMA form per lane, out[64..127] = DPP form per lane
 __global__ void __launch_bounds__(64) k_debug_wave_sum(const double *__restrict__ in, double *__restrict__ out) {
   const double v = in[threadIdx.x];
   out[threadIdx.x] = wave_sum_mfma(v);
   out[64 + threadIdx.x] = wave_sum(v);
 }
+#endif
 
 static int fdm_setup() {
   if (g_invD) return CUP3D_OK;
@@ -498,14 +505,16 @@ int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
     return CUP3D_OK;
   }
   ProfileScope ps("poisson_block_cg");
-  // Production (block_solver 0) contracts a*b+c into FMAs here (and only here) and evaluates the wave sums / the two divisions as
-  // described above k_precond: its result sits behind two wave reductions per iteration whose summation order already differs from
-  // the CPU's, and the CG's own truncation is 1e-7, so this is a tolerance-level deviation (tests: <= 2e-5 of the reference's z,
-  // measured ~1e-7).  block_solver 2 = the reference's association (no contraction, IEEE divisions); 3 = the round-1 kernel.
+  // Production (block_solver 0, kCgProduction = EV 0) contracts a*b+c into FMAs here (and only here); wave sums by DPP, IEEE divisions
+  // (the matrix-pipe sums and reciprocal divisions described above k_precond were measured slower and exist in the testing flavour
+  // only).  Its result sits behind two wave reductions per iteration whose summation order already differs from the CPU's, and the
+  // CG's own truncation is 1e-7, so the contraction is a tolerance-level deviation (tests bound it against the reference's z).
+  // block_solver 2 = the reference's association (no contraction).
   const dim3 G(launch_groups(g)), B(64);
   int *it = profile_on() ? cg_iters_buffer(s) : nullptr;  // for the FP64 roofline of bench.py (cup3d_debug_block_cg_iterations)
 #define CG(FMA_, EV_) hipLaunchKernelGGL((k_precond<FMA_, false, EV_>), G, B, 0, stream(), g, in, out, sums, 0.0, 0.0, it)
   switch (s->block_solver) {
+#ifdef CUP3D_TESTING
     case 0:  // production: kCgProduction, or (tuning) the evaluation selected with cup3d_debug_set_option("cg_variant", 8 + bits)
       switch (debug_option("cg_variant") >= 8 ? debug_option("cg_variant") - 8 : kCgProduction) {
         case 0: CG(true, 0); break;
@@ -531,13 +540,17 @@ int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
         default: set_error("unknown cg_variant"); return CUP3D_EINVAL;
       }
       break;
-    case 2: CG(false, 0); break;
-    case 3: CG(true, 0); break;
-    case 4: {  // two blocks per wavefront
+    case 3: CG(true, 0); break;  // alias of 0 (the round-1 kernel IS the production evaluation), kept for old scripts
+    case 4: {  // two blocks per wavefront (A/B timing)
       const int pchunk = ((g.nblocks + 1) / 2 + 7) / 8;
       hipLaunchKernelGGL((k_precond_pair<true, false>), dim3(8 * pchunk), B, 0, stream(), g, pchunk, in, out, sums, 0.0, 0.0, it);
       break;
     }
+#else
+    case 0: CG(true, kCgProduction); break;
+    case 3: case 4: return not_in_release("block_solver 3 / 4 (A/B variants of the block CG)");
+#endif
+    case 2: CG(false, 0); break;
     default: set_error("unknown block_solver %d", s->block_solver); return CUP3D_EINVAL;
   }
 #undef CG
@@ -561,6 +574,79 @@ struct Vecs {
   double *v[NVEC];
   const double *xin;  // where the second loop reads x from: v[X_], or the x_opt snapshot right after one was taken (see solve())
 };
+
+// ------------------------------------------------------------------ the scalar recurrences, resident on the device
+// The scalars of PoissonSolverAMR::solve -- alpha, beta, omega, r0r_prev (14443, 14493, 14558-14564), the breakdown test (14566), the
+// x_opt bookkeeping (14594-14600) and the stopping rule (14601) -- as ONE struct and ONE pair of functions compiled for host and
+// device.  In the fused iterations (k % 50 != 0) the struct lives in device memory: the kernel that totals the dot products (or, over
+// ranks, a one-thread kernel behind the all-reduce) steps it, the next loop kernel reads alpha / beta / omega from it, and the host
+// only WATCHES: it enqueues iteration k + 1 before it has seen the outcome of iteration k, through a ring of pinned status slots.  A
+// launch never waits for the host.  When the outcome is "converged" or "serious breakdown", the kernels of the iteration enqueued
+// ahead find state != kRun and return at once; the host then finishes, or runs the restart (14567-14593) and re-enqueues.
+// The every-50th iterations (true-residual refresh through _lhs) and the other block solvers step the same struct on the host.
+enum { kRun = 0, kDone = 1, kRestart = 2 };
+struct SolverCtl {
+  double alpha, beta, omega, r0r_prev;
+  double norm, init_norm, min_norm;
+  double tol, tol_rel;
+  int state;
+  int restarts, max_restarts;
+  int xcur, xopt;  // which of the two x buffers holds x / the best iterate so far (x_opt; -1: none yet)
+  int iter;        // iterations completed
+};
+struct CtlSlot { SolverCtl c; unsigned seq; unsigned pad; };  // pinned status ring, slot = seq & 3
+// x is updated in place unless the buffer that holds it is also the x_opt snapshot: then the update goes to the other buffer
+// (x_opt = x without a copy: x is read once and written once by the second loop anyway)
+__host__ __device__ inline int ctl_xwrite(const SolverCtl &c) { return c.xopt == c.xcur ? 1 - c.xcur : c.xcur; }
+// after the first loop's dot products (q.y, y.y): 14493
+__host__ __device__ inline void ctl_step1(SolverCtl &c, const double *t) { c.omega = t[0] / (t[1] + 1e-100); }
+// after the second loop's seven (14546): 14558-14566, 14594-14601.  The restart itself (kernel launches) is the host's.
+__host__ __device__ inline void ctl_step2(SolverCtl &c, const double *t) {
+  const double eps = 1e-100;
+  const double r0r = t[0], r0w = t[1], r0s = t[2], r0z = t[3], norm_1 = t[4], norm_2 = t[5];
+  const double norm = sqrt(t[6]);
+  const double omega = c.omega;
+  double alpha = c.alpha;
+  const double beta = alpha / (omega + eps) * r0r / (c.r0r_prev + eps);  // 14558
+  alpha = r0r / (r0w + beta * r0s - beta * omega * r0z);                 // 14559
+  double alphat = 1.0 / (omega + eps) + r0w / (r0r + eps) - beta * omega * r0z / (r0r + eps);
+  alphat = 1.0 / (alphat + eps);
+  if (fabs(alphat) < 10 * fabs(alpha)) alpha = alphat;                   // 14563-14564
+  c.alpha = alpha;
+  c.beta = beta;
+  c.r0r_prev = r0r;
+  c.norm = norm;
+  c.xcur = ctl_xwrite(c);  // x lives where the second loop wrote it
+  c.iter++;
+  int state = kRun;
+  if (r0r * r0r < 1e-16 * norm_1 * norm_2 && c.restarts < c.max_restarts) {  // serious breakdown, 14566-14567
+    c.restarts++;
+    state = kRestart;
+  }
+  if (norm < c.min_norm) {  // 14594-14600
+    c.min_norm = norm;
+    c.xopt = c.xcur;
+  }
+  if (norm < c.tol || norm / (c.init_norm + eps) < c.tol_rel) state = kDone;  // 14601
+  c.state = state;
+}
+__device__ __forceinline__ void ctl_publish(const SolverCtl *c, CtlSlot *ring, unsigned seq) {
+  CtlSlot *sl = ring + (seq & 3);
+  sl->c = *c;
+  __threadfence_system();
+  __hip_atomic_store(&sl->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// several ranks: the totals are all-reduced first (communication stream); this one-thread kernel behind the all-reduce steps the
+// struct -- identically on every rank, the all-reduced bits are the same everywhere -- and the compute stream waits for its event
+template <int STEP>
+__global__ void k_ctl_step(SolverCtl *ctl, const double *__restrict__ tot, CtlSlot *ring, unsigned seq) {
+  if (ctl->state != kRun) return;  // an iteration enqueued ahead of a stop / restart: nothing happened, nothing to step
+  SolverCtl c = *ctl;
+  if (STEP == 1) ctl_step1(c, tot); else ctl_step2(c, tot);
+  *ctl = c;
+  if (STEP == 2) ctl_publish(ctl, ring, seq);
+}
+__global__ void k_ctl_set(SolverCtl *ctl, SolverCtl v) { *ctl = v; }
 
 #define GRID_STRIDE(j, n) for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < (n); j += (long)gridDim.x * 256)
 // 16 B per lane (double2): n is a multiple of 512
@@ -600,17 +686,19 @@ __device__ __forceinline__ double dot2(double2 a, double2 b, double acc) { acc +
 // (wave tree) and the per-block values by k_sums_finish, another order than the grid-stride partials of the unfused kernels.
 // block_dots layout: [K][nb].
 struct Loop1Args { double alpha, beta, omega; };
-struct Loop2Args { double alpha, omega; const double *xin; };
+struct Loop2Args { double alpha, omega; };
 
 #define NTL(v, j) __builtin_nontemporal_load(&(v)[j])
 #define NTS(v, j, val) __builtin_nontemporal_store((val), &(v)[j])
 
 template <bool FMA, int EV>
-__device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, const Loop1Args &a, double *__restrict__ block_dots, long nb,
+__device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb,
                                               double *__restrict__ block_sums, int *__restrict__ iters_out) {
   __shared__ double P[kCgLds];
   const int slot = block_slot(g);
   if (slot < 0) return;
+  if (ctl->state != kRun) return;  // enqueued ahead of a stop or a restart (see SolverCtl)
+  const Loop1Args a{ctl->alpha, ctl->beta, ctl->omega};
   const int l = threadIdx.x;
   const double invh = 1 / block_h(g, slot);
   double r[8], d0 = 0, d1 = 0;
@@ -652,24 +740,29 @@ __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, c
   cg_block<FMA, false, EV>(g, slot, r, V.v[ZHAT], block_sums, 0.0, 0.0, iters_out, P);  // zhat = M^-1 z, 14488
 }
 template <bool FMA, int EV>
-__global__ void __launch_bounds__(64) k_loop1_cg(GridDev g, Vecs V, Loop1Args a, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
+__global__ void __launch_bounds__(64) k_loop1_cg(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
                                                  int *__restrict__ iters_out) {
-  loop1_cg_body<FMA, EV>(g, V, a, block_dots, nb, block_sums, iters_out);
+  loop1_cg_body<FMA, EV>(g, V, ctl, block_dots, nb, block_sums, iters_out);
 }
 
 template <bool FMA, int EV>
-__device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, const Loop2Args &a, double *__restrict__ block_dots, long nb,
+__device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb,
                                               double *__restrict__ block_sums, int *__restrict__ iters_out) {
   __shared__ double P[kCgLds];
   const int slot = block_slot(g);
   if (slot < 0) return;
+  if (ctl->state != kRun) return;
+  const Loop2Args a{ctl->alpha, ctl->omega};
+  // the two x buffers are v[X_] and v[XOPT] for the whole solve; which one holds x and which one receives the update is the struct's
+  const int xc = ctl->xcur, xw = ctl_xwrite(*ctl);
+  const double *const xin = xc ? V.v[XOPT] : V.v[X_];
   const int l = threadIdx.x;
   const double invh = 1 / block_h(g, slot);
   double r[8], acc[6] = {0, 0, 0, 0, 0, 0};
   const size_t bo = (size_t)slot * 512;
-  const double *const src[12] = {V.v[QHAT] + bo, V.v[Y_] + bo, V.v[R0] + bo, a.xin + bo, V.v[PHAT] + bo, V.v[Q_] + bo, V.v[WHAT] + bo, V.v[ZHAT] + bo,
+  const double *const src[12] = {V.v[QHAT] + bo, V.v[Y_] + bo, V.v[R0] + bo, xin + bo, V.v[PHAT] + bo, V.v[Q_] + bo, V.v[WHAT] + bo, V.v[ZHAT] + bo,
                                  V.v[T_] + bo, V.v[V_] + bo, V.v[S_] + bo, V.v[Z_] + bo};
-  double *const oX = V.v[X_] + bo, *const oR = V.v[R_] + bo, *const oRH = V.v[RHAT] + bo, *const oW = V.v[W_] + bo;
+  double *const oX = (xw ? V.v[XOPT] : V.v[X_]) + bo, *const oR = V.v[R_] + bo, *const oRH = V.v[RHAT] + bo, *const oW = V.v[W_] + bo;
   double in[2][12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) in[0][i] = NTL(src[i], l);
@@ -709,22 +802,34 @@ __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, c
 // CG held to 80 registers for 6 wavefronts -- loses (12-14 spills inside the loops: 5.3 ms instead of 3.88; CG 0.43 instead of 0.40).
 template <bool FMA, int EV>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
-k_loop2_cg(GridDev g, Vecs V, Loop2Args a, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums, int *__restrict__ iters_out) {
-  loop2_cg_body<FMA, EV>(g, V, a, block_dots, nb, block_sums, iters_out);
+k_loop2_cg(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums, int *__restrict__ iters_out) {
+  loop2_cg_body<FMA, EV>(g, V, ctl, block_dots, nb, block_sums, iters_out);
 }
 // A/B (debug option "loop2_four_waves"): the register allocation the compiler picks on its own, 122 -> 4 wavefronts per SIMD
 template <bool FMA, int EV>
-__global__ void __launch_bounds__(64) k_loop2_cg_w4(GridDev g, Vecs V, Loop2Args a, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
+__global__ void __launch_bounds__(64) k_loop2_cg_w4(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
                                                     int *__restrict__ iters_out) {
-  loop2_cg_body<FMA, EV>(g, V, a, block_dots, nb, block_sums, iters_out);
+  loop2_cg_body<FMA, EV>(g, V, ctl, block_dots, nb, block_sums, iters_out);
 }
 
 // K sums of nb per-block values each ([K][nb]) finished in one launch: 64 workgroups, the last one to arrive totals the partials.
 // MEAN: one more sum rides along -- the per-block sums of zhat h^3 / what h^3 the fused kernel left in mean_src; the total lands in
 // ro.out[K], where the LHS application that follows takes its mean-constraint row from (no k_mean_finish launch, and over ranks no
 // second all-reduce: the total travels with the dot products)
+// STEP 1 / 2: one rank -- the last workgroup also steps the solver's scalar struct with the totals (ctl_step1 / ctl_step2) and, after
+// the second loop, publishes it to the host's status ring; STEP 0: totals only (several ranks: the all-reduce comes first, k_ctl_step)
+struct CtlThen {
+  SolverCtl *ctl; CtlSlot *ring; unsigned seq; int step;
+  __device__ __forceinline__ void operator()(const double *tot) const {
+    if (step == 0 || ctl->state != kRun) return;  // (an iteration enqueued ahead of a stop / restart summed stale partials: dropped)
+    SolverCtl c = *ctl;
+    if (step == 1) ctl_step1(c, tot); else ctl_step2(c, tot);
+    *ctl = c;
+    if (step == 2) ctl_publish(ctl, ring, seq);
+  }
+};
 template <int K, bool MEAN>
-__global__ void __launch_bounds__(256) k_sums_finish(const double *__restrict__ v, long nb, RedOut ro, const double *__restrict__ mean_src) {
+__global__ void __launch_bounds__(256) k_sums_finish(const double *__restrict__ v, long nb, RedOut ro, const double *__restrict__ mean_src, CtlThen then) {
   double acc[K + (MEAN ? 1 : 0)];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -737,7 +842,7 @@ __global__ void __launch_bounds__(256) k_sums_finish(const double *__restrict__ 
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (long)gridDim.x * 256) t += mean_src[i];
     acc[K] = t;
   }
-  grid_sum_finish<K + (MEAN ? 1 : 0)>(acc, ro);
+  grid_sum_finish<K + (MEAN ? 1 : 0)>(acc, ro, then);
 }
 
 // b = r = rhs, x = pres   (main.cpp:14408-14415)
@@ -911,6 +1016,7 @@ struct Reducer {
   int wait() {
     const volatile unsigned *flag = reinterpret_cast<const volatile unsigned *>(s->h_red + 16);
     const unsigned want = s->red_seq;
+    const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spin = 1; *flag != want; ++spin) {
       __builtin_ia32_pause();
       if ((spin & 0x3fff) == 0) {  // every ~16k polls: has the stream finished (or failed) without raising the flag?
@@ -920,6 +1026,7 @@ struct Reducer {
       }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    stats_host_wait(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return CUP3D_OK;
   }
 };
@@ -928,6 +1035,12 @@ static int ensure_vectors(Sim *s) {
   if (!s->d_block_dots) {
     int rc = sim_alloc(&s->d_block_dots, (size_t)7 * s->nb, s);
     if (rc) return rc;
+  }
+  if (!s->d_ctl) {  // the solver's scalar struct (device) and the pinned ring its outcome reaches the host through
+    CUP3D_HIP(hipMalloc(&s->d_ctl, sizeof(SolverCtl)));
+    CUP3D_HIP(hipHostMalloc(&s->h_ctl, 4 * sizeof(CtlSlot), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(s->h_ctl, 0, 4 * sizeof(CtlSlot));
+    CUP3D_HIP(hipHostGetDevicePointer(&s->h_ctl_dev, s->h_ctl, 0));
   }
   if (s->sv[0]) return CUP3D_OK;
   for (int i = 0; i < NVEC; ++i) {
@@ -942,6 +1055,30 @@ static int ensure_vectors(Sim *s) {
 #define LAUNCH_VEC_S(kern, ...) hipLaunchKernelGGL(kern, dim3(Gs), dim3(256), 0, stream(), __VA_ARGS__)
 #define TRY(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
+// the host waits for the outcome of a fused iteration: slot seq & 3 of the pinned ring carries `seq` once the struct is in place
+static int wait_status(Sim *s, unsigned seq, SolverCtl *out) {
+  const CtlSlot *sl = reinterpret_cast<const CtlSlot *>(s->h_ctl) + (seq & 3);
+  const volatile unsigned *flag = &sl->seq;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 1; *flag != seq; ++spin) {
+    __builtin_ia32_pause();
+    if ((spin & 0x3fff) == 0) {  // every ~16k polls: have the streams drained (or failed) without the slot being written?
+      hipError_t e = hipStreamQuery(stream());
+      if (e == hipSuccess && s->comm_stream) e = hipStreamQuery(s->comm_stream);
+      if (e == hipSuccess) {
+        if (*flag == seq) break;
+        set_error("BiCGSTAB: the device finished without reporting iteration status %u", seq);
+        return CUP3D_ESTATE;
+      }
+      if (e != hipErrorNotReady) return hip_fail(e, "hipStreamQuery", __FILE__, __LINE__);
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  memcpy(out, (const void *)&sl->c, sizeof(SolverCtl));
+  stats_host_wait(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  return CUP3D_OK;
+}
+
 // helm != nullptr: DiffusionSolver::solve (main.cpp:6896-7146) -- the same routine on the Helmholtz operator of one velocity
 // component, with no mean constraint and no cap on the breakdown restarts
 static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *res, const HelmholtzOp *helm = nullptr) {
@@ -949,11 +1086,10 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   s->block_solver = P.block_solver;
   Vecs V;
   for (int i = 0; i < NVEC; ++i) V.v[i] = s->sv[i];
-  V.xin = V.v[X_];
+  double *const XB[2] = {s->sv[X_], s->sv[XOPT]};  // the two x buffers; SolverCtl::xcur / xopt say which is which
   const long N = s->nb * 512L;
   const unsigned G = vec_groups(N), Gs = vec_groups_simple(N);
   const int mc = helm ? 0 : P.mean_constraint;
-  const int max_restarts = helm ? 0x7fffffff : P.max_restarts;
   const double eps = 1e-100;
   Reducer red{s};
   auto LHS = [&](int in, int out) {  // _lhs, 9365-9393 / 6836-6875
@@ -969,6 +1105,19 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   double *const sums = want_sums ? s->d_partials + (size_t)s->max_groups * 8 : nullptr;
   int *const cg_it = profile_on() ? cg_iters_buffer(s) : nullptr;
   const GridDev gd = s->gdev();
+  SolverCtl *const d_ctl = reinterpret_cast<SolverCtl *>(s->d_ctl);
+  CtlSlot *const ring = reinterpret_cast<CtlSlot *>(s->h_ctl_dev);
+
+  SolverCtl hs;  // the host's copy of the scalars: current whenever no fused iteration is in flight
+  memset(&hs, 0, sizeof hs);
+  hs.tol = P.tol; hs.tol_rel = P.tol_rel;
+  hs.max_restarts = helm ? 0x7fffffff : P.max_restarts;
+  hs.min_norm = 1e50;
+  hs.xcur = 0; hs.xopt = -1;
+  hs.state = kRun;
+  // host-driven launches address x through V: v[X_] = the buffer the next update of x writes, xin = the one that holds x
+  auto x_ptrs = [&]() { const int xw = ctl_xwrite(hs); V.v[X_] = XB[xw]; V.v[XOPT] = XB[1 - xw]; V.xin = XB[hs.xcur]; };
+  x_ptrs();
 
   if ((mc == 1 || mc > 2) && s->grid->corner_slot >= 0)  // rhs(0,0,0) = 0, 14404-14407
     hipLaunchKernelGGL(k_set_one, dim3(1), dim3(1), 0, stream(), s->lhs, (size_t)s->grid->corner_slot * 512, 0.0);
@@ -978,120 +1127,162 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   TRY(PRE(R0, RHAT)); TRY(LHS(RHAT, W_)); TRY(PRE(W_, WHAT)); TRY(LHS(WHAT, T_));
   { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots_r0, V, N, red.out()); }
   TRY(red.begin(2)); TRY(red.wait());
-  double alpha = s->h_red[0] / (s->h_red[1] + eps);  // 14443
-  double r0r_prev = s->h_red[0];
-  double norm = std::sqrt(s->h_red[0]);
-  const double init_norm = norm;
-  double beta = 0.0, omega = 0.0, min_norm = 1e50;
-  bool use_xopt = false;
-  int restarts = 0, k;
-  for (k = 0; k < P.max_iter; ++k) {
-    const bool fused_now = fuse && k % 50 != 0;
-    if (fused_now) {
-      {
-        ProfileScope ps("bicgstab_loop1_cg");
-        const Loop1Args la{alpha, beta, omega};
-        if (P.block_solver == 0) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, la, s->d_block_dots, (long)s->nb, sums, cg_it);
-        else hipLaunchKernelGGL((k_loop1_cg<false, 0>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, la, s->d_block_dots, (long)s->nb, sums, cg_it);
-      }
-      s->sums_of = want_sums ? V.v[ZHAT] : nullptr;
-      ProfileScope ps("bicgstab_dots_finish");
-      if (want_sums) {
-        hipLaunchKernelGGL((k_sums_finish<2, true>), dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, red.out(), sums);
-        s->mean_total_of = V.v[ZHAT];
-        s->mean_total = s->d_red + 2;
-      } else {
-        hipLaunchKernelGGL((k_sums_finish<2, false>), dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, red.out(), nullptr);
-      }
-    } else if (k % 50 != 0) {
+  hs.alpha = s->h_red[0] / (s->h_red[1] + eps);  // 14443
+  hs.r0r_prev = s->h_red[0];
+  hs.norm = hs.init_norm = std::sqrt(s->h_red[0]);
+
+  // the restart of 14567-14593 / 7096-7120 (the breakdown was detected, and counted, by ctl_step2)
+  auto restart = [&]() -> int {
+    { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_copy, V.v[R_], V.v[R0], N); }
+    TRY(PRE(R0, RHAT)); TRY(LHS(RHAT, W_));
+    { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots_r0, V, N, red.out()); }
+    TRY(red.begin(2));
+    TRY(PRE(W_, WHAT)); TRY(LHS(WHAT, T_));
+    TRY(red.wait());
+    hs.alpha = s->h_red[0] / (s->h_red[1] + eps);
+    hs.r0r_prev = s->h_red[0];
+    hs.beta = 0.0;
+    hs.omega = 0.0;
+    hs.state = kRun;
+    return CUP3D_OK;
+  };
+
+  // one iteration driven by the host: every 50th one (s, z and the true residual recomputed through _lhs), and all of them for the
+  // block solvers without a fused kernel and for the Helmholtz solves
+  auto host_iteration = [&](int k) -> int {
+    x_ptrs();
+    if (k % 50 != 0) {
       ProfileScope ps("bicgstab_loop1");
-      if (!debug_option("loops_no_nt")) LAUNCH_VEC(k_loop1<true>, V, N, alpha, beta, omega, red.out());
-      else LAUNCH_VEC(k_loop1<false>, V, N, alpha, beta, omega, red.out());
+      if (!debug_option("loops_no_nt")) LAUNCH_VEC(k_loop1<true>, V, N, hs.alpha, hs.beta, hs.omega, red.out());
+      else LAUNCH_VEC(k_loop1<false>, V, N, hs.alpha, hs.beta, hs.omega, red.out());
     } else {
-      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_loop1_phat, V, N, beta, omega); }
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_loop1_phat, V, N, hs.beta, hs.omega); }
       TRY(LHS(PHAT, S_)); TRY(PRE(S_, SHAT)); TRY(LHS(SHAT, Z_));
-      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_loop1_tail, V, N, alpha, red.out()); }
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_loop1_tail, V, N, hs.alpha, red.out()); }
     }
-    TRY(red.begin(fused_now && want_sums ? 3 : 2));  // MPI_Iallreduce(2), 14486 (+ the mean-constraint sum of zhat, 9295)
-    if (!fused_now) TRY(PRE(Z_, ZHAT));      // overlapped with the reduction read-back, 14488-14489
+    TRY(red.begin(2));         // MPI_Iallreduce(2), 14486
+    TRY(PRE(Z_, ZHAT));        // overlapped with the reduction read-back, 14488-14489
     TRY(LHS(ZHAT, V_));
     TRY(red.wait());
-    omega = s->h_red[0] / (s->h_red[1] + eps);  // 14493
-    if (fused_now) {
-      {
-        ProfileScope ps("bicgstab_loop2_cg");
-        const Loop2Args la{alpha, omega, V.xin};
-        if (P.block_solver == 0 && four_waves) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, la, s->d_block_dots, (long)s->nb, sums, cg_it);
-        else if (P.block_solver == 0) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, la, s->d_block_dots, (long)s->nb, sums, cg_it);
-        else hipLaunchKernelGGL((k_loop2_cg<false, 0>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, la, s->d_block_dots, (long)s->nb, sums, cg_it);
-      }
-      s->sums_of = want_sums ? V.v[WHAT] : nullptr;
-      ProfileScope ps("bicgstab_dots_finish");
-      if (want_sums) {
-        hipLaunchKernelGGL((k_sums_finish<7, true>), dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, red.out(), sums);
-        s->mean_total_of = V.v[WHAT];
-        s->mean_total = s->d_red + 7;
-      } else {
-        hipLaunchKernelGGL((k_sums_finish<7, false>), dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, red.out(), nullptr);
-      }
-    } else if (k % 50 != 0) {
+    ctl_step1(hs, s->h_red);   // 14493
+    if (k % 50 != 0) {
       ProfileScope ps("bicgstab_loop2");
-      if (!debug_option("loops_no_nt")) LAUNCH_VEC(k_loop2<true>, V, N, alpha, omega, red.out());
-      else LAUNCH_VEC(k_loop2<false>, V, N, alpha, omega, red.out());
+      if (!debug_option("loops_no_nt")) LAUNCH_VEC(k_loop2<true>, V, N, hs.alpha, hs.omega, red.out());
+      else LAUNCH_VEC(k_loop2<false>, V, N, hs.alpha, hs.omega, red.out());
     } else {
-      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_loop2_x, V, N, alpha, omega); }
-    }
-    V.xin = V.v[X_];  // x now lives in v[X_] again
-    if (k % 50 == 0) {
-      TRY(LHS(X_, R_));
+      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_loop2_x, V, N, hs.alpha, hs.omega); }
+      TRY(LHS(X_, R_));        // v[X_] is where x was just written
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_true_resid, V, N); }
       TRY(PRE(R_, RHAT)); TRY(LHS(RHAT, W_));
       { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots7, V, N, red.out()); }
     }
-    TRY(red.begin(fused_now && want_sums ? 8 : 7));  // MPI_Iallreduce(7), 14546 (+ the mean-constraint sum of what)
-    if (!fused_now) TRY(PRE(W_, WHAT));      // 14548-14549
+    TRY(red.begin(7));         // MPI_Iallreduce(7), 14546
+    TRY(PRE(W_, WHAT));        // 14548-14549
     TRY(LHS(WHAT, T_));
     TRY(red.wait());
-    const double r0r = s->h_red[0], r0w = s->h_red[1], r0s = s->h_red[2], r0z = s->h_red[3];
-    const double norm_1 = s->h_red[4], norm_2 = s->h_red[5];
-    norm = std::sqrt(s->h_red[6]);
-    beta = alpha / (omega + eps) * r0r / (r0r_prev + eps);              // 14558
-    alpha = r0r / (r0w + beta * r0s - beta * omega * r0z);              // 14559
-    double alphat = 1.0 / (omega + eps) + r0w / (r0r + eps) - beta * omega * r0z / (r0r + eps);
-    alphat = 1.0 / (alphat + eps);
-    if (std::fabs(alphat) < 10 * std::fabs(alpha)) alpha = alphat;      // 14563-14564
-    r0r_prev = r0r;
-    const bool serious_breakdown = r0r * r0r < 1e-16 * norm_1 * norm_2;  // 14566
-    if (serious_breakdown && restarts < max_restarts) {                 // 14567-14593 / 7096-7120
-      restarts++;
-      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_copy, V.v[R_], V.v[R0], N); }
-      TRY(PRE(R0, RHAT)); TRY(LHS(RHAT, W_));
-      { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots_r0, V, N, red.out()); }
-      TRY(red.begin(2));
-      TRY(PRE(W_, WHAT)); TRY(LHS(WHAT, T_));
-      TRY(red.wait());
-      alpha = s->h_red[0] / (s->h_red[1] + eps);
-      r0r_prev = s->h_red[0];
-      beta = 0.0;
-      omega = 0.0;
+    ctl_step2(hs, s->h_red);   // 14558-14566, 14594-14601 (moves xcur to the buffer just written)
+    if (hs.state == kRestart) TRY(restart());
+    return CUP3D_OK;
+  };
+
+  // one fused iteration, enqueued without waiting for anything: both loop kernels take their scalars from d_ctl
+  const bool direct = red.direct();
+  auto finish = [&](int K, int step, unsigned seq) -> int {  // totals of the K (+1) block-wise sums -> d_red -> the struct
+    ProfileScope ps("bicgstab_dots_finish");
+    const RedOut ro{s->d_partials, s->d_counters, s->d_red, nullptr, nullptr, 0u};
+    const CtlThen then{d_ctl, ring, seq, direct ? step : 0};
+    if (K == 2) {
+      if (want_sums) hipLaunchKernelGGL((k_sums_finish<2, true>), dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, sums, then);
+      else hipLaunchKernelGGL((k_sums_finish<2, false>), dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, (const double *)nullptr, then);
+    } else {
+      if (want_sums) hipLaunchKernelGGL((k_sums_finish<7, true>), dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, sums, then);
+      else hipLaunchKernelGGL((k_sums_finish<7, false>), dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, (const double *)nullptr, then);
     }
-    if (norm < min_norm) {                                              // 14594-14600
-      // x_opt = x without the copy (16 B/cell in two iterations out of three): the buffer that holds x becomes the
-      // snapshot, and the next update of x reads it and writes the other buffer (x is read once and written once there anyway)
-      use_xopt = true;
-      min_norm = norm;
-      std::swap(V.v[XOPT], V.v[X_]);
-      V.xin = V.v[XOPT];
+    CUP3D_HIP(hipGetLastError());
+    if (direct) return CUP3D_OK;
+    // MPI_Iallreduce (14486, 14546) + the mean-constraint sum (9295) in one call on the communication stream, the struct stepped
+    // behind it; the preconditioner-free LHS enqueued next on the compute stream overlaps both, the next loop kernel waits (ev_a)
+    hipStream_t cs = scalar_stream(s);
+    if (cs != stream()) {
+      CUP3D_HIP(hipEventRecord(s->ev_b, stream()));
+      CUP3D_HIP(hipStreamWaitEvent(cs, s->ev_b, 0));
     }
-    if (norm < P.tol || norm / (init_norm + eps) < P.tol_rel) break;   // 14601
+    TRY(allreduce(s, s->d_red, K + (want_sums ? 1 : 0), false, cs));
+    if (step == 1) hipLaunchKernelGGL(k_ctl_step<1>, dim3(1), dim3(1), 0, cs, d_ctl, (const double *)s->d_red, ring, seq);
+    else hipLaunchKernelGGL(k_ctl_step<2>, dim3(1), dim3(1), 0, cs, d_ctl, (const double *)s->d_red, ring, seq);
+    CUP3D_HIP(hipGetLastError());
+    CUP3D_HIP(hipEventRecord(s->ev_a, cs));
+    return CUP3D_OK;
+  };
+  auto scalars_ready = [&]() -> int {  // the compute stream waits for the struct stepped on the communication stream
+    if (!direct && scalar_stream(s) != stream()) CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_a, 0));
+    return CUP3D_OK;
+  };
+  auto enqueue_fused = [&](unsigned seq) -> int {
+    V.v[X_] = XB[0]; V.v[XOPT] = XB[1];  // fixed roles: the kernels pick by SolverCtl::xcur / xopt
+    {
+      ProfileScope ps("bicgstab_loop1_cg");
+      if (P.block_solver == 0) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, cg_it);
+      else hipLaunchKernelGGL((k_loop1_cg<false, 0>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, cg_it);
+    }
+    s->sums_of = want_sums ? V.v[ZHAT] : nullptr;
+    TRY(finish(2, 1, seq));
+    if (want_sums) { s->mean_total_of = V.v[ZHAT]; s->mean_total = s->d_red + 2; }
+    TRY(LHS(ZHAT, V_));
+    TRY(scalars_ready());
+    {
+      ProfileScope ps("bicgstab_loop2_cg");
+      if (P.block_solver == 0 && four_waves) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, cg_it);
+      else if (P.block_solver == 0) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, cg_it);
+      else hipLaunchKernelGGL((k_loop2_cg<false, 0>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, cg_it);
+    }
+    s->sums_of = want_sums ? V.v[WHAT] : nullptr;
+    TRY(finish(7, 2, seq));
+    if (want_sums) { s->mean_total_of = V.v[WHAT]; s->mean_total = s->d_red + 7; }
+    TRY(LHS(WHAT, T_));
+    TRY(scalars_ready());
+    return CUP3D_OK;
+  };
+
+  int k = 0;
+  while (k < P.max_iter && hs.state != kDone) {
+    if (!fuse || k % 50 == 0) {
+      TRY(host_iteration(k));
+      ++k;
+      continue;
+    }
+    // a run of fused iterations, up to the next multiple of 50: the host stays one iteration ahead of the device
+    hs.state = kRun;
+    hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, stream(), d_ctl, hs);
+    int enq = k;  // next iteration to enqueue; k = next iteration whose outcome the host has not seen
+    unsigned seq_of[2] = {0, 0};
+    for (;;) {
+      while (enq < P.max_iter && enq % 50 != 0 && enq - k < 2) {
+        seq_of[enq & 1] = ++s->ctl_seq;
+        TRY(enqueue_fused(seq_of[enq & 1]));
+        ++enq;
+      }
+      if (k == enq) break;  // nothing in flight: a host iteration is next, or the cap is reached
+      TRY(wait_status(s, seq_of[k & 1], &hs));
+      ++k;
+      if (hs.state == kDone) break;
+      if (hs.state == kRestart) {  // what was enqueued ahead returned at once (state != kRun on the device)
+        enq = k;
+        x_ptrs();
+        TRY(restart());
+        hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, stream(), d_ctl, hs);
+      }
+    }
   }
-  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_copy, use_xopt ? V.v[XOPT] : V.v[X_], s->pres, N); }  // 14605-14615
+  const bool use_xopt = hs.xopt >= 0;
+  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_copy, XB[use_xopt ? hs.xopt : hs.xcur], s->pres, N); }  // 14605-14615
   CUP3D_HIP(hipGetLastError());
+  stats_solver_iterations(hs.iter);
   if (res) {
-    res->iterations = k < P.max_iter ? k + 1 : P.max_iter;
-    res->restarts = restarts;
-    res->norm0 = init_norm;
-    res->norm = norm;
+    res->iterations = hs.iter;
+    res->restarts = hs.restarts;
+    res->norm0 = hs.init_norm;
+    res->norm = hs.norm;
     res->used_xopt = use_xopt;
   }
   return CUP3D_OK;
@@ -1130,6 +1321,9 @@ int cup3d_debug_block_cg_iterations(cup3d_sim_t *h, long *total, long *nblocks) 
 
 // TEST SUPPORT: see k_debug_wave_sum (in64 -> out128, host arrays)
 int cup3d_debug_wave_sum(const double *in64, double *out128) {
+#ifndef CUP3D_TESTING
+  return not_in_release("cup3d_debug_wave_sum");
+#else
   if (!in64 || !out128) return CUP3D_EINVAL;
   double *d = nullptr;
   CUP3D_HIP(hipMalloc((void **)&d, 192 * sizeof(double)));
@@ -1142,6 +1336,7 @@ int cup3d_debug_wave_sum(const double *in64, double *out128) {
   hipFree(d);
   if (e != hipSuccess) return hip_fail(e, "cup3d_debug_wave_sum", __FILE__, __LINE__);
   return CUP3D_OK;
+#endif
 }
 
 int cup3d_preconditioner(cup3d_sim_t *h, int block_solver) {

@@ -1,7 +1,9 @@
 // Device block store, host<->device transfers, pointwise operators.  See sim.hpp.
+#include <atomic>
 #include <cstdarg>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <thread>
 
 #include "sim.hpp"
@@ -34,6 +36,9 @@ static std::vector<long> g_prof_launches;
 static std::vector<double> g_prof_ms;
 static std::vector<ProfileRec> g_prof_open;
 static std::vector<hipEvent_t> g_event_pool;  // events are reused: creating two per launch costs more host time than the launch
+// one lock around the profiler's tables and the event pool: the ranks of the in-process test communicator are host threads that all
+// open ProfileScopes (uncontended in a one-thread process: ~20 ns per scope, and only while profiling is on)
+static std::mutex g_prof_mutex;
 static hipEvent_t pooled_event() {
   if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;
@@ -54,6 +59,7 @@ static void profile_drain() {
 }
 ProfileScope::ProfileScope(const char *name) : idx(-1), start(nullptr) {
   if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mutex);
   for (size_t i = 0; i < g_prof_names.size(); ++i)
     if (g_prof_names[i] == name) idx = (int)i;
   if (idx < 0) {
@@ -67,6 +73,7 @@ ProfileScope::ProfileScope(const char *name) : idx(-1), start(nullptr) {
 }
 ProfileScope::~ProfileScope() {
   if (idx < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mutex);
   hipEvent_t stop = pooled_event();
   if (!stop) { g_event_pool.push_back(start); return; }
   hipEventRecord(stop, g_stream);
@@ -74,11 +81,26 @@ ProfileScope::~ProfileScope() {
   if (g_prof_open.size() > 4096) profile_drain();
 }
 
+#ifdef CUP3D_TESTING
 static std::map<std::string, int> g_debug_opts;
+#endif
+int not_in_release(const char *what) {
+  set_error("%s is test / tuning support: load libcup3d_hip_testing.so (built with -DCUP3D_TESTING)", what);
+  return CUP3D_ESTATE;
+}
+// ---- cup3d_stats_*: process-wide counters (the ranks of the in-process test communicator are threads, hence atomics)
+static std::atomic<long> g_st_halo{0}, g_st_halo_bytes{0}, g_st_allreduce{0}, g_st_waits{0}, g_st_wait_ns{0}, g_st_iters{0};
+void stats_host_wait(double seconds) { g_st_waits++; g_st_wait_ns += (long)(seconds * 1e9); }
+void stats_solver_iterations(long n) { g_st_iters += n; }
+void stats_halo(size_t bytes_sent) { g_st_halo++; g_st_halo_bytes += (long)bytes_sent; }
+void stats_allreduce() { g_st_allreduce++; }
+
+#ifdef CUP3D_TESTING
 int debug_option(const char *name) {
   auto it = g_debug_opts.find(name);
   return it == g_debug_opts.end() ? 0 : it->second;
 }
+#endif
 
 // ------------------------------------------------------------------ Sim
 GridDev Sim::gdev(bool boundary_only, bool inner_only) const {
@@ -155,6 +177,20 @@ __global__ void __launch_bounds__(256) k_soa_to_aos_list(const double *__restric
   const int r = (int)(i - blk * 512L * nc);
   const int cell = r / nc, c = r - cell * nc;
   aos[i] = field[((size_t)slots[blk] * nc + c) * 512 + cell];
+}
+// wrapping sum of the 64-bit patterns of n doubles (cup3d_sim_checksum): one atomic per workgroup; integer addition commutes, so the
+// result does not depend on the launch geometry or on how the blocks are spread over ranks
+__global__ void __launch_bounds__(256) k_checksum(const double *__restrict__ p, long n, unsigned long long *__restrict__ out) {
+  __shared__ unsigned long long part[256];
+  unsigned long long a = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a += __builtin_bit_cast(unsigned long long, p[i]);
+  part[threadIdx.x] = a;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(out, part[0]);
 }
 __global__ void __launch_bounds__(256) k_fill(double *__restrict__ p, long n, double v) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
@@ -250,18 +286,24 @@ int cup3d_device_synchronize(void) {
 // TEST / TUNING SUPPORT: select kernel variants (A/B timing, ablations); 0 = production
 int cup3d_debug_set_option(const char *name, int value) {
   if (!name) return CUP3D_EINVAL;
+#ifdef CUP3D_TESTING
   g_debug_opts[name] = value;
   return CUP3D_OK;
+#else
+  return value == 0 ? CUP3D_OK : not_in_release("cup3d_debug_set_option");  // 0 = production behaviour: what this build always does
+#endif
 }
 
 int cup3d_profile_enable(int on) { g_prof_on = on != 0; return CUP3D_OK; }
 int cup3d_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mutex);
   profile_drain();
   std::fill(g_prof_ms.begin(), g_prof_ms.end(), 0.0);
   std::fill(g_prof_launches.begin(), g_prof_launches.end(), 0L);
   return CUP3D_OK;
 }
 int cup3d_profile_read(cup3d_profile_entry *e, int max, int *n) {
+  std::lock_guard<std::mutex> lk(g_prof_mutex);
   profile_drain();
   const int m = (int)g_prof_names.size();
   if (n) *n = m;
@@ -378,23 +420,23 @@ int cup3d_sim_create(const cup3d_grid_t *gh, cup3d_sim_t **out) {
   return CUP3D_OK;
 }
 
+static void release_stage(Sim *s);
 void cup3d_sim_destroy(cup3d_sim_t *h) {
   if (!h) return;
   Sim *s = reinterpret_cast<Sim *>(h);
   vcomm_unregister(s);
   hipStreamSynchronize(g_stream);
   mg_destroy(s);
-  double *ptrs[] = {s->vel, s->vel2, s->tmpV, s->pres, s->lhs, s->chi, s->pold, s->d_partials, s->d_red, s->d_stage, s->halo_recv, s->halo_send, s->d_block_dots,
+  double *ptrs[] = {s->vel, s->vel2, s->tmpV, s->pres, s->lhs, s->chi, s->pold, s->d_partials, s->d_red, s->halo_recv, s->halo_send, s->d_block_dots,
                     s->d_hb, s->d_flux};
   for (double *p : ptrs) if (p) hipFree(p);
   for (double *p : s->sv) if (p) hipFree(p);
   if (s->h_red) hipHostFree(s->h_red);
+  if (s->d_ctl) hipFree(s->d_ctl);
+  if (s->h_ctl) hipHostFree(s->h_ctl);
   if (s->d_counters) hipFree(s->d_counters);
   if (s->d_cg_iters) hipFree(s->d_cg_iters);
-  if (s->h_stage) hipHostFree(s->h_stage);
-  if (s->h_stage_slots) hipHostFree(s->h_stage_slots);
-  for (hipEvent_t e : s->ev_stage) if (e) hipEventDestroy(e);
-  if (s->d_stage_slots) hipFree(s->d_stage_slots);
+  release_stage(s);
   int32_t *ip[] = {s->d_nbr, s->d_inner, s->d_boundary, s->d_send_faces, s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_index,
                    s->d_restrict_list, s->d_prolong_list, s->d_fix_list[0], s->d_fix_list[1], s->d_fix_list[2], s->d_send_blocks, s->d_send_flux, s->d_raw_list};
   if (s->d_raw_mask) hipFree(s->d_raw_mask);
@@ -423,6 +465,14 @@ static int mark_written(Sim *s, int field) {
   if (field == CUP3D_FIELD_CHI) s->chi_nonzero = true;   // obstacles present: KernelPressureRHS must read chi/udef
   if (field == CUP3D_FIELD_TMPV) s->udef_nonzero = true;  // the caller placed udef in tmpV for the next projection
   return CUP3D_OK;
+}
+// zero-copy hosts write through cup3d_sim_device_ptr; the library cannot see those stores, so they say so here
+int cup3d_sim_mark_written(cup3d_sim_t *h, int field) {
+  if (!h) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  int nc;
+  if (!s->field(field, &nc)) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+  return mark_written(s, field);
 }
 
 int cup3d_sim_upload_blocks(cup3d_sim_t *h, int field, const void *const *ptrs);
@@ -456,14 +506,31 @@ int cup3d_sim_download(cup3d_sim_t *h, int field, double *blocks) {
 //   * the gather / scatter runs on up to 16 host threads (more were slower on the two-socket GPU host) (a single core copies ~10 GB/s, PCIe Gen5 x16 carries ~55);
 //   * two pinned staging buffers and two device staging buffers alternate, so that the host works on chunk k+1 while chunk k is on
 //     the bus and in the layout kernel (events, no stream synchronisation inside the loop).
+static void release_stage(Sim *s) {
+  if (s->h_stage) hipHostFree(s->h_stage);
+  if (s->d_stage) hipFree(s->d_stage);
+  if (s->h_stage_slots) hipHostFree(s->h_stage_slots);
+  if (s->d_stage_slots) hipFree(s->d_stage_slots);
+  for (hipEvent_t &e : s->ev_stage) { if (e) hipEventDestroy(e); e = nullptr; }
+  s->h_stage = s->d_stage = nullptr;
+  s->h_stage_slots = s->d_stage_slots = nullptr;
+}
 static int ensure_stage(Sim *s) {
-  if (s->h_stage) return CUP3D_OK;
-  s->stage_blocks = 16384;  // per buffer: 192 MiB of vector blocks
-  CUP3D_HIP(hipHostMalloc((void **)&s->h_stage, 2 * s->stage_blocks * 1536 * sizeof(double), hipHostMallocDefault));
-  CUP3D_HIP(hipMalloc((void **)&s->d_stage, 2 * s->stage_blocks * 1536 * sizeof(double)));
-  CUP3D_HIP(hipHostMalloc((void **)&s->h_stage_slots, s->stage_blocks * sizeof(int32_t), hipHostMallocDefault));
-  CUP3D_HIP(hipMalloc((void **)&s->d_stage_slots, s->stage_blocks * sizeof(int32_t)));
-  for (int i = 0; i < 2; ++i) CUP3D_HIP(hipEventCreateWithFlags(&s->ev_stage[i], hipEventDisableTiming));
+  if (s->stage_ready) return CUP3D_OK;
+  // per buffer: at most 16384 vector blocks (192 MiB), never more than the sim holds -- a 64-block test sim pins 1.5 MiB, not 400
+  s->stage_blocks = (size_t)std::min<int64_t>(16384, std::max<int64_t>(s->nb, 1));
+  const size_t nd = 2 * s->stage_blocks * 1536;
+  hipError_t e = hipHostMalloc((void **)&s->h_stage, nd * sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc((void **)&s->d_stage, nd * sizeof(double));
+  if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_stage_slots, s->stage_blocks * sizeof(int32_t), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc((void **)&s->d_stage_slots, s->stage_blocks * sizeof(int32_t));
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&s->ev_stage[i], hipEventDisableTiming);
+  if (e != hipSuccess) {  // all or nothing: a later call must not find half a staging area
+    release_stage(s);
+    return hip_fail(e, "ensure_stage", __FILE__, __LINE__);
+  }
+  s->bytes += nd * sizeof(double) + s->stage_blocks * sizeof(int32_t);  // the device half (the pinned host half is as large)
+  s->stage_ready = true;
   return CUP3D_OK;
 }
 int cup3d_sim_upload_blocks(cup3d_sim_t *h, int field, const void *const *ptrs) {
@@ -570,6 +637,33 @@ int cup3d_sim_download_block_list(cup3d_sim_t *h, int field, long nlist, const i
     CUP3D_HIP(hipStreamSynchronize(g_stream));
     for (size_t i = 0; i < n; ++i) memcpy(ptrs[b0 + i], s->h_stage + i * per, per * sizeof(double));
   }
+  return CUP3D_OK;
+}
+
+int cup3d_stats_reset(void) {
+  g_st_halo = 0; g_st_halo_bytes = 0; g_st_allreduce = 0; g_st_waits = 0; g_st_wait_ns = 0; g_st_iters = 0;
+  return CUP3D_OK;
+}
+int cup3d_stats_read(cup3d_run_stats *o) {
+  if (!o) return CUP3D_EINVAL;
+  o->halo_exchanges = g_st_halo; o->halo_bytes_sent = (double)g_st_halo_bytes; o->allreduces = g_st_allreduce;
+  o->host_waits = g_st_waits; o->host_wait_seconds = g_st_wait_ns * 1e-9; o->solver_iterations = g_st_iters;
+  return CUP3D_OK;
+}
+
+int cup3d_sim_checksum(cup3d_sim_t *h, int field, unsigned long long *sum) {
+  if (!h || !sum) return CUP3D_EINVAL;
+  Sim *s = reinterpret_cast<Sim *>(h);
+  int nc;
+  const double *p = s->field(field, &nc);
+  if (!p) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+  unsigned long long *d = reinterpret_cast<unsigned long long *>(s->d_red + 12);  // scratch behind the reduced scalars
+  CUP3D_HIP(hipMemsetAsync(d, 0, sizeof *d, g_stream));
+  const long n = (long)s->nb * 512 * nc;  // the rank's own blocks; ghost blocks of a rank view sit behind them
+  hipLaunchKernelGGL(k_checksum, dim3(stride_groups(n)), dim3(256), 0, g_stream, p, n, d);
+  CUP3D_HIP(hipGetLastError());
+  CUP3D_HIP(hipMemcpyAsync(sum, d, sizeof *d, hipMemcpyDeviceToHost, g_stream));
+  CUP3D_HIP(hipStreamSynchronize(g_stream));
   return CUP3D_OK;
 }
 

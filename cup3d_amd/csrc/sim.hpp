@@ -28,7 +28,16 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
   } while (0)
 
 hipStream_t stream();  // compute stream (cup3d_set_stream)
+// Two flavours of the library are built from these sources (Makefile): libcup3d_hip.so, the release build, and
+// libcup3d_hip_testing.so (-DCUP3D_TESTING), which adds what tests and tuning scans need and a deployment does not: the debug-option
+// map read on launch paths, the in-process "virtual" communicator (comm.hip), the evaluation variants of the block CG.  In the
+// release build debug_option() is a constant 0 and the variant branches fold away.
+#ifdef CUP3D_TESTING
 int debug_option(const char *name);  // cup3d_debug_set_option; 0 when unset (production behaviour)
+#else
+constexpr int debug_option(const char *) { return 0; }
+#endif
+int not_in_release(const char *what);  // sets the error text, returns CUP3D_ESTATE
 bool profile_on();                   // cup3d_profile_enable
 
 // ---- per-kernel timing (cup3d_profile_*) ----
@@ -38,6 +47,12 @@ struct ProfileScope {
   int idx;
   hipEvent_t start;
 };
+
+// ---- run statistics (cup3d_stats_*): what crossed ranks and how long the host waited for the device
+void stats_host_wait(double seconds);
+void stats_solver_iterations(long n);
+void stats_halo(size_t bytes_sent);
+void stats_allreduce();
 
 struct Comm;  // RCCL state (comm.cpp)
 Comm *comm();  // nullptr when single rank
@@ -92,12 +107,16 @@ struct Sim {
   double *h_stage = nullptr;  // pinned; two buffers of stage_blocks vector blocks each, like d_stage
   hipEvent_t ev_stage[2] = {nullptr, nullptr};
   size_t stage_blocks = 0;
+  bool stage_ready = false;  // every staging resource exists (ensure_stage is all-or-nothing)
   int32_t *d_stage_slots = nullptr, *h_stage_slots = nullptr;  // block lists of the partial transfers (cup3d_sim_*_block_list)
   // multi-level mesh tables (amr.hip); all nullptr / 0 on uniform grids
   int32_t *d_amr_faces = nullptr, *d_amr_fine = nullptr, *d_nbr27 = nullptr, *d_index = nullptr;
   int32_t *d_restrict_list = nullptr, *d_prolong_list = nullptr, *d_fix_list[3] = {nullptr, nullptr, nullptr};
   const double *mean_total_of = nullptr, *mean_total = nullptr;  // the vector whose sum(p h^3) total is already in *mean_total (device)
   unsigned red_seq = 0;  // last sequence number handed to a reduction kernel (Reducer, poisson.hip)
+  // BiCGSTAB's scalar recurrences on the device (SolverCtl, poisson.hip): the struct, and the pinned ring its outcome reaches the host through
+  void *d_ctl = nullptr, *h_ctl = nullptr, *h_ctl_dev = nullptr;
+  unsigned ctl_seq = 0;
   unsigned n_restrict = 0, n_prolong = 0;
   unsigned n_restrict_inner = 0, n_prolong_inner = 0;  // leading entries of the two lists that belong to inner blocks (rank views)
   struct { const double *field = nullptr; int nc = 0, w = 0, bc_dir = -1; double *slabs = nullptr; bool open = false; } pending_fill;  // halo_begin -> halo_finish

@@ -88,8 +88,11 @@ struct RedOut {
   unsigned *flag;     // with `host`: pinned word that receives `seq` once the K totals are visible to the host (it spins on it)
   unsigned seq;
 };
-template <int K>
-__device__ __forceinline__ void grid_sum_finish(double (&acc)[K], const RedOut &ro) {
+struct NoContinuation { __device__ __forceinline__ void operator()(const double *) const {} };
+// `then(totals)`: run by thread 0 of the last workgroup once the K totals are stored and before the host flag is raised -- where the
+// solver's scalar recurrences live on one rank (poisson.hip), so that the launch that follows finds them in device memory
+template <int K, class Then = NoContinuation>
+__device__ __forceinline__ void grid_sum_finish(double (&acc)[K], const RedOut &ro, Then then = Then()) {
   __shared__ double red[4];
   __shared__ int is_last;
 #pragma unroll
@@ -104,16 +107,20 @@ __device__ __forceinline__ void grid_sum_finish(double (&acc)[K], const RedOut &
   __syncthreads();
   if (!is_last) return;
   __threadfence();  // acquire the other workgroups' partials
+  double tot[K];
+#pragma unroll
   for (int i = 0; i < K; ++i) {
     double s = 0;
     for (int j = threadIdx.x; j < (int)gridDim.x; j += 256) s += ro.partials[(size_t)j * 8 + i];
     s = group_sum<4>(s, red);
+    tot[i] = s;
     if (threadIdx.x == 0) {
       ro.out[i] = s;
       if (ro.host) ro.host[i] = s;
     }
   }
   if (threadIdx.x == 0) {
+    then(tot);
     *ro.counter = 0;
     if (ro.host) {
       __threadfence_system();  // the totals (this thread's own stores) before the flag

@@ -305,6 +305,13 @@ class SimulationData:
         p.block_solver = self.blockSolver
         return p
 
+    def checksum(self, field):
+        """Wrapping 64-bit sum of the bit patterns of this rank's blocks of `field` (cup3d_sim_checksum): sums over ranks mod 2^64
+        are independent of the partition."""
+        out = C.c_ulonglong(0)
+        check(lib().cup3d_sim_checksum(self.handle, FIELDS[field], C.byref(out)))
+        return int(out.value)
+
     def device_bytes(self):
         return lib().cup3d_sim_device_bytes(self.handle)
 

@@ -169,6 +169,16 @@ int cup3d_sim_fill(cup3d_sim_t *, int field, double value);
  * advects (cup3d_advect_diffuse, cup3d_advect_diffuse_implicit, cup3d_advect_implicit): those write the new velocity into a second
  * buffer and swap the two, so re-query it after every such call; the other fields never move. */
 int cup3d_sim_device_ptr(cup3d_sim_t *, int field, void **ptr);
+/* A host that WRITES a field through that pointer must say so afterwards: the library tracks two facts the operators branch on --
+ * "chi is non-zero" (KernelPressureRHS then reads chi and udef, main.cpp:14858-14871) and "tmpV holds the udef of the next
+ * projection" (otherwise cup3d_pressure_project clears tmpV as the reference does at 15076-15078) -- and upload / fill /
+ * cup3d_update_tmpv set them, stores through a raw pointer cannot.  CHI and TMPV are the fields that matter; others are accepted. */
+int cup3d_sim_mark_written(cup3d_sim_t *, int field);
+/* Wrapping 64-bit sum of the bit patterns of every FP64 value of the rank's own blocks of `field` (ghost blocks of a rank view
+ * excluded).  Integer addition commutes, so the sum of the ranks' values is independent of the partition: bench.py all-gathers it
+ * after the first AdvectionDiffusion and compares it with the constant the CPU oracle produced for the same step (the stencil
+ * operators are bit-exact under any sharding; the reference's own partition is main.cpp:2970-2986). */
+int cup3d_sim_checksum(cup3d_sim_t *, int field, unsigned long long *sum);
 
 /* AdvectionDiffusion::operator()(dt) (main.cpp:9640-9728): low-storage RK3 of
  * KernelAdvectDiffuse (9461-9549) on vel, scratch tmpV; fused into 3 launches. */
@@ -186,14 +196,12 @@ typedef struct {
   int max_restarts;    /* 100  (main.cpp:14374) */
   int block_solver;    /* how the block preconditioner M^-1 (getZImplParallel, 14704-14745) is evaluated:
                           0 = the reference's block-local CG, iteration for iteration, as the device evaluates it fastest: a*b+c
-                              contracted to FMA, the two wave-wide sums on the FP64 matrix pipe, the two divisions by reciprocal +
-                              Newton refinement (<= 1 ulp from the IEEE quotient).  Differs from the reference's z at the 1e-7 level of
-                              the CG's own truncation (tests bound it by 2e-5);
+                              contracted to FMA (wave-wide sums by DPP reductions, IEEE divisions).  Differs from the reference's z
+                              by less than the CG's own 1e-7 truncation (tests: measured against block_solver 2 and the reference);
                           1 = direct block solve by fast diagonalisation (same operator, exact to rounding);
-                          2 = the block CG in the reference's association: no FMA contraction, IEEE divisions (only the ORDER of the
-                              512-term sums differs from the CPU); slower, for parity checks;
-                          3 = the round-1 kernel (FMA, DPP reductions), kept for A/B timing;
-                          4 = the block CG with two blocks per wavefront (A/B timing);
+                          2 = the block CG in the reference's association: no FMA contraction (only the ORDER of the 512-term sums
+                              differs from the CPU); slower, for parity checks;
+                          3, 4 = A/B timing variants (3: alias of 0; 4: two blocks per wavefront), libcup3d_hip_testing.so only;
                           5 = NOT the reference's preconditioner: one geometric-multigrid V(2,2)-cycle (red-black Gauss-Seidel in LDS,
                               summed-residual restriction, piecewise-constant prolongation) on the hierarchy of uniform block grids --
                               same operator, same stopping rule, same converged pressure to solver tolerance, O(10) instead of O(150)
@@ -309,6 +317,19 @@ int cup3d_profile_enable(int on);
 int cup3d_profile_reset(void);
 /* fills up to max entries; returns the number of distinct kernels in *n */
 typedef struct { char name[48]; long launches; double total_ms; } cup3d_profile_entry;
+/* run statistics since the last reset, this process: what the rank handed to RCCL (the payload of the reference's MPI_Isend at
+ * main.cpp:2402 and of its MPI_(I)allreduce sites) and how long the host thread sat waiting for device results (the reference's
+ * MPI_Waitall / MPI_Wait, 2324, 14490, 14550) */
+typedef struct {
+  long halo_exchanges;      /* face-slab / ghost-block / face-flux exchanges started */
+  double halo_bytes_sent;   /* bytes of those this rank sent */
+  long allreduces;          /* scalar all-reduces issued */
+  long host_waits;          /* times the host waited for scalars of the device */
+  double host_wait_seconds; /* ... and for how long in total */
+  long solver_iterations;   /* BiCGSTAB iterations (Poisson and Helmholtz solves) */
+} cup3d_run_stats;
+int cup3d_stats_reset(void);
+int cup3d_stats_read(cup3d_run_stats *);
 int cup3d_profile_read(cup3d_profile_entry *entries, int max, int *n);
 
 #ifdef __cplusplus

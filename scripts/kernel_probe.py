@@ -15,6 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("CUP3D_HIP_FLAVOUR", "testing")  # the A/B switches (cup3d_debug_set_option) exist in libcup3d_hip_testing.so only
 import cup3d_amd as cu  # noqa: E402
 from bench import taylor_green_blocks  # noqa: E402
 from cup3d_amd.capi import ProfileEntry, check, lib  # noqa: E402

@@ -8,6 +8,10 @@ import pytest
 # libgomp loads (i.e. before tests/oracle_lib.py dlopens the oracle).
 os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
 
+# the suite drives the test-support entry points (virtual communicator, debug options, kernel variants): the testing flavour of the
+# library (cup3d_amd/capi.py); tests/test_gpu_release_flavour.py runs the release build in subprocesses
+os.environ.setdefault("CUP3D_HIP_FLAVOUR", "testing")
+
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 

@@ -84,6 +84,33 @@ def field_case(name, bpd, lmax, lstart, bc, seed):
     print(name, "blocks", nb, "solve iters", solve_iters, "project iters", proj_iters)
 
 
+def mean3_case():
+    """-bMeanConstraint 3 (any value > 2): ComputeLHS pins the corner cell, LHS(0,0,0) = p(0,0,0) (main.cpp:9316-9325), and
+    solve() zeroes the right-hand side there (14404-14407).  One LHS application, one solve and one projection of the reference."""
+    name, bpd, lmax, lstart, bc, seed = "mean3_mixed", (2, 2, 2), 1, 0, ("freespace", "wall", "periodic"), 17
+    rng = np.random.default_rng(seed)
+    NX, NY, NZ = [(b << lstart) * 8 for b in bpd]
+    velg, presg, rhsg = rng.uniform(-1, 1, (NZ, NY, NX, 3)), rng.uniform(-1, 1, (NZ, NY, NX)), rng.uniform(-1, 1, (NZ, NY, NX))
+    wd = O.tempfile.mkdtemp(prefix="golden_")
+    for n, a in (("vel", velg), ("pres", presg), ("rhs", rhsg)):
+        a.tofile(os.path.join(wd, n + "_in.bin"))
+    dt, step = 0.01, 5
+    script = ["tables tables.bin", "zero chi", "set mean 3", "set nu 0.02",
+              "loadg pres pres_in.bin", "op lhs", "dump lhs lhs.bin",
+              "loadg lhs rhs_in.bin", "loadg pres pres_in.bin", "op solve", "dump pres solve.bin",
+              "loadg vel vel_in.bin", "loadg pres pres_in.bin", f"set step {step}", f"op project {dt}", "dump vel pr_vel.bin", "dump pres pr_pres.bin"]
+    recs, wd = O.run_ref(script, O.ref_args(bpd, lmax, lstart, EXT, bc), threads=1, workdir=wd)
+    t, geom = O.read_tables(os.path.join(wd, "tables.bin"))
+    nb = t.shape[0]
+    rb = lambda f, nc: O.read_blocks(os.path.join(wd, f), nb, nc)  # noqa: E731
+    out = dict(bpd=np.array(bpd), level_max=lmax, level=lstart, bc=np.array([O.BC[b] for b in bc]), extent=EXT, dt=dt, step=step, tables=t,
+               vel_in=velg, pres_in=presg, rhs_in=rhsg, lhs=rb("lhs.bin", 1), solve=rb("solve.bin", 1),
+               solve_iters=[int(r["iters"]) for r in recs if r["op"] == "solve"][0],
+               pr_vel=rb("pr_vel.bin", 3), pr_pres=rb("pr_pres.bin", 1), pr_iters=[int(r["iters"]) for r in recs if r["op"] == "project"][0])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "solve iters", out["solve_iters"], "project iters", out["pr_iters"])
+
+
 def traj_case():
     """Full reference time stepping (calcMaxTimestep + advance) from the Taylor-Green IC."""
     bpd, lmax, lstart, bc = (2, 2, 2), 1, 0, ("periodic", "periodic", "periodic")
@@ -508,6 +535,9 @@ def sfc_cases():
 if __name__ == "__main__":
     if not O.have_ref_tool():
         sys.exit("oracle/_ref/ref_tool missing: run `make -C oracle ref` where /root/reference exists")
+    if sys.argv[1:] == ["mean3"]:   # one case only (added in round 3; the others regenerate identically)
+        mean3_case()
+        sys.exit(0)
     sfc_cases()
     adapt_cases()
     for c in AMR_CASES:
@@ -515,6 +545,7 @@ if __name__ == "__main__":
     amr_adapt_case("amr_adapt_mixed", (2, 2, 2), 3, ("freespace", "wall", "periodic"), 2, 12)
     for c in FIELD_CASES:
         field_case(*c)
+    mean3_case()
     traj_case()
     vorticity_cases()
     grad_chi_cases()

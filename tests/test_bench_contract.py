@@ -69,3 +69,89 @@ def test_committed_bench_records_obey_the_contract():
         assert r["value"] > 0 and r["ms_per_step"] > 0
         seen += 1
     assert seen >= 3
+
+
+def test_gpus_n_without_a_launcher_relaunches_or_says_what_it_needs():
+    """`python bench.py --gpus 2` as the driver types it (no WORLD_SIZE): with fewer than 2 devices it must exit 2 with a clear message,
+    not fall over inside torch.distributed or run on one device (here: zero devices)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 2, out.stderr.decode()[-400:]
+    assert b"needs 2 devices" in out.stderr and out.stdout.strip() == b""
+
+
+def test_report_carries_the_checksum_and_marks_a_mismatch_invalid():
+    prof = {"bicgstab_loop2_cg": (10, 39.0)}
+    ok = {"ok": True, "exact_field": {"value": 1, "expected": 1, "ok": True}, "taylor_green": {"value": 2, "expected": 2, "ok": True}}
+    bad = {"ok": False, "exact_field": {"value": 1, "expected": 3, "ok": False}, "taylor_green": {"value": 2, "expected": 2, "ok": True}}
+    for ck, valid in ((ok, True), (bad, False)):
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            bench.report(_args(checksum=ck, comm={"rccl_ranks": 2}), _Sim(), prof, 7.4, [156, 150], 2)
+        r = json.loads(buf.getvalue().strip())
+        assert r["config"]["checksum"] == ck and r["config"]["communication"]["rccl_ranks"] == 2 and r["config"]["bicgstab_iters_by_step"] == [156, 150]
+        assert r.get("valid", True) is valid and r["n_gpus"] == 2
+
+
+def test_checksum_fixture_is_what_the_oracle_produces():
+    """tests/golden/advdiff_checksums.json (the constants bench.py compares the device with at every N) regenerated for the small sizes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import cup3d_amd as cu
+    import oracle_lib as O
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "advdiff_checksums.json")))
+    assert {"64", "128", "256", "512"} <= set(gold)
+    ext = 2 * np.pi
+    for size in (64, 128):
+        level = (size // 8).bit_length() - 1
+        g = O.OracleGrid((1, 1, 1), level + 1, level, ext, ("wall",) * 3)
+        G = cu.Grid((1, 1, 1), level + 1, level, ext, ("wall",) * 3)
+        assert gold[str(size)]["dt"] == bench.checksum_dt(size)
+        for key, vel in (("exact_field", bench.exact_test_field_blocks(G, size)), ("taylor_green", bench.taylor_green_blocks(G, [ext] * 3, 1.0))):
+            g.advect_diffuse(vel, np.zeros_like(vel), bench.checksum_dt(size), 0.01, (0.0, 0.0, 0.0))
+            assert int(vel.view(np.uint64).sum(dtype=np.uint64)) == gold[str(size)][key], (size, key)
+
+
+def _checksum_worker(rank, world, port, size, q):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import cup3d_amd as cu
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        level = (size // 8).bit_length() - 1
+        G = cu.Grid((1, 1, 1), level + 1, level, 2 * np.pi, ("wall",) * 3, rank, world)   # this rank's Hilbert range (main.cpp:2970-2986)
+        mine = int(bench.exact_test_field_blocks(G, size).view(np.uint64).sum(dtype=np.uint64))
+        parts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]                  # bench.advdiff_checksums' gather, gloo for RCCL
+        dist.all_gather(parts, torch.tensor([mine - (1 << 64) if mine >= (1 << 63) else mine], dtype=torch.int64))
+        q.put((rank, sum(int(p.item()) for p in parts) % (1 << 64), int(G.nblocks)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_checksum_is_independent_of_the_partition_over_gloo():
+    """The per-rank wrapping sums of the exact test field, gathered and added as bench.py does, equal the one-rank sum on 2 and 3 ranks
+    (the operator in between is bit-exact per block: tests/test_gpu_multirank.py)."""
+    import socket
+    import numpy as np
+    import torch.multiprocessing as mp
+    import cup3d_amd as cu
+    size = 64
+    G = cu.Grid((1, 1, 1), 4, 3, 2 * np.pi, ("wall",) * 3)
+    want = int(bench.exact_test_field_blocks(G, size).view(np.uint64).sum(dtype=np.uint64))
+    for world in (2, 3):
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_checksum_worker, args=(r, world, port, size, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=120) for _ in range(world)]
+        for p in procs:
+            p.join(60)
+        assert sum(g[2] for g in got) == G.nblocks
+        assert all(g[1] == want for g in got), (world, got, want)

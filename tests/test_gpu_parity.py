@@ -56,8 +56,13 @@ def load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz"))
 
 
-def iters_close(got, ref):
-    return got <= 1.3 * ref + 5
+def iters_close(got, ref, block_solver=0):
+    """BiCGSTAB iteration count against the single-thread oracle (= reference), SURVEY 8c: within 10 % (+ 2), both ways, for the
+    reference's own preconditioner (block CG: block_solver 0, 2, 3, 4 differ from the CPU in summation order only).  The direct block
+    solve (1) evaluates M^-1 exactly and needs FEWER iterations (15-25 %): bounded from above only."""
+    if block_solver in (1, 5):
+        return got <= 1.1 * ref + 2
+    return abs(got - ref) <= 0.1 * ref + 2
 
 
 def assert_fields_close(got, ref, scale, what, tol):
@@ -227,7 +232,7 @@ def test_golden_poisson_solve(golden_dir, name, block_solver):
     sim.upload("pres", g.to_blocks(z["pres_in"]))
     r = cu.makePoissonSolver(sim).solve()
     got, ref = sim.download("pres"), z["solve"]
-    assert iters_close(r.iterations, int(z["solve_iters"]))
+    assert iters_close(r.iterations, int(z["solve_iters"]), block_solver), (r.iterations, int(z["solve_iters"]))
     # the returned iterate satisfies the reference's stopping rule, so does the reference's: bound on the difference
     o = O.OracleGrid(z["bpd"], int(z["level_max"]), int(z["level"]), float(z["extent"]), [int(b) for b in z["bc"]])
     assert_two_valid_iterates(o, g.index, got, ref, tau_of(r))
@@ -250,7 +255,7 @@ def test_golden_projection(golden_dir, name, tag, step, block_solver):
     sim.upload("pres", g.to_blocks(z["pres_in"]))
     sim.step = int(z["step"]) if step is None else step
     r = cu.PressureProjection(sim)(float(z["dt"]))
-    assert iters_close(r.iterations, int(z[tag + "_iters"]))
+    assert iters_close(r.iterations, int(z[tag + "_iters"]), block_solver), (r.iterations, int(z[tag + "_iters"]))
     v, p = sim.download("vel"), sim.download("pres")
     o = O.OracleGrid(z["bpd"], int(z["level_max"]), int(z["level"]), float(z["extent"]), [int(b) for b in z["bc"]])
     assert_two_valid_iterates(o, g.index, p, z[tag + "_pres"], tau_of(r), v, z[tag + "_vel"], float(z["dt"]), g.h)
@@ -270,7 +275,7 @@ def test_trajectory_against_reference(golden_dir, block_solver):
         dt = S.calcMaxTimestep()
         assert abs(dt - z["dts"][n]) <= 1e-6 * z["dts"][n]
         S.advance(dt)
-        assert iters_close(sim.last_poisson.iterations, int(z["iters"][n]))
+        assert iters_close(sim.last_poisson.iterations, int(z["iters"][n]), block_solver), (n, sim.last_poisson.iterations, int(z["iters"][n]))
         # smooth periodic flow: the projection correction is small and the trajectories stay within 1e-4
         assert np.abs(sim.download("vel") - z["vel"][n + 1]).max() <= 1e-4
         # (a trajectory: the pressures of step n come from velocities that already differ by the previous steps' solver error)
@@ -341,7 +346,7 @@ def test_oracle_random_fields(bpd, lmax, level, bc):
     r = cu.PressureProjection(sim)(dt)
     pref = np.zeros((o.nb, 8, 8, 8))
     info, _, _ = o.project(ref, pref, dt, 3)
-    assert iters_close(r.iterations, info.iters)
+    assert iters_close(r.iterations, info.iters), (r.iterations, info.iters)
     assert_two_valid_iterates(o, o.index, sim.download("pres"), pref, tau_of(r), sim.download("vel"), ref, dt, o.h)
     assert_tight_projection_parity(sim, o, before, np.zeros((o.nb, 8, 8, 8)), dt, 3)
 
@@ -629,7 +634,7 @@ def test_medium_128_oracle_advect_diffuse_and_solver():
     r = cu.PressureProjection(sim)(dt)
     pref = np.zeros((o.nb, 8, 8, 8))
     info, _, _ = o.project(ref, pref, dt, 4)
-    assert iters_close(r.iterations, info.iters)
+    assert iters_close(r.iterations, info.iters), (r.iterations, info.iters)
     assert_two_valid_iterates(o, o.index, sim.download("pres"), pref, tau_of(r), sim.download("vel"), ref, dt, o.h)
 
 
@@ -728,3 +733,140 @@ def test_partial_block_transfers():
     from cup3d_amd.capi import Cup3dError
     with pytest.raises(Cup3dError):
         sim.download_block_list("pres", np.array([nb], dtype=np.int32))
+
+
+# ------------------------------------------------------------------ round 3: device-resident scalar recurrences, bMeanConstraint > 2, API additions
+def test_mean_constraint_3_against_the_reference(golden_dir):
+    """-bMeanConstraint 3 (main.cpp:9316-9325, 14404-14407): LHS bit-exact with the reference's (the corner row is p itself, no global
+    sum involved), the solve and the projection within the stopping rule's bound, iteration counts within 10 %."""
+    z = load(golden_dir, "mean3_mixed")
+    for block_solver in (0, 2):
+        sim = make_sim(z, blockSolver=block_solver, bMeanConstraint=3)
+        g = sim.grid
+        sim.upload("pres", g.to_blocks(z["pres_in"]))
+        cu.ComputeLHS(sim)(0)
+        assert np.array_equal(sim.download("lhs"), z["lhs"])
+        sim.upload("lhs", g.to_blocks(z["rhs_in"]))
+        sim.upload("pres", g.to_blocks(z["pres_in"]))
+        r = cu.makePoissonSolver(sim).solve()
+        assert iters_close(r.iterations, int(z["solve_iters"])), (r.iterations, int(z["solve_iters"]))
+        o = O.OracleGrid(z["bpd"], int(z["level_max"]), int(z["level"]), float(z["extent"]), [int(b) for b in z["bc"]])
+        assert_two_valid_iterates(o, g.index, sim.download("pres"), z["solve"], tau_of(r))
+        sim.upload("vel", g.to_blocks(z["vel_in"]))
+        sim.upload("pres", g.to_blocks(z["pres_in"]))
+        sim.step = int(z["step"])
+        r = cu.PressureProjection(sim)(float(z["dt"]))
+        assert iters_close(r.iterations, int(z["pr_iters"])), (r.iterations, int(z["pr_iters"]))
+        assert_two_valid_iterates(o, g.index, sim.download("pres"), z["pr_pres"], tau_of(r), sim.download("vel"), z["pr_vel"], float(z["dt"]), g.h)
+
+
+@pytest.mark.parametrize("level,bc", [(3, ("wall",) * 3), (4, ("wall",) * 3), (3, ("freespace", "wall", "periodic"))])
+def test_solver_runs_ahead_of_the_host_across_restarts_and_refreshes(level, bc):
+    """All-wall Taylor-Green, three projections from step 21: 70-120 BiCGSTAB iterations each, i.e. runs of fused iterations whose
+    scalars never leave the device (SolverCtl, poisson.hip) interrupted by the host-driven every-50th iterations, and serious
+    breakdowns (the oracle restarts in several of these solves) that the device reports one iteration after the host enqueued the
+    next one.  Iteration counts within 10 % of the oracle's, every returned iterate within the stopping rule's bound; the same
+    solves with the host-driven loops (`no_fuse`) agree with the fused ones in count (same arithmetic, other summation order)."""
+    ext = 2 * np.pi
+    o = O.OracleGrid((1, 1, 1), level + 1, level, ext, bc)
+    sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=level + 1, levelStart=level, extent=ext, nu=0.01, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2])
+    vel = o.taylor_green([ext] * 3, 1.0)
+    vel[..., 2] = 0.3 * vel[..., 0] * vel[..., 1]
+    dt = 0.3 * o.h
+    o.advect_diffuse(vel, np.zeros_like(vel), dt, 0.01)
+    ref, pref = vel.copy(), np.zeros((o.nb, 8, 8, 8))
+    sim.upload("vel", vel)
+    seen_restart = False
+    for step in (21, 22, 23):
+        before, pbefore = sim.download("vel"), sim.download("pres")
+        sim.step = step
+        r = cu.PressureProjection(sim)(dt)
+        rv, rp = before.copy(), pbefore.copy()
+        info, _, _ = o.project(rv, rp, dt, step)                 # the oracle from the DEVICE's state: one step, no drift between the two
+        print(f"level {level} {bc[0]}: step {step}: device {r.iterations} its / {r.restarts} restarts, oracle {info.iters} / {info.restarts}")
+        assert iters_close(r.iterations, info.iters), (step, r.iterations, info.iters)
+        assert abs(r.restarts - info.restarts) <= 2
+        seen_restart |= r.restarts > 0 or info.restarts > 0
+        assert_two_valid_iterates(o, o.index, sim.download("pres"), rp, tau_of(r), sim.download("vel"), rv, dt, o.h)
+        # the host-driven loops on the same input
+        cu.capi.check(cu.lib().cup3d_debug_set_option(b"no_fuse", 1))
+        try:
+            s2 = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=level + 1, levelStart=level, extent=ext, nu=0.01, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2])
+            s2.upload("vel", before)
+            s2.upload("pres", pbefore)
+            s2.step = step
+            r2 = cu.PressureProjection(s2)(dt)
+        finally:
+            cu.capi.check(cu.lib().cup3d_debug_set_option(b"no_fuse", 0))
+        assert iters_close(r2.iterations, info.iters), (step, r2.iterations, info.iters)
+        assert_two_valid_iterates(o, o.index, s2.download("pres"), rp, tau_of(r2))
+        del s2
+    assert seen_restart or level == 3
+
+
+def test_iteration_cap_and_status_ring():
+    """max_iter below convergence: the run of fused iterations stops at the cap (nothing is enqueued beyond it), the result reports
+    exactly max_iter iterations, and a later solve on the same sim starts clean (status ring, sequence numbers)."""
+    ext = 2 * np.pi
+    bc = ("wall",) * 3
+    sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=4, levelStart=3, extent=ext, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2])
+    rng = np.random.default_rng(5)
+    rhs = rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8))
+    counts = []
+    for cap in (7, 1000, 3, 1000):
+        sim.upload("lhs", rhs)
+        sim.fill("pres", 0.0)
+        p = sim.poisson_params()
+        p.max_iter = cap
+        r = cu.capi.PoissonResult()
+        cu.capi.check(cu.lib().cup3d_poisson_solve(sim.handle, C.byref(p), C.byref(r)))
+        counts.append(r.iterations)
+        if cap < 1000:
+            assert r.iterations == cap
+    assert counts[1] == counts[3] and counts[1] > 7            # deterministic: the same solve twice
+
+
+def test_checksum_entry_point():
+    sim = cu.SimulationData(bpdx=2, bpdy=3, bpdz=2, levelMax=1, extent=1.0, BC_x="periodic", BC_y="wall", BC_z="periodic")
+    rng = np.random.default_rng(9)
+    v = rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8, 3))
+    v[0, 0, 0, 0, 0] = -0.0
+    sim.upload("vel", v)
+    assert sim.checksum("vel") == int(v.view(np.uint64).sum(dtype=np.uint64))
+    p = rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8))
+    sim.upload("pres", p)
+    assert sim.checksum("pres") == int(p.view(np.uint64).sum(dtype=np.uint64))
+
+
+def test_udef_written_through_the_device_pointer_survives_the_projection(golden_dir):
+    """A zero-copy host places udef in tmpV through cup3d_sim_device_ptr and says so with cup3d_sim_mark_written: the projection must
+    use it (KernelPressureRHS reads chi and udef, main.cpp:14858-14871) instead of clearing tmpV as for an untouched field."""
+    import torch
+    z = load(golden_dir, "f16_mixed")
+    res = {}
+    for how in ("upload", "pointer", "pointer_unmarked"):
+        sim = make_sim(z)
+        g = sim.grid
+        sim.upload("vel", g.to_blocks(z["vel_in"]))
+        sim.upload("chi", g.to_blocks(z["chi_in"]))
+        udef = g.to_blocks(z["udef_in"])
+        sim.upload("tmpV", udef)
+        if how != "upload":
+            soa = torch.from_numpy(np.ascontiguousarray(np.moveaxis(udef.reshape(sim.nblocks, 512, 3), 2, 1))).cuda()   # [nb][3][512], the slab layout
+            sim.fill("tmpV", 0.0)
+            sim.step = 1
+            cu.PressureProjection(sim)(float(z["dt"]))       # consumes (and clears) the udef flag; state as after any earlier step
+            sim.upload("vel", g.to_blocks(z["vel_in"]))
+            sim.fill("pres", 0.0)
+            ptr = C.c_void_p()
+            cu.capi.check(cu.lib().cup3d_sim_device_ptr(sim.handle, cu.capi.FIELD_TMPV, C.byref(ptr)))
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            assert hip.hipMemcpy(ptr, C.c_void_p(soa.data_ptr()), soa.numel() * 8, 3) == 0   # device to device
+            if how == "pointer":
+                cu.capi.check(cu.lib().cup3d_sim_mark_written(sim.handle, cu.capi.FIELD_TMPV))
+        sim.step = 1
+        cu.PressureProjection(sim)(float(z["dt"]))
+        res[how] = sim.download("vel")
+    assert np.abs(res["upload"] - res["pointer"]).max() <= 1e-9 * np.abs(res["upload"]).max()
+    assert np.abs(res["upload"] - res["pointer_unmarked"]).max() > 1e-6   # unmarked: cleared like the reference's tmpV = 0 (15076-15078)

@@ -1,0 +1,63 @@
+"""bench.py over real processes and real RCCL (one process per GPU), as the driver launches it.
+
+On a box with >= 2 devices: `python bench.py --gpus 2` (no launcher environment: bench.py re-executes itself under
+torch.distributed.run) must print ONE JSON line whose partition-independent checksum equals the CPU oracle's constant -- the halo
+exchange (ncclSend / ncclRecv of packed face slabs, comm.hip; reference: SynchronizerMPI_AMR::sync, main.cpp:2356-2405) carried the
+right bits -- and whose BiCGSTAB iteration counts stay within 10 % of the one-process run of the same command (the all-reduces,
+main.cpp:14486 / 14546, only reorder the sums).  On a one-GPU box those tests are skipped and the refusal path is checked instead."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import cup3d_amd as cu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+
+
+def test_one_process_bench_carries_a_matching_checksum():
+    out = run_bench("--size", "128", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-alt", "--no-pcie")
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = out.stdout.decode().strip().splitlines()
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    ck = r["config"]["checksum"]
+    assert ck["ok"] is True and ck["exact_field"]["ok"] is True and ck["exact_field"]["value"] == ck["exact_field"]["expected"]
+    assert ck["taylor_green"]["value"] == ck["taylor_green"]["expected"]   # holds as long as numpy's sin / cos equal the build container's
+    assert r["config"]["communication"]["rccl_ranks"] == 1 and r.get("valid", True) is True
+    assert len(r["config"]["bicgstab_iters_by_step"]) == 2
+
+
+def test_more_gpus_than_devices_is_refused_clearly():
+    n = cu.capi.device_count()
+    out = run_bench("--gpus", str(n + 1), "--size", "64", "--steps", "1", "--warmup", "0", "--no-cpu")
+    assert out.returncode == 2 and f"needs {n + 1} devices".encode() in out.stderr and out.stdout.strip() == b""
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_bench_over_rccl_matches_the_one_process_run(n):
+    if cu.capi.device_count() < n:
+        pytest.skip(f"{n} devices needed, {cu.capi.device_count()} visible")
+    args = ("--size", "128", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-alt", "--no-pcie")
+    one = run_bench(*args)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    many = run_bench("--gpus", str(n), *args)
+    assert many.returncode == 0, many.stderr.decode()[-3000:]
+    lines = many.stdout.decode().strip().splitlines()
+    assert len(lines) == 1, lines
+    r1, rn = json.loads(one.stdout.decode().strip()), json.loads(lines[0])
+    assert rn["n_gpus"] == n and rn["config"]["communication"]["rccl_ranks"] == n
+    assert rn["config"]["checksum"]["ok"] is True
+    assert rn["config"]["checksum"]["exact_field"]["value"] == r1["config"]["checksum"]["exact_field"]["value"]
+    assert rn["config"]["checksum"]["taylor_green"]["value"] == r1["config"]["checksum"]["taylor_green"]["value"]
+    for a, b in zip(r1["config"]["bicgstab_iters_by_step"], rn["config"]["bicgstab_iters_by_step"]):
+        assert abs(a - b) <= 0.1 * a + 2, (r1["config"]["bicgstab_iters_by_step"], rn["config"]["bicgstab_iters_by_step"])
+    assert rn["config"]["communication"]["halo_exchanges_per_iteration"] > 0

@@ -145,3 +145,18 @@ def test_mesh_adaptation_block_operators(golden_dir, name):
     assert np.array_equal(O.restrict_field(g1, g0, z["vel_fine"]), z["vel_coarse"])
     assert np.array_equal(O.restrict_field(g1, g0, z["pres_fine"]), z["pres_coarse"])
     assert np.array_equal(O.tag_blocks(g0, v0, float(z["tag_rtol"]), float(z["tag_ctol"])), clamp_tags(z["tags"], 0, int(z["level_max"])))
+
+
+def test_mean_constraint_3_bit_exact(golden_dir):
+    """-bMeanConstraint > 2 (main.cpp:9316-9325, 14404-14407): LHS, solve (iteration count included) and projection of the reference."""
+    z, g = load(golden_dir, "mean3_mixed")
+    pres, rhs, vel = g.to_blocks(z["pres_in"]), g.to_blocks(z["rhs_in"]), g.to_blocks(z["vel_in"])
+    assert np.array_equal(g.lhs(pres, 3), z["lhs"])
+    corner = np.where((g.index == 0).all(axis=1))[0][0]
+    assert z["lhs"][corner, 0, 0, 0] == pres[corner, 0, 0, 0]          # the pinned cell
+    x = pres.copy()
+    info = g.solve(rhs, x, mean_constraint=3)
+    assert info.iters == int(z["solve_iters"]) and np.array_equal(x, z["solve"])
+    v, p = vel.copy(), pres.copy()
+    info, _, _ = g.project(v, p, float(z["dt"]), int(z["step"]), mean_constraint=3)
+    assert info.iters == int(z["pr_iters"]) and np.array_equal(v, z["pr_vel"]) and np.array_equal(p, z["pr_pres"])
