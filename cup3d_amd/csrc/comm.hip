@@ -50,8 +50,14 @@ Comm *comm() { return g_comm_ready ? &g_comm : nullptr; }
 static int load_rccl() {
   if (g_comm.dl) return CUP3D_OK;
   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // an RCCL the process has loaded already (torch.distributed brings its own copy) is the one to use: two copies of the library in
+  // one process corrupt each other's teardown.  Hosts that load RCCL themselves do so before cup3d_comm_init (bench.py imports torch first).
   for (const char *n : names)
-    if ((g_comm.dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if ((g_comm.dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD))) break;
+  for (const char *n : names) {
+    if (g_comm.dl) break;
+    g_comm.dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  }
   if (!g_comm.dl) { set_error("cannot dlopen librccl: %s", dlerror()); return CUP3D_ECOMM; }
 #define SYM(field, name)                                                      \
   *(void **)(&g_comm.field) = dlsym(g_comm.dl, name);                         \

@@ -1,0 +1,53 @@
+#!/bin/bash
+# One gpurun call of round 3.  Usage: gpurun --timeout 1500 -- 'bash scripts/gpu_round3.sh <tag> [stages...]'
+# stages: smoke newtests tests multirank bench128 bench256 bench512 flavours window256 trace pmc probe
+TAG=${1:-r03a}; shift
+STAGES=${@:-smoke newtests bench128 bench256}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd "$(dirname "$0")/.."
+has() { [[ " $STAGES " == *" $1 "* ]]; }
+echo "== host: $(nproc) cpus, $(free -g | awk '/Mem:/{print $2}') GB, devices: $(python -c 'import cup3d_amd.capi as c; print(c.device_count())' 2>/dev/null)"
+if has smoke; then echo "== smoke (release build)"
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1 ; echo "smoke rc=$?" ; tail -3 $OUT/smoke.log; fi
+if has newtests; then echo "== pytest: round-3 tests first"
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_release_flavour.py tests/test_gpu_rccl.py -m gpu -q --durations=8 -s ${NEW_ARGS} > $OUT/pytest_new.log 2>&1 ; echo "pytest rc=$?"
+  grep -E "level [0-9]|passed|failed|FAILED|Error|assert" $OUT/pytest_new.log | tail -60 | cut -c1-400; fi
+if has tests; then echo "== pytest -m gpu (everything)"
+  timeout 1500 python -m pytest tests -m gpu -q --durations=10 > $OUT/pytest_gpu.log 2>&1 ; echo "pytest rc=$?" ; grep -E "passed|failed|FAILED|Error" $OUT/pytest_gpu.log | tail -40 | cut -c1-300; tail -12 $OUT/pytest_gpu.log | cut -c1-300; fi
+if has resttests; then echo "== pytest -m gpu (all but the files of newtests)"
+  timeout 1500 python -m pytest tests -m gpu -q --durations=10 --ignore=tests/test_gpu_parity.py --ignore=tests/test_gpu_release_flavour.py --ignore=tests/test_gpu_rccl.py > $OUT/pytest_rest.log 2>&1 ; echo "pytest rc=$?" ; grep -E "passed|failed|FAILED|Error" $OUT/pytest_rest.log | tail -40 | cut -c1-300; tail -12 $OUT/pytest_rest.log | cut -c1-300; fi
+summ() { python - "$1" <<'PY'
+import json, sys
+try:
+    r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+except Exception as e:
+    print("  (no JSON)", e); sys.exit(0)
+c = r["config"]
+its = c.get("bicgstab_iters_per_step") or 0
+print("  value", r["value"], "ms/step", r["ms_per_step"], "its/step", its, "ms/iteration", round(r["ms_per_step"] / its, 4) if its else None, "lib", c.get("library"))
+print("  checksum", (c.get("checksum") or {}).get("ok"), "comm", c.get("communication"))
+for k in r.get("kernels", [])[:7]:
+    print("   ", k["kernel"], k["launches"], k["avg_ms"], k.get("frac"))
+PY
+}
+for S in 128 256 512; do
+  if has bench$S; then echo "== bench $S (release build, no cpu baseline, no alt)"
+    timeout 900 python bench.py --size $S --no-cpu --no-alt --no-pcie --steps ${BENCH_STEPS:-10} --warmup ${BENCH_WARMUP:-3} > $OUT/bench_$S.json 2> $OUT/bench_$S.err ; echo "bench rc=$?" ; summ $OUT/bench_$S.json ; tail -2 $OUT/bench_$S.err
+  fi
+done
+if has flavours; then echo "== release vs testing build, 256^3, no per-kernel events"
+  for F in release testing release testing; do
+    CUP3D_HIP_FLAVOUR=$F timeout 600 python bench.py --size 256 --no-cpu --no-alt --no-pcie --no-profile --no-checksum --steps 10 --warmup 3 > $OUT/flavour_$F.json 2>> $OUT/flavour.err ; echo "$F rc=$?"; summ $OUT/flavour_$F.json; done; fi
+if has nofuse; then echo "== A/B: host-driven unfused loops, 256^3"
+  timeout 600 python bench.py --size 256 --no-cpu --no-alt --no-pcie --no-fuse --steps 5 --warmup 2 > $OUT/bench_256_nofuse.json 2>> $OUT/flavour.err; summ $OUT/bench_256_nofuse.json; fi
+if has window256; then echo "== the driver's window at 256^3 (steps 26-45 after 5 warm-up steps) for profiles/r03/reference_window_256.json"
+  timeout 900 python bench.py --size 256 --no-cpu --no-alt --no-pcie --steps 20 --warmup 5 > $OUT/bench_256_window.json 2> $OUT/bench_256_window.err ; echo "rc=$?"; summ $OUT/bench_256_window.json; fi
+if has full512; then echo "== the driver's command"
+  timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_512_driver.json 2> $OUT/bench_512_driver.err ; echo "rc=$?"; summ $OUT/bench_512_driver.json; tail -3 $OUT/bench_512_driver.err; fi
+if has trace; then echo "== rocprofv3 kernel trace of the bench command (3 steps)"
+  rocprofv3 --kernel-trace --stats -d $OUT/rocprof -o trace -- python bench.py --no-cpu --no-alt --no-pcie --no-checksum --steps 3 --warmup 1 > $OUT/trace_bench.json 2> $OUT/trace.err ; echo "rc=$?"
+  find $OUT/rocprof -name "*kernel_stats*.csv" | head -1 | xargs -I{} sh -c 'head -25 {} | cut -c1-220'
+  find $OUT/rocprof -name "*kernel_trace*.csv" -delete ; find $OUT/rocprof -name "*.db" -delete; fi
+echo "== done"
