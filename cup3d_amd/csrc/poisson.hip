@@ -22,6 +22,7 @@
 
 #include "sim.hpp"
 #include "tile.hpp"
+#include "tile7.hpp"
 
 namespace cup3d {
 
@@ -691,42 +692,143 @@ struct Loop2Args { double alpha, omega; };
 #define NTL(v, j) __builtin_nontemporal_load(&(v)[j])
 #define NTS(v, j, val) __builtin_nontemporal_store((val), &(v)[j])
 
-template <bool FMA, int EV>
+// ---- the LHS application folded into the loop kernel that needs its result (uniform grids)
+// Per iteration the reference applies  v = A zhat  after the first loop and  t = A what  after the second (14489, 14549), and each
+// loop then streams t and v like any other vector.  On the device that was two launches of k_lhs (16 B/cell each, 12 % of an
+// iteration, with the all-reduce tucked behind them).  With FLHS the wavefront that owns a block builds the ghosted tile of the
+// block's what (first loop) / zhat (second loop) in LDS -- its own column of 8 planes plus the six face slabs, fetched from the
+// neighbour slots, the domain-face rule (zero-gradient: own face cell) or the halo slabs of other ranks, i.e. what load_scalar_tile
+// does for a 256-thread workgroup -- evaluates  h (xm + xp + ym + yp + zm + zp - 6 c)  in k_lhs's association (BIT-IDENTICAL t and
+// v), uses the value in place of the streamed one and stores it for the other loop.  One stream fewer to read, no k_lhs launch.
+// Tile layout: 10 planes (0 and 9: the z ghosts) of pitch 96 doubles = 10 rows of 8 (rows 0 and 9: the y ghosts) + 8 x-minus ghosts
+// + 8 x-plus ghosts.  960 doubles; the block CG's LDS (zeroed again when the CG starts) is inside it.  Every stencil operand is one
+// ds_read_b64 with an immediate plane offset: nothing is carried in registers from plane to plane.
+constexpr int kTilePitch = 96, kTileLds = 10 * kTilePitch;
+static_assert(kTileLds >= kCgLds, "the block CG reuses the tile's LDS");
+struct LhsIn {
+  const double *halo;   // face slabs received from other ranks (Sim::halo_recv)
+  const double *total;  // sum(u h^3) over all ranks, for the mean-constraint row (9283-9326); device memory
+  int mode;             // bMeanConstraint as ComputeLHS uses it: 0 none, 1 corner row = total, 2 += total h^3 everywhere, 3 corner row = u
+  int corner_slot;      // slot of the block with index (0,0,0) on this rank, or -1
+};
+__device__ __forceinline__ void load_tile_1w(const GridDev &g, int slot, const double *__restrict__ f, const double *__restrict__ halo, double *T, int l) {
+  const double *own = f + (size_t)slot * 512;
+  double c[8], gv[6];
+#pragma unroll
+  for (int z = 0; z < 8; ++z) c[z] = own[z * 64 + l];
+#pragma unroll
+  for (int face = 0; face < 6; ++face) {  // all 14 loads are in flight before the first LDS write
+    const int n = g.nbr[slot * 6 + face];
+    int nb_cell, own_cell, lds;
+    face1(face, l, nb_cell, own_cell, lds);
+    const double *__restrict__ base = n >= kNbrHalo ? halo + (size_t)(n - kNbrHalo) * 64 : (n >= 0 ? f + (size_t)n * 512 : own);
+    gv[face] = base[n >= kNbrHalo ? l : (n >= 0 ? nb_cell : own_cell)];
+  }
+  const int base = ((l >> 3) + 1) * 8 + (l & 7), a1 = l & 7, a2 = (l >> 3) + 1;
+#pragma unroll
+  for (int z = 0; z < 8; ++z) T[(z + 1) * kTilePitch + base] = c[z];
+  T[a2 * kTilePitch + 80 + a1] = gv[0];  // x faces: lane = (a1 = y, z = a2 - 1)
+  T[a2 * kTilePitch + 88 + a1] = gv[1];
+  T[a2 * kTilePitch + a1] = gv[2];       // y faces: lane = (a1 = x, z = a2 - 1) -> rows 0 and 9
+  T[a2 * kTilePitch + 72 + a1] = gv[3];
+  T[base] = gv[4];                       // z faces: lane = (x, y) -> planes 0 and 9
+  T[9 * kTilePitch + base] = gv[5];
+  __syncthreads();
+}
+// per-lane tile offsets of the x neighbours (the edge lanes read the ghost slots behind the rows)
+struct TileIdx { int base, ixm, ixp; };
+__device__ __forceinline__ TileIdx tile_idx(int l) {
+  const int x = l & 7, y = l >> 3, base = (y + 1) * 8 + x;
+  return TileIdx{base, x > 0 ? base - 1 : 80 + y, x < 7 ? base + 1 : 88 + y};
+}
+// the mean-constraint fix-ups of ComputeLHS (9299-9326), decided once per wavefront so that the plane loop stays one basic block
+// (a branch per plane makes the compiler keep every stream's address in a VGPR pair: +34 registers)
+struct LhsFix {
+  double total, add;  // sum(u h^3) over all ranks; total * h^3 (mode 2)
+  bool add_mean;      // mode 2: t += total h^3 in every cell (9314)
+  bool row_total;     // this lane holds the corner cell (plane 0) and mode 1: t = total (9299-9304)
+  bool row_self;      // ... and mode > 2: t = u (9316-9325)
+};
+__device__ __forceinline__ LhsFix lhs_fix(const LhsIn &L, int slot, int l, double h) {
+  LhsFix f;
+  f.total = (L.mode == 1 || L.mode == 2) ? L.total[0] : 0.0;
+  f.add = f.total * (h * h * h);
+  f.add_mean = L.mode == 2;
+  const bool corner = slot == L.corner_slot && l == 0;
+  f.row_total = corner && L.mode == 1;
+  f.row_self = corner && L.mode > 2;
+  return f;
+}
+// KernelLHSPoisson (9211-9214) for the cell of lane l in plane zz, in k_lhs's association; cc = the cell's own value
+template <int ZZ>
+__device__ __forceinline__ double tile_lhs(const double *T, const TileIdx &ix, double &cc, double h, const LhsFix &f) {
+  // volatile LDS pointers (address space kept): one ds_read_b64 per operand, in this order, plane offset in the instruction
+  typedef const volatile __attribute__((address_space(3))) double lds_cvd;
+  lds_cvd *Q = (lds_cvd *)(T + (ZZ + 1) * kTilePitch);
+  cc = Q[ix.base];
+  double t = Q[ix.ixm] + Q[ix.ixp];
+  t += Q[ix.base - 8];
+  t += Q[ix.base + 8];
+  t += Q[ix.base - kTilePitch];
+  t += Q[ix.base + kTilePitch];
+  t = h * (t - 6.0 * cc);
+  if (ZZ == 0) {  // the corner cell is cell 0 of its block: selects, no branches
+    t = f.row_total ? f.total : t;
+    t = f.row_self ? cc : t;
+  }
+  const double t2 = t + f.add;
+  return f.add_mean ? t2 : t;
+}
+
+template <bool FMA, int EV, bool FLHS>
 __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb,
-                                              double *__restrict__ block_sums, int *__restrict__ iters_out) {
-  __shared__ double P[kCgLds];
+                                              double *__restrict__ block_sums, int *__restrict__ iters_out, const LhsIn &L) {
+  __shared__ double P[FLHS ? kTileLds : kCgLds];
   const int slot = block_slot(g);
   if (slot < 0) return;
   if (ctl->state != kRun) return;  // enqueued ahead of a stop or a restart (see SolverCtl)
   const Loop1Args a{ctl->alpha, ctl->beta, ctl->omega};
   const int l = threadIdx.x;
-  const double invh = 1 / block_h(g, slot);
+  const double hq = block_h(g, slot), invh = 1 / hq;
   double r[8], d0 = 0, d1 = 0;
   // plane zz + 1 is requested before plane zz is computed and stored (two planes = 22 x 512 B per wavefront in flight): the loads
   // may alias the stores as far as the compiler knows, so the order has to be written out
   // (block base pointers are wave-uniform -> scalar registers; the per-lane part of every address is one 32-bit offset)
   const size_t bo = (size_t)slot * 512;
-  const double *const src[11] = {V.v[RHAT] + bo, V.v[W_] + bo, V.v[SHAT] + bo, V.v[Z_] + bo, V.v[PHAT] + bo, V.v[S_] + bo, V.v[WHAT] + bo, V.v[ZHAT] + bo,
+  // FLHS: what comes from the tile and t is computed from it -- streams 6 and 8 are not loaded
+  enum { iRHAT, iW, iSHAT, iZ, iPHAT, iS, iWHAT, iZHAT, iT, iV, iR, NS };
+  const double *const src[NS] = {V.v[RHAT] + bo, V.v[W_] + bo, V.v[SHAT] + bo, V.v[Z_] + bo, V.v[PHAT] + bo, V.v[S_] + bo, V.v[WHAT] + bo, V.v[ZHAT] + bo,
                                  V.v[T_] + bo, V.v[V_] + bo, V.v[R_] + bo};
   double *const oP = V.v[PHAT] + bo, *const oS = V.v[S_] + bo, *const oSH = V.v[SHAT] + bo, *const oZ = V.v[Z_] + bo, *const oQ = V.v[Q_] + bo,
-               *const oQH = V.v[QHAT] + bo, *const oY = V.v[Y_] + bo;
-  double in[2][11];
-#pragma unroll
-  for (int i = 0; i < 11; ++i) in[0][i] = NTL(src[i], l);
+               *const oQH = V.v[QHAT] + bo, *const oY = V.v[Y_] + bo, *const oT = V.v[T_] + bo;
+  double in[2][NS];
+#define LOAD_PLANE(buf, off)                                                            \
+  _Pragma("unroll") for (int i = 0; i < NS; ++i)                                        \
+    if (!(FLHS && (i == iWHAT || i == iT))) in[buf][i] = NTL(src[i], off);
+  TileIdx ix{0, 0, 0};
+  LhsFix fx{};
+  if constexpr (FLHS) {  // the tile first (its 14 loads need their registers only until the LDS writes), then the streams
+    fx = lhs_fix(L, slot, l, hq);
+    load_tile_1w(g, slot, V.v[WHAT], L.halo, P, l);
+    ix = tile_idx(l);
+  }
+  LOAD_PLANE(0, l)
 #pragma unroll
   for (int zz = 0; zz < 8; ++zz) {  // first fused loop, 14454-14464, on plane zz of this block
     const int j = zz * 64 + l;
-    if (zz < 7) {
-#pragma unroll
-      for (int i = 0; i < 11; ++i) in[(zz + 1) & 1][i] = NTL(src[i], j + 64);
-    }
+    if (zz < 7) { LOAD_PLANE((zz + 1) & 1, j + 64) }
     const double *c = in[zz & 1];
-    const double rhat = c[0], w = c[1], shat0 = c[2], z0 = c[3];
-    const double phat = rhat + a.beta * (c[4] - a.omega * shat0);
-    const double sv = w + a.beta * (c[5] - a.omega * z0);
-    const double shat = c[6] + a.beta * (shat0 - a.omega * c[7]);
-    const double z = c[8] + a.beta * (z0 - a.omega * c[9]);
-    const double q = c[10] - a.alpha * sv;
+    double what = c[iWHAT], t = c[iT];
+    if constexpr (FLHS) {
+      t = zz == 0 ? tile_lhs<0>(P, ix, what, hq, fx) : tile_lhs<1>(P + (zz - 1) * kTilePitch, ix, what, hq, fx);   // t = A what, 14549
+      NTS(oT, j, t);                                                              // the second loop streams it
+    }
+    const double rhat = c[iRHAT], w = c[iW], shat0 = c[iSHAT], z0 = c[iZ];
+    const double phat = rhat + a.beta * (c[iPHAT] - a.omega * shat0);
+    const double sv = w + a.beta * (c[iS] - a.omega * z0);
+    const double shat = what + a.beta * (shat0 - a.omega * c[iZHAT]);
+    const double z = t + a.beta * (z0 - a.omega * c[iV]);
+    const double q = c[iR] - a.alpha * sv;
     const double qhat = rhat - a.alpha * shat;
     const double y = w - a.alpha * z;
     NTS(oP, j, phat); NTS(oS, j, sv); NTS(oSH, j, shat); NTS(oZ, j, z); NTS(oQ, j, q); NTS(oQH, j, qhat); NTS(oY, j, y);
@@ -734,21 +836,23 @@ __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, c
     d1 += y * y;
     r[zz] = invh * z;  // the right-hand side of the block solve, main.cpp:14723
   }
+#undef LOAD_PLANE
   d0 = wave_sum(d0);
   d1 = wave_sum(d1);
   if (l == 0) { block_dots[slot] = d0; block_dots[nb + slot] = d1; }
+  if constexpr (FLHS) __syncthreads();  // the tile is read no more: the block CG takes over its LDS
   cg_block<FMA, false, EV>(g, slot, r, V.v[ZHAT], block_sums, 0.0, 0.0, iters_out, P);  // zhat = M^-1 z, 14488
 }
-template <bool FMA, int EV>
+template <bool FMA, int EV, bool FLHS>
 __global__ void __launch_bounds__(64) k_loop1_cg(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
-                                                 int *__restrict__ iters_out) {
-  loop1_cg_body<FMA, EV>(g, V, ctl, block_dots, nb, block_sums, iters_out);
+                                                 int *__restrict__ iters_out, LhsIn L) {
+  loop1_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L);
 }
 
-template <bool FMA, int EV>
+template <bool FMA, int EV, bool FLHS>
 __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb,
-                                              double *__restrict__ block_sums, int *__restrict__ iters_out) {
-  __shared__ double P[kCgLds];
+                                              double *__restrict__ block_sums, int *__restrict__ iters_out, const LhsIn &L) {
+  __shared__ double P[FLHS ? kTileLds : kCgLds];
   const int slot = block_slot(g);
   if (slot < 0) return;
   if (ctl->state != kRun) return;
@@ -757,59 +861,74 @@ __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, c
   const int xc = ctl->xcur, xw = ctl_xwrite(*ctl);
   const double *const xin = xc ? V.v[XOPT] : V.v[X_];
   const int l = threadIdx.x;
-  const double invh = 1 / block_h(g, slot);
+  const double hq = block_h(g, slot), invh = 1 / hq;
   double r[8], acc[6] = {0, 0, 0, 0, 0, 0};
   const size_t bo = (size_t)slot * 512;
-  const double *const src[12] = {V.v[QHAT] + bo, V.v[Y_] + bo, V.v[R0] + bo, xin + bo, V.v[PHAT] + bo, V.v[Q_] + bo, V.v[WHAT] + bo, V.v[ZHAT] + bo,
+  // FLHS: zhat comes from the tile and v is computed from it -- streams 7 and 9 are not loaded
+  enum { iQHAT, iY, iR0, iX, iPHAT, iQ, iWHAT, iZHAT, iT, iV, iS, iZ, NS };
+  const double *const src[NS] = {V.v[QHAT] + bo, V.v[Y_] + bo, V.v[R0] + bo, xin + bo, V.v[PHAT] + bo, V.v[Q_] + bo, V.v[WHAT] + bo, V.v[ZHAT] + bo,
                                  V.v[T_] + bo, V.v[V_] + bo, V.v[S_] + bo, V.v[Z_] + bo};
-  double *const oX = (xw ? V.v[XOPT] : V.v[X_]) + bo, *const oR = V.v[R_] + bo, *const oRH = V.v[RHAT] + bo, *const oW = V.v[W_] + bo;
-  double in[2][12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) in[0][i] = NTL(src[i], l);
+  double *const oX = (xw ? V.v[XOPT] : V.v[X_]) + bo, *const oR = V.v[R_] + bo, *const oRH = V.v[RHAT] + bo, *const oW = V.v[W_] + bo, *const oV = V.v[V_] + bo;
+  double in[2][NS];
+#define LOAD_PLANE(buf, off)                                                            \
+  _Pragma("unroll") for (int i = 0; i < NS; ++i)                                        \
+    if (!(FLHS && (i == iZHAT || i == iV))) in[buf][i] = NTL(src[i], off);
+  TileIdx ix{0, 0, 0};
+  LhsFix fx{};
+  if constexpr (FLHS) {  // the tile first (its 14 loads need their registers only until the LDS writes), then the streams
+    fx = lhs_fix(L, slot, l, hq);
+    load_tile_1w(g, slot, V.v[ZHAT], L.halo, P, l);
+    ix = tile_idx(l);
+  }
+  LOAD_PLANE(0, l)
 #pragma unroll
   for (int zz = 0; zz < 8; ++zz) {  // second fused loop, 14503-14515
     const int j = zz * 64 + l;
-    if (zz < 7) {
-#pragma unroll
-      for (int i = 0; i < 12; ++i) in[(zz + 1) & 1][i] = NTL(src[i], j + 64);
-    }
+    if (zz < 7) { LOAD_PLANE((zz + 1) & 1, j + 64) }
     const double *c = in[zz & 1];
-    const double qhat = c[0], y = c[1], r0 = c[2];
-    const double x = c[3] + a.alpha * c[4] + a.omega * qhat;
-    const double rv = c[5] - a.omega * y;
-    const double rhat = qhat - a.omega * (c[6] - a.alpha * c[7]);
-    const double w = y - a.omega * (c[8] - a.alpha * c[9]);
+    double zhat = c[iZHAT], v = c[iV];
+    if constexpr (FLHS) {
+      v = zz == 0 ? tile_lhs<0>(P, ix, zhat, hq, fx) : tile_lhs<1>(P + (zz - 1) * kTilePitch, ix, zhat, hq, fx);   // v = A zhat, 14489
+      NTS(oV, j, v);                                                              // the next first loop streams it
+    }
+    const double qhat = c[iQHAT], y = c[iY], r0 = c[iR0];
+    const double x = c[iX] + a.alpha * c[iPHAT] + a.omega * qhat;
+    const double rv = c[iQ] - a.omega * y;
+    const double rhat = qhat - a.omega * (c[iWHAT] - a.alpha * zhat);
+    const double w = y - a.omega * (c[iT] - a.alpha * v);
     NTS(oX, j, x); NTS(oR, j, rv); NTS(oRH, j, rhat); NTS(oW, j, w);
     acc[0] += r0 * rv;
     acc[1] += r0 * w;
-    acc[2] += r0 * c[10];
-    acc[3] += r0 * c[11];
+    acc[2] += r0 * c[iS];
+    acc[3] += r0 * c[iZ];
     acc[4] += rv * rv;   // norm_1
     acc[5] += r0 * r0;   // norm_2
     r[zz] = invh * w;
   }
+#undef LOAD_PLANE
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const double t = wave_sum(acc[i]);
     if (l == 0) block_dots[(size_t)i * nb + slot] = t;
     if (i == 4 && l == 0) block_dots[(size_t)6 * nb + slot] = t;  // norm = the same sum as norm_1 (14512-14514)
   }
+  if constexpr (FLHS) __syncthreads();
   cg_block<FMA, false, EV>(g, slot, r, V.v[WHAT], block_sums, 0.0, 0.0, iters_out, P);  // what = M^-1 w, 14548
 }
 // Production: held to 96 registers (2 of the 122 the body asks for are spilled, outside the CG loop) -> 5 wavefronts per SIMD like the
 // first fused kernel: 3.63-3.70 ms instead of 3.75 at 512^3, 0.457-0.461 instead of 0.497 at 256^3
 // (profiles/r02/probe_fused_kernel_occupancy.jsonl).  The same test on the other side -- the first kernel or the stand-alone block
 // CG held to 80 registers for 6 wavefronts -- loses (12-14 spills inside the loops: 5.3 ms instead of 3.88; CG 0.43 instead of 0.40).
-template <bool FMA, int EV>
+template <bool FMA, int EV, bool FLHS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
-k_loop2_cg(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums, int *__restrict__ iters_out) {
-  loop2_cg_body<FMA, EV>(g, V, ctl, block_dots, nb, block_sums, iters_out);
+k_loop2_cg(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums, int *__restrict__ iters_out, LhsIn L) {
+  loop2_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L);
 }
-// A/B (debug option "loop2_four_waves"): the register allocation the compiler picks on its own, 122 -> 4 wavefronts per SIMD
-template <bool FMA, int EV>
+// A/B (debug option "loop2_four_waves"): the register allocation the compiler picks on its own -> 4 wavefronts per SIMD
+template <bool FMA, int EV, bool FLHS>
 __global__ void __launch_bounds__(64) k_loop2_cg_w4(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
-                                                    int *__restrict__ iters_out) {
-  loop2_cg_body<FMA, EV>(g, V, ctl, block_dots, nb, block_sums, iters_out);
+                                                    int *__restrict__ iters_out, LhsIn L) {
+  loop2_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L);
 }
 
 // K sums of nb per-block values each ([K][nb]) finished in one launch: 64 workgroups, the last one to arrive totals the partials.
@@ -1131,6 +1250,9 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   hs.r0r_prev = s->h_red[0];
   hs.norm = hs.init_norm = std::sqrt(s->h_red[0]);
 
+  // the mean-constraint total of `what` for the first fused loop (FLHS): d_red[7] after a fused iteration (k_sums_finish<7, true>),
+  // d_red[8] after a host-driven LHS(WHAT, T_) (k_mean_finish inside launch_lhs); of `zhat` for the second loop it is d_red[2]
+  const double *what_total = s->d_red + 8;
   // the restart of 14567-14593 / 7096-7120 (the breakdown was detected, and counted, by ctl_step2)
   auto restart = [&]() -> int {
     { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_copy, V.v[R_], V.v[R0], N); }
@@ -1144,6 +1266,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     hs.beta = 0.0;
     hs.omega = 0.0;
     hs.state = kRun;
+    what_total = s->d_red + 8;
     return CUP3D_OK;
   };
 
@@ -1182,6 +1305,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     TRY(red.wait());
     ctl_step2(hs, s->h_red);   // 14558-14566, 14594-14601 (moves xcur to the buffer just written)
     if (hs.state == kRestart) TRY(restart());
+    what_total = s->d_red + 8;  // LHS(WHAT, T_) left sum(what h^3) there (k_mean_finish)
     return CUP3D_OK;
   };
 
@@ -1218,28 +1342,53 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     if (!direct && scalar_stream(s) != stream()) CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_a, 0));
     return CUP3D_OK;
   };
+  // FLHS: v = A zhat and t = A what are formed inside the loop kernels (uniform grids; on multi-level meshes the LHS needs the
+  // coarse/fine ghost slabs and the flux correction, so it stays a launch of its own)
+  const bool flhs = fuse && !s->grid->multilevel && !debug_option("no_fuse_lhs");
+  const bool split = s->grid->nranks > 1;
+  auto launch_loop = [&](int which, const double *u, const LhsIn &L) -> int {  // one loop kernel; over ranks: inner blocks while u's face slabs travel, then the rest
+    if (flhs && split) TRY(halo_begin(s, u, 1, 1));
+    for (int pass = 0; pass < (flhs && split ? 2 : 1); ++pass) {
+      const GridDev gp = flhs && split ? s->gdev(pass == 1, pass == 0) : gd;
+      if (pass == 1) TRY(halo_finish(s));
+      if (gp.nblocks == 0) continue;
+      ProfileScope ps(which == 1 ? "bicgstab_loop1_cg" : "bicgstab_loop2_cg");
+      const dim3 GG(launch_groups(gp)), BB(64);
+#define LOOP_ARGS gp, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, cg_it, L
+      if (which == 1) {
+        if (P.block_solver == 0 && flhs) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (P.block_solver == 0) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (flhs) hipLaunchKernelGGL((k_loop1_cg<false, 0, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        else hipLaunchKernelGGL((k_loop1_cg<false, 0, false>), GG, BB, 0, stream(), LOOP_ARGS);
+      } else {
+        // with the LHS inside, the second loop asks for 128 registers: 4 wavefronts per SIMD without spills (k_loop2_cg_w4; held to 96 it
+        // spills 30 registers inside the plane loop), and the 7.5 KB tile needs 16 wavefronts per CU or fewer anyway
+        if (P.block_solver == 0 && flhs) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (P.block_solver == 0 && four_waves) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (P.block_solver == 0) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (flhs) hipLaunchKernelGGL((k_loop2_cg_w4<false, 0, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        else hipLaunchKernelGGL((k_loop2_cg<false, 0, false>), GG, BB, 0, stream(), LOOP_ARGS);
+      }
+#undef LOOP_ARGS
+      CUP3D_HIP(hipGetLastError());
+    }
+    return CUP3D_OK;
+  };
   auto enqueue_fused = [&](unsigned seq) -> int {
     V.v[X_] = XB[0]; V.v[XOPT] = XB[1];  // fixed roles: the kernels pick by SolverCtl::xcur / xopt
-    {
-      ProfileScope ps("bicgstab_loop1_cg");
-      if (P.block_solver == 0) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, cg_it);
-      else hipLaunchKernelGGL((k_loop1_cg<false, 0>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, cg_it);
-    }
+    const int lhs_mode = !flhs ? -1 : (mc > 2 ? 3 : mc);
+    TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, what_total, lhs_mode, s->grid->corner_slot}));  // (t = A what,) loop 1, zhat = M^-1 z
     s->sums_of = want_sums ? V.v[ZHAT] : nullptr;
     TRY(finish(2, 1, seq));
     if (want_sums) { s->mean_total_of = V.v[ZHAT]; s->mean_total = s->d_red + 2; }
-    TRY(LHS(ZHAT, V_));
+    if (!flhs) TRY(LHS(ZHAT, V_));
     TRY(scalars_ready());
-    {
-      ProfileScope ps("bicgstab_loop2_cg");
-      if (P.block_solver == 0 && four_waves) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, cg_it);
-      else if (P.block_solver == 0) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, cg_it);
-      else hipLaunchKernelGGL((k_loop2_cg<false, 0>), dim3(launch_groups(gd)), dim3(64), 0, stream(), gd, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, cg_it);
-    }
+    TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, s->d_red + 2, lhs_mode, s->grid->corner_slot}));  // (v = A zhat,) loop 2, what = M^-1 w
     s->sums_of = want_sums ? V.v[WHAT] : nullptr;
     TRY(finish(7, 2, seq));
     if (want_sums) { s->mean_total_of = V.v[WHAT]; s->mean_total = s->d_red + 7; }
-    TRY(LHS(WHAT, T_));
+    what_total = s->d_red + 7;
+    if (!flhs) TRY(LHS(WHAT, T_));
     TRY(scalars_ready());
     return CUP3D_OK;
   };

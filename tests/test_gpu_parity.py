@@ -877,3 +877,35 @@ def test_udef_written_through_the_device_pointer_survives_the_projection(golden_
         res[how] = sim.download("vel")
     assert np.abs(res["upload"] - res["pointer"]).max() <= 1e-9 * np.abs(res["upload"]).max()
     assert np.abs(res["upload"] - res["pointer_unmarked"]).max() > 1e-6   # unmarked: cleared like the reference's tmpV = 0 (15076-15078)
+
+
+@pytest.mark.parametrize("mc", [0, 1, 2, 3])
+@pytest.mark.parametrize("bpd,lmax,level,bc", [
+    ((1, 1, 1), 4, 3, ("wall", "wall", "wall")),
+    ((2, 1, 3), 2, 1, ("periodic", "freespace", "wall")),
+    ((1, 1, 2), 1, 0, ("periodic", "periodic", "periodic")),   # a block that is its own neighbour
+])
+def test_lhs_inside_the_loop_kernels_is_bit_identical(bpd, lmax, level, bc, mc):
+    """v = A zhat and t = A what formed inside the fused loop kernels (one wavefront per block, ghosted tile in LDS, poisson.hip FLHS)
+    against the same solve with k_lhs launches (`no_fuse_lhs`): the stencil keeps k_lhs's association and the mean-constraint rows
+    (main.cpp:9299-9326) are applied to the same cells, so t and v -- hence every iterate, the iteration count and the returned
+    pressure -- are the same BITS.  Every bMeanConstraint mode."""
+    rng = np.random.default_rng(31 + mc)
+    res = {}
+    for opt in (0, 1):
+        cu.capi.check(cu.lib().cup3d_debug_set_option(b"no_fuse_lhs", opt))
+        try:
+            sim = cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=level, extent=2 * np.pi,
+                                    BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], bMeanConstraint=mc, poissonTol=1e-9, poissonTolRel=1e-7)
+            if opt == 0:
+                rhs = rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8))
+                rhs -= rhs.mean()
+            sim.upload("lhs", rhs)
+            sim.fill("pres", 0.0)
+            r = cu.makePoissonSolver(sim).solve()
+            res[opt] = (r.iterations, r.restarts, r.norm, sim.download("pres"))
+        finally:
+            cu.capi.check(cu.lib().cup3d_debug_set_option(b"no_fuse_lhs", 0))
+    assert res[0][0] > 3
+    assert res[0][:3] == res[1][:3], (res[0][:3], res[1][:3])
+    assert np.array_equal(res[0][3], res[1][3])
