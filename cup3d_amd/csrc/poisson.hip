@@ -711,28 +711,31 @@ struct LhsIn {
   int mode;             // bMeanConstraint as ComputeLHS uses it: 0 none, 1 corner row = total, 2 += total h^3 everywhere, 3 corner row = u
   int corner_slot;      // slot of the block with index (0,0,0) on this rank, or -1
 };
-__device__ __forceinline__ void load_tile_1w(const GridDev &g, int slot, const double *__restrict__ f, const double *__restrict__ halo, double *T, int l) {
+struct TileRegs { double c[8], gv[6]; };
+// the 14 loads of a tile (own column + six face slabs); the caller issues the first plane of its streams behind them, then commits
+__device__ __forceinline__ void tile_issue(const GridDev &g, int slot, const double *__restrict__ f, const double *__restrict__ halo, int l, TileRegs &R) {
   const double *own = f + (size_t)slot * 512;
-  double c[8], gv[6];
 #pragma unroll
-  for (int z = 0; z < 8; ++z) c[z] = own[z * 64 + l];
+  for (int z = 0; z < 8; ++z) R.c[z] = own[z * 64 + l];
 #pragma unroll
-  for (int face = 0; face < 6; ++face) {  // all 14 loads are in flight before the first LDS write
+  for (int face = 0; face < 6; ++face) {
     const int n = g.nbr[slot * 6 + face];
     int nb_cell, own_cell, lds;
     face1(face, l, nb_cell, own_cell, lds);
     const double *__restrict__ base = n >= kNbrHalo ? halo + (size_t)(n - kNbrHalo) * 64 : (n >= 0 ? f + (size_t)n * 512 : own);
-    gv[face] = base[n >= kNbrHalo ? l : (n >= 0 ? nb_cell : own_cell)];
+    R.gv[face] = base[n >= kNbrHalo ? l : (n >= 0 ? nb_cell : own_cell)];
   }
+}
+__device__ __forceinline__ void tile_commit(const TileRegs &R, double *T, int l) {
   const int base = ((l >> 3) + 1) * 8 + (l & 7), a1 = l & 7, a2 = (l >> 3) + 1;
 #pragma unroll
-  for (int z = 0; z < 8; ++z) T[(z + 1) * kTilePitch + base] = c[z];
-  T[a2 * kTilePitch + 80 + a1] = gv[0];  // x faces: lane = (a1 = y, z = a2 - 1)
-  T[a2 * kTilePitch + 88 + a1] = gv[1];
-  T[a2 * kTilePitch + a1] = gv[2];       // y faces: lane = (a1 = x, z = a2 - 1) -> rows 0 and 9
-  T[a2 * kTilePitch + 72 + a1] = gv[3];
-  T[base] = gv[4];                       // z faces: lane = (x, y) -> planes 0 and 9
-  T[9 * kTilePitch + base] = gv[5];
+  for (int z = 0; z < 8; ++z) T[(z + 1) * kTilePitch + base] = R.c[z];
+  T[a2 * kTilePitch + 80 + a1] = R.gv[0];  // x faces: lane = (a1 = y, z = a2 - 1)
+  T[a2 * kTilePitch + 88 + a1] = R.gv[1];
+  T[a2 * kTilePitch + a1] = R.gv[2];       // y faces: lane = (a1 = x, z = a2 - 1) -> rows 0 and 9
+  T[a2 * kTilePitch + 72 + a1] = R.gv[3];
+  T[base] = R.gv[4];                       // z faces: lane = (x, y) -> planes 0 and 9
+  T[9 * kTilePitch + base] = R.gv[5];
   __syncthreads();
 }
 // per-lane tile offsets of the x neighbours (the edge lanes read the ghost slots behind the rows)
@@ -807,12 +810,14 @@ __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, c
     if (!(FLHS && (i == iWHAT || i == iT))) in[buf][i] = NTL(src[i], off);
   TileIdx ix{0, 0, 0};
   LhsFix fx{};
-  if constexpr (FLHS) {  // the tile first (its 14 loads need their registers only until the LDS writes), then the streams
+  TileRegs tr;
+  if constexpr (FLHS) {  // the tile's loads first, the first plane of the streams right behind them, then the tile goes to LDS
     fx = lhs_fix(L, slot, l, hq);
-    load_tile_1w(g, slot, V.v[WHAT], L.halo, P, l);
+    tile_issue(g, slot, V.v[WHAT], L.halo, l, tr);
     ix = tile_idx(l);
   }
   LOAD_PLANE(0, l)
+  if constexpr (FLHS) tile_commit(tr, P, l);
 #pragma unroll
   for (int zz = 0; zz < 8; ++zz) {  // first fused loop, 14454-14464, on plane zz of this block
     const int j = zz * 64 + l;
@@ -875,12 +880,14 @@ __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, c
     if (!(FLHS && (i == iZHAT || i == iV))) in[buf][i] = NTL(src[i], off);
   TileIdx ix{0, 0, 0};
   LhsFix fx{};
-  if constexpr (FLHS) {  // the tile first (its 14 loads need their registers only until the LDS writes), then the streams
+  TileRegs tr;
+  if constexpr (FLHS) {  // the tile's loads first, the first plane of the streams right behind them, then the tile goes to LDS
     fx = lhs_fix(L, slot, l, hq);
-    load_tile_1w(g, slot, V.v[ZHAT], L.halo, P, l);
+    tile_issue(g, slot, V.v[ZHAT], L.halo, l, tr);
     ix = tile_idx(l);
   }
   LOAD_PLANE(0, l)
+  if constexpr (FLHS) tile_commit(tr, P, l);
 #pragma unroll
   for (int zz = 0; zz < 8; ++zz) {  // second fused loop, 14503-14515
     const int j = zz * 64 + l;

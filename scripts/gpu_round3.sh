@@ -40,6 +40,11 @@ done
 if has flavours; then echo "== release vs testing build, 256^3, no per-kernel events"
   for F in release testing release testing; do
     CUP3D_HIP_FLAVOUR=$F timeout 600 python bench.py --size 256 --no-cpu --no-alt --no-pcie --no-profile --no-checksum --steps 10 --warmup 3 > $OUT/flavour_$F.json 2>> $OUT/flavour.err ; echo "$F rc=$?"; summ $OUT/flavour_$F.json; done; fi
+if has ablhs; then echo "== A/B: LHS as k_lhs launches (no_fuse_lhs=1, testing build) vs inside the loop kernels (default), same box"
+  for S in ${AB_SIZES:-256 512}; do
+    timeout 900 python bench.py --size $S --no-cpu --no-alt --no-pcie --no-checksum --debug-option no_fuse_lhs=1 --steps ${BENCH_STEPS:-10} --warmup ${BENCH_WARMUP:-3} > $OUT/ab_${S}_klhs.json 2>> $OUT/ab.err; echo "k_lhs launches, $S:"; summ $OUT/ab_${S}_klhs.json
+    timeout 900 python bench.py --size $S --no-cpu --no-alt --no-pcie --no-checksum --debug-option no_fuse_lhs=0 --steps ${BENCH_STEPS:-10} --warmup ${BENCH_WARMUP:-3} > $OUT/ab_${S}_flhs.json 2>> $OUT/ab.err; echo "LHS in the loop kernels, $S:"; summ $OUT/ab_${S}_flhs.json
+  done; fi
 if has nofuse; then echo "== A/B: host-driven unfused loops, 256^3"
   timeout 600 python bench.py --size 256 --no-cpu --no-alt --no-pcie --no-fuse --steps 5 --warmup 2 > $OUT/bench_256_nofuse.json 2>> $OUT/flavour.err; summ $OUT/bench_256_nofuse.json; fi
 if has window256; then echo "== the driver's window at 256^3 (steps 26-45 after 5 warm-up steps) for profiles/r03/reference_window_256.json"
