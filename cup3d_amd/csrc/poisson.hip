@@ -848,8 +848,10 @@ __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, c
   if constexpr (FLHS) __syncthreads();  // the tile is read no more: the block CG takes over its LDS
   cg_block<FMA, false, EV>(g, slot, r, V.v[ZHAT], block_sums, 0.0, 0.0, iters_out, P);  // zhat = M^-1 z, 14488
 }
+// held to 96 registers: with the LHS inside, the compiler left to itself takes 110 (4 wavefronts per SIMD); asked for 5 it needs 94 and
+// spills nothing
 template <bool FMA, int EV, bool FLHS>
-__global__ void __launch_bounds__(64) k_loop1_cg(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) k_loop1_cg(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
                                                  int *__restrict__ iters_out, LhsIn L) {
   loop1_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L);
 }
@@ -1370,7 +1372,8 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       } else {
         // with the LHS inside, the second loop asks for 128 registers: 4 wavefronts per SIMD without spills (k_loop2_cg_w4; held to 96 it
         // spills 30 registers inside the plane loop), and the 7.5 KB tile needs 16 wavefronts per CU or fewer anyway
-        if (P.block_solver == 0 && flhs) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        if (P.block_solver == 0 && flhs && debug_option("loop2_flhs_five_waves")) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);  // A/B: 96 registers, 30 spilled
+        else if (P.block_solver == 0 && flhs) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0 && four_waves) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (flhs) hipLaunchKernelGGL((k_loop2_cg_w4<false, 0, true>), GG, BB, 0, stream(), LOOP_ARGS);

@@ -45,6 +45,12 @@ if has ablhs; then echo "== A/B: LHS as k_lhs launches (no_fuse_lhs=1, testing b
     timeout 900 python bench.py --size $S --no-cpu --no-alt --no-pcie --no-checksum --debug-option no_fuse_lhs=1 --steps ${BENCH_STEPS:-10} --warmup ${BENCH_WARMUP:-3} > $OUT/ab_${S}_klhs.json 2>> $OUT/ab.err; echo "k_lhs launches, $S:"; summ $OUT/ab_${S}_klhs.json
     timeout 900 python bench.py --size $S --no-cpu --no-alt --no-pcie --no-checksum --debug-option no_fuse_lhs=0 --steps ${BENCH_STEPS:-10} --warmup ${BENCH_WARMUP:-3} > $OUT/ab_${S}_flhs.json 2>> $OUT/ab.err; echo "LHS in the loop kernels, $S:"; summ $OUT/ab_${S}_flhs.json
   done; fi
+if has abl2; then echo "== A/B: second fused kernel with the LHS inside at 5 wavefronts per SIMD (96 registers, spills) vs 4 (default)"
+  for S in ${AB_SIZES:-256 512}; do
+    for O in 1 0; do
+    timeout 900 python bench.py --size $S --no-cpu --no-alt --no-pcie --no-checksum --debug-option loop2_flhs_five_waves=$O --steps ${BENCH_STEPS:-10} --warmup ${BENCH_WARMUP:-3} > $OUT/abl2_${S}_$O.json 2>> $OUT/ab.err; echo "five_waves=$O, $S:"; summ $OUT/abl2_${S}_$O.json
+    done
+  done; fi
 if has nofuse; then echo "== A/B: host-driven unfused loops, 256^3"
   timeout 600 python bench.py --size 256 --no-cpu --no-alt --no-pcie --no-fuse --steps 5 --warmup 2 > $OUT/bench_256_nofuse.json 2>> $OUT/flavour.err; summ $OUT/bench_256_nofuse.json; fi
 if has window256; then echo "== the driver's window at 256^3 (steps 26-45 after 5 warm-up steps) for profiles/r03/reference_window_256.json"
