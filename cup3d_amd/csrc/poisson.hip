@@ -848,10 +848,10 @@ __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, c
   if constexpr (FLHS) __syncthreads();  // the tile is read no more: the block CG takes over its LDS
   cg_block<FMA, false, EV>(g, slot, r, V.v[ZHAT], block_sums, 0.0, 0.0, iters_out, P);  // zhat = M^-1 z, 14488
 }
-// held to 96 registers: with the LHS inside, the compiler left to itself takes 110 (4 wavefronts per SIMD); asked for 5 it needs 94 and
-// spills nothing
+// (with the LHS inside the compiler takes 110 registers -> 4 wavefronts per SIMD; held to 5 wavefronts it fits 94 without a spill and is
+//  SLOWER: 0.54 instead of 0.51 ms at 256^3, 3.96 instead of 3.93 at 512^3 -- gpurun_out r03c / r03d, profiles/r03)
 template <bool FMA, int EV, bool FLHS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) k_loop1_cg(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
+__global__ void __launch_bounds__(64) k_loop1_cg(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
                                                  int *__restrict__ iters_out, LhsIn L) {
   loop1_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L);
 }
