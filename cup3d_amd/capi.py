@@ -152,6 +152,7 @@ DEBUG_SIGNATURES = {
     "cup3d_debug_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "cup3d_debug_amr_slabs": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "cup3d_debug_virtual_comm": (C.c_int, [C.c_int]),
+    "cup3d_debug_host_transport": (C.c_int, [C.c_int, C.c_int, _vp]),
     "cup3d_debug_wave_sum": (C.c_int, [_dp, _dp]),
     "cup3d_debug_block_cg_iterations": (C.c_int, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
 }

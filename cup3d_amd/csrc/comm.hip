@@ -17,6 +17,7 @@
 #include <mutex>
 #include <vector>
 
+#include "../../include/cup3d_hip_testing.h"
 #include "sim.hpp"
 
 namespace cup3d {
@@ -117,6 +118,40 @@ static VComm *g_vcomm = nullptr;
 static constexpr VComm *g_vcomm = nullptr;
 #endif
 VComm *vcomm() { return g_vcomm; }
+
+// ------------------------------------------------------------------ host-memory transport (TEST SUPPORT, cup3d_hip_testing.h)
+// One process per rank as under RCCL, but the bytes travel device -> host -> the caller's transport (MPI in the harness) -> host ->
+// device, synchronously.  Everything else -- plans, pack kernels, streams, the order of the collectives -- is the production code.
+#ifdef CUP3D_TESTING
+static cup3d_host_transport g_ht;
+static bool g_ht_on = false;
+#else
+static constexpr bool g_ht_on = false;
+static constexpr cup3d_host_transport g_ht{nullptr, nullptr, nullptr};
+#endif
+bool host_transport() { return g_ht_on; }
+// send_count / recv_count items of `per` doubles per peer, peer-major buffers on the device; `skip` = a rank whose share is not sent
+// (exchange_items handles the caller's own share itself) but still occupies its place in both buffers
+static int ht_exchange(const double *d_send, const std::vector<int64_t> &send_count, double *d_recv, const std::vector<int64_t> &recv_count, size_t per, int skip,
+                       hipStream_t st) {
+  const int n = (int)send_count.size();
+  std::vector<long> so(n), sb(n), ro(n), rb(n);
+  size_t ts = 0, tr = 0;
+  for (int p = 0; p < n; ++p) {
+    so[p] = (long)(ts * sizeof(double)); ro[p] = (long)(tr * sizeof(double));
+    const size_t ns = (size_t)send_count[p] * per, nr = (size_t)recv_count[p] * per;
+    sb[p] = p == skip ? 0 : (long)(ns * sizeof(double)); rb[p] = p == skip ? 0 : (long)(nr * sizeof(double));
+    ts += ns; tr += nr;
+  }
+  std::vector<double> hs(ts ? ts : 1), hr(tr ? tr : 1);
+  CUP3D_HIP(hipStreamSynchronize(st));  // the pack kernel
+  if (ts) CUP3D_HIP(hipMemcpy(hs.data(), d_send, ts * sizeof(double), hipMemcpyDeviceToHost));
+  if (g_ht.exchange(g_ht.ctx, hs.data(), so.data(), sb.data(), hr.data(), ro.data(), rb.data())) { set_error("host transport: exchange failed"); return CUP3D_ECOMM; }
+  for (int p = 0; p < n; ++p)  // only what arrived: the skipped rank's place in d_recv belongs to the caller
+    if (rb[p]) CUP3D_HIP(hipMemcpyAsync((char *)d_recv + ro[p], (const char *)hr.data() + ro[p], (size_t)rb[p], hipMemcpyHostToDevice, st));
+  CUP3D_HIP(hipStreamSynchronize(st));
+  return CUP3D_OK;
+}
 void vcomm_register(Sim *s) {
   if (g_vcomm && s->grid->nranks == g_vcomm->n) g_vcomm->sims[s->grid->rank] = s;
 }
@@ -221,6 +256,7 @@ static int view_transfer(Sim *s, double *dst, size_t per, const std::vector<int6
     if (flux) return vcomm_pull(s, dst, per, recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_flux_count; }, exchange_stream(s));
     return vcomm_pull(s, dst, per, recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_block_count; }, exchange_stream(s));
   }
+  if (g_ht_on) return ht_exchange(s->halo_send, send_count, dst, recv_count, per, -1, exchange_stream(s));
   Comm *c = comm();
   if (!c) { set_error("multi-rank mesh without cup3d_comm_init"); return CUP3D_ESTATE; }
   CUP3D_NCCL(c->GroupStart());
@@ -298,8 +334,8 @@ int exchange_items(Sim *s, const double *sendbuf, const std::vector<int64_t> &se
   if (send_count[me]) CUP3D_HIP(hipMemcpyAsync(recvbuf + ro[me], sendbuf + so[me], (size_t)send_count[me] * per * sizeof(double), hipMemcpyDeviceToDevice, stream()));
   if (n == 1) return CUP3D_OK;
   stats_halo(sent_bytes(send_count, per, me));
-  Comm *c = g_vcomm ? nullptr : comm();
-  if (!g_vcomm && !c) { set_error("multi-rank mesh without cup3d_comm_init"); return CUP3D_ESTATE; }
+  Comm *c = (g_vcomm || g_ht_on) ? nullptr : comm();
+  if (!g_vcomm && !g_ht_on && !c) { set_error("multi-rank mesh without cup3d_comm_init"); return CUP3D_ESTATE; }
   hipStream_t st = g_vcomm ? exchange_stream(s) : (s->comm_stream ? s->comm_stream : stream());
   if (st != stream()) {
     CUP3D_HIP(hipEventRecord(s->ev_h1, stream()));
@@ -325,6 +361,9 @@ int exchange_items(Sim *s, const double *sendbuf, const std::vector<int64_t> &se
     if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the block exchange"); return CUP3D_ECOMM; }
     for (int p = 0; p < n; ++p)  // a send completes when the data has left: the callers free their send buffers after the compute stream drains
       if (p != me && send_count[p] && vc->cur[p]) CUP3D_HIP(hipStreamWaitEvent(st, vc->cur[p]->ev_vc_done, 0));
+  } else if (g_ht_on) {
+    int rc = ht_exchange(sendbuf, send_count, recvbuf, recv_count, per, me, st);
+    if (rc) return rc;
   } else {
     CUP3D_NCCL(c->GroupStart());
     for (int p = 0; p < n; ++p) {
@@ -346,6 +385,7 @@ static int slab_transfer(Sim *s, size_t per_face, hipStream_t st) {
   const Grid *g = s->grid;
   stats_halo(sent_bytes(g->send_count, per_face));
   if (g_vcomm) return vcomm_pull(s, s->halo_recv, per_face, g->recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_count; }, st);
+  if (g_ht_on) return ht_exchange(s->halo_send, g->send_count, s->halo_recv, g->recv_count, per_face, -1, st);
   Comm *c = comm();
   if (!c) { set_error("multi-rank grid without cup3d_comm_init"); return CUP3D_ESTATE; }
   CUP3D_NCCL(c->GroupStart());
@@ -440,6 +480,16 @@ int allreduce(Sim *s, double *d_buf, int n, bool is_max, hipStream_t st) {
     CUP3D_HIP(hipMemcpyAsync(d_buf, vc->d_tmp + 16 * r, n * sizeof(double), hipMemcpyDeviceToDevice, st));
     return CUP3D_OK;
   }
+  if (g_ht_on) {
+    double h[16];
+    if (n > 16) { set_error("host transport: at most 16 values per all-reduce"); return CUP3D_EINVAL; }
+    CUP3D_HIP(hipStreamSynchronize(st));
+    CUP3D_HIP(hipMemcpy(h, d_buf, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (g_ht.allreduce(g_ht.ctx, h, n, is_max ? 1 : 0)) { set_error("host transport: all-reduce failed"); return CUP3D_ECOMM; }
+    CUP3D_HIP(hipMemcpyAsync(d_buf, h, n * sizeof(double), hipMemcpyHostToDevice, st));
+    CUP3D_HIP(hipStreamSynchronize(st));
+    return CUP3D_OK;
+  }
   Comm *c = comm();
   if (!c) { set_error("multi-rank grid without cup3d_comm_init"); return CUP3D_ESTATE; }
   CUP3D_NCCL(c->AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, is_max ? ncclMax : ncclSum, c->comm, st));
@@ -485,6 +535,20 @@ int cup3d_comm_finalize(void) {
   }
   g_comm_ready = false;
   return CUP3D_OK;
+}
+
+// TEST SUPPORT: see cup3d_hip_testing.h
+int cup3d_debug_host_transport(int rank, int nranks, const cup3d_host_transport *t) {
+#ifndef CUP3D_TESTING
+  (void)rank; (void)nranks;
+  return t ? not_in_release("cup3d_debug_host_transport") : CUP3D_OK;
+#else
+  if (!t) { g_ht_on = false; return CUP3D_OK; }
+  if (nranks < 1 || rank < 0 || rank >= nranks || !t->exchange || !t->allreduce) return CUP3D_EINVAL;
+  g_ht = *t;
+  g_ht_on = nranks > 1;
+  return CUP3D_OK;
+#endif
 }
 
 // TEST SUPPORT: several ranks' sims in one process on one GPU; exchanges become no-ops

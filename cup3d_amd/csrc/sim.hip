@@ -408,7 +408,7 @@ int cup3d_sim_create(const cup3d_grid_t *gh, cup3d_sim_t **out) {
   const Grid *g = reinterpret_cast<const Grid *>(gh);
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess) { set_error("cup3d_sim_create: no HIP device (call cup3d_device_init first)"); return CUP3D_EDEVICE; }
-  if (g->nranks > 1 && !comm() && !virtual_ranks()) { set_error("grid spans %d ranks but cup3d_comm_init was not called", g->nranks); return CUP3D_ESTATE; }
+  if (g->nranks > 1 && !comm() && !virtual_ranks() && !host_transport()) { set_error("grid spans %d ranks but cup3d_comm_init was not called", g->nranks); return CUP3D_ESTATE; }
   Sim *s = new Sim();
   const int rc = sim_build(s, g);
   if (rc != CUP3D_OK) {  // whatever was allocated so far goes back (an out-of-memory at 512^3 must not strand the slabs already made)

@@ -57,6 +57,7 @@ void stats_allreduce();
 struct Comm;  // RCCL state (comm.cpp)
 Comm *comm();  // nullptr when single rank
 bool virtual_ranks();  // test mode (cup3d_debug_virtual_ranks)
+bool host_transport();  // test mode (cup3d_debug_host_transport): exchanges staged through host memory and the caller's transport
 
 // Device-side description of the topology, passed by value to kernels.
 struct GridDev {

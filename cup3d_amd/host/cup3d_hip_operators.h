@@ -22,8 +22,35 @@
 #include <vector>
 
 #include "../../include/cup3d_hip.h"
+#ifdef CUP3D_HIP_SHIM_TEST_TRANSPORT  // test builds only (oracle/Makefile: ref_tool_hip_mpi_testing, linked against libcup3d_hip_testing.so)
+#include "../../include/cup3d_hip_testing.h"
+#endif
 
 namespace cup3d_hip {
+
+#ifdef CUP3D_HIP_SHIM_TEST_TRANSPORT
+// The library's exchanges carried by the host's own MPI through host memory instead of RCCL (cup3d_debug_host_transport): RCCL
+// refuses two ranks on one device, so this is how the multi-rank branch below runs as real MPI processes on a one-GPU box.
+// Selected at run time with CUP3D_HIP_HOST_TRANSPORT=1; a production build of the shim does not contain it.
+struct HostTransport {
+  MPI_Comm comm;
+  static int exchange(void *ctx, const void *sb, const long *so, const long *sn, void *rb, const long *ro, const long *rn) {
+    MPI_Comm c = static_cast<HostTransport *>(ctx)->comm;
+    int size = 1;
+    MPI_Comm_size(c, &size);
+    std::vector<MPI_Request> rq;
+    for (int p = 0; p < size; ++p)
+      if (rn[p]) { rq.emplace_back(); MPI_Irecv((char *)rb + ro[p], (int)rn[p], MPI_BYTE, p, 4711, c, &rq.back()); }
+    for (int p = 0; p < size; ++p)
+      if (sn[p]) { rq.emplace_back(); MPI_Isend((const char *)sb + so[p], (int)sn[p], MPI_BYTE, p, 4711, c, &rq.back()); }
+    return MPI_Waitall((int)rq.size(), rq.data(), MPI_STATUSES_IGNORE) == MPI_SUCCESS ? 0 : 1;
+  }
+  static int allreduce(void *ctx, double *buf, int n, int is_max) {
+    MPI_Comm c = static_cast<HostTransport *>(ctx)->comm;
+    return MPI_Allreduce(MPI_IN_PLACE, buf, n, MPI_DOUBLE, is_max ? MPI_MAX : MPI_SUM, c) == MPI_SUCCESS ? 0 : 1;
+  }
+};
+#endif
 
 inline void die(const char *what, int rc) {
   fprintf(stderr, "cup3d_hip: %s failed (%d): %s\n", what, rc, cup3d_last_error());
@@ -137,6 +164,14 @@ private:
       int ndev = 0;
       CUP3D_HIP_CALL(cup3d_device_count(&ndev));
       CUP3D_HIP_CALL(cup3d_device_init(ndev > 0 ? rank % ndev : 0));  // one process per GPU
+#ifdef CUP3D_HIP_SHIM_TEST_TRANSPORT
+      if (size > 1 && getenv("CUP3D_HIP_HOST_TRANSPORT")) {
+        static HostTransport ht;
+        ht.comm = sim.comm;
+        const cup3d_host_transport t = {&ht, &HostTransport::exchange, &HostTransport::allreduce};
+        CUP3D_HIP_CALL(cup3d_debug_host_transport(rank, size, &t));
+      } else
+#endif
       if (size > 1) {  // bootstrap the library's RCCL communicator over the host MPI
         unsigned char id[128] = {0};
         if (rank == 0) CUP3D_HIP_CALL(cup3d_comm_unique_id(id));

@@ -1,0 +1,96 @@
+"""BASELINE configs[3] and configs[4] END TO END on real MPI ranks: the unmodified reference translation unit (fish geometry,
+CreateObstacles, UpdateObstacles, Penalization with its force all-reduce 13913-13938, adaptMesh with the LoadBalancer 4729-5021,
+ComputeForces) with the two hot-path operators swapped for the HIP ones by the C++ shim (cup3d_amd/host/cup3d_hip_operators.h) --
+every rank a process of its own, the shim's multi-rank branch live: gather the leaves, take the rank's view of the mesh
+(cup3d_grid_rank_view), ghost-block and face-flux exchanges, all-reduced BiCGSTAB scalars, the mirror rebuilt after every adaptation
+and migration the reference performs.
+
+The builder's and the driver's test boxes have ONE GPU and RCCL refuses two ranks on one device, so the bytes travel through the
+library's host-memory test transport (cup3d_debug_host_transport, include/cup3d_hip_testing.h) carried by the reference's own MPI --
+everything but ncclSend / ncclRecv / ncclAllReduce themselves is the production path.  Compared with the SAME harness running the
+reference's CPU operators on the same number of ranks: per-rank block lists (level, Z, ownership) identical after 12 and 30 steps,
+chi / velocity / pressure to solver round-off (Poisson tolerance 1e-9 / 1e-8 on both sides).
+
+  configs[3]: single StefanFish, chi-penalisation, 3 levels (levelMax 4, levels 1-3, ~320 blocks), 2 ranks
+  configs[4]: two-fish school (the factory of the reference's run.sh), 4 levels (levelMax 5, levels 1-4, ~820 blocks = a 256^3-
+              effective mesh; 1024^3-effective is levelMax 7 and minutes of CPU reference per step), 8 ranks
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+REF_MPI = O.REF_TOOL_MPI
+REF_HIP_MPI = os.path.join(O.ORACLE_DIR, "_ref", "ref_tool_hip_mpi_testing")
+ENV = dict(os.environ, OMP_NUM_THREADS="1", LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:/opt/conda/lib:" + os.environ.get("LD_LIBRARY_PATH", ""),
+           HSA_ENABLE_IPC_MODE_LEGACY="0")
+COMMON = ["-bMeanConstraint", "2", "-bpdx", "2", "-bpdy", "2", "-bpdz", "2", "-CFL", "0.4", "-Ctol", "0.1", "-extentx", "1", "-levelStart", "1", "-nu", "0.001",
+          "-poissonSolver", "iterative", "-Rtol", "5", "-tdump", "0", "-tend", "0", "-factory", "", "-poissonTol", "1e-9", "-poissonTolRel", "1e-8"]
+ONE_FISH = "StefanFish L=0.4 T=1.0 xpos=0.5 ypos=0.5 zpos=0.5 heightProfile=danio widthProfile=stefan bFixFrameOfRef=1"
+TWO_FISH = ("StefanFish L=0.4 T=1.0 xpos=0.25 ypos=0.5 zpos=0.5 planarAngle=180 heightProfile=danio widthProfile=stefan bFixFrameOfRef=1\n"
+            "StefanFish L=0.4 T=1.0 xpos=0.7 ypos=0.5 zpos=0.5 heightProfile=danio widthProfile=stefan")
+SCRIPT = ["op steps 12", "tables t12.bin", "op steps 18", "tables t30.bin", "dump vel v.bin", "dump pres p.bin", "dump chi c.bin"]
+
+_launcher = None
+
+
+def launcher():
+    """mpiexec with whatever this box needs to start local ranks (the container hostname may not resolve)."""
+    global _launcher
+    if _launcher is None:
+        for extra in ([], ["-hosts", "127.0.0.1"], ["-launcher", "fork", "-hosts", "127.0.0.1"], ["-iface", "lo"]):
+            try:
+                if subprocess.run([O.MPIEXEC] + extra + ["-n", "2", "/bin/true"], env=ENV, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60).returncode == 0:
+                    _launcher = [O.MPIEXEC] + extra
+                    break
+            except Exception:
+                pass
+        else:
+            _launcher = []
+    return _launcher
+
+
+def run(tool, nranks, pre, args, wd, extra_env=None):
+    os.makedirs(wd, exist_ok=True)
+    with open(os.path.join(wd, "script.txt"), "w") as f:
+        f.write("\n".join(pre + SCRIPT) + "\n")
+    out = subprocess.run(launcher() + ["-n", str(nranks), tool, "script.txt", "--"] + args, cwd=wd, env=dict(ENV, **(extra_env or {})),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert out.returncode == 0, (out.stdout.decode()[-1500:], out.stderr.decode()[-3000:])
+    res = []
+    for r in range(nranks):
+        t12, t30 = O.read_tables(os.path.join(wd, f"t12.bin.r{r}"))[0], O.read_tables(os.path.join(wd, f"t30.bin.r{r}"))[0]
+        nb = len(t30)
+        res.append((t12, t30, O.read_blocks(os.path.join(wd, f"v.bin.r{r}"), nb, 3), O.read_blocks(os.path.join(wd, f"p.bin.r{r}"), nb, 1),
+                    O.read_blocks(os.path.join(wd, f"c.bin.r{r}"), nb, 1)))
+    return res
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("name,nranks,level_max,fish,min_levels", [("configs3_one_fish_3_levels_2_ranks", 2, 4, ONE_FISH, 3),
+                                                                   ("configs4_two_fish_4_levels_8_ranks", 8, 5, TWO_FISH, 4)])
+def test_fish_with_amr_over_mpi_ranks_through_the_shim(tmp_path, name, nranks, level_max, fish, min_levels):
+    if not (os.path.exists(REF_MPI) and os.path.exists(REF_HIP_MPI) and os.path.exists(O.MPIEXEC)):
+        pytest.skip("needs oracle/_ref/ref_tool_mpi, ref_tool_hip_mpi_testing (built where /root/reference exists) and an mpiexec")
+    if not launcher():
+        pytest.skip("mpiexec cannot start local ranks on this box")
+    args = COMMON + ["-levelMax", str(level_max), "-factory-content", fish]
+    cpu = run(REF_MPI, nranks, [], args, str(tmp_path / "cpu"))
+    hip = run(REF_HIP_MPI, nranks, ["hip on"], args, str(tmp_path / "hip"), {"CUP3D_HIP_HOST_TRANSPORT": "1"})
+    levels, nblocks, vmax, pmax, wet = set(), 0, 0.0, 0.0, 0
+    for c in cpu:
+        levels |= set(c[1][:, 0].tolist())
+        nblocks += len(c[1])
+        vmax, pmax, wet = max(vmax, np.abs(c[2]).max()), max(pmax, np.abs(c[3]).max()), wet + int((c[4] > 0).sum())
+    assert len(levels) >= min_levels and nblocks > 100 * nranks // 2      # the mesh the config names, spread over the ranks
+    assert wet > 100 and vmax > 1e-3                                      # there IS a fish, and it moves the fluid
+    for r, (c, h) in enumerate(zip(cpu, hip)):
+        assert np.array_equal(c[0], h[0]) and np.array_equal(c[1], h[1]), f"rank {r}: block lists differ"   # incl. who owns what
+        assert np.abs(c[4] - h[4]).max() <= 1e-6, f"rank {r}: chi"
+        assert np.abs(c[2] - h[2]).max() <= 1e-6 * vmax, f"rank {r}: velocity {np.abs(c[2] - h[2]).max()} vs {vmax}"
+        assert np.abs(c[3] - h[3]).max() <= 1e-4 * pmax, f"rank {r}: pressure {np.abs(c[3] - h[3]).max()} vs {pmax}"
+    print(f"{name}: {nblocks} blocks on levels {sorted(levels)}, {nranks} ranks: block lists identical, fields to solver round-off")
