@@ -9,7 +9,11 @@ The builder's and the driver's test boxes have ONE GPU and RCCL refuses two rank
 library's host-memory test transport (cup3d_debug_host_transport, include/cup3d_hip_testing.h) carried by the reference's own MPI --
 everything but ncclSend / ncclRecv / ncclAllReduce themselves is the production path.  Compared with the SAME harness running the
 reference's CPU operators on the same number of ranks: per-rank block lists (level, Z, ownership) identical after 12 and 30 steps,
-chi / velocity / pressure to solver round-off (Poisson tolerance 1e-9 / 1e-8 on both sides).
+chi / velocity / pressure to solver round-off (Poisson tolerance 1e-9 / 1e-8 on both sides).  "Solver round-off" is MEASURED, not
+assumed: on these three- and four-level meshes the reference's BiCGSTAB stagnates above its tolerance, and the reference run with 2
+OpenMP threads per rank differs from the reference run with 1 (nothing but the order of its reductions changes) by 7e-4 of the
+velocity and 1e-2 of the pressure within 8 steps (scripts/diag_fish_mpi.py; at levelMax 3 both differences are 1e-7).  The device
+must stay within 5x the reference's own spread (or 1e-6 / 1e-4 relative where the reference agrees with itself better than that).
 
   configs[3]: single StefanFish, chi-penalisation, 3 levels (levelMax 4, levels 1-3, ~320 blocks), 2 ranks
   configs[4]: two-fish school (the factory of the reference's run.sh), 4 levels (levelMax 5, levels 1-4, ~820 blocks = a 256^3-
@@ -55,7 +59,7 @@ def launcher():
 
 
 def run(tool, nranks, pre, args, wd, extra_env=None):
-    os.makedirs(wd, exist_ok=True)
+    os.makedirs(wd)
     with open(os.path.join(wd, "script.txt"), "w") as f:
         f.write("\n".join(pre + SCRIPT) + "\n")
     out = subprocess.run(launcher() + ["-n", str(nranks), tool, "script.txt", "--"] + args, cwd=wd, env=dict(ENV, **(extra_env or {})),
@@ -80,6 +84,7 @@ def test_fish_with_amr_over_mpi_ranks_through_the_shim(tmp_path, name, nranks, l
         pytest.skip("mpiexec cannot start local ranks on this box")
     args = COMMON + ["-levelMax", str(level_max), "-factory-content", fish]
     cpu = run(REF_MPI, nranks, [], args, str(tmp_path / "cpu"))
+    cpu2 = run(REF_MPI, nranks, [], args, str(tmp_path / "cpu2"), {"OMP_NUM_THREADS": "2"})   # the reference against itself
     hip = run(REF_HIP_MPI, nranks, ["hip on"], args, str(tmp_path / "hip"), {"CUP3D_HIP_HOST_TRANSPORT": "1"})
     levels, nblocks, vmax, pmax, wet = set(), 0, 0.0, 0.0, 0
     for c in cpu:
@@ -88,9 +93,16 @@ def test_fish_with_amr_over_mpi_ranks_through_the_shim(tmp_path, name, nranks, l
         vmax, pmax, wet = max(vmax, np.abs(c[2]).max()), max(pmax, np.abs(c[3]).max()), wet + int((c[4] > 0).sum())
     assert len(levels) >= min_levels and nblocks > 100 * nranks // 2      # the mesh the config names, spread over the ranks
     assert wet > 100 and vmax > 1e-3                                      # there IS a fish, and it moves the fluid
+    same_mesh = all(np.array_equal(a[1], b[1]) for a, b in zip(cpu, cpu2))
+    noise_v = max(np.abs(a[2] - b[2]).max() for a, b in zip(cpu, cpu2)) if same_mesh else 0.0
+    noise_p = max(np.abs(a[3] - b[3]).max() for a, b in zip(cpu, cpu2)) if same_mesh else 0.0
+    tol_v, tol_p = 5 * max(noise_v, 1e-6 * vmax), 5 * max(noise_p, 1e-4 * pmax)
+    dv = dp = 0.0
     for r, (c, h) in enumerate(zip(cpu, hip)):
         assert np.array_equal(c[0], h[0]) and np.array_equal(c[1], h[1]), f"rank {r}: block lists differ"   # incl. who owns what
         assert np.abs(c[4] - h[4]).max() <= 1e-6, f"rank {r}: chi"
-        assert np.abs(c[2] - h[2]).max() <= 1e-6 * vmax, f"rank {r}: velocity {np.abs(c[2] - h[2]).max()} vs {vmax}"
-        assert np.abs(c[3] - h[3]).max() <= 1e-4 * pmax, f"rank {r}: pressure {np.abs(c[3] - h[3]).max()} vs {pmax}"
-    print(f"{name}: {nblocks} blocks on levels {sorted(levels)}, {nranks} ranks: block lists identical, fields to solver round-off")
+        dv, dp = max(dv, np.abs(c[2] - h[2]).max()), max(dp, np.abs(c[3] - h[3]).max())
+    print(f"{name}: {nblocks} blocks on levels {sorted(levels)}, {nranks} ranks: block lists identical; max|dv| = {dv:.2e} (reference vs itself "
+          f"{noise_v:.2e}, |v| = {vmax:.2e}), max|dp| = {dp:.2e} (reference vs itself {noise_p:.2e}, |p| = {pmax:.2e})")
+    assert dv <= tol_v, (dv, tol_v)
+    assert dp <= tol_p, (dp, tol_p)
