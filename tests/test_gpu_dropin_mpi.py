@@ -10,10 +10,11 @@ library's host-memory test transport (cup3d_debug_host_transport, include/cup3d_
 everything but ncclSend / ncclRecv / ncclAllReduce themselves is the production path.  Compared with the SAME harness running the
 reference's CPU operators on the same number of ranks: per-rank block lists (level, Z, ownership) identical after 12 and 30 steps,
 chi / velocity / pressure to solver round-off (Poisson tolerance 1e-9 / 1e-8 on both sides).  "Solver round-off" is MEASURED, not
-assumed: on these three- and four-level meshes the reference's BiCGSTAB stagnates above its tolerance, and the reference run with 2
-OpenMP threads per rank differs from the reference run with 1 (nothing but the order of its reductions changes) by 7e-4 of the
-velocity and 1e-2 of the pressure within 8 steps (scripts/diag_fish_mpi.py; at levelMax 3 both differences are 1e-7).  The device
-must stay within 5x the reference's own spread (or 1e-6 / 1e-4 relative where the reference agrees with itself better than that).
+assumed: on these three- and four-level meshes the reference's BiCGSTAB stagnates above its tolerance, and the reference differs from
+ITSELF when nothing but the order of its reductions changes -- 1 or 3 OpenMP threads on one rank: 7e-4 of the velocity and 1e-2 of
+the pressure within 8 steps (scripts/diag_fish_mpi.py; at levelMax 3 both are 1e-7).  Here the reference on ONE rank is the second
+opinion (with more than one thread per MPI rank this build of the reference crashes): the device on N ranks must stay within 5x the
+spread between the reference on N ranks and the reference on one (or 1e-6 / 1e-4 relative where that spread is smaller).
 
   configs[3]: single StefanFish, chi-penalisation, 3 levels (levelMax 4, levels 1-3, ~320 blocks), 2 ranks
   configs[4]: two-fish school (the factory of the reference's run.sh), 4 levels (levelMax 5, levels 1-4, ~820 blocks = a 256^3-
@@ -62,15 +63,16 @@ def run(tool, nranks, pre, args, wd, extra_env=None):
     os.makedirs(wd)
     with open(os.path.join(wd, "script.txt"), "w") as f:
         f.write("\n".join(pre + SCRIPT) + "\n")
-    out = subprocess.run(launcher() + ["-n", str(nranks), tool, "script.txt", "--"] + args, cwd=wd, env=dict(ENV, **(extra_env or {})),
+    out = subprocess.run((launcher() + ["-n", str(nranks)] if nranks > 1 else []) + [tool, "script.txt", "--"] + args, cwd=wd, env=dict(ENV, **(extra_env or {})),
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert out.returncode == 0, (out.stdout.decode()[-1500:], out.stderr.decode()[-3000:])
     res = []
     for r in range(nranks):
-        t12, t30 = O.read_tables(os.path.join(wd, f"t12.bin.r{r}"))[0], O.read_tables(os.path.join(wd, f"t30.bin.r{r}"))[0]
+        suf = f".r{r}" if nranks > 1 else ""
+        t12, t30 = O.read_tables(os.path.join(wd, "t12.bin" + suf))[0], O.read_tables(os.path.join(wd, "t30.bin" + suf))[0]
         nb = len(t30)
-        res.append((t12, t30, O.read_blocks(os.path.join(wd, f"v.bin.r{r}"), nb, 3), O.read_blocks(os.path.join(wd, f"p.bin.r{r}"), nb, 1),
-                    O.read_blocks(os.path.join(wd, f"c.bin.r{r}"), nb, 1)))
+        res.append((t12, t30, O.read_blocks(os.path.join(wd, "v.bin" + suf), nb, 3), O.read_blocks(os.path.join(wd, "p.bin" + suf), nb, 1),
+                    O.read_blocks(os.path.join(wd, "c.bin" + suf), nb, 1)))
     return res
 
 
@@ -84,7 +86,7 @@ def test_fish_with_amr_over_mpi_ranks_through_the_shim(tmp_path, name, nranks, l
         pytest.skip("mpiexec cannot start local ranks on this box")
     args = COMMON + ["-levelMax", str(level_max), "-factory-content", fish]
     cpu = run(REF_MPI, nranks, [], args, str(tmp_path / "cpu"))
-    cpu2 = run(REF_MPI, nranks, [], args, str(tmp_path / "cpu2"), {"OMP_NUM_THREADS": "2"})   # the reference against itself
+    one = run(O.REF_TOOL, 1, [], args, str(tmp_path / "one"), {"OMP_NUM_THREADS": "4"})   # the reference against itself: one rank, four threads
     hip = run(REF_HIP_MPI, nranks, ["hip on"], args, str(tmp_path / "hip"), {"CUP3D_HIP_HOST_TRANSPORT": "1"})
     levels, nblocks, vmax, pmax, wet = set(), 0, 0.0, 0.0, 0
     for c in cpu:
@@ -93,9 +95,16 @@ def test_fish_with_amr_over_mpi_ranks_through_the_shim(tmp_path, name, nranks, l
         vmax, pmax, wet = max(vmax, np.abs(c[2]).max()), max(pmax, np.abs(c[3]).max()), wet + int((c[4] > 0).sum())
     assert len(levels) >= min_levels and nblocks > 100 * nranks // 2      # the mesh the config names, spread over the ranks
     assert wet > 100 and vmax > 1e-3                                      # there IS a fish, and it moves the fluid
-    same_mesh = all(np.array_equal(a[1], b[1]) for a, b in zip(cpu, cpu2))
-    noise_v = max(np.abs(a[2] - b[2]).max() for a, b in zip(cpu, cpu2)) if same_mesh else 0.0
-    noise_p = max(np.abs(a[3] - b[3]).max() for a, b in zip(cpu, cpu2)) if same_mesh else 0.0
+    # the one-rank run holds the same leaves (the mesh does not depend on the number of ranks): match blocks by (level, Z)
+    where = {(int(l), int(z)): i for i, (l, z) in enumerate(one[0][1][:, :2])}
+    noise_v = noise_p = 0.0
+    for c in cpu:
+        idx = [where.get((int(l), int(z)), -1) for l, z in c[1][:, :2]]
+        if min(idx) < 0:            # the two reference runs adapted differently: no second opinion on the fields
+            noise_v = noise_p = 0.0
+            break
+        noise_v = max(noise_v, np.abs(c[2] - one[0][2][idx]).max())
+        noise_p = max(noise_p, np.abs(c[3] - one[0][3][idx]).max())
     tol_v, tol_p = 5 * max(noise_v, 1e-6 * vmax), 5 * max(noise_p, 1e-4 * pmax)
     dv = dp = 0.0
     for r, (c, h) in enumerate(zip(cpu, hip)):
