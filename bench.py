@@ -155,12 +155,15 @@ def cpu_baseline(size_cpu, steps, threads):
     if O.have_ref_tool():
         args = O.ref_args((1, 1, 1), level + 1, level, 2 * np.pi, ("wall",) * 3, nu=0.01, cfl=0.3, extra=["-rampup", "0"])
         try:
-            recs, _ = O.run_ref(["zero chi", "set step 21", "rep 1", f"op steps {steps}"], args, threads=threads, timeout=400)
-            sec = [r for r in recs if r["op"] == "steps"][0]["seconds"]
-            its = [r for r in recs if r["op"] == "steps"][0]["iters"]
-            return {"value": size_cpu ** 3 * steps / sec / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "reference",
-                    "sample": f"reference main.cpp operators, {size_cpu}^3 all-wall TGV, {steps} steps from step 21, "
-                              f"{sec:.2f} s, {its / steps:.1f} BiCGSTAB its/step", "bicgstab_iters_per_step": its / steps, "size": size_cpu}
+            # `steps` separate steps of the reference's own time loop, each timed by the harness: the MEDIAN step is the sample
+            recs, _ = O.run_ref(["zero chi", "set step 21", f"rep {steps}", "op steps 1"], args, threads=threads, timeout=600)
+            rs = [r for r in recs if r["op"] == "steps"]
+            secs, its = sorted(r["seconds"] for r in rs), [r["iters"] for r in rs]
+            sec = secs[len(secs) // 2]
+            return {"value": size_cpu ** 3 / sec / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "reference",
+                    "sample": f"reference main.cpp operators, {size_cpu}^3 all-wall TGV, median of {len(rs)} steps from step 21 "
+                              f"({', '.join('%.2f' % x for x in secs)} s), {np.mean(its):.1f} BiCGSTAB its/step",
+                    "seconds_per_step": [round(x, 3) for x in secs], "bicgstab_iters_per_step": float(np.mean(its)), "size": size_cpu}
         except Exception as e:  # fall through to the port
             sys.stderr.write(f"bench: ref_tool failed ({e}); timing the oracle port instead\n")
     g = O.OracleGrid((1, 1, 1), level + 1, level, 2 * np.pi, ("wall",) * 3)
@@ -271,7 +274,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=512, help="cells per side (a multiple of 8; 512 = the BASELINE workload, 768 = the largest that leaves room on one 288 GB GPU)")
     ap.add_argument("--cpu-size", type=int, default=256, help="cells per side of the CPU-baseline sample (512 needs ~35 GB and minutes per step)")
-    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=3, help="steps of the CPU-baseline sample; the median step is reported")
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="OpenMP threads of the reference; 32 is its best on the 256-thread GPU host (see report()); 0: all host cores")
     ap.add_argument("--no-cpu", action="store_true")
@@ -474,13 +477,28 @@ def main():
 
 
 def ref_iters(a):
-    """BiCGSTAB iterations per step of the REFERENCE on this very workload, from the recorded campaign run
-    (scripts/campaigns/baseline_sizes_vs_reference.py -> profiles/r02/reference_step_<size>.json); None if never recorded."""
+    """BiCGSTAB iterations per step of the REFERENCE on this very workload, from recorded runs of the compiled reference:
+    profiles/r03/reference_window_<size>.json = per-step counts over steps 21.. of the bench's own time loop (the window bench.py
+    times with --warmup W --steps K is steps 21+W .. 21+W+K-1), else the one-step record of round 2; None if never recorded."""
+    if a.stencil_only or a.implicit_diffusion:
+        return None
+    f = os.path.join(ROOT, "profiles", "r03", f"reference_window_{a.size}.json")
+    if os.path.exists(f):
+        rec = json.load(open(f))
+        by_step = {s["step"]: s["iters"] for s in rec["steps"]}
+        win = [by_step[n] for n in range(21 + a.warmup, 21 + a.warmup + a.steps) if n in by_step]
+        out = {"value": round(float(np.mean(win)), 2) if win else None, "steps_covered": len(win), "of": a.steps,
+               "window": f"steps {21 + a.warmup}..{21 + a.warmup + a.steps - 1} (the timed region of this run)",
+               "by_step": win, "reference_threads": rec.get("threads"),
+               "source": f"profiles/r03/reference_window_{a.size}.json (compiled reference, {len(rec['steps'])} steps from step 21; its OpenMP "
+                         "reductions make the count vary from run to run by ~10-20 %)"}
+        return out
     f = os.path.join(ROOT, "profiles", "r02", f"reference_step_{a.size}.json")
-    if a.stencil_only or a.implicit_diffusion or not os.path.exists(f):
+    if not os.path.exists(f):
         return None
     rec = json.load(open(f))
     out = {"value": rec["ref_iters_per_step"], "device_in_the_same_run": rec["device_iters_per_step"], "steps": len(rec["steps"]),
+           "window": "step 21 only -- NOT the window this run times",
            "source": f"profiles/r02/reference_step_{a.size}.json (compiled reference, one step from step 21)"}
     f1 = os.path.join(ROOT, "profiles", "r02", f"reference_step_{a.size}_first_run.json")
     if os.path.exists(f1):  # the reference's count is not reproducible (OpenMP reduction order): an earlier run of the same campaign
@@ -563,6 +581,10 @@ def report(a, sim, prof, sec, iters, world, alt=None):
         threads = min(a.cpu_threads or (os.cpu_count() or 1), os.cpu_count() or 1)
         out["cpu_baseline"] = cpu_baseline(a.cpu_size, a.cpu_steps, threads)
         out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        # the all-core figure SURVEY 8d asks for, quoted from the recorded scan (one step takes 5.6 minutes there: not re-run here)
+        out["cpu_baseline"]["all_cores_recorded"] = {"value": round(256 ** 3 / 338.49 / 1e6, 4), "unit": "Mcell-updates/s", "cores": 256, "size": 256,
+                                                     "also": {"64 threads": round(256 ** 3 / 30.31 / 1e6, 3), "32 threads": round(256 ** 3 / 18.17 / 1e6, 3)},
+                                                     "source": "profiles/r02/probe_reference_threads_256cubed.txt (one 256^3 step each; the reference anti-scales beyond 32 threads)"}
         if a.cpu_size != 128:
             out["cpu_baseline_128"] = cpu_baseline(128, 10, min(32, os.cpu_count() or 1))
     ck = getattr(a, "checksum", None)
