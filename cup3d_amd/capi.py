@@ -106,6 +106,7 @@ SIGNATURES = {
     "cup3d_sim_fill": (C.c_int, [_vp, C.c_int, C.c_double]),
     "cup3d_sim_device_ptr": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "cup3d_sim_mark_written": (C.c_int, [_vp, C.c_int]),
+    "cup3d_sim_set_obstacles": (C.c_int, [_vp, C.c_int]),
     "cup3d_sim_checksum": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_ulonglong)]),
     "cup3d_stats_reset": (C.c_int, []),
     "cup3d_stats_read": (C.c_int, [C.POINTER(RunStats)]),

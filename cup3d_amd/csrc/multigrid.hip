@@ -4,8 +4,9 @@
 // smoother / restrict / prolong ... red-black Gauss-Seidel smoother"; this file is that wording taken literally, behind the same
 // BiCGSTAB driver, the same operator A = h (sum6 - 6 p) (KernelLHSPoisson, 9205-9215), the same mean constraint and the same
 // stopping rule -- so the CONVERGED pressure is the reference's to solver tolerance (tests), while the iteration count drops
-// from O(150) to O(10) at 512^3.  bench.py reports it under `alt_multigrid`, never as `value`.  Uniform grids; over several ranks each
-// rank cycles on its own blocks (additive Schwarz, see mg_setup).
+// from O(150) to O(10) at 512^3.  bench.py reports it under `alt_multigrid`, never as `value`.  Uniform grids (over several ranks the
+// levels exchange face slabs before every launch, see mg_setup) and multi-level meshes on one rank (mg_setup_amr: the octree's own
+// levels are the hierarchy; restriction / prolongation across the refinement levels, AverageDown / TestInterp's place, main.cpp:3877-3906).
 //
 // One application M^-1 r = one V(2,2)-cycle from a zero guess on the hierarchy of uniform block grids, level L (the solver's grid)
 // down to level 0 (the bpd[0] x bpd[1] x bpd[2] box of 8^3 blocks):
@@ -33,20 +34,28 @@ struct MGLevel {
   int32_t *d_nbr = nullptr;     // [nb][6]
   int32_t *d_parent = nullptr;  // [nb][2]: slot of the parent block on the next coarser level, octant (x + 2y + 4z)
   double *x = nullptr, *x2 = nullptr, *b = nullptr;  // coarse levels; the finest level uses the caller's vectors + x2
+  bool own_nbr = false;
+  // multi-level meshes (mg_setup_amr): the nodes of octree level l = its leaves + the ancestors of finer leaves
+  int32_t *d_leaf = nullptr;    // [nb] slot of the leaf in the solver's mesh, -1 for an ancestor
+  int32_t *d_cf = nullptr;      // [ncf][4] faces without a same-level neighbour: coarse node slot (level l-1), direction, side, tangential parities
+  int64_t ncf = 0;
+  double *slabs = nullptr;      // [ncf][64] ghost values behind those faces, injected from the coarse iterate
+  Sim *xch = nullptr;           // several ranks: what halo_exchange() needs for this level's iterate (the solver's Sim on the finest level)
+  bool own_xch = false;
 };
 struct Multigrid {
   std::vector<MGLevel> lev;  // [0] coarsest ... [L] finest
   double *zeros = nullptr;   // ghost values behind faces owned by other ranks (see mg_setup); the x pointer itself on one rank
   bool local = false;        // a rank-local hierarchy (several ranks)
+  bool amr = false;          // hierarchy of a multi-level mesh (mg_setup_amr)
   ~Multigrid() {
     if (zeros) hipFree(zeros);
     for (size_t i = 0; i < lev.size(); ++i) {
       MGLevel &l = lev[i];
-      if (l.grid && l.d_nbr) hipFree(l.d_nbr);
-      if (l.d_parent) hipFree(l.d_parent);
-      if (l.x) hipFree(l.x);
-      if (l.x2) hipFree(l.x2);
-      if (l.b) hipFree(l.b);
+      if ((l.grid || l.own_nbr) && l.d_nbr) hipFree(l.d_nbr);
+      if (l.own_xch) sim_comm_only_destroy(l.xch);
+      void *p[] = {l.d_parent, l.x, l.x2, l.b, l.d_leaf, l.d_cf, l.slabs};
+      for (void *q : p) if (q) hipFree(q);
     }
   }
 };
@@ -140,6 +149,28 @@ __global__ void __launch_bounds__(256) k_mg_remove_mean(double *__restrict__ b, 
   for (long i = threadIdx.x; i < n; i += 256) b[i] -= m;
 }
 
+// ---- multi-level meshes
+// b of the level's leaf nodes <- the solver's vector; the solver's vector <- x of the leaf nodes
+__global__ void __launch_bounds__(256) k_mg_gather(const int32_t *__restrict__ leaf, const double *__restrict__ in, double *__restrict__ b) {
+  const int ls = leaf[blockIdx.x];
+  if (ls < 0) return;
+  for (int i = threadIdx.x; i < 512; i += 256) b[(size_t)blockIdx.x * 512 + i] = in[(size_t)ls * 512 + i];
+}
+__global__ void __launch_bounds__(256) k_mg_scatter(const int32_t *__restrict__ leaf, const double *__restrict__ x, double *__restrict__ out) {
+  const int ls = leaf[blockIdx.x];
+  if (ls < 0) return;
+  for (int i = threadIdx.x; i < 512; i += 256) out[(size_t)ls * 512 + i] = x[(size_t)blockIdx.x * 512 + i];
+}
+// ghost slab behind a face whose neighbour exists one level coarser only: every fine ghost cell takes the value of the coarse cell
+// that contains it (piecewise-constant, like the prolongation).  Slab element order = face1() of tile7.hpp.
+__global__ void __launch_bounds__(64) k_mg_cf_ghosts(const int32_t *__restrict__ cf, const double *__restrict__ xc, double *__restrict__ slabs) {
+  const int e = blockIdx.x, lane = threadIdx.x, a1 = lane & 7, a2 = lane >> 3;
+  const int cs = cf[4 * e], d = cf[4 * e + 1], side = cf[4 * e + 2], par = cf[4 * e + 3];
+  const int t1 = 4 * (par & 1) + (a1 >> 1), t2 = 4 * (par >> 1) + (a2 >> 1), q = side ? 0 : 7;  // behind the minus face lies the coarse block's last layer
+  const int cell = d == 2 ? q * 64 + t2 * 8 + t1 : (d == 1 ? t2 * 64 + q * 8 + t1 : t2 * 64 + t1 * 8 + q);
+  slabs[(size_t)e * 64 + lane] = xc[(size_t)cs * 512 + cell];
+}
+
 static GridDev level_gdev(const MGLevel &L) {
   GridDev g;
   g.nbr = L.d_nbr;
@@ -153,18 +184,115 @@ static GridDev level_gdev(const MGLevel &L) {
   return g;
 }
 
+// Multi-level meshes (one rank).  The hierarchy is the octree itself: level l holds the leaves of level l AND the ancestors (at level l)
+// of every finer leaf, so a coarse level is a complete mesh of the region its blocks cover and the fine levels sit on top of parts
+// of it.  One V-cycle from a zero guess:
+//   down, l = lmax .. 1:  b_l = r on the leaves of level l (on ancestors: the summed residual of their children, from the step before);
+//                         smooth A_l x_l = b_l on all nodes of the level, ghosts behind faces whose neighbour exists only one level
+//                         coarser = 0 (the coarse iterate is still zero); restrict the residual into the parents;
+//   level 0:              mean removed, many sweeps;
+//   up, l = 1 .. lmax:    x_l += the parent's value (piecewise constant); ghosts behind coarse/fine faces = the coarse neighbour's
+//                         cell values (k_mg_cf_ghosts); smooth;
+//   z = x_l on the leaves.
+// A fixed linear operator (the smoother is block-Jacobi with frozen ghosts, as on uniform grids).  It ignores the reference's
+// coarse/fine flux matching and its quadratic ghost interpolation (those are in A, which BiCGSTAB applies exactly): as a
+// preconditioner it only has to be close.
+static int mg_setup_amr(Sim *s) {
+  const Grid *g = s->grid;
+  if (g->nranks > 1 || g->n_local >= 0) { set_error("the multigrid preconditioner on a multi-level mesh runs on one rank"); return CUP3D_EINVAL; }
+  std::unique_ptr<Multigrid> mg(new Multigrid());
+  mg->amr = true;
+  const int64_t nb = g->nblocks();
+  int lmax = 0;
+  for (int64_t b = 0; b < nb; ++b) lmax = std::max(lmax, (int)g->blevel[(size_t)b]);
+  const int nlev = lmax + 1;
+  mg->lev.resize(nlev);
+  struct Node { int c[3]; int32_t leaf; };
+  std::vector<std::vector<Node>> nodes(nlev);
+  std::vector<std::vector<int32_t>> map(nlev);
+  auto dim = [&](int l, int d) { return g->bpd[d] << l; };
+  auto at = [&](int l, const int c[3]) -> int32_t & { return map[l][((size_t)c[2] * dim(l, 1) + c[1]) * dim(l, 0) + c[0]]; };
+  for (int l = 0; l < nlev; ++l) map[l].assign((size_t)dim(l, 0) * dim(l, 1) * dim(l, 2), -1);
+  for (int64_t b = 0; b < nb; ++b) {
+    const int l = g->blevel[(size_t)b];
+    Node n{{g->index[3 * b], g->index[3 * b + 1], g->index[3 * b + 2]}, (int32_t)b};
+    at(l, n.c) = (int32_t)nodes[l].size();
+    nodes[l].push_back(n);
+  }
+  for (int l = lmax; l >= 1; --l)  // ancestors: nodes[l] is complete when level l is visited
+    for (size_t i = 0; i < nodes[l].size(); ++i) {
+      const int pc[3] = {nodes[l][i].c[0] >> 1, nodes[l][i].c[1] >> 1, nodes[l][i].c[2] >> 1};
+      if (at(l - 1, pc) < 0) {
+        at(l - 1, pc) = (int32_t)nodes[l - 1].size();
+        nodes[l - 1].push_back(Node{{pc[0], pc[1], pc[2]}, -1});
+      }
+    }
+  auto up = [&](int32_t **d, const std::vector<int32_t> &v) -> int {
+    CUP3D_HIP(hipMalloc((void **)d, std::max<size_t>(v.size(), 1) * sizeof(int32_t)));
+    if (!v.empty()) CUP3D_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return CUP3D_OK;
+  };
+  int rc;
+  for (int l = 0; l < nlev; ++l) {
+    MGLevel &M = mg->lev[l];
+    const size_t n = nodes[l].size();
+    M.nb = (int64_t)n;
+    M.h = g->maxextent / (8.0 * std::max(std::max(dim(l, 0), dim(l, 1)), dim(l, 2)));  // Info::h of level l (h_gridpoint, main.cpp:15405-15415)
+    std::vector<int32_t> nbr(6 * n), par(2 * n, 0), leaf(n), cf;
+    for (size_t i = 0; i < n; ++i) {
+      const Node &nd = nodes[l][i];
+      leaf[i] = nd.leaf;
+      if (l > 0) {
+        const int pc[3] = {nd.c[0] >> 1, nd.c[1] >> 1, nd.c[2] >> 1};
+        par[2 * i] = at(l - 1, pc);
+        par[2 * i + 1] = (nd.c[0] & 1) + 2 * (nd.c[1] & 1) + 4 * (nd.c[2] & 1);
+      }
+      for (int f = 0; f < 6; ++f) {
+        const int d = f >> 1, side = f & 1;
+        int c[3] = {nd.c[0], nd.c[1], nd.c[2]};
+        c[d] += side ? 1 : -1;
+        if (c[d] < 0 || c[d] >= dim(l, d)) {
+          if (g->bc[d] != 1) { nbr[6 * i + f] = -1; continue; }  // zero-gradient pressure tile behind every non-periodic domain face
+          c[d] = (c[d] + dim(l, d)) % dim(l, d);
+        }
+        const int32_t m = at(l, c);
+        if (m >= 0) { nbr[6 * i + f] = m; continue; }
+        const int cc[3] = {c[0] >> 1, c[1] >> 1, c[2] >> 1};
+        const int32_t cs = l > 0 ? at(l - 1, cc) : -1;
+        if (cs < 0) { set_error("multigrid: mesh is not 2:1 balanced at level %d", l); return CUP3D_EINVAL; }
+        const int t1 = d == 0 ? 1 : 0, t2 = d == 2 ? 1 : 2;  // the slab's (a1, a2) directions, face1()
+        nbr[6 * i + f] = kNbrHalo + (int32_t)(cf.size() / 4);
+        cf.push_back(cs); cf.push_back(d); cf.push_back(side); cf.push_back((nd.c[t1] & 1) | ((nd.c[t2] & 1) << 1));
+      }
+    }
+    M.own_nbr = true;
+    M.ncf = (int64_t)cf.size() / 4;
+    if ((rc = up(&M.d_nbr, nbr)) || (rc = up(&M.d_parent, par)) || (rc = up(&M.d_leaf, leaf)) || (rc = up(&M.d_cf, cf))) return rc;
+    const size_t bytes = n * 512 * sizeof(double), sb = (size_t)std::max<int64_t>(M.ncf, 1) * 64 * sizeof(double);
+    CUP3D_HIP(hipMalloc((void **)&M.x, bytes));
+    CUP3D_HIP(hipMalloc((void **)&M.x2, bytes));
+    CUP3D_HIP(hipMalloc((void **)&M.b, bytes));
+    CUP3D_HIP(hipMalloc((void **)&M.slabs, sb));
+    CUP3D_HIP(hipMemset(M.slabs, 0, sb));
+    s->bytes += 3 * bytes + sb;
+  }
+  s->mg = mg.release();
+  return CUP3D_OK;
+}
+
 static int mg_setup(Sim *s) {
   if (s->mg) return CUP3D_OK;
   const Grid *g = s->grid;
-  if (g->multilevel) { set_error("the multigrid preconditioner (block_solver 5) runs on uniform grids"); return CUP3D_EINVAL; }
+  if (g->multilevel) return mg_setup_amr(s);
   std::unique_ptr<Multigrid> mg(new Multigrid());
   const int L = g->level, N = g->nranks;
-  // Several ranks: every rank runs the V-cycle on ITS blocks only, with zero ghost values behind the faces other ranks own -- an
-  // additive-Schwarz preconditioner whose subdomain solves are multigrid cycles, the reference's block-local preconditioner
-  // (zero ghosts around every 8^3 block) scaled up from a block to a rank.  No message is exchanged inside M^-1; BiCGSTAB's own
-  // LHS applications and dot products couple the ranks.  The hierarchy goes down as far as the Hilbert-range partition of the
-  // coarser grid still nests in this one (every rank's share a whole number of parent blocks): level 1 for 2, 4 or 8 ranks of a
-  // cubic base grid of one block.
+  // Several ranks: ONE V-cycle over all ranks.  Every level is partitioned by the same rule as the solver's grid (Hilbert ranges),
+  // and its iterate crosses ranks as face slabs before every launch that reads ghosts (halo_exchange: pack kernel + one grouped
+  // send/recv per peer on the communication stream) -- so on the levels it has, the cycle computes what the one-rank cycle computes
+  // (the smoother is block-Jacobi with frozen ghosts: a ghost is the neighbour's previous iterate wherever the neighbour lives).
+  // The hierarchy goes down as far as the partition of the coarser grid still nests in this one (every rank's share a whole number of
+  // parent blocks): level 1 for 2, 4 or 8 ranks of a cubic base grid of one block; that level is then solved by sweeps (mean removed
+  // over all ranks).  Round 2 ran rank-local cycles with zero ghosts instead (additive Schwarz: 27-29 iterations where this needs 5-8).
   mg->local = N > 1;
   auto nblocks_at = [&](int l) { return (int64_t)g->bpd[0] * g->bpd[1] * g->bpd[2] << (3 * l); };
   int lmin = L;
@@ -185,6 +313,11 @@ static int mg_setup(Sim *s) {
       if (i < nlev - 1) {
         M.grid.reset(new Grid(g->bpd, g->level_max, lmin + i, g->maxextent, g->bc, g->rank, N));
         gl = M.grid.get();
+        if (N > 1) {
+          M.xch = sim_comm_only(gl, s->comm_stream);
+          M.own_xch = true;
+          if (!M.xch) { set_error("multigrid setup: exchange buffers of level %d", lmin + i); return CUP3D_ENOMEM; }
+        }
         if ((rc = up(&M.d_nbr, gl->nbr))) return rc;
         const size_t bytes = (size_t)gl->nblocks() * 512 * sizeof(double);
         CUP3D_HIP(hipMalloc((void **)&M.x, bytes));
@@ -193,6 +326,7 @@ static int mg_setup(Sim *s) {
         s->bytes += 3 * bytes;
       } else {
         M.d_nbr = s->d_nbr;
+        if (N > 1) M.xch = s;
         CUP3D_HIP(hipMalloc((void **)&M.x2, (size_t)s->nb * 512 * sizeof(double)));
         s->bytes += (size_t)s->nb * 512 * sizeof(double);
       }
@@ -200,11 +334,7 @@ static int mg_setup(Sim *s) {
       M.h = gl->h;
       max_halo_faces = std::max<int64_t>(max_halo_faces, gl->n_recv_faces);
     }
-    if (N > 1) {
-      const size_t bytes = (size_t)std::max<int64_t>(max_halo_faces, 1) * 64 * sizeof(double);
-      CUP3D_HIP(hipMalloc((void **)&mg->zeros, bytes));
-      CUP3D_HIP(hipMemset(mg->zeros, 0, bytes));
-    }
+    (void)max_halo_faces;
     for (int i = nlev - 1; i >= 1; --i) {  // parent tables
       const Grid *gf = i == nlev - 1 ? g : mg->lev[i].grid.get(), *gc = mg->lev[i - 1].grid.get();
       std::vector<int32_t> par(2 * (size_t)gf->nblocks());
@@ -230,19 +360,77 @@ void mg_destroy(Sim *s) {
   s->mg = nullptr;
 }
 
-// `launches` smoothing launches of `sweeps` sweeps each on one level; the iterate alternates between *xa and *xb and ends in *xa
-static void mg_smooth(const MGLevel &M, const double *zeros, double **xa, double **xb, const double *rhs, int launches, int sweeps, bool from_zero) {
+// `launches` smoothing launches of `sweeps` sweeps each on one level; the iterate alternates between *xa and *xb and ends in *xa.
+// Several ranks: the face slabs of the iterate travel before every launch that reads them (not before the first one of a cycle, whose
+// iterate is zero everywhere).
+static int mg_smooth(const MGLevel &M, const double *zeros, double **xa, double **xb, const double *rhs, int launches, int sweeps, bool from_zero) {
   const GridDev g = level_gdev(M);
   const dim3 G(launch_groups(g)), B(256);
-  ProfileScope ps("mg_smooth");
   for (int i = 0; i < launches; ++i) {
-    const double *halo = zeros ? zeros : (const double *)*xa;
-    if (from_zero && i == 0) hipLaunchKernelGGL(k_mg_smooth<true>, G, B, 0, stream(), g, (const double *)nullptr, halo, rhs, *xb, sweeps);
+    const bool zero = from_zero && i == 0;
+    if (M.xch && !zero) { int rc = halo_exchange(M.xch, *xa, 1, 1); if (rc) return rc; }
+    const double *halo = M.xch ? (const double *)M.xch->halo_recv : (zeros ? zeros : (const double *)*xa);
+    if (!halo) halo = *xa;  // a rank without remote faces
+    ProfileScope ps("mg_smooth");
+    if (zero) hipLaunchKernelGGL(k_mg_smooth<true>, G, B, 0, stream(), g, (const double *)nullptr, halo, rhs, *xb, sweeps);
     else hipLaunchKernelGGL(k_mg_smooth<false>, G, B, 0, stream(), g, (const double *)*xa, halo, rhs, *xb, sweeps);
     double *t = *xa;
     *xa = *xb;
     *xb = t;
   }
+  return CUP3D_OK;
+}
+
+// several ranks, coarsest level: b -= mean(b) over ALL ranks
+__global__ void __launch_bounds__(256) k_mg_local_sum(const double *__restrict__ b, long n, double *__restrict__ out) {
+  __shared__ double red[4];
+  double s = 0;
+  for (long i = threadIdx.x; i < n; i += 256) s += b[i];
+  s = group_sum<4>(s, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+__global__ void __launch_bounds__(256) k_mg_sub(double *__restrict__ b, long n, const double *__restrict__ total, double inv_n_global) {
+  const double m = total[0] * inv_n_global;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) b[i] -= m;
+}
+
+static int mg_vcycle_amr(Multigrid &mg, const double *in, double *out, int nu, int sw) {
+  const int L = (int)mg.lev.size() - 1;
+  std::vector<double *> xa(L + 1), xb(L + 1);
+  for (int l = 0; l <= L; ++l) {
+    MGLevel &M = mg.lev[l];
+    xa[l] = M.x;
+    xb[l] = M.x2;
+    ProfileScope ps("mg_gather");
+    hipLaunchKernelGGL(k_mg_gather, dim3((unsigned)M.nb), dim3(256), 0, stream(), (const int32_t *)M.d_leaf, in, M.b);
+    if (M.ncf) CUP3D_HIP(hipMemsetAsync(M.slabs, 0, (size_t)M.ncf * 64 * sizeof(double), stream()));  // the coarse iterate is zero on the way down
+  }
+  for (int l = L; l >= 1; --l) {
+    MGLevel &M = mg.lev[l];
+    mg_smooth(M, M.slabs, &xa[l], &xb[l], M.b, nu, sw, true);
+    const GridDev g = level_gdev(M);
+    ProfileScope ps("mg_residual_restrict");
+    hipLaunchKernelGGL(k_mg_residual_restrict, dim3(launch_groups(g)), dim3(256), 0, stream(), g, (const double *)xa[l], (const double *)M.slabs, (const double *)M.b,
+                       (const int32_t *)M.d_parent, mg.lev[l - 1].b);
+  }
+  if (L > 0) hipLaunchKernelGGL(k_mg_remove_mean, dim3(1), dim3(256), 0, stream(), mg.lev[0].b, (long)mg.lev[0].nb * 512);
+  if (mg.lev[0].nb == 1) mg_smooth(mg.lev[0], mg.lev[0].slabs, &xa[0], &xb[0], mg.lev[0].b, 1, 64, true);
+  else mg_smooth(mg.lev[0], mg.lev[0].slabs, &xa[0], &xb[0], mg.lev[0].b, 16, 4, true);
+  for (int l = 1; l <= L; ++l) {
+    MGLevel &M = mg.lev[l];
+    {
+      ProfileScope ps("mg_prolong_add");
+      hipLaunchKernelGGL(k_mg_prolong_add, dim3((unsigned)M.nb), dim3(256), 0, stream(), (int)M.nb, xa[l], (const int32_t *)M.d_parent, (const double *)xa[l - 1]);
+      if (M.ncf) hipLaunchKernelGGL(k_mg_cf_ghosts, dim3((unsigned)M.ncf), dim3(64), 0, stream(), (const int32_t *)M.d_cf, (const double *)xa[l - 1], M.slabs);
+    }
+    mg_smooth(M, M.slabs, &xa[l], &xb[l], M.b, nu, sw, false);
+  }
+  for (int l = 0; l <= L; ++l) {
+    ProfileScope ps("mg_gather");
+    hipLaunchKernelGGL(k_mg_scatter, dim3((unsigned)mg.lev[l].nb), dim3(256), 0, stream(), (const int32_t *)mg.lev[l].d_leaf, (const double *)xa[l], out);
+  }
+  CUP3D_HIP(hipGetLastError());
+  return CUP3D_OK;
 }
 
 // out = V-cycle(in) from a zero guess; `in` is not modified
@@ -250,6 +438,7 @@ int mg_vcycle(Sim *s, const double *in, double *out) {
   int rc = mg_setup(s);
   if (rc) return rc;
   Multigrid &mg = *reinterpret_cast<Multigrid *>(s->mg);
+  if (mg.amr) return mg_vcycle_amr(mg, in, out, debug_option("mg_launches") > 0 ? debug_option("mg_launches") : 2, debug_option("mg_sweeps") > 0 ? debug_option("mg_sweeps") : 2);
   const int L = (int)mg.lev.size() - 1;
   // smoothing launches before / after the coarse-grid correction, sweeps per launch (ghosts are frozen within a launch);
   // cup3d_debug_set_option("mg_launches" / "mg_sweeps") for tuning scans
@@ -263,25 +452,40 @@ int mg_vcycle(Sim *s, const double *in, double *out) {
   }
 
   for (int l = L; l >= 1; --l) {  // downward leg
-    mg_smooth(mg.lev[l], mg.zeros, &xa[l], &xb[l], rhs[l], nu, sw, true);
+    if ((rc = mg_smooth(mg.lev[l], mg.zeros, &xa[l], &xb[l], rhs[l], nu, sw, true))) return rc;
     const GridDev g = level_gdev(mg.lev[l]);
+    Sim *xs = mg.lev[l].xch;
+    if (xs && (rc = halo_exchange(xs, xa[l], 1, 1))) return rc;
+    const double *halo = xs && xs->halo_recv ? (const double *)xs->halo_recv : (const double *)xa[l];
     ProfileScope ps("mg_residual_restrict");
-    hipLaunchKernelGGL(k_mg_residual_restrict, dim3(launch_groups(g)), dim3(256), 0, stream(), g, (const double *)xa[l], mg.zeros ? (const double *)mg.zeros : (const double *)xa[l], rhs[l], (const int32_t *)mg.lev[l].d_parent,
+    hipLaunchKernelGGL(k_mg_residual_restrict, dim3(launch_groups(g)), dim3(256), 0, stream(), g, (const double *)xa[l], halo, rhs[l], (const int32_t *)mg.lev[l].d_parent,
                        mg.lev[l - 1].b);
   }
   // coarsest level.  Its right-hand side loses its mean (the all-Neumann operator is singular) -- except in a ONE-level hierarchy, where
   // that would make the whole M^-1 singular (it would annihilate the constant component of every input and BiCGSTAB could never
   // reduce the residual along it); there the sweeps just carry a multiple of mean(b) along, a fixed linear map like the rest.
   if (L > 0 && !mg.local) hipLaunchKernelGGL(k_mg_remove_mean, dim3(1), dim3(256), 0, stream(), mg.lev[0].b, (long)mg.lev[0].nb * 512);
-  if (mg.lev[0].nb == 1) mg_smooth(mg.lev[0], mg.zeros, &xa[0], &xb[0], rhs[0], 1, 64, true);
-  else mg_smooth(mg.lev[0], mg.zeros, &xa[0], &xb[0], rhs[0], 16, 4, true);
+  if (L > 0 && mg.local) {  // the same over all ranks: local sums, one all-reduce on the communication stream, subtraction
+    double *tot = s->d_red + 14;
+    const long n = (long)mg.lev[0].nb * 512;
+    hipLaunchKernelGGL(k_mg_local_sum, dim3(1), dim3(256), 0, stream(), (const double *)mg.lev[0].b, n, tot);
+    hipStream_t cs = scalar_stream(s);
+    if (cs != stream()) { CUP3D_HIP(hipEventRecord(s->ev_b, stream())); CUP3D_HIP(hipStreamWaitEvent(cs, s->ev_b, 0)); }
+    if ((rc = allreduce(s, tot, 1, false, cs))) return rc;
+    if (cs != stream()) { CUP3D_HIP(hipEventRecord(s->ev_a, cs)); CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_a, 0)); }
+    const double ncells = 512.0 * (double)mg.lev[0].grid->total_blocks;
+    hipLaunchKernelGGL(k_mg_sub, dim3(64), dim3(256), 0, stream(), mg.lev[0].b, n, (const double *)tot, 1.0 / ncells);
+  }
+  if (mg.lev[0].nb == 1 && !mg.local) rc = mg_smooth(mg.lev[0], mg.zeros, &xa[0], &xb[0], rhs[0], 1, 64, true);
+  else rc = mg_smooth(mg.lev[0], mg.zeros, &xa[0], &xb[0], rhs[0], 16, 4, true);
+  if (rc) return rc;
   for (int l = 1; l <= L; ++l) {  // upward leg
     {
       ProfileScope ps("mg_prolong_add");
       hipLaunchKernelGGL(k_mg_prolong_add, dim3((unsigned)mg.lev[l].nb), dim3(256), 0, stream(), (int)mg.lev[l].nb, xa[l], (const int32_t *)mg.lev[l].d_parent,
                          (const double *)xa[l - 1]);
     }
-    mg_smooth(mg.lev[l], mg.zeros, &xa[l], &xb[l], rhs[l], nu, sw, false);
+    if ((rc = mg_smooth(mg.lev[l], mg.zeros, &xa[l], &xb[l], rhs[l], nu, sw, false))) return rc;
   }
   if (xa[L] != out)  // an odd number of buffer swaps on the finest level cannot happen with nu + nu launches, but stay safe
     CUP3D_HIP(hipMemcpyAsync(out, xa[L], (size_t)s->nb * 512 * sizeof(double), hipMemcpyDeviceToDevice, stream()));

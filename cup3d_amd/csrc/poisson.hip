@@ -1525,7 +1525,7 @@ int cup3d_pressure_project(cup3d_sim_t *h, double dt, int step, const cup3d_pois
   // tmpV = 0 (15076-15078) matters only as the udef lab of KernelPressureRHS; without obstacles the RHS kernel does not read it
   // (adding -0*fac*0 is the identity).  With a resident chi it does: unless the caller has placed udef there since the last
   // projection (upload / fill / cup3d_update_tmpv), tmpV still holds the previous step's gradP scratch and is cleared here.
-  if ((s->chi_nonzero || s->grid->nranks > 1) && !s->udef_nonzero) TRY(cup3d_sim_fill(h, CUP3D_FIELD_TMPV, 0.0));
+  if (s->chi_path() && !s->udef_nonzero) TRY(cup3d_sim_fill(h, CUP3D_FIELD_TMPV, 0.0));
   TRY(cup3d_pressure_rhs(h, dt));
   s->udef_nonzero = false;
   if (second_order) {

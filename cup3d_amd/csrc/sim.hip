@@ -403,6 +403,44 @@ static int sim_build(Sim *s, const Grid *g) {
   return CUP3D_OK;
 }
 
+}  // extern "C"
+
+namespace cup3d {
+// The part of a Sim the face-slab exchange needs, for a grid that holds no fields of its own: the coarse levels of the multigrid
+// preconditioner exchange their iterates through halo_exchange() like every other kernel's input (multigrid.hip).  The communication
+// stream is the finest level's (every RCCL call of a rank goes through one stream, in one order).
+Sim *sim_comm_only(const Grid *g, hipStream_t comm_stream) {
+  Sim *s = new Sim();
+  s->grid = g;
+  s->nb = s->nvis = g->nblocks();
+  s->comm_stream = comm_stream;
+  bool ok = true;
+  auto up = [&](int32_t **d, const std::vector<int32_t> &v) {
+    if (v.empty()) return;
+    ok = ok && hipMalloc((void **)d, v.size() * sizeof(int32_t)) == hipSuccess && hipMemcpy(*d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
+  };
+  up(&s->d_send_faces, g->send_faces);
+  if (g->n_recv_faces) ok = ok && hipMalloc((void **)&s->halo_recv, (size_t)g->n_recv_faces * 64 * sizeof(double)) == hipSuccess;
+  if (!g->send_faces.empty()) ok = ok && hipMalloc((void **)&s->halo_send, g->send_faces.size() * 64 * sizeof(double)) == hipSuccess;
+  hipEvent_t *ev[] = {&s->ev_h1, &s->ev_h2, &s->ev_vc_pack, &s->ev_vc_done};
+  for (hipEvent_t *e : ev) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+  if (!ok) { sim_comm_only_destroy(s); return nullptr; }
+  return s;
+}
+void sim_comm_only_destroy(Sim *s) {
+  if (!s) return;
+  vcomm_unregister(s);
+  if (s->d_send_faces) hipFree(s->d_send_faces);
+  if (s->halo_recv) hipFree(s->halo_recv);
+  if (s->halo_send) hipFree(s->halo_send);
+  hipEvent_t ev[] = {s->ev_h1, s->ev_h2, s->ev_vc_pack, s->ev_vc_done};
+  for (hipEvent_t e : ev) if (e) hipEventDestroy(e);
+  delete s;  // the communication stream belongs to the finest level's Sim
+}
+}  // namespace cup3d
+
+extern "C" {
+
 int cup3d_sim_create(const cup3d_grid_t *gh, cup3d_sim_t **out) {
   if (!gh || !out) return CUP3D_EINVAL;
   const Grid *g = reinterpret_cast<const Grid *>(gh);
@@ -464,6 +502,11 @@ int cup3d_sim_device_ptr(cup3d_sim_t *h, int field, void **ptr) {
 static int mark_written(Sim *s, int field) {
   if (field == CUP3D_FIELD_CHI) s->chi_nonzero = true;   // obstacles present: KernelPressureRHS must read chi/udef
   if (field == CUP3D_FIELD_TMPV) s->udef_nonzero = true;  // the caller placed udef in tmpV for the next projection
+  return CUP3D_OK;
+}
+int cup3d_sim_set_obstacles(cup3d_sim_t *h, int any_rank_has_obstacles) {
+  if (!h) return CUP3D_EINVAL;
+  reinterpret_cast<Sim *>(h)->obstacles_global = any_rank_has_obstacles < 0 ? -1 : (any_rank_has_obstacles != 0);
   return CUP3D_OK;
 }
 // zero-copy hosts write through cup3d_sim_device_ptr; the library cannot see those stores, so they say so here

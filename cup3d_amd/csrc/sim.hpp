@@ -88,6 +88,11 @@ struct Sim {
   double *pold = nullptr;
   bool chi_nonzero = false;   // chi was uploaded / filled non-zero: the pressure RHS reads chi and udef (= tmpV)
   bool udef_nonzero = false;  // tmpV holds the udef of the NEXT projection (uploaded, filled or cup3d_update_tmpv since the last one)
+  // cup3d_sim_set_obstacles: does ANY rank hold an obstacle (the reference's obstacle_vector is replicated, every rank knows)?
+  // -1 = not told: several ranks then always take the chi / udef path of the pressure right-hand side, because its udef exchange is a
+  // collective and chi_nonzero is per-rank state
+  int obstacles_global = -1;
+  bool chi_path() const { return obstacles_global >= 0 ? obstacles_global != 0 : (chi_nonzero || grid->nranks > 1); }
   int block_solver = 0;  // cup3d_poisson_params.block_solver of the running solve
   int scalar_bc_dir = -1;  // >= 0 while a Helmholtz solve of the implicit diffusion runs: domain-face rule of the scalar tiles
   // solver vectors (allocated on first solve), each [nb][512]
@@ -138,6 +143,8 @@ struct Sim {
 };
 
 int sim_alloc(double **p, size_t n_doubles, Sim *s);
+Sim *sim_comm_only(const Grid *g, hipStream_t comm_stream);  // exchange-only Sim of a coarse multigrid level (sim.hip)
+void sim_comm_only_destroy(Sim *s);
 
 // halo exchange of the face slabs of `field` (ncomp components, w ghost layers); no-op on one rank
 int halo_exchange(Sim *s, const double *field, int ncomp, int w);

@@ -446,7 +446,8 @@ int cup3d_pressure_rhs(cup3d_sim_t *h, double dt) {
   int rc;
   // several ranks: every rank takes the chi / udef path (adding -0*fac*0 where there is no obstacle is the identity), because the
   // udef exchange below is a collective and chi_nonzero is per-rank state (an obstacle covers blocks of some ranks only)
-  const bool obst = s->chi_nonzero || s->grid->nranks > 1;
+  // (cup3d_sim_set_obstacles(.., 0) says no rank has one: the obstacle-free run then skips the exchange of zeros)
+  const bool obst = s->chi_path();
   double *halo_u = nullptr;
   if (obst && s->grid->multilevel) {
     halo_u = s->halo_recv + (size_t)s->grid->n_amr_faces() * 3 * 64;

@@ -403,7 +403,7 @@ public:
       CUP3D_HIP_CALL(cup3d_sim_fill(dev.handle(), CUP3D_FIELD_CHI, 0.0));
       had_obstacles = false;
     }
-    dev.handle();
+    CUP3D_HIP_CALL(cup3d_sim_set_obstacles(dev.handle(), obstacles ? 1 : 0));  // obstacle_vector is replicated: the same on every rank
     if (!dev.vel_on_device) dev.upload(CUP3D_FIELD_VEL);
     else if (obstacles) dev.upload_obstacle_blocks(CUP3D_FIELD_VEL);  // what UpdateObstacles / Penalization changed on the host
     dev.vel_on_device = false;

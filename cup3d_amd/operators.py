@@ -232,6 +232,8 @@ class SimulationData:
         if a.shape != want:
             raise ValueError(f"{field}: expected block array of shape {want}, got {a.shape}")
         check(lib().cup3d_sim_upload(self.handle, fid, a))
+        if field == "chi":
+            self._chi_uploaded = True   # chi set by hand (tests): PressureProjection lets the library decide which right-hand side to use
 
     def download(self, field):
         fid = FIELDS[field]
@@ -507,6 +509,10 @@ class PressureProjection(Operator):
         if s.obstacles:  # tmpV = 0; kernelUpdateTmpV (15066-15082): chi must be resident (sim.upload("chi", ...))
             s.fill("tmpV", 0.0)
             check(lib().cup3d_update_tmpv(s.handle, len(s.obstacles), _obstacle_array(s.obstacles)))
+        # every rank knows whether obstacles exist (the list is replicated, like the reference's obstacle_vector); chi placed by hand
+        # without an ObstacleData list (tests) leaves the decision to the library
+        by_hand = getattr(s, "_chi_uploaded", False) or getattr(s, "chi_resident", False)
+        check(lib().cup3d_sim_set_obstacles(s.handle, 1 if s.obstacles else (-1 if by_hand else 0)))
         p, r = s.poisson_params(), PoissonResult()
         check(lib().cup3d_pressure_project(s.handle, dt, s.step, C.byref(p), C.byref(r)))
         s.last_poisson = r

@@ -174,6 +174,11 @@ int cup3d_sim_device_ptr(cup3d_sim_t *, int field, void **ptr);
  * projection" (otherwise cup3d_pressure_project clears tmpV as the reference does at 15076-15078) -- and upload / fill /
  * cup3d_update_tmpv set them, stores through a raw pointer cannot.  CHI and TMPV are the fields that matter; others are accepted. */
 int cup3d_sim_mark_written(cup3d_sim_t *, int field);
+/* Does ANY rank hold an obstacle?  The reference's obstacle_vector is replicated on every rank (sim.obstacle_vector->nObstacles(),
+ * main.cpp:15081), so the host knows without communicating; the same value on every rank (it decides whether the collective udef
+ * exchange of the pressure right-hand side runs).  1: chi / udef path (KernelPressureRHS 14858-14871); 0: obstacle-free path, no udef
+ * exchange, tmpV not cleared; -1 (default): not told -- one rank decides by "chi was written", several ranks always take the chi path. */
+int cup3d_sim_set_obstacles(cup3d_sim_t *, int any_rank_has_obstacles);
 /* Wrapping 64-bit sum of the bit patterns of every FP64 value of the rank's own blocks of `field` (ghost blocks of a rank view
  * excluded).  Integer addition commutes, so the sum of the ranks' values is independent of the partition: bench.py all-gathers it
  * after the first AdvectionDiffusion and compares it with the constant the CPU oracle produced for the same step (the stencil

@@ -57,8 +57,26 @@ if has window256; then echo "== the driver's window at 256^3 (steps 26-45 after 
   timeout 900 python bench.py --size 256 --no-cpu --no-alt --no-pcie --steps 20 --warmup 5 > $OUT/bench_256_window.json 2> $OUT/bench_256_window.err ; echo "rc=$?"; summ $OUT/bench_256_window.json; fi
 if has full512; then echo "== the driver's command"
   timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_512_driver.json 2> $OUT/bench_512_driver.err ; echo "rc=$?"; summ $OUT/bench_512_driver.json; tail -3 $OUT/bench_512_driver.err; fi
-if has trace; then echo "== rocprofv3 kernel trace of the bench command (3 steps)"
-  rocprofv3 --kernel-trace --stats -d $OUT/rocprof -o trace -- python bench.py --no-cpu --no-alt --no-pcie --no-checksum --steps 3 --warmup 1 > $OUT/trace_bench.json 2> $OUT/trace.err ; echo "rc=$?"
-  find $OUT/rocprof -name "*kernel_stats*.csv" | head -1 | xargs -I{} sh -c 'head -25 {} | cut -c1-220'
-  find $OUT/rocprof -name "*kernel_trace*.csv" -delete ; find $OUT/rocprof -name "*.db" -delete; fi
+ROOT=$PWD
+if has trace; then echo "== rocprofv3 kernel trace of the bench command (512^3 full step, 5 steps)"
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace -o t -- python $ROOT/bench.py --no-cpu --no-alt --no-pcie --no-checksum --steps 5 --warmup 2 > $ROOT/$OUT/trace.log 2>&1 )
+  for f in $(find $OUT/trace -name "*kernel_stats.csv" | head -1); do cp $f $OUT/rocprofv3_kernel_stats_512cubed_fullstep_bench.csv; head -14 $f | cut -c1-220; done
+  grep -E "^\{" $OUT/trace.log | tail -c 600
+  rm -rf $OUT/trace; fi
+if has pmc; then echo "== rocprofv3 PMC passes (one pressure projection at 512^3): FETCH_SIZE, WRITE_SIZE in separate runs"
+  for C in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_$C -o p -- python $ROOT/scripts/kernel_probe.py one --size 512 --kernel solve > $ROOT/$OUT/pmc_$C.log 2>&1 )
+    for f in $(find $OUT/pmc_$C -name "*counter_collection.csv" | head -1); do python - "$f" $C <<'PY' | tee -a $OUT/pmc_solver_kernels_512cubed.txt
+import csv, sys, collections
+f, c = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if r.get("Counter_Name") == c:
+        acc[r["Kernel_Name"][:70]].append(float(r["Counter_Value"]))
+for k, v in sorted(acc.items()):
+    print(c, k, "launches", len(v), "mean_KB", round(sum(v) / len(v), 1))
+PY
+    done
+    rm -rf $OUT/pmc_$C
+  done; fi
 echo "== done"

@@ -222,6 +222,38 @@ def test_poisson_path(golden_dir, name, block_solver):
         assert np.abs(sim.download("vel") - v).max() <= 1e-6 * corr, step  # 22-block mesh, random field: cond(A) * 1e-10
 
 
+@pytest.mark.parametrize("name", MESHES + ["random_3_levels"])
+def test_multigrid_preconditioner_on_multilevel_meshes(golden_dir, name):
+    """block_solver 5 on a multi-level mesh: the octree's own levels as the multigrid hierarchy (restriction = summed residual of the
+    eight children, prolongation and coarse/fine ghosts piecewise constant, multigrid.hip mg_setup_amr).  Not the reference's
+    preconditioner -- the reference has no multigrid -- so parity is on the CONVERGED pressure: both sides solved to 1e-12 / 1e-10,
+    same operator, same mean constraint, same stopping rule -> the oracle's pressure to 1e-6, in at most 15 BiCGSTAB iterations where
+    the block CG needs 80-150."""
+    if name == "random_3_levels":
+        bpd, lmax, bc = (2, 2, 2), 4, ("periodic", "wall", "freespace")
+        lv, zs = O.build_balanced_mesh(bpd, lmax, bc, [(0, 1, 1, 0), (1, 2, 3, 1), (1, 3, 3, 1), (2, 5, 6, 3), (0, 0, 0, 1)])
+        m = O.OracleMesh(bpd, lmax, EXT, bc, lv, zs)
+        sim = cu.SimulationData(bpdx=2, bpdy=2, bpdz=2, levelMax=lmax, levelStart=0, extent=EXT, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], leaves=(lv, zs), blockSolver=5)
+        rng = np.random.default_rng(11)
+        f = dict(vel=rng.uniform(-1, 1, (m.nb, 8, 8, 8, 3)), pres=rng.uniform(-1, 1, (m.nb, 8, 8, 8)))
+        assert len(set(lv.tolist())) >= 3
+    else:
+        m, sim, f = make(golden_dir, name, blockSolver=5)
+    dt, step, tol, tolrel = 0.01, 5, 1e-12, 1e-10
+    sim.PoissonErrorTol, sim.PoissonErrorTolRel = tol, tolrel
+    sim.upload("vel", f["vel"]); sim.upload("pres", f["pres"])
+    sim.fill("chi", 0.0)
+    sim.step = step
+    r = cu.PressureProjection(sim)(dt)
+    v, p = f["vel"].copy(), f["pres"].copy()
+    info, _, _ = m.project(v, p, dt, step, tol=tol, tol_rel=tolrel)
+    print(f"{name}: multigrid-preconditioned BiCGSTAB {r.iterations} iterations, block CG (oracle) {info.iters}; {m.nb} blocks")
+    corr = np.abs(v - f["vel"]).max()
+    assert np.abs(sim.download("pres") - p).max() <= 1e-6 * np.abs(p).max()
+    assert np.abs(sim.download("vel") - v).max() <= 1e-6 * corr
+    assert r.iterations <= 15, (r.iterations, info.iters)
+
+
 def test_time_steps_on_a_fixed_mesh(golden_dir):
     """advect-diffuse + projection for a few steps on the three-level mesh from a smooth field, both sides at tight
     Poisson tolerance: the trajectories stay together to round-off of the solve."""

@@ -8,7 +8,7 @@ and migration the reference performs.
 The builder's and the driver's test boxes have ONE GPU and RCCL refuses two ranks on one device, so the bytes travel through the
 library's host-memory test transport (cup3d_debug_host_transport, include/cup3d_hip_testing.h) carried by the reference's own MPI --
 everything but ncclSend / ncclRecv / ncclAllReduce themselves is the production path.  Compared with the SAME harness running the
-reference's CPU operators on the same number of ranks: per-rank block lists (level, Z, ownership) identical after 12 and 30 steps,
+reference's CPU operators on the same number of ranks: per-rank block lists (level, Z, ownership) identical half way and at the end (30 steps for configs[3], 14 for configs[4]: every one of the first ten steps adapts the mesh),
 chi / velocity / pressure to solver round-off (Poisson tolerance 1e-9 / 1e-8 on both sides).  "Solver round-off" is MEASURED, not
 assumed: on these three- and four-level meshes the reference's BiCGSTAB stagnates above its tolerance, and the reference differs from
 ITSELF when nothing but the order of its reductions changes -- 1 or 3 OpenMP threads on one rank: 7e-4 of the velocity and 1e-2 of
@@ -38,7 +38,8 @@ COMMON = ["-bMeanConstraint", "2", "-bpdx", "2", "-bpdy", "2", "-bpdz", "2", "-C
 ONE_FISH = "StefanFish L=0.4 T=1.0 xpos=0.5 ypos=0.5 zpos=0.5 heightProfile=danio widthProfile=stefan bFixFrameOfRef=1"
 TWO_FISH = ("StefanFish L=0.4 T=1.0 xpos=0.25 ypos=0.5 zpos=0.5 planarAngle=180 heightProfile=danio widthProfile=stefan bFixFrameOfRef=1\n"
             "StefanFish L=0.4 T=1.0 xpos=0.7 ypos=0.5 zpos=0.5 heightProfile=danio widthProfile=stefan")
-SCRIPT = ["op steps 12", "tables t12.bin", "op steps 18", "tables t30.bin", "dump vel v.bin", "dump pres p.bin", "dump chi c.bin"]
+def script(nsteps):   # two check points of the block lists; adaptMesh runs at every step below 10 and every 20th (main.cpp:15314)
+    return [f"op steps {nsteps // 2}", "tables t12.bin", f"op steps {nsteps - nsteps // 2}", "tables t30.bin", "dump vel v.bin", "dump pres p.bin", "dump chi c.bin"]
 
 _launcher = None
 
@@ -59,10 +60,10 @@ def launcher():
     return _launcher
 
 
-def run(tool, nranks, pre, args, wd, extra_env=None):
+def run(tool, nranks, pre, args, wd, extra_env=None, nsteps=30):
     os.makedirs(wd)
     with open(os.path.join(wd, "script.txt"), "w") as f:
-        f.write("\n".join(pre + SCRIPT) + "\n")
+        f.write("\n".join(pre + script(nsteps)) + "\n")
     out = subprocess.run((launcher() + ["-n", str(nranks)] if nranks > 1 else []) + [tool, "script.txt", "--"] + args, cwd=wd, env=dict(ENV, **(extra_env or {})),
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert out.returncode == 0, (out.stdout.decode()[-1500:], out.stderr.decode()[-3000:])
@@ -77,17 +78,17 @@ def run(tool, nranks, pre, args, wd, extra_env=None):
 
 
 @pytest.mark.timeout(1800)
-@pytest.mark.parametrize("name,nranks,level_max,fish,min_levels", [("configs3_one_fish_3_levels_2_ranks", 2, 4, ONE_FISH, 3),
-                                                                   ("configs4_two_fish_4_levels_8_ranks", 8, 5, TWO_FISH, 4)])
-def test_fish_with_amr_over_mpi_ranks_through_the_shim(tmp_path, name, nranks, level_max, fish, min_levels):
+@pytest.mark.parametrize("name,nranks,level_max,fish,min_levels,nsteps", [("configs3_one_fish_3_levels_2_ranks", 2, 4, ONE_FISH, 3, 30),
+                                                                          ("configs4_two_fish_4_levels_8_ranks", 8, 5, TWO_FISH, 4, 14)])
+def test_fish_with_amr_over_mpi_ranks_through_the_shim(tmp_path, name, nranks, level_max, fish, min_levels, nsteps):
     if not (os.path.exists(REF_MPI) and os.path.exists(REF_HIP_MPI) and os.path.exists(O.MPIEXEC)):
         pytest.skip("needs oracle/_ref/ref_tool_mpi, ref_tool_hip_mpi_testing (built where /root/reference exists) and an mpiexec")
     if not launcher():
         pytest.skip("mpiexec cannot start local ranks on this box")
     args = COMMON + ["-levelMax", str(level_max), "-factory-content", fish]
-    cpu = run(REF_MPI, nranks, [], args, str(tmp_path / "cpu"))
-    one = run(O.REF_TOOL, 1, [], args, str(tmp_path / "one"), {"OMP_NUM_THREADS": "4"})   # the reference against itself: one rank, four threads
-    hip = run(REF_HIP_MPI, nranks, ["hip on"], args, str(tmp_path / "hip"), {"CUP3D_HIP_HOST_TRANSPORT": "1"})
+    cpu = run(REF_MPI, nranks, [], args, str(tmp_path / "cpu"), nsteps=nsteps)
+    one = run(O.REF_TOOL, 1, [], args, str(tmp_path / "one"), {"OMP_NUM_THREADS": "4"}, nsteps=nsteps)   # the reference against itself: one rank, four threads
+    hip = run(REF_HIP_MPI, nranks, ["hip on"], args, str(tmp_path / "hip"), {"CUP3D_HIP_HOST_TRANSPORT": "1"}, nsteps=nsteps)
     levels, nblocks, vmax, pmax, wet = set(), 0, 0.0, 0.0, 0
     for c in cpu:
         levels |= set(c[1][:, 0].tolist())
