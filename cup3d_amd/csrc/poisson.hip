@@ -486,6 +486,8 @@ static int *cg_iters_buffer(Sim *s) {  // per-block CG iteration counts of the l
   return s->d_cg_iters;
 }
 
+constexpr int kLoopPrio = 0;    // LhsIn::prio of the production launch (measured: profiles/r03)
+constexpr int kSumsGroups = 64;  // workgroups of k_sums_finish
 // evaluation of the production block CG (EV bits of k_precond); measured on MI355X: see profiles/r02/probe_block_cg_variants.jsonl
 constexpr int kCgProduction = 0;
 
@@ -710,6 +712,7 @@ struct LhsIn {
   const double *total;  // sum(u h^3) over all ranks, for the mean-constraint row (9283-9326); device memory
   int mode;             // bMeanConstraint as ComputeLHS uses it: 0 none, 1 corner row = total, 2 += total h^3 everywhere, 3 corner row = u
   int corner_slot;      // slot of the block with index (0,0,0) on this rank, or -1
+  int prio;             // wave priority (s_setprio) while the wavefront streams its block; back to 0 when the block CG starts
 };
 struct TileRegs { double c[8], gv[6]; };
 // the 14 loads of a tile (own column + six face slabs); the caller issues the first plane of its streams behind them, then commits
@@ -816,6 +819,8 @@ __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, c
     tile_issue(g, slot, V.v[WHAT], L.halo, l, tr);
     ix = tile_idx(l);
   }
+  // (a streaming wavefront's loads and stores go out ahead of the arithmetic of the wavefronts that sit in their block CG)
+  if (L.prio == 1) __builtin_amdgcn_s_setprio(1); else if (L.prio == 2) __builtin_amdgcn_s_setprio(2); else if (L.prio == 3) __builtin_amdgcn_s_setprio(3);
   LOAD_PLANE(0, l)
   if constexpr (FLHS) tile_commit(tr, P, l);
 #pragma unroll
@@ -845,6 +850,7 @@ __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, c
   d0 = wave_sum(d0);
   d1 = wave_sum(d1);
   if (l == 0) { block_dots[slot] = d0; block_dots[nb + slot] = d1; }
+  if (L.prio) __builtin_amdgcn_s_setprio(0);
   if constexpr (FLHS) __syncthreads();  // the tile is read no more: the block CG takes over its LDS
   cg_block<FMA, false, EV>(g, slot, r, V.v[ZHAT], block_sums, 0.0, 0.0, iters_out, P);  // zhat = M^-1 z, 14488
 }
@@ -888,6 +894,7 @@ __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, c
     tile_issue(g, slot, V.v[ZHAT], L.halo, l, tr);
     ix = tile_idx(l);
   }
+  if (L.prio == 1) __builtin_amdgcn_s_setprio(1); else if (L.prio == 2) __builtin_amdgcn_s_setprio(2); else if (L.prio == 3) __builtin_amdgcn_s_setprio(3);
   LOAD_PLANE(0, l)
   if constexpr (FLHS) tile_commit(tr, P, l);
 #pragma unroll
@@ -921,6 +928,7 @@ __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, c
     if (l == 0) block_dots[(size_t)i * nb + slot] = t;
     if (i == 4 && l == 0) block_dots[(size_t)6 * nb + slot] = t;  // norm = the same sum as norm_1 (14512-14514)
   }
+  if (L.prio) __builtin_amdgcn_s_setprio(0);
   if constexpr (FLHS) __syncthreads();
   cg_block<FMA, false, EV>(g, slot, r, V.v[WHAT], block_sums, 0.0, 0.0, iters_out, P);  // what = M^-1 w, 14548
 }
@@ -1324,12 +1332,13 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     ProfileScope ps("bicgstab_dots_finish");
     const RedOut ro{s->d_partials, s->d_counters, s->d_red, nullptr, nullptr, 0u};
     const CtlThen then{d_ctl, ring, seq, direct ? step : 0};
+    const dim3 SG(debug_option("sums_groups") > 0 ? debug_option("sums_groups") : kSumsGroups);
     if (K == 2) {
-      if (want_sums) hipLaunchKernelGGL((k_sums_finish<2, true>), dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, sums, then);
-      else hipLaunchKernelGGL((k_sums_finish<2, false>), dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, (const double *)nullptr, then);
+      if (want_sums) hipLaunchKernelGGL((k_sums_finish<2, true>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, sums, then);
+      else hipLaunchKernelGGL((k_sums_finish<2, false>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, (const double *)nullptr, then);
     } else {
-      if (want_sums) hipLaunchKernelGGL((k_sums_finish<7, true>), dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, sums, then);
-      else hipLaunchKernelGGL((k_sums_finish<7, false>), dim3(64), dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, (const double *)nullptr, then);
+      if (want_sums) hipLaunchKernelGGL((k_sums_finish<7, true>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, sums, then);
+      else hipLaunchKernelGGL((k_sums_finish<7, false>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, (const double *)nullptr, then);
     }
     CUP3D_HIP(hipGetLastError());
     if (direct) return CUP3D_OK;
@@ -1387,13 +1396,14 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   auto enqueue_fused = [&](unsigned seq) -> int {
     V.v[X_] = XB[0]; V.v[XOPT] = XB[1];  // fixed roles: the kernels pick by SolverCtl::xcur / xopt
     const int lhs_mode = !flhs ? -1 : (mc > 2 ? 3 : mc);
-    TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, what_total, lhs_mode, s->grid->corner_slot}));  // (t = A what,) loop 1, zhat = M^-1 z
+    const int prio = debug_option("loop_prio") ? debug_option("loop_prio") - 1 : kLoopPrio;  // tuning: option value = priority + 1
+    TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, what_total, lhs_mode, s->grid->corner_slot, prio}));  // (t = A what,) loop 1, zhat = M^-1 z
     s->sums_of = want_sums ? V.v[ZHAT] : nullptr;
     TRY(finish(2, 1, seq));
     if (want_sums) { s->mean_total_of = V.v[ZHAT]; s->mean_total = s->d_red + 2; }
     if (!flhs) TRY(LHS(ZHAT, V_));
     TRY(scalars_ready());
-    TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, s->d_red + 2, lhs_mode, s->grid->corner_slot}));  // (v = A zhat,) loop 2, what = M^-1 w
+    TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, s->d_red + 2, lhs_mode, s->grid->corner_slot, prio}));  // (v = A zhat,) loop 2, what = M^-1 w
     s->sums_of = want_sums ? V.v[WHAT] : nullptr;
     TRY(finish(7, 2, seq));
     if (want_sums) { s->mean_total_of = V.v[WHAT]; s->mean_total = s->d_red + 7; }

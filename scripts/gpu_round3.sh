@@ -51,6 +51,18 @@ if has abl2; then echo "== A/B: second fused kernel with the LHS inside at 5 wav
     timeout 900 python bench.py --size $S --no-cpu --no-alt --no-pcie --no-checksum --debug-option loop2_flhs_five_waves=$O --steps ${BENCH_STEPS:-10} --warmup ${BENCH_WARMUP:-3} > $OUT/abl2_${S}_$O.json 2>> $OUT/ab.err; echo "five_waves=$O, $S:"; summ $OUT/abl2_${S}_$O.json
     done
   done; fi
+if has tune; then echo "== tuning scan: wave priority while streaming (loop_prio = priority + 1), workgroups of the dot-product totals (sums_groups)"
+  for S in ${AB_SIZES:-256 512}; do
+    for O in "loop_prio=0" "loop_prio=2" "loop_prio=4" "sums_groups=256" "loop_prio=4 --debug-option sums_groups=256"; do
+      timeout 900 python bench.py --size $S --no-cpu --no-alt --no-pcie --no-checksum --debug-option $O --steps ${BENCH_STEPS:-6} --warmup ${BENCH_WARMUP:-2} > $OUT/tune_${S}.json 2>> $OUT/ab.err; echo "$S $O:"; summ $OUT/tune_${S}.json | head -4 | grep -E "value|loop|finish"
+      python - $OUT/tune_${S}.json "$S $O" >> $OUT/tune.jsonl <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+k = {x["kernel"]: x["avg_ms"] for x in r["kernels"]}
+print(json.dumps({"case": sys.argv[2], "ms_per_iteration": round(r["ms_per_step"] / r["config"]["bicgstab_iters_per_step"], 4), "loop1_cg": k.get("bicgstab_loop1_cg"), "loop2_cg": k.get("bicgstab_loop2_cg"), "dots_finish": k.get("bicgstab_dots_finish")}))
+PY
+    done
+  done; cat $OUT/tune.jsonl; fi
 if has nofuse; then echo "== A/B: host-driven unfused loops, 256^3"
   timeout 600 python bench.py --size 256 --no-cpu --no-alt --no-pcie --no-fuse --steps 5 --warmup 2 > $OUT/bench_256_nofuse.json 2>> $OUT/flavour.err; summ $OUT/bench_256_nofuse.json; fi
 if has window256; then echo "== the driver's window at 256^3 (steps 26-45 after 5 warm-up steps) for profiles/r03/reference_window_256.json"
