@@ -487,7 +487,9 @@ static int *cg_iters_buffer(Sim *s) {  // per-block CG iteration counts of the l
 }
 
 constexpr int kLoopPrio = 0;    // LhsIn::prio of the production launch (measured: profiles/r03)
-constexpr int kSumsGroups = 64;  // workgroups of k_sums_finish
+// workgroups of k_sums_finish: 64 below 2^17 blocks, 256 from there on (0.027 instead of 0.051 ms per launch at 512^3, 0.016 instead of
+// 0.014 at 256^3; wave priority 1..3 while streaming changes nothing: profiles/r03/probe_tuning_prio_sums.jsonl)
+inline int sums_groups(int64_t nb) { return nb >= (1 << 17) ? 256 : 64; }
 // evaluation of the production block CG (EV bits of k_precond); measured on MI355X: see profiles/r02/probe_block_cg_variants.jsonl
 constexpr int kCgProduction = 0;
 
@@ -1332,7 +1334,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     ProfileScope ps("bicgstab_dots_finish");
     const RedOut ro{s->d_partials, s->d_counters, s->d_red, nullptr, nullptr, 0u};
     const CtlThen then{d_ctl, ring, seq, direct ? step : 0};
-    const dim3 SG(debug_option("sums_groups") > 0 ? debug_option("sums_groups") : kSumsGroups);
+    const dim3 SG(debug_option("sums_groups") > 0 ? debug_option("sums_groups") : sums_groups(s->nb));
     if (K == 2) {
       if (want_sums) hipLaunchKernelGGL((k_sums_finish<2, true>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, sums, then);
       else hipLaunchKernelGGL((k_sums_finish<2, false>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, (const double *)nullptr, then);
