@@ -30,6 +30,8 @@ constexpr int kZPitch = 72;                     // pitch of the z ghost planes
 constexpr int kZGSize = 6 * kZPitch;            // z ghost planes: [-1,-2,-3, 8,9,10][y][x]
 constexpr int kCompStride = kXYSize + kZGSize;  // 2032 doubles per component
 
+constexpr int kAdvProduction = 0;  // 0: k_advdiff (one workgroup per block), 6: k_advdiff_pc (one per block and component); measured, profiles/r03
+
 struct AdvArgs {
   const double *vel;   // [nb][3][512] in
   double *vel_out;     // [nb][3][512] out (double buffer: neighbours still read `vel`)
@@ -420,6 +422,101 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
   }
 }
 
+// ---- the same stage with one WORKGROUP per (block, component) (uniform grids).
+// The components are independent once a cell's own velocity is known (see k_advdiff_c), so three workgroups can share a block: each
+// stages the star tile of ITS component only (16.3 KB of LDS instead of 48.8), reads the block's three centre values per cell (the
+// advecting velocity; the other two workgroups' reads of the same lines hit the XCD's L2: the three workgroups of a block are
+// consecutive workgroups of one XCD) and writes its component of vel' and tmpV.  No serialisation of the components as in
+// k_advdiff_c, three times the workgroups, a third of the LDS and fewer registers each: more wavefronts per SIMD to overlap one
+// workgroup's load -> LDS -> compute -> store sequence with the others'.  Arithmetic and association are those of k_advdiff:
+// bit-identical results.
+template <bool FIRST_STAGE>
+__global__ void __launch_bounds__(256) k_advdiff_pc(GridDev g, AdvArgs a) {
+  __shared__ double tile[kCompStride];
+  const int bid = blockIdx.x, jj = bid >> 3, c = jj % 3, bi = (bid & 7) * g.chunk + jj / 3;
+  if (bi >= g.nblocks) return;
+  const int slot = g.list ? g.list[bi] : bi;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const double *__restrict__ own = a.vel + (size_t)slot * 1536;
+  const int x = lane & 7, z0 = (lane >> 3) & 3, y = 2 * wave + (lane >> 5);
+  const int cell0 = z0 * 64 + y * 8 + x;  // second cell: + 256
+  double uc[2][3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) uc[k][q] = own[q * 512 + k * 256 + cell0];
+  double told[2] = {0.0, 0.0};
+  if (!FIRST_STAGE) {
+    const double *__restrict__ tp = a.tmp + (size_t)slot * 1536 + c * 512;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) told[k] = __builtin_nontemporal_load(&tp[k * 256 + cell0]);
+  }
+  // ghosts of component c: element e = t + 256 j of the 6 x 192 behind the faces; every load is out before the first LDS write
+  double gv[5];
+  int glds[5];
+  bool gon[5], gneg[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int e = t + 256 * j;
+    gon[j] = e < 1152;
+    const int f = gon[j] ? e / 192 : 0, idx = gon[j] ? e - 192 * f : 0;
+    int nb_cell, own_cell, lds, hal;
+    face_element(f, idx, nb_cell, own_cell, lds, hal);
+    const int n = g.nbr[slot * 6 + f];
+    glds[j] = lds;
+    gneg[j] = n < 0 && (n == -3 || (f >> 1) == c);  // wall: every component negated; freespace: the normal one (main.cpp:6137-6153, 6384-6394)
+    const double *src = n >= kNbrHalo ? a.halo + ((size_t)(n - kNbrHalo) * 3 + c) * 192 + hal
+                                      : (n >= 0 ? a.vel + (size_t)n * 1536 + c * 512 + nb_cell : own + c * 512 + own_cell);
+    gv[j] = gon[j] ? src[0] : 0.0;
+  }
+  const int xy = (y + 3) * kXYPitch + (x + 3);
+  double *L = tile;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) L[(z0 + 4 * k) * kPlane + xy] = c == 0 ? uc[k][0] : (c == 1 ? uc[k][1] : uc[k][2]);
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+    if (gon[j]) L[glds[j]] = gneg[j] ? -gv[j] : gv[j];
+  __syncthreads();
+  const double h = g.h, h3 = h * h * h;
+  const double facA = -a.dt / h * h3 * 1.0;                 // main.cpp:9487 (coef = 1)
+  const double facD = (a.nu / h) * (a.dt / h) * h3 * 1.0;   // main.cpp:9488
+  double *__restrict__ vout = a.vel_out + (size_t)slot * 1536 + c * 512;
+  double *__restrict__ tout = a.tmp + (size_t)slot * 1536 + c * 512;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int z = z0 + 4 * k;
+    int zo[7];
+#pragma unroll
+    for (int dz = -3; dz <= 3; ++dz) {
+      const int zz = z + dz;
+      zo[dz + 3] = (zz >= 0 && zz < 8) ? zz * kPlane + xy : kXYSize + (zz < 0 ? -1 - zz : zz - 5) * kZPitch + y * 8 + x;
+    }
+    const int b = z * kPlane + xy;
+    const double ua0 = uc[k][0] + a.u0, ua1 = uc[k][1] + a.u1, ua2 = uc[k][2] + a.u2;  // uAbs, 9492-9494
+    const bool p0 = ua0 > 0, p1 = ua1 > 0, p2 = ua2 > 0;
+    const double cc = c == 0 ? uc[k][0] : (c == 1 ? uc[k][1] : uc[k][2]);
+    const double xm1 = L[b - 1], xp1 = L[b + 1], ym1 = L[b - kXYPitch], yp1 = L[b + kXYPitch], zm1 = L[zo[2]], zp1 = L[zo[4]];
+    const double dx = upwind5<true>(p0, L[b - 3], L[b - 2], xm1, cc, xp1, L[b + 2], L[b + 3]);
+    const double dy = upwind5<true>(p1, L[b - 3 * kXYPitch], L[b - 2 * kXYPitch], ym1, cc, yp1, L[b + 2 * kXYPitch], L[b + 3 * kXYPitch]);
+    const double dz = upwind5<true>(p2, L[zo[0]], L[zo[1]], zm1, cc, zp1, L[zo[5]], L[zo[6]]);
+    const double sx = xp1 + xm1, sy = yp1 + ym1, sz = zp1 + zm1;
+    double lap, adv;  // the three components use three association orders, main.cpp:9531-9545
+    if (c == 0) {
+      lap = (sx + (sy + sz)) - 6 * cc;
+      adv = ua0 * dx + (ua1 * dy + ua2 * dz);
+    } else if (c == 1) {
+      lap = (sy + (sz + sx)) - 6 * cc;
+      adv = ua1 * dy + (ua2 * dz + ua0 * dx);
+    } else {
+      lap = (sz + (sx + sy)) - 6 * cc;
+      adv = ua2 * dz + (ua0 * dx + ua1 * dy);
+    }
+    const double tn = told[k] + (facA * adv + facD * lap);                               // o += ..., main.cpp:9546-9548
+    __builtin_nontemporal_store(cc + tn * a.alpha, &vout[k * 256 + cell0]);              // V += tmpV*ih3, 9718-9720
+    __builtin_nontemporal_store(tn * a.beta, &tout[k * 256 + cell0]);                    // tmpV *= beta, 9721-9723
+  }
+}
+
 // face slabs of `field` behind the faces listed in send_faces -> packed send buffer
 // [(s*nc + c)*w + gl][64]  (the device-side `pack`, main.cpp:1128-1157)
 __global__ void __launch_bounds__(64) k_pack_faces(const double *__restrict__ field, const int32_t *__restrict__ send_faces, int nc, int w,
@@ -527,12 +624,19 @@ static int advdiff_stage(Sim *s, int rk, double dt, double nu, const double uinf
 #define ADV(FIRST, CPT, VAR) hipLaunchKernelGGL((k_advdiff<FIRST, CPT, VAR>), G, dim3(512 / CPT), 0, stream(), g, a)
 #define ADV2(CPT, VAR) do { if (rk == 0) ADV(true, CPT, VAR); else ADV(false, CPT, VAR); } while (0)
 #ifndef CUP3D_TESTING
-      ADV2(2, 0);  // release build: the production kernel only
+      if (kAdvProduction == 6) {
+        if (rk == 0) hipLaunchKernelGGL((k_advdiff_pc<true>), dim3(3 * launch_groups(g)), dim3(256), 0, stream(), g, a);
+        else hipLaunchKernelGGL((k_advdiff_pc<false>), dim3(3 * launch_groups(g)), dim3(256), 0, stream(), g, a);
+      } else ADV2(2, 0);  // release build: the production kernel only
 #else
-      switch (debug_option("advdiff_variant")) {  // 0 = production; 1 and 4 are A/B variants with the SAME results
+      switch (debug_option("advdiff_variant") ? debug_option("advdiff_variant") % 16 : kAdvProduction) {  // 0 / 16 = k_advdiff; 1 and 4 are A/B variants with the SAME results
         case 0: ADV2(2, 0); break;
         case 1: ADV2(2, 1); break;
         case 4: ADV2(2, 4); break;
+        case 6:  // one workgroup per (block, component) (k_advdiff_pc)
+          if (rk == 0) hipLaunchKernelGGL((k_advdiff_pc<true>), dim3(3 * launch_groups(g)), dim3(256), 0, stream(), g, a);
+          else hipLaunchKernelGGL((k_advdiff_pc<false>), dim3(3 * launch_groups(g)), dim3(256), 0, stream(), g, a);
+          break;
         case 5:  // one component tile at a time (k_advdiff_c)
           if (rk == 0) hipLaunchKernelGGL((k_advdiff_c<true>), G, dim3(256), 0, stream(), g, a);
           else hipLaunchKernelGGL((k_advdiff_c<false>), G, dim3(256), 0, stream(), g, a);
