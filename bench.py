@@ -260,7 +260,8 @@ def run_amr(a):
                       "interface_faces": int(lib().cup3d_grid_ninterface_faces(sim.grid.handle)), "block_history": history,
                       "finest_uniform_equivalent_cells": int((8 << (lmax - 1)) ** 3), "mesh_build_seconds": round(adapt_s, 3),
                       "bicgstab_iters_per_step": round(float(np.mean(iters)), 2),
-                      "block_preconditioner": ("block CG (reference algorithm)", "direct block solve (fast diagonalisation)")[a.block_solver]},
+                      "block_preconditioner": {0: "block CG (reference algorithm)", 1: "direct block solve (fast diagonalisation)",
+                                               5: "geometric multigrid V-cycle over the octree's levels (NOT the reference's preconditioner)"}.get(a.block_solver, str(a.block_solver))},
            "roofline": ({k: with_roof[0][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": with_roof[0]["kernel"]}) if with_roof else None,
            "kernels": kernels}
     print(json.dumps(out))

@@ -67,6 +67,12 @@ if has nofuse; then echo "== A/B: host-driven unfused loops, 256^3"
   timeout 600 python bench.py --size 256 --no-cpu --no-alt --no-pcie --no-fuse --steps 5 --warmup 2 > $OUT/bench_256_nofuse.json 2>> $OUT/flavour.err; summ $OUT/bench_256_nofuse.json; fi
 if has window256; then echo "== the driver's window at 256^3 (steps 26-45 after 5 warm-up steps) for profiles/r03/reference_window_256.json"
   timeout 900 python bench.py --size 256 --no-cpu --no-alt --no-pcie --steps 20 --warmup 5 > $OUT/bench_256_window.json 2> $OUT/bench_256_window.err ; echo "rc=$?"; summ $OUT/bench_256_window.json; fi
+if has extras; then echo "== the other bench modes: stencil-only 512^3, multi-level mesh, implicit diffusion"
+  timeout 600 python bench.py --stencil-only --no-cpu --steps 10 --warmup 3 > $OUT/bench_512_stencil_only.json 2> $OUT/extras.err; echo "stencil-only rc=$?"; summ $OUT/bench_512_stencil_only.json | head -5
+  timeout 900 python bench.py --amr --steps 5 --warmup 2 > $OUT/bench_amr_3level.json 2>> $OUT/extras.err; echo "amr rc=$?"; summ $OUT/bench_amr_3level.json | head -6
+  timeout 900 python bench.py --amr --block-solver 5 --steps 5 --warmup 2 > $OUT/bench_amr_3level_multigrid.json 2>> $OUT/extras.err; echo "amr multigrid rc=$?"; summ $OUT/bench_amr_3level_multigrid.json | head -6
+  timeout 900 python bench.py --implicit-diffusion --no-cpu --steps 3 --warmup 1 > $OUT/bench_512_implicit.json 2>> $OUT/extras.err; echo "implicit rc=$?"; summ $OUT/bench_512_implicit.json | head -4
+  tail -3 $OUT/extras.err; fi
 if has full512; then echo "== the driver's command"
   timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_512_driver.json 2> $OUT/bench_512_driver.err ; echo "rc=$?"; summ $OUT/bench_512_driver.json; tail -3 $OUT/bench_512_driver.err; fi
 ROOT=$PWD
