@@ -3,7 +3,7 @@ import os, subprocess, sys, tempfile
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import oracle_lib as O
-import test_gpu_dropin_mpi as T
+import test_gpu_00_dropin_mpi as T
 REF_HIP = os.path.join(O.ORACLE_DIR, "_ref", "ref_tool_hip")
 
 def run(tool, n, pre, args, script, env=None):
