@@ -86,7 +86,22 @@ public:
   // must call invalidate().  Off by default for that reason.
   bool across_steps = false;
   bool host_vel_clean = false, host_pres_clean = false;  // host copy == device copy
-  void invalidate() { host_vel_clean = host_pres_clean = false; }
+  // DEVICE-LED (install(sim, 3) / CUP3D_HIP_RESIDENT=3): vel and pres live in HBM from one step to the next and the host copy is only
+  // refreshed on demand (sync_host(): before adaptMesh, a dump, or anything else on the host that reads them).  Needs the ONE edit of
+  // the reference this shim cannot make from outside: Simulation::calcMaxTimestep (15254-15305) reads the host velocity through
+  // findMaxU (15259) every step, so the time loop must call cup3d_hip::calcMaxTimestep(simulation, mirror) instead -- the same
+  // function with the maximum taken on the device.  Obstacle-free pipelines only: ComputeForces reads the
+  // host fields every step (12250-12495), so with obstacles the mode falls back to `across_steps`.
+  bool device_led = false;
+  bool dev_current = false;  // the device copies of vel and pres are newer than the host's
+  void invalidate() { host_vel_clean = host_pres_clean = false; dev_current = false; }
+  void sync_host() {
+    if (!dev_current) return;
+    download(CUP3D_FIELD_VEL);
+    download(CUP3D_FIELD_PRES);
+    dev_current = false;
+    host_vel_clean = host_pres_clean = true;
+  }
   void upload(int field) {
     ensure();
     const std::vector<Info> &I = infos(field);
@@ -278,7 +293,7 @@ public:
   void operator()(const Real dt) override {
     (void)dt;  // KernelAdvectDiffuse reads sim.dt (9465), which advance() passes as dt
     dev.handle();  // (re)builds the mirror when the block list changed, which drops the clean flags
-    if (!(dev.across_steps && dev.host_vel_clean)) dev.upload(CUP3D_FIELD_VEL);
+    if (!(dev.dev_current || (dev.across_steps && dev.host_vel_clean))) dev.upload(CUP3D_FIELD_VEL);
     dev.host_vel_clean = false;  // the device is about to move on
     const double uinf[3] = {sim.uinf[0], sim.uinf[1], sim.uinf[2]};
     CUP3D_HIP_CALL(cup3d_advect_diffuse(dev.handle(), sim.dt, sim.nu, uinf));
@@ -407,9 +422,15 @@ public:
     if (!dev.vel_on_device) dev.upload(CUP3D_FIELD_VEL);
     else if (obstacles) dev.upload_obstacle_blocks(CUP3D_FIELD_VEL);  // what UpdateObstacles / Penalization changed on the host
     dev.vel_on_device = false;
-    if (!(dev.across_steps && dev.host_pres_clean)) dev.upload(CUP3D_FIELD_PRES);
+    if (!(dev.dev_current || (dev.across_steps && dev.host_pres_clean))) dev.upload(CUP3D_FIELD_PRES);
     const cup3d_poisson_params p = poisson_params(sim);
     CUP3D_HIP_CALL(cup3d_pressure_project(dev.handle(), dt, sim.step, &p, &last));
+    if (dev.device_led && !obstacles) {  // nothing comes down: the next step starts from the device copies (see DeviceMirror::device_led)
+      dev.dev_current = true;
+      dev.host_vel_clean = dev.host_pres_clean = false;
+      return;
+    }
+    dev.dev_current = false;
     dev.download(CUP3D_FIELD_VEL);
     dev.download(CUP3D_FIELD_PRES);
     dev.host_vel_clean = dev.host_pres_clean = true;
@@ -469,6 +490,7 @@ inline Installed install(SimulationData &sim, int resident = -1) {
   }
   r.mirror->resident = resident != 0 && safe;
   r.mirror->across_steps = resident >= 2 && safe;
+  r.mirror->device_led = resident >= 3 && safe;
   for (auto &op : sim.pipeline) {
     if (std::dynamic_pointer_cast<AdvectionDiffusion>(op)) {
       r.advdiff = std::make_shared<AdvectionDiffusionHIP>(sim, r.mirror);
@@ -488,6 +510,58 @@ inline Installed install(SimulationData &sim, int resident = -1) {
     }
   }
   return r;
+}
+
+// Simulation::calcMaxTimestep (main.cpp:15254-15305) with findMaxU (8603-8623, incl. its MAX all-reduce) on the device: what the
+// time loop calls instead of simulation.calcMaxTimestep() in device-led mode (DeviceMirror::device_led).  The expressions are the
+// reference's, compiled by the same host compiler; cup3d_max_u is exact (a maximum), so dt and coefU are the reference's bits.
+inline Real calcMaxTimestep(Simulation &S, DeviceMirror &dev) {
+  SimulationData &sim = S.sim;
+  if (!dev.dev_current) return S.calcMaxTimestep();  // the host copy is the current one (first step, after an adaptation, with obstacles)
+  const Real dt_old = sim.dt;
+  sim.dt_old = sim.dt;
+  const Real hMin = sim.hmin;
+  Real CFL = sim.CFL;
+  const double uinf[3] = {sim.uinf[0], sim.uinf[1], sim.uinf[2]};
+  double umax = 0;
+  CUP3D_HIP_CALL(cup3d_max_u(dev.handle(), uinf, &umax));
+  sim.uMax_measured = umax;
+  if (sim.uMax_measured > sim.uMax_allowed) {
+    if (sim.rank == 0) fprintf(stderr, "maxU = %g exceeded uMax_allowed = %g. Aborting...\n", (double)sim.uMax_measured, (double)sim.uMax_allowed);
+    MPI_Abort(sim.comm, 1);
+  }
+  if (CFL > 0) {
+    const Real dtDiffusion = (sim.implicitDiffusion && sim.step > 10) ? 0.1 : (1.0 / 6.0) * hMin * hMin / (sim.nu + (1.0 / 6.0) * hMin * sim.uMax_measured);
+    const Real dtAdvection = hMin / (sim.uMax_measured + 1e-8);
+    if (sim.step < sim.rampup) {
+      const Real x = sim.step / (Real)sim.rampup;
+      const Real rampCFL = std::exp(std::log(1e-3) * (1 - x) + std::log(CFL) * x);
+      sim.dt = std::min(dtDiffusion, rampCFL * dtAdvection);
+    } else
+      sim.dt = std::min(dtDiffusion, CFL * dtAdvection);
+  } else {
+    CFL = (sim.uMax_measured + 1e-8) * sim.dt / hMin;
+  }
+  if (sim.dt <= 0) {
+    fprintf(stderr, "dt <= 0. CFL=%f, hMin=%f, sim.uMax_measured=%f. Aborting...\n", (double)CFL, (double)hMin, (double)sim.uMax_measured);
+    MPI_Abort(sim.comm, 1);
+  }
+  if (sim.DLM > 0) sim.lambda = sim.DLM / sim.dt;
+  if (sim.rank == 0) printf("main.cpp: step: %d, time: %f\n", sim.step, sim.time);
+  if (sim.step > sim.step_2nd_start) {
+    const Real a = dt_old, b = sim.dt;
+    const Real c1 = -(a + b) / (a * b), c2 = b / (a + b) / a;
+    sim.coefU[0] = -b * (c1 + c2);
+    sim.coefU[1] = b * c1;
+    sim.coefU[2] = b * c2;
+  }
+  return sim.dt;
+}
+// ... and the companion of Simulation::advance (15306-15326) in that mode: adaptMesh (15314) and dump (15307-15313) read the host fields
+inline bool advance(Simulation &S, DeviceMirror &dev, const Real dt) {
+  SimulationData &sim = S.sim;
+  if ((sim.dumpTime > 0 && sim.time >= sim.nextDumpTime) || sim.step % 20 == 0 || sim.step < 10) dev.sync_host();
+  return S.advance(dt);
 }
 
 }  // namespace cup3d_hip

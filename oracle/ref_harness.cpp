@@ -271,7 +271,8 @@ int main(int argc, char **argv) {
 #ifdef CUP3D_WITH_HIP
       static cup3d_hip::Installed inst;
       /* `hip resident`: vel stays in HBM between the two operators; `hip resident2`: also across steps (DeviceMirror::across_steps) */
-      inst = cup3d_hip::install(sd, v == "resident2" ? 2 : (v == "resident" ? 1 : -1));
+      /* `hip resident3`: device-led -- vel / pres never come down between steps; `op steps` then uses cup3d_hip::calcMaxTimestep / advance */
+      inst = cup3d_hip::install(sd, v == "resident3" ? 3 : (v == "resident2" ? 2 : (v == "resident" ? 1 : -1)));
       hip_adv = inst.advdiff; hip_proj = inst.projection;
       hip_mirror = inst.mirror;
 #else
@@ -466,10 +467,21 @@ int main(int argc, char **argv) {
         else if (op == "forcing") { ExternalForcing f(sd); f(arg); }
         else if (op == "steps") {
           for (int n = 0; n < (int)arg; n++) {
+#ifdef CUP3D_WITH_HIP
+            if (hip_mirror && hip_mirror->device_led) {  /* the time loop of the one-edit integration */
+              const Real dt = cup3d_hip::calcMaxTimestep(*S, *hip_mirror);
+              cup3d_hip::advance(*S, *hip_mirror, dt);
+              value = dt;
+              continue;
+            }
+#endif
             const Real dt = S->calcMaxTimestep();
             S->advance(dt);
             value = dt;
           }
+#ifdef CUP3D_WITH_HIP
+          if (hip_mirror) hip_mirror->sync_host();  /* whatever the script does next (dump, tables, another op) sees the host fields */
+#endif
         } else { fprintf(stderr, "ref_tool: unknown op %s\n", op.c_str()); exit(2); }
         const double t1 = now();
         printf("REF %s seconds=%.6f iters=%ld value=%.17g\n", op.c_str(), t1 - t0, cup3d_stub_iallreduce7, value);

@@ -256,3 +256,25 @@ def test_resident_mode_with_an_obstacle(tmp_path, implicit):
         assert np.abs(res["cpu"][0] - res[tag][0]).max() <= 1e-6 * change, tag
         assert np.abs(res["cpu"][1] - res[tag][1]).max() <= 1e-6 * np.abs(res["cpu"][1]).max(), tag
         assert np.array_equal(res["cpu"][2], res[tag][2]), tag    # penalisation force / torque: host operator on identical inputs
+
+
+@pytest.mark.parametrize("bc", [("wall", "wall", "wall"), ("freespace", "periodic", "wall")])
+def test_device_led_time_loop_without_findmaxu_on_the_host(tmp_path, bc):
+    """`hip resident3` (DeviceMirror::device_led): vel and pres never come down between steps; the time loop calls
+    cup3d_hip::calcMaxTimestep -- Simulation::calcMaxTimestep (main.cpp:15254-15305) with findMaxU (15259) taken on the device -- and
+    cup3d_hip::advance, which refreshes the host copy only before adaptMesh / a dump.  Same device operators, same dt expressions, an
+    exact maximum: the 24-step trajectory (across the adaptMesh calls of steps 0-9 and 20, frozen mesh) is BIT-IDENTICAL to
+    `hip resident2`, dt for dt and field for field, and the reference's CPU run stays as close as in the other modes."""
+    bpd, lmax, lstart, nsteps = (1, 1, 1), 3, 2, 24
+    args = O.ref_args(bpd, lmax, lstart, 2 * np.pi, bc, nu=0.01, cfl=0.3, extra=["-rampup", "3"])
+    tail = ["zero chi", f"rep {nsteps}", "op steps 1", "rep 1", "dump vel v.bin", "dump pres p.bin"]
+    res = {}
+    for tag, tool, pre in (("cpu", O.REF_TOOL, []), ("r2", REF_HIP, ["hip resident2"]), ("r3", REF_HIP, ["hip resident3"])):
+        d = tmp_path / tag
+        d.mkdir()
+        rec = run(tool, pre + tail, args, str(d))
+        res[tag] = ([r["value"] for r in rec if r["op"] == "steps"], O.read_blocks(str(d / "v.bin"), 64, 3), O.read_blocks(str(d / "p.bin"), 64, 1))
+    assert len(res["r3"][0]) == nsteps and res["r3"][0] == res["r2"][0]                       # every dt, bit for bit
+    assert np.array_equal(res["r3"][1], res["r2"][1]) and np.array_equal(res["r3"][2], res["r2"][2])
+    assert np.abs(res["cpu"][1] - res["r3"][1]).max() <= 5e-3 * max(1.0, np.abs(res["cpu"][1]).max())
+    assert max(abs(a - b) / a for a, b in zip(res["cpu"][0], res["r3"][0])) <= 1e-3

@@ -230,6 +230,28 @@ def test_golden_preconditioner(golden_dir, name, block_solver):
     assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("name", FIELD_CASES)
+def test_reference_association_block_cg_is_the_closer_one(golden_dir, name):
+    """block_solver 2 exists to be CLOSER to the reference's block CG than the production kernel: it keeps the reference's association (no
+    FMA contraction), so only the order of the 512-term sums differs from the CPU.  Both kernels run the same number of CG iterations on
+    almost every block; measured against the reference's z, the uncontracted one is at rounding level (1e-9 of max|z|: a block whose
+    residual grazes the stopping criterion may take one iteration more or less -- the CG's own truncation, 1e-7 -- on either side), and it
+    is never farther away than the contracted one by more than that."""
+    z = load(golden_dir, name)
+    err = {}
+    for bs in (0, 2):
+        sim = make_sim(z, blockSolver=bs)
+        sim.upload("pres", sim.grid.to_blocks(z["pres_in"]))
+        cu.makePoissonSolver(sim).preconditioner()
+        d = np.abs(sim.download("pres") - z["precond"]).reshape(sim.nblocks, -1).max(axis=1) / np.abs(z["precond"]).max()
+        err[bs] = d
+    print(f"{name}: block CG vs the reference's z, per block: FMA-contracted median {np.median(err[0]):.1e} max {err[0].max():.1e}; "
+          f"reference association median {np.median(err[2]):.1e} max {err[2].max():.1e}")
+    assert np.median(err[2]) <= 1e-9                       # the typical block: rounding level
+    assert np.median(err[2]) <= np.median(err[0]) + 1e-12  # ... and not farther than the contracted kernel's
+    assert err[2].max() <= 1e-6 and err[0].max() <= 2e-5
+
+
 @pytest.mark.parametrize("block_solver", [0, 1, 2, 4])
 @pytest.mark.parametrize("name", FIELD_CASES)
 def test_golden_poisson_solve(golden_dir, name, block_solver):
