@@ -430,7 +430,10 @@ def main():
         step_s = sec / a.steps
         cells = float(a.size) ** 3
         modes = {}
-        for mode, up, down in (("round_trip", 2 * gb + gb / 3, 4 * gb + gb / 3), ("resident", gb + gb / 3, gb + gb / 3), ("resident_across_steps", 0.0, gb + gb / 3)):
+        # device_led (CUP3D_HIP_RESIDENT=3 + cup3d_hip::calcMaxTimestep / advance in the time loop): vel and pres come down only before
+        # adaptMesh, i.e. every 20th step (main.cpp:15314), and go up again only if the mesh changed
+        for mode, up, down in (("round_trip", 2 * gb + gb / 3, 4 * gb + gb / 3), ("resident", gb + gb / 3, gb + gb / 3), ("resident_across_steps", 0.0, gb + gb / 3),
+                               ("device_led", 0.0, (gb + gb / 3) / 20)):
             t = step_s + up / rates["upload"] + down / rates["download"]
             modes[mode] = {"GB_up_per_step": round(up, 2), "GB_down_per_step": round(down, 2), "Mcell_updates_per_s": round(cells / t / 1e6, 2)}
         a.pcie = {"upload_GBps": round(rates["upload"], 1), "download_GBps": round(rates["download"], 1), "shim_modes": modes,
