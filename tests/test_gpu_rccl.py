@@ -3,7 +3,7 @@
 On a box with >= 2 devices: `python bench.py --gpus 2` (no launcher environment: bench.py re-executes itself under
 torch.distributed.run) must print ONE JSON line whose partition-independent checksum equals the CPU oracle's constant -- the halo
 exchange (ncclSend / ncclRecv of packed face slabs, comm.hip; reference: SynchronizerMPI_AMR::sync, main.cpp:2356-2405) carried the
-right bits -- and whose BiCGSTAB iteration counts stay within 10 % of the one-process run of the same command (the all-reduces,
+right bits -- and whose BiCGSTAB iteration counts stay within the erratic-case band of the one-process run of the same command (the all-reduces,
 main.cpp:14486 / 14546, only reorder the sums).  On a one-GPU box those tests are skipped and the refusal path is checked instead."""
 import json
 import os
@@ -58,6 +58,10 @@ def test_bench_over_rccl_matches_the_one_process_run(n):
     assert rn["config"]["checksum"]["ok"] is True
     assert rn["config"]["checksum"]["exact_field"]["value"] == r1["config"]["checksum"]["exact_field"]["value"]
     assert rn["config"]["checksum"]["taylor_green"]["value"] == r1["config"]["checksum"]["taylor_green"]["value"]
-    for a, b in zip(r1["config"]["bicgstab_iters_by_step"], rn["config"]["bicgstab_iters_by_step"]):
-        assert abs(a - b) <= 0.1 * a + 2, (r1["config"]["bicgstab_iters_by_step"], rn["config"]["bicgstab_iters_by_step"])
+    # the all-reduces change the order of the dot-product sums: on this all-wall workload BiCGSTAB's count moves by tens of per cent with
+    # the rounding alone (tests/test_gpu_parity.py::iters_band) -- a factor of 1.5 either way per step, 25 % on the sum
+    i1, im = r1["config"]["bicgstab_iters_by_step"], rn["config"]["bicgstab_iters_by_step"]
+    for a, b in zip(i1, im):
+        assert b <= 1.5 * a + 5 and a <= 1.5 * b + 5, (i1, im)
+    assert abs(sum(i1) - sum(im)) <= 0.25 * sum(i1) + 5, (i1, im)
     assert rn["config"]["communication"]["halo_exchanges_per_iteration"] > 0
