@@ -145,6 +145,11 @@ int cup3d_device_synchronize(void);
 /* RCCL communicator owned by the library (replaces sim.comm's role on the hot path:
  * halo Isend/Irecv 2370/2402 and the Allreduce/Iallreduce sites 8620, 9295, 14442,
  * 14486, 14546, 14584, 15123).  id is the 128-byte ncclUniqueId from rank 0. */
+/* COLLECTIVES AND ERRORS.  On a grid that spans several ranks every operator entry point is a collective: all ranks call it, in the
+ * same order (the library issues its RCCL calls from one stream per rank in that order).  A non-zero status on ONE rank -- a bad
+ * argument, a HIP error -- leaves the others inside the collective, exactly as a failing rank does under the reference's MPI: treat any
+ * non-zero status as fatal for the job, as the reference does (MPI_Abort at 8444, 15265, 15289; the C++ shim's CUP3D_HIP_CALL and
+ * torch.distributed.run's process group do that for their hosts).  There is no rank-local error recovery. */
 int cup3d_comm_unique_id(void *id128);
 int cup3d_comm_init(int rank, int nranks, const void *id128);
 int cup3d_comm_finalize(void);
