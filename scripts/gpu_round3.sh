@@ -97,4 +97,24 @@ PY
     done
     rm -rf $OUT/pmc_$C
   done; fi
+if has pmcsq; then echo "== rocprofv3 SQ counters of the fused kernels with the LHS inside (256^3, one pressure projection)"
+  rm -f $OUT/pmc_fused_kernels_sq_256cubed.txt
+  for SET in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+    TAGC=$(echo $SET | cut -d" " -f1)
+    ( cd /tmp && timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $ROOT/$OUT/pmc4_$TAGC -o p -- python $ROOT/scripts/kernel_probe.py one --size 256 --kernel solve > $ROOT/$OUT/pmc4_$TAGC.log 2>&1 )
+    for f in $(find $OUT/pmc4_$TAGC -name "*counter_collection.csv" | head -1); do python - "$f" <<'PY' | tee -a $OUT/pmc_fused_kernels_sq_256cubed.txt
+import csv, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"][:52]
+    if "k_loop1_cg" in k or "k_loop2_cg" in k or "k_precond<" in k or "k_lhs" in k:
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in sorted(acc.items()):
+    for c, v in sorted(d.items()):
+        print(k, c, "launches", len(v), "mean", round(sum(v) / len(v), 1))
+PY
+    done
+    tail -2 $OUT/pmc4_$TAGC.log
+    rm -rf $OUT/pmc4_$TAGC
+  done; fi
 echo "== done"
