@@ -117,8 +117,8 @@ def advdiff_checksums(sim, a, dist, world):
         adv(checksum_dt(a.size))
         mine = sim.checksum("vel")
         if dist is not None:
-            parts = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
-            dist.all_gather(parts, torch.tensor([mine - (1 << 64) if mine >= (1 << 63) else mine], dtype=torch.int64, device="cuda"))
+            parts = [torch.zeros(1, dtype=torch.int64, device=a.tdev) for _ in range(world)]
+            dist.all_gather(parts, torch.tensor([mine - (1 << 64) if mine >= (1 << 63) else mine], dtype=torch.int64, device=a.tdev))
             mine = sum(int(p.item()) for p in parts) % (1 << 64)
         exp = expected.get(key)
         out[key] = {"value": mine, "expected": exp, "ok": (mine == exp) if exp is not None else None}
@@ -127,14 +127,64 @@ def advdiff_checksums(sim, a, dist, world):
     return out
 
 
-def relaunch_under_torchrun(n):
+def install_host_transport(dist, rank, world):
+    """--transport host: the library's exchanges (face slabs, scalar all-reduces) staged through host memory and carried by
+    torch.distributed's gloo backend -- cup3d_debug_host_transport of libcup3d_hip_testing.so (include/cup3d_hip_testing.h), the same
+    stand-in for RCCL the MPI-rank tests of the C++ shim use.  Everything else is the production multi-process path of this file."""
+    import torch
+    from cup3d_amd.capi import check, lib
+    EXCH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long))
+    ARED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+
+    class Transport(C.Structure):
+        _fields_ = [("ctx", C.c_void_p), ("exchange", EXCH), ("allreduce", ARED)]
+
+    def exchange(ctx, sb, so, sn, rb, ro, rn):
+        try:
+            reqs, recvs = [], []
+            for p in range(world):
+                if rn[p]:
+                    t = torch.empty(rn[p], dtype=torch.uint8)
+                    recvs.append((t, ro[p]))
+                    reqs.append(dist.irecv(t, src=p))
+            for p in range(world):
+                if sn[p]:
+                    src = np.ctypeslib.as_array((C.c_ubyte * sn[p]).from_address(sb + so[p]))
+                    reqs.append(dist.isend(torch.from_numpy(src.copy()), dst=p))
+            for r in reqs:
+                r.wait()
+            for t, off in recvs:
+                C.memmove(rb + off, t.numpy().ctypes.data, t.numel())
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            sys.stderr.write(f"bench: host transport exchange failed on rank {rank}: {e}\n")
+            return 1
+
+    def allreduce(ctx, buf, n, is_max):
+        try:
+            t = torch.tensor([buf[i] for i in range(n)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if is_max else dist.ReduceOp.SUM)
+            for i in range(n):
+                buf[i] = float(t[i])
+            return 0
+        except Exception as e:
+            sys.stderr.write(f"bench: host transport all-reduce failed on rank {rank}: {e}\n")
+            return 1
+
+    tr = Transport(None, EXCH(exchange), ARED(allreduce))
+    lib().cup3d_debug_host_transport.argtypes = [C.c_int, C.c_int, C.POINTER(Transport)]
+    check(lib().cup3d_debug_host_transport(rank, world, C.byref(tr)))
+    return tr
+
+
+def relaunch_under_torchrun(n, need_devices=True):
     """`python bench.py --gpus N` (N > 1) as the driver types it: one process per GPU via torch.distributed.run, rendezvous on
     127.0.0.1; rank 0's JSON line is the only thing on stdout."""
     import socket
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and need_devices:
         sys.stderr.write(f"bench.py --gpus {n} needs {n} devices; {have} visible on this host\n")
         sys.exit(2)
     with socket.socket() as so:
@@ -282,6 +332,10 @@ def main():
     ap.add_argument("--stencil-only", action="store_true", help="BASELINE configs[1]: periodic, advect-diffuse only")
     ap.add_argument("--block-solver", type=int, default=0, help="0: block CG as in the reference, 1: direct block solve, 5: multigrid V-cycle")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed region with the other block solver")
+    ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
+                    help="what carries the library's exchanges over ranks.  rccl: production (one device per rank).  host: the library's "
+                         "host-memory TEST transport over torch.distributed/gloo (libcup3d_hip_testing.so): lets --gpus N run on fewer than N "
+                         "devices to check the multi-process path and config.checksum; its rate says nothing about scaling")
     ap.add_argument("--no-checksum", action="store_true", help="skip config.checksum (one extra AdvectionDiffusion on two fields before the timed region)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host<->device transfer measurement behind `pcie_inclusive`")
     ap.add_argument("--debug-option", action="append", help="name=value for cup3d_debug_set_option (tuning scans)")
@@ -295,7 +349,7 @@ def main():
     ap.add_argument("--amr-levels", type=int, default=3, help="--amr: number of levels of the final mesh")
     ap.add_argument("--amr-fraction", type=float, default=0.3, help="--amr: fraction of the blocks refined per pass")
     a = ap.parse_args()
-    if a.no_fuse or a.debug_option or a.block_solver in (3, 4):
+    if a.no_fuse or a.debug_option or a.block_solver in (3, 4) or a.transport == "host":
         os.environ["CUP3D_HIP_FLAVOUR"] = "testing"   # A/B switches live in libcup3d_hip_testing.so only; everything else times the release build
     if a.amr:
         if int(os.environ.get("WORLD_SIZE", "1")) > 1:
@@ -311,15 +365,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
-            return relaunch_under_torchrun(a.gpus)
+            return relaunch_under_torchrun(a.gpus, a.transport == "rccl")
         a.gpus = world
 
     import torch
     import cup3d_amd as cu
     from cup3d_amd.capi import ProfileEntry, RunStats, check, lib
 
-    torch.cuda.set_device(local_rank)
-    cu.device_init(local_rank)
+    ndev = max(1, torch.cuda.device_count())
+    if a.transport == "rccl" and local_rank >= ndev:
+        sys.exit(f"bench.py: rank {rank} has no device (RCCL wants one per rank; {ndev} visible)")
+    local_dev = local_rank % ndev   # host transport: ranks may share a device
+    torch.cuda.set_device(local_dev)
+    cu.device_init(local_dev)
     if a.no_fuse:
         check(lib().cup3d_debug_set_option(b"no_fuse", 1))
     for opt in (a.debug_option or []):   # tuning scans: --debug-option name=value (cup3d_debug_set_option)
@@ -329,17 +387,22 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        # bootstrap the library's own RCCL communicator with rank 0's unique id
-        idbuf = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            raw = (C.c_ubyte * 128)()
-            check(lib().cup3d_comm_unique_id(raw))
-            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
-        idbuf = idbuf.cuda()
-        dist.broadcast(idbuf, 0)
-        raw = (C.c_ubyte * 128)(*idbuf.cpu().tolist())
-        check(lib().cup3d_comm_init(rank, world, raw))
+        if a.transport == "host":
+            dist.init_process_group(backend="gloo")
+            a.host_transport = install_host_transport(dist, rank, world)   # keeps the ctypes callbacks alive
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            # bootstrap the library's own RCCL communicator with rank 0's unique id
+            idbuf = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                raw = (C.c_ubyte * 128)()
+                check(lib().cup3d_comm_unique_id(raw))
+                idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+            idbuf = idbuf.cuda()
+            dist.broadcast(idbuf, 0)
+            raw = (C.c_ubyte * 128)(*idbuf.cpu().tolist())
+            check(lib().cup3d_comm_init(rank, world, raw))
+    a.tdev = "cpu" if a.transport == "host" else "cuda"   # where torch.distributed's own tensors live (gloo / nccl)
 
     nb1 = a.size // 8
     assert nb1 >= 2 and 8 * nb1 == a.size, "--size must be a multiple of 8"
@@ -399,7 +462,7 @@ def main():
               "host_wait_fraction": round(st.host_wait_seconds / sec, 4)}
     a.diffusion_iters = round(float(np.mean(diff_iters[-a.steps:])), 2) if diff_iters else None
     if dist is not None:
-        t = torch.tensor([sec], dtype=torch.float64, device="cuda")
+        t = torch.tensor([sec], dtype=torch.float64, device=a.tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         sec = float(t.item())
     ents = (ProfileEntry * 64)()
@@ -463,7 +526,7 @@ def main():
             fence()
             sec2 = time.perf_counter() - t0
             if dist is not None:
-                t = torch.tensor([sec2], dtype=torch.float64, device="cuda")
+                t = torch.tensor([sec2], dtype=torch.float64, device=a.tdev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 sec2 = float(t.item())
             alts[solver] = {"block_preconditioner": SOLVERS[solver], "value": round(float(a.size) ** 3 * a.steps / sec2 / 1e6, 2), "unit": "Mcell-updates/s",
@@ -474,6 +537,8 @@ def main():
     if rank == 0:
         report(a, sim, prof, sec, main_iters, world, alt)
     if dist is not None:
+        if a.transport == "host":
+            lib().cup3d_debug_host_transport(0, 1, None)
         lib().cup3d_comm_finalize()
         dist.destroy_process_group()
     if invalid:
@@ -564,7 +629,9 @@ def report(a, sim, prof, sec, iters, world, alt=None):
                    "helmholtz_iters_per_step (3 solves)": getattr(a, "diffusion_iters", None),
                    "block_preconditioner": {0: "block CG (reference algorithm)", 1: "direct block solve (fast diagonalisation)",
                                             5: "geometric multigrid V-cycle (not the reference's)"}.get(a.block_solver, str(a.block_solver)),
-                   "library": os.path.basename(getattr(sys.modules.get("cup3d_amd.capi"), "LIB_PATH", "libcup3d_hip.so"))},
+                   "library": os.path.basename(getattr(sys.modules.get("cup3d_amd.capi"), "LIB_PATH", "libcup3d_hip.so")),
+                   "transport": "rccl" if getattr(a, "transport", "rccl") == "rccl" else
+                                "host-memory TEST transport over gloo, ranks may share a device: checks the multi-process path and the checksum, NOT a scaling measurement"},
         "roofline": ({k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": dominant["kernel"]})
         if dominant else None,
         "kernels": kernels,

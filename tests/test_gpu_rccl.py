@@ -65,3 +65,29 @@ def test_bench_over_rccl_matches_the_one_process_run(n):
         assert b <= 1.5 * a + 5 and a <= 1.5 * b + 5, (i1, im)
     assert abs(sum(i1) - sum(im)) <= 0.25 * sum(i1) + 5, (i1, im)
     assert rn["config"]["communication"]["halo_exchanges_per_iteration"] > 0
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_multi_process_path_over_the_host_transport(n):
+    """`bench.py --gpus N --transport host`: bench.py's own multi-process path -- it re-executes itself under torch.distributed.run, every
+    rank builds its Hilbert range of the grid, the checksum pass and the timed steps run with halo exchanges and all-reduced BiCGSTAB
+    scalars -- on ONE GPU: the library's exchanges are staged through host memory and carried by gloo (cup3d_debug_host_transport)
+    where production uses RCCL.  The partition-independent checksums must equal the CPU oracle's constants on 2 and on 3 ranks (an
+    odd split of the Hilbert curve), and the iteration counts stay in the band of the one-process run."""
+    args = ("--size", "128", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-alt", "--no-pcie")
+    one = run_bench(*args)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    many = run_bench("--gpus", str(n), "--transport", "host", *args, timeout=800)
+    assert many.returncode == 0, many.stderr.decode()[-3000:]
+    lines = [l for l in many.stdout.decode().strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, many.stdout.decode()[-2000:]
+    r1, rn = json.loads(one.stdout.decode().strip()), json.loads(lines[0])
+    assert rn["n_gpus"] == n and rn["config"]["communication"]["rccl_ranks"] == n and "host-memory" in rn["config"]["transport"]
+    ck1, ckn = r1["config"]["checksum"], rn["config"]["checksum"]
+    assert ckn["ok"] is True and ckn["exact_field"]["value"] == ck1["exact_field"]["value"] == ckn["exact_field"]["expected"]
+    assert ckn["taylor_green"]["value"] == ck1["taylor_green"]["value"]
+    i1, im = r1["config"]["bicgstab_iters_by_step"], rn["config"]["bicgstab_iters_by_step"]
+    for a, b in zip(i1, im):
+        assert b <= 1.5 * a + 5 and a <= 1.5 * b + 5, (i1, im)
+    assert rn["config"]["communication"]["halo_exchanges_per_iteration"] >= 2 and rn["config"]["communication"]["allreduces_per_iteration"] >= 2
