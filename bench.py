@@ -423,8 +423,11 @@ def main():
     adv = S.pipeline[0]  # AdvectionDiffusion, or AdvectionDiffusionImplicit with --implicit-diffusion
     iters, diff_iters = [], []
 
+    umax = []
+
     def one_step():
         dt = S.calcMaxTimestep()
+        umax.append(float(sim.uMax_measured))   # findMaxU of the state this step starts from (all-reduced MAX: the same on every rank)
         if a.stencil_only:
             adv(dt)
             sim.step += 1
@@ -453,6 +456,7 @@ def main():
     fence()
     sec = time.perf_counter() - t0
     main_iters = list(iters)
+    a.umax_by_step = umax[-a.steps:] + [float(cu.findMaxU(sim))]
     st = RunStats()
     lib().cup3d_stats_read(C.byref(st))
     nit = max(1, st.solver_iterations)
@@ -622,6 +626,9 @@ def report(a, sim, prof, sec, iters, world, alt=None):
                    "cells": int(cells), "blocks": int(cells // 512), "block": "8^3", "partition": f"hilbert-range x{world}",
                    "bicgstab_iters_per_step": round(float(np.mean(iters)), 2) if iters else None,
                    "bicgstab_iters_by_step": [int(i) for i in iters] if iters else None,
+                   # max|u| entering every timed step and after the last one: a solver-level signal that must not depend on the number
+                   # of ranks beyond the stopping tolerance of the projection (the checksum below covers the stencil path bit for bit)
+                   "umax_by_step": getattr(a, "umax_by_step", None),
                    "ref_iters_per_step": ref_iters(a),
                    "checksum": getattr(a, "checksum", None),
                    "communication": getattr(a, "comm", None),

@@ -61,9 +61,9 @@ def test_bench_over_rccl_matches_the_one_process_run(n):
     # the all-reduces change the order of the dot-product sums: on this all-wall workload BiCGSTAB's count moves by tens of per cent with
     # the rounding alone (tests/test_gpu_parity.py::iters_band) -- a factor of 1.5 either way per step, 25 % on the sum
     i1, im = r1["config"]["bicgstab_iters_by_step"], rn["config"]["bicgstab_iters_by_step"]
-    for a, b in zip(i1, im):
-        assert b <= 1.5 * a + 5 and a <= 1.5 * b + 5, (i1, im)
-    assert abs(sum(i1) - sum(im)) <= 0.25 * sum(i1) + 5, (i1, im)
+    u1, un = r1["config"]["umax_by_step"], rn["config"]["umax_by_step"]
+    assert max(abs(a - b) / a for a, b in zip(u1, un)) <= 2e-3, (u1, un)   # the projections agree to their stopping tolerance
+    assert all(5 < b < 400 for b in im), (i1, im)                            # (the count itself is erratic on this workload)
     assert rn["config"]["communication"]["halo_exchanges_per_iteration"] > 0
 
 
@@ -87,7 +87,12 @@ def test_bench_multi_process_path_over_the_host_transport(n):
     ck1, ckn = r1["config"]["checksum"], rn["config"]["checksum"]
     assert ckn["ok"] is True and ckn["exact_field"]["value"] == ck1["exact_field"]["value"] == ckn["exact_field"]["expected"]
     assert ckn["taylor_green"]["value"] == ck1["taylor_green"]["value"]
+    # the solver over ranks: both runs project to the same stopping tolerance, so max|u| along the run agrees to ~1e-4; the iteration
+    # COUNT of this all-wall workload is not a usable signal at 128^3 (131 / 105 on one rank, 93 / 53 on two: the count at which the
+    # residual first dips below the tolerance moves by a factor of two with the order of the sums)
+    u1, un = r1["config"]["umax_by_step"], rn["config"]["umax_by_step"]
+    assert len(u1) == len(un) == 3 and max(abs(a - b) / a for a, b in zip(u1, un)) <= 2e-3, (u1, un)
     i1, im = r1["config"]["bicgstab_iters_by_step"], rn["config"]["bicgstab_iters_by_step"]
-    for a, b in zip(i1, im):
-        assert b <= 1.5 * a + 5 and a <= 1.5 * b + 5, (i1, im)
+    assert all(5 < b < 400 for b in im), (i1, im)
+    print(f"{n} ranks over the host transport: iterations {im} (one process: {i1}); max|u| {un} vs {u1}")
     assert rn["config"]["communication"]["halo_exchanges_per_iteration"] >= 2 and rn["config"]["communication"]["allreduces_per_iteration"] >= 2
