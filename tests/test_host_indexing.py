@@ -24,6 +24,25 @@ def test_every_header_symbol_is_exported():
         assert getattr(L, n) is not None
 
 
+def test_both_builds_export_the_boundary_and_the_test_support_symbols():
+    """libcup3d_hip.so (release) and libcup3d_hip_testing.so export every symbol of include/cup3d_hip.h AND of include/cup3d_hip_testing.h
+    (the release build's test-support entry points exist and refuse: CUP3D_ESTATE), and capi.DEBUG_SIGNATURES lists exactly the latter."""
+    import re
+    from cup3d_amd.capi import DEBUG_SIGNATURES
+    inc = os.path.join(os.path.dirname(__file__), "..", "include")
+    names = set(re.findall(r"\b(cup3d_[a-z0-9_]+)\s*\(", open(os.path.join(inc, "cup3d_hip.h")).read()))
+    dbg = set(re.findall(r"\b(cup3d_debug_[a-z0-9_]+)\s*\(", open(os.path.join(inc, "cup3d_hip_testing.h")).read()))
+    assert dbg == set(DEBUG_SIGNATURES), dbg ^ set(DEBUG_SIGNATURES)
+    for so in ("libcup3d_hip.so", "libcup3d_hip_testing.so"):
+        lib = C.CDLL(os.path.join(os.path.dirname(__file__), "..", "cup3d_amd", so))
+        for n in names | dbg:
+            assert getattr(lib, n) is not None, (so, n)
+    rel = C.CDLL(os.path.join(os.path.dirname(__file__), "..", "cup3d_amd", "libcup3d_hip.so"))
+    rel.cup3d_debug_set_option.argtypes = [C.c_char_p, C.c_int]
+    assert rel.cup3d_debug_set_option(b"no_fuse", 1) == -5 and rel.cup3d_debug_set_option(b"no_fuse", 0) == 0   # no GPU needed to refuse
+    assert rel.cup3d_debug_virtual_comm(2) == -5
+
+
 def test_sfc_tables_match_reference(golden_dir):
     z = np.load(os.path.join(golden_dir, "sfc_tables.npz"))
     for key in z.files:
