@@ -156,6 +156,7 @@ DEBUG_SIGNATURES = {
     "cup3d_debug_host_transport": (C.c_int, [C.c_int, C.c_int, _vp]),
     "cup3d_debug_wave_sum": (C.c_int, [_dp, _dp]),
     "cup3d_debug_block_cg_iterations": (C.c_int, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "cup3d_debug_ctl_step": (C.c_int, [C.c_int, _dp, _dp]),
 }
 
 _lib = None

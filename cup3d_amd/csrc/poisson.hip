@@ -1490,6 +1490,26 @@ int cup3d_debug_block_cg_iterations(cup3d_sim_t *h, long *total, long *nblocks) 
   return CUP3D_OK;
 }
 
+// TEST SUPPORT (no GPU needed): the scalar recurrences of the solver, host side of the one pair of functions the device runs too.
+// io[16] = alpha, beta, omega, r0r_prev, norm, init_norm, min_norm, tol, tol_rel, state, restarts, max_restarts, xcur, xopt, iter, (unused);
+// step 1: totals[2] = q.y, y.y (main.cpp:14493); step 2: totals[7] = r0.r, r0.w, r0.s, r0.z, |r|^2 (norm_1), |r0|^2 (norm_2), |r|^2 (14558-14601)
+int cup3d_debug_ctl_step(int step, double *io, const double *totals) {
+#ifndef CUP3D_TESTING
+  (void)step; (void)io; (void)totals;
+  return not_in_release("cup3d_debug_ctl_step");
+#else
+  if (!io || !totals || (step != 1 && step != 2)) return CUP3D_EINVAL;
+  SolverCtl c;
+  c.alpha = io[0]; c.beta = io[1]; c.omega = io[2]; c.r0r_prev = io[3]; c.norm = io[4]; c.init_norm = io[5]; c.min_norm = io[6];
+  c.tol = io[7]; c.tol_rel = io[8]; c.state = (int)io[9]; c.restarts = (int)io[10]; c.max_restarts = (int)io[11];
+  c.xcur = (int)io[12]; c.xopt = (int)io[13]; c.iter = (int)io[14];
+  if (step == 1) ctl_step1(c, totals); else ctl_step2(c, totals);
+  io[0] = c.alpha; io[1] = c.beta; io[2] = c.omega; io[3] = c.r0r_prev; io[4] = c.norm; io[5] = c.init_norm; io[6] = c.min_norm;
+  io[9] = c.state; io[10] = c.restarts; io[12] = c.xcur; io[13] = c.xopt; io[14] = c.iter;
+  return CUP3D_OK;
+#endif
+}
+
 // TEST SUPPORT: see k_debug_wave_sum (in64 -> out128, host arrays)
 int cup3d_debug_wave_sum(const double *in64, double *out128) {
 #ifndef CUP3D_TESTING

@@ -21,6 +21,10 @@ int cup3d_debug_advdiff_stage(cup3d_sim_t *, int rk, double dt, double nu, const
 int cup3d_debug_amr_slabs(cup3d_sim_t *, int field, int w, double *out);
 int cup3d_debug_wave_sum(const double *in64, double *out128);
 int cup3d_debug_block_cg_iterations(cup3d_sim_t *, long *total, long *nblocks);
+/* the solver's scalar recurrences (SolverCtl, poisson.hip) stepped on the host -- the same functions the device runs; no GPU needed.
+ * io[16] = alpha, beta, omega, r0r_prev, norm, init_norm, min_norm, tol, tol_rel, state (0 run, 1 done, 2 restart), restarts,
+ * max_restarts, xcur, xopt, iter; step 1 takes totals[2] (main.cpp:14493), step 2 totals[7] (14558-14601) */
+int cup3d_debug_ctl_step(int step, double *io, const double *totals);
 
 /* HOST-MEMORY TRANSPORT in RCCL's place: one process per rank as in production, but every exchange of the library (face slabs, ghost
  * blocks, face fluxes, block migration, scalar all-reduces) is staged through host memory and carried by the CALLER's transport --
