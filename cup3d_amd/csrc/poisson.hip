@@ -822,15 +822,14 @@ __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, c
   TileRegs tr;
   if constexpr (FLHS) {  // the tile's loads first, the first plane of the streams right behind them, then the tile goes to LDS
     fx = lhs_fix(L, slot, l, hq);
-    if (L.prio & 4) { tile_issue_own(slot, V.v[WHAT], l, tr); tile_issue_faces(g, slot, V.v[WHAT], L.halo, l, tr); }  // A/B: both groups first
-    else tile_issue_own(slot, V.v[WHAT], l, tr);
+    tile_issue_own(slot, V.v[WHAT], l, tr);
     ix = tile_idx(l);
   }
   // (a streaming wavefront's loads and stores go out ahead of the arithmetic of the wavefronts that sit in their block CG)
-  if ((L.prio & 3) == 1) __builtin_amdgcn_s_setprio(1); else if ((L.prio & 3) == 2) __builtin_amdgcn_s_setprio(2); else if ((L.prio & 3) == 3) __builtin_amdgcn_s_setprio(3);
+  if (L.prio == 1) __builtin_amdgcn_s_setprio(1); else if (L.prio == 2) __builtin_amdgcn_s_setprio(2); else if (L.prio == 3) __builtin_amdgcn_s_setprio(3);
   LOAD_PLANE(0, l)
   if constexpr (FLHS) {
-    if (!(L.prio & 4)) tile_issue_faces(g, slot, V.v[WHAT], L.halo, l, tr);
+    tile_issue_faces(g, slot, V.v[WHAT], L.halo, l, tr);  // (before or behind the first plane: no measurable difference, profiles/r03)
     tile_commit(tr, P, l);
   }
 #pragma unroll
@@ -860,7 +859,7 @@ __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, c
   d0 = wave_sum(d0);
   d1 = wave_sum(d1);
   if (l == 0) { block_dots[slot] = d0; block_dots[nb + slot] = d1; }
-  if (L.prio & 3) __builtin_amdgcn_s_setprio(0);
+  if (L.prio) __builtin_amdgcn_s_setprio(0);
   if constexpr (FLHS) __syncthreads();  // the tile is read no more: the block CG takes over its LDS
   cg_block<FMA, false, EV>(g, slot, r, V.v[ZHAT], block_sums, 0.0, 0.0, iters_out, P);  // zhat = M^-1 z, 14488
 }
@@ -901,14 +900,13 @@ __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, c
   TileRegs tr;
   if constexpr (FLHS) {  // the tile's loads first, the first plane of the streams right behind them, then the tile goes to LDS
     fx = lhs_fix(L, slot, l, hq);
-    if (L.prio & 4) { tile_issue_own(slot, V.v[ZHAT], l, tr); tile_issue_faces(g, slot, V.v[ZHAT], L.halo, l, tr); }  // A/B: both groups first
-    else tile_issue_own(slot, V.v[ZHAT], l, tr);
+    tile_issue_own(slot, V.v[ZHAT], l, tr);
     ix = tile_idx(l);
   }
-  if ((L.prio & 3) == 1) __builtin_amdgcn_s_setprio(1); else if ((L.prio & 3) == 2) __builtin_amdgcn_s_setprio(2); else if ((L.prio & 3) == 3) __builtin_amdgcn_s_setprio(3);
+  if (L.prio == 1) __builtin_amdgcn_s_setprio(1); else if (L.prio == 2) __builtin_amdgcn_s_setprio(2); else if (L.prio == 3) __builtin_amdgcn_s_setprio(3);
   LOAD_PLANE(0, l)
   if constexpr (FLHS) {
-    if (!(L.prio & 4)) tile_issue_faces(g, slot, V.v[ZHAT], L.halo, l, tr);
+    tile_issue_faces(g, slot, V.v[ZHAT], L.halo, l, tr);  // (before or behind the first plane: no measurable difference, profiles/r03)
     tile_commit(tr, P, l);
   }
 #pragma unroll
@@ -942,7 +940,7 @@ __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, c
     if (l == 0) block_dots[(size_t)i * nb + slot] = t;
     if (i == 4 && l == 0) block_dots[(size_t)6 * nb + slot] = t;  // norm = the same sum as norm_1 (14512-14514)
   }
-  if (L.prio & 3) __builtin_amdgcn_s_setprio(0);
+  if (L.prio) __builtin_amdgcn_s_setprio(0);
   if constexpr (FLHS) __syncthreads();
   cg_block<FMA, false, EV>(g, slot, r, V.v[WHAT], block_sums, 0.0, 0.0, iters_out, P);  // what = M^-1 w, 14548
 }
