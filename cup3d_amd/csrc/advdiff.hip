@@ -624,7 +624,7 @@ static int advdiff_stage(Sim *s, int rk, double dt, double nu, const double uinf
 #define ADV(FIRST, CPT, VAR) hipLaunchKernelGGL((k_advdiff<FIRST, CPT, VAR>), G, dim3(512 / CPT), 0, stream(), g, a)
 #define ADV2(CPT, VAR) do { if (rk == 0) ADV(true, CPT, VAR); else ADV(false, CPT, VAR); } while (0)
 #ifndef CUP3D_TESTING
-      if (kAdvProduction == 6) {
+      if constexpr (kAdvProduction == 6) {
         if (rk == 0) hipLaunchKernelGGL((k_advdiff_pc<true>), dim3(3 * launch_groups(g)), dim3(256), 0, stream(), g, a);
         else hipLaunchKernelGGL((k_advdiff_pc<false>), dim3(3 * launch_groups(g)), dim3(256), 0, stream(), g, a);
       } else ADV2(2, 0);  // release build: the production kernel only

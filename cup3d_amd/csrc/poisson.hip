@@ -1393,9 +1393,12 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       } else {
         // with the LHS inside, the second loop asks for 128 registers: 4 wavefronts per SIMD without spills (k_loop2_cg_w4; held to 96 it
         // spills 30 registers inside the plane loop), and the 7.5 KB tile needs 16 wavefronts per CU or fewer anyway
-        if (P.block_solver == 0 && flhs && debug_option("loop2_flhs_five_waves")) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);  // A/B: 96 registers, 30 spilled
-        else if (P.block_solver == 0 && flhs) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
-        else if (P.block_solver == 0 && four_waves) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
+#ifdef CUP3D_TESTING  // A/B of the occupancy, test builds only: with the LHS inside at 96 registers (30 spilled); without it at 4 wavefronts
+        if (P.block_solver == 0 && flhs && debug_option("loop2_flhs_five_waves")) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (P.block_solver == 0 && !flhs && four_waves) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
+        else
+#endif
+        if (P.block_solver == 0 && flhs) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (flhs) hipLaunchKernelGGL((k_loop2_cg_w4<false, 0, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else hipLaunchKernelGGL((k_loop2_cg<false, 0, false>), GG, BB, 0, stream(), LOOP_ARGS);
