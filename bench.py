@@ -549,7 +549,7 @@ def main():
         sys.exit(3)
 
 
-def ref_iters(a):
+def ref_iters(a, device_iters=None):
     """BiCGSTAB iterations per step of the REFERENCE on this very workload, from recorded runs of the compiled reference:
     profiles/r03/reference_window_<size>.json = per-step counts over steps 21.. of the bench's own time loop (the window bench.py
     times with --warmup W --steps K is steps 21+W .. 21+W+K-1), else the one-step record of round 2; None if never recorded."""
@@ -563,6 +563,8 @@ def ref_iters(a):
         out = {"value": round(float(np.mean(win)), 2) if win else None, "steps_covered": len(win), "of": a.steps,
                "window": f"steps {21 + a.warmup}..{21 + a.warmup + a.steps - 1} (the timed region of this run)",
                "by_step": win, "reference_threads": rec.get("threads"),
+               # the device's mean over exactly the steps the recording covers (they are the first ones of the window)
+               "device_over_the_same_steps": round(float(np.mean(device_iters[:len(win)])), 2) if win and device_iters and len(device_iters) >= len(win) else None,
                "source": f"profiles/r03/reference_window_{a.size}.json (compiled reference, {len(rec['steps'])} steps from step 21; its OpenMP "
                          "reductions make the count vary from run to run by ~10-20 %)"}
         return out
@@ -629,7 +631,7 @@ def report(a, sim, prof, sec, iters, world, alt=None):
                    # max|u| entering every timed step and after the last one: a solver-level signal that must not depend on the number
                    # of ranks beyond the stopping tolerance of the projection (the checksum below covers the stencil path bit for bit)
                    "umax_by_step": getattr(a, "umax_by_step", None),
-                   "ref_iters_per_step": ref_iters(a),
+                   "ref_iters_per_step": ref_iters(a, iters),
                    "checksum": getattr(a, "checksum", None),
                    "communication": getattr(a, "comm", None),
                    "nu": a.nu, "implicit_diffusion": bool(a.implicit_diffusion),
