@@ -475,7 +475,7 @@ def main():
     lib().cup3d_profile_enable(0)
     prof = {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n.value)}
     tot, nblk = C.c_long(0), C.c_long(0)
-    lib().cup3d_debug_block_cg_iterations(sim.handle, C.byref(tot), C.byref(nblk))
+    lib().cup3d_profile_block_cg_iterations(sim.handle, C.byref(tot), C.byref(nblk))
     a.cg_iters_per_block = tot.value / nblk.value if nblk.value else None
 
     # PCIe-inclusive rate of the C++ shim (never `value`): the boundary hands over one host pointer per block; measured here through

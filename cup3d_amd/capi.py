@@ -144,6 +144,7 @@ SIGNATURES = {
     "cup3d_profile_enable": (C.c_int, [C.c_int]),
     "cup3d_profile_reset": (C.c_int, []),
     "cup3d_profile_read": (C.c_int, [C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),
+    "cup3d_profile_block_cg_iterations": (C.c_int, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
 }
 # test-support symbols (not part of the drop-in surface)
 DEBUG_SIGNATURES = {
@@ -155,7 +156,6 @@ DEBUG_SIGNATURES = {
     "cup3d_debug_virtual_comm": (C.c_int, [C.c_int]),
     "cup3d_debug_host_transport": (C.c_int, [C.c_int, C.c_int, _vp]),
     "cup3d_debug_wave_sum": (C.c_int, [_dp, _dp]),
-    "cup3d_debug_block_cg_iterations": (C.c_int, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "cup3d_debug_ctl_step": (C.c_int, [C.c_int, _dp, _dp]),
 }
 
@@ -170,7 +170,8 @@ def lib():
             raise Cup3dError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
         L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-        for table in (SIGNATURES, DEBUG_SIGNATURES):
+        # the test-support names exist in libcup3d_hip_testing.so only; the release library does not export them
+        for table in (SIGNATURES, DEBUG_SIGNATURES) if os.path.basename(LIB_PATH).endswith("_testing.so") else (SIGNATURES,):
             for name, (res, args) in table.items():
                 fn = getattr(L, name)
                 fn.restype = res

@@ -671,7 +671,9 @@ extern "C" int cup3d_advect_diffuse(cup3d_sim_t *hs, double dt, double nu, const
   return CUP3D_OK;
 }
 // TEST SUPPORT: a single RK stage (tmpV must be 0 before stage 0), for the virtual-rank tests
+#ifdef CUP3D_TESTING  // test / tuning support: not in the release library at all
 extern "C" int cup3d_debug_advdiff_stage(cup3d_sim_t *hs, int rk, double dt, double nu, const double uinf[3]) {
   if (!hs || !uinf || rk < 0 || rk > 2) return CUP3D_EINVAL;
   return advdiff_stage(reinterpret_cast<Sim *>(hs), rk, dt, nu, uinf);
 }
+#endif

@@ -789,68 +789,78 @@ extern "C" int cup3d_adapt_transfer(cup3d_sim_t *src_h, cup3d_sim_t *dst_h, int 
 // one-rank adaptation bit for bit, wherever the blocks end up.
 extern "C" int cup3d_adapt_migrate(const cup3d_grid_t *old_mesh_h, const int32_t *old_owner, cup3d_sim_t *src_h, const cup3d_grid_t *new_mesh_h,
                                    const int32_t *new_owner, cup3d_sim_t *dst_h, int field) {
-  if (!old_mesh_h || !old_owner || !src_h || !new_mesh_h || !new_owner || !dst_h) return CUP3D_EINVAL;
-  const Grid *om = reinterpret_cast<const Grid *>(old_mesh_h), *nm = reinterpret_cast<const Grid *>(new_mesh_h);
+  if (!src_h || !dst_h) return CUP3D_EINVAL;  // (without the sims there is no communicator to tell the other ranks through)
   Sim *src = reinterpret_cast<Sim *>(src_h), *dst = reinterpret_cast<Sim *>(dst_h);
-  int nc, nc2;
-  const double *fs = src->field(field, &nc);
-  double *fd = dst->field(field, &nc2);
-  if (!fs || !fd) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
-  if (!om->multilevel || !nm->multilevel || om->n_local >= 0 || nm->n_local >= 0) { set_error("cup3d_adapt_migrate needs the two GLOBAL mesh objects"); return CUP3D_EINVAL; }
+  const Grid *om = reinterpret_cast<const Grid *>(old_mesh_h), *nm = reinterpret_cast<const Grid *>(new_mesh_h);
   const int me = src->grid->rank, nranks = src->grid->nranks;
-  if (dst->grid->rank != me || dst->grid->nranks != nranks) { set_error("cup3d_adapt_migrate: the two sims belong to different ranks"); return CUP3D_EINVAL; }
+  int nc = 0, nc2 = 0;
+  const double *fs = nullptr;
+  double *fd = nullptr;
   std::unique_ptr<Grid> tv;
   std::vector<NewBlock> mine;               // what this rank produces, ordered by (consumer, new global slot)
   std::vector<int64_t> send_count(nranks, 0), recv_count(nranks, 0);
   std::vector<int32_t> recv_slots;          // local slots of dst in arrival order: by (producer, new global slot)
-  try {
-    tv = om->rank_view(old_owner, me, nranks, /*tensorial=*/true);
-    if (tv->n_local != src->nb) throw std::invalid_argument("the source sim does not hold this rank's blocks of the old mesh");
-    std::vector<std::vector<NewBlock>> by_consumer(nranks);
-    std::vector<std::vector<int32_t>> by_producer(nranks);
-    int32_t my_slot = 0;
-    for (int64_t b = 0; b < nm->nblocks(); ++b) {
-      const int l = nm->blevel[b];
-      const int idx[3] = {nm->index[3 * b], nm->index[3 * b + 1], nm->index[3 * b + 2]};
-      int32_t origin = om->leaf(l, idx);
-      if (origin < 0 && l > 0) { const int pi[3] = {idx[0] >> 1, idx[1] >> 1, idx[2] >> 1}; origin = om->leaf(l - 1, pi); }
-      if (origin < 0 && l + 1 < om->level_max) { const int ci[3] = {2 * idx[0], 2 * idx[1], 2 * idx[2]}; origin = om->leaf(l + 1, ci); }
-      if (origin < 0) throw std::invalid_argument("a block of the new mesh is neither a block, a child nor the parent of blocks of the old mesh");
-      const int producer = old_owner[origin], consumer = new_owner[b];
-      if (producer < 0 || producer >= nranks || consumer < 0 || consumer >= nranks) throw std::invalid_argument("owner out of range");
-      if (producer == me) by_consumer[consumer].push_back(NewBlock{l, {idx[0], idx[1], idx[2]}, 0});
-      if (consumer == me) by_producer[producer].push_back(my_slot++);
-    }
-    if (my_slot != dst->nb) throw std::invalid_argument("the destination sim does not hold this rank's blocks of the new mesh");
-    for (int p = 0; p < nranks; ++p) {
-      send_count[p] = (int64_t)by_consumer[p].size();
-      recv_count[p] = (int64_t)by_producer[p].size();
-      for (NewBlock &nbk : by_consumer[p]) { nbk.dst = (int32_t)mine.size(); mine.push_back(nbk); }
-      recv_slots.insert(recv_slots.end(), by_producer[p].begin(), by_producer[p].end());
-    }
-  } catch (const std::exception &e) {
-    set_error("cup3d_adapt_migrate: %s", e.what());
-    return CUP3D_EINVAL;
-  }
-  const size_t per = (size_t)nc * 512, nvis = tv->Z.size();
-  DevBuf F, prod, recv;
+  size_t per = 0;
+  DevBuf F, prod, recv, pack;
   DevInts d_send, d_recv_slots;
-  int rc;
-  if ((rc = F.alloc(nvis * per * sizeof(double))) || (rc = prod.alloc(std::max<size_t>(mine.size(), 1) * per * sizeof(double))) ||
-      (rc = recv.alloc(std::max<size_t>(recv_slots.size(), 1) * per * sizeof(double))))
-    return rc;
-  // the old field on the tensorial view: local blocks, then the ghost blocks from their owners
-  CUP3D_HIP(hipMemcpyAsync(F.p, fs, (size_t)src->nb * per * sizeof(double), hipMemcpyDeviceToDevice, stream()));
-  {
-    DevBuf pack;
-    if ((rc = pack.alloc(std::max<size_t>(tv->send_blocks.size(), 1) * per * sizeof(double))) || (rc = d_send.upload(tv->send_blocks))) return rc;
+  // everything this rank can get wrong on its own -- arguments, the plan, allocations -- happens in here; the ranks then agree on the
+  // outcome BEFORE the first exchange, so that a bad call on one rank returns an error on every rank instead of blocking the others
+  auto local_part = [&]() -> int {
+    if (!old_mesh_h || !old_owner || !new_mesh_h || !new_owner) { set_error("cup3d_adapt_migrate: null argument"); return CUP3D_EINVAL; }
+    fs = src->field(field, &nc);
+    fd = dst->field(field, &nc2);
+    if (!fs || !fd) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
+    if (!om->multilevel || !nm->multilevel || om->n_local >= 0 || nm->n_local >= 0) { set_error("cup3d_adapt_migrate needs the two GLOBAL mesh objects"); return CUP3D_EINVAL; }
+    if (dst->grid->rank != me || dst->grid->nranks != nranks) { set_error("cup3d_adapt_migrate: the two sims belong to different ranks"); return CUP3D_EINVAL; }
+    try {
+      tv = om->rank_view(old_owner, me, nranks, /*tensorial=*/true);
+      if (tv->n_local != src->nb) throw std::invalid_argument("the source sim does not hold this rank's blocks of the old mesh");
+      std::vector<std::vector<NewBlock>> by_consumer(nranks);
+      std::vector<std::vector<int32_t>> by_producer(nranks);
+      int32_t my_slot = 0;
+      for (int64_t b = 0; b < nm->nblocks(); ++b) {
+        const int l = nm->blevel[b];
+        const int idx[3] = {nm->index[3 * b], nm->index[3 * b + 1], nm->index[3 * b + 2]};
+        int32_t origin = om->leaf(l, idx);
+        if (origin < 0 && l > 0) { const int pi[3] = {idx[0] >> 1, idx[1] >> 1, idx[2] >> 1}; origin = om->leaf(l - 1, pi); }
+        if (origin < 0 && l + 1 < om->level_max) { const int ci[3] = {2 * idx[0], 2 * idx[1], 2 * idx[2]}; origin = om->leaf(l + 1, ci); }
+        if (origin < 0) throw std::invalid_argument("a block of the new mesh is neither a block, a child nor the parent of blocks of the old mesh");
+        const int producer = old_owner[origin], consumer = new_owner[b];
+        if (producer < 0 || producer >= nranks || consumer < 0 || consumer >= nranks) throw std::invalid_argument("owner out of range");
+        if (producer == me) by_consumer[consumer].push_back(NewBlock{l, {idx[0], idx[1], idx[2]}, 0});
+        if (consumer == me) by_producer[producer].push_back(my_slot++);
+      }
+      if (my_slot != dst->nb) throw std::invalid_argument("the destination sim does not hold this rank's blocks of the new mesh");
+      for (int p = 0; p < nranks; ++p) {
+        send_count[p] = (int64_t)by_consumer[p].size();
+        recv_count[p] = (int64_t)by_producer[p].size();
+        for (NewBlock &nbk : by_consumer[p]) { nbk.dst = (int32_t)mine.size(); mine.push_back(nbk); }
+        recv_slots.insert(recv_slots.end(), by_producer[p].begin(), by_producer[p].end());
+      }
+    } catch (const std::exception &e) {
+      set_error("cup3d_adapt_migrate: %s", e.what());
+      return CUP3D_EINVAL;
+    }
+    per = (size_t)nc * 512;
+    const size_t nvis = tv->Z.size();
+    int rc;
+    if ((rc = F.alloc(nvis * per * sizeof(double))) || (rc = prod.alloc(std::max<size_t>(mine.size(), 1) * per * sizeof(double))) ||
+        (rc = recv.alloc(std::max<size_t>(recv_slots.size(), 1) * per * sizeof(double))) ||
+        (rc = pack.alloc(std::max<size_t>(tv->send_blocks.size(), 1) * per * sizeof(double))) || (rc = d_send.upload(tv->send_blocks)))
+      return rc;
+    // the old field on the tensorial view: local blocks (the ghost blocks arrive from their owners below)
+    CUP3D_HIP(hipMemcpyAsync(F.p, fs, (size_t)src->nb * per * sizeof(double), hipMemcpyDeviceToDevice, stream()));
     if (!tv->send_blocks.empty())
       hipLaunchKernelGGL(k_pack_blocks, dim3((unsigned)tv->send_blocks.size()), dim3(256), 0, stream(), (const double *)F.p, d_send.p, nc, (double *)pack.p);
     CUP3D_HIP(hipGetLastError());
-    if ((rc = exchange_items(src, (const double *)pack.p, tv->send_block_count, (double *)F.p + (size_t)tv->n_local * per, tv->recv_block_count, per))) return rc;
-    CUP3D_HIP(hipStreamSynchronize(stream()));
-  }
-  if ((rc = adapt_produce(tv.get(), mine, (const double *)F.p, (double *)prod.p, nc))) return rc;
+    return CUP3D_OK;
+  };
+  int rc = agree(src, local_part(), "cup3d_adapt_migrate");
+  if (rc) return rc;
+  if ((rc = exchange_items(src, (const double *)pack.p, tv->send_block_count, (double *)F.p + (size_t)tv->n_local * per, tv->recv_block_count, per))) return rc;
+  CUP3D_HIP(hipStreamSynchronize(stream()));
+  // producing the new blocks is rank-local again (kernels, table uploads): agree once more before they travel
+  if ((rc = agree(src, adapt_produce(tv.get(), mine, (const double *)F.p, (double *)prod.p, nc), "cup3d_adapt_migrate (produce)"))) return rc;
   if ((rc = exchange_items(src, (const double *)prod.p, send_count, (double *)recv.p, recv_count, per))) return rc;
   if (!recv_slots.empty()) {
     if ((rc = d_recv_slots.upload(recv_slots))) return rc;
@@ -932,36 +942,43 @@ extern "C" int cup3d_grad_chi_on_tmp(cup3d_sim_t *h, double Rtol, double Ctol, i
 // cup3d_adapt_migrate); chi of the edge / corner / finer neighbours other ranks own arrives first (the plan of the rank's tensorial view),
 // then the one-rank kernel runs on the rank's blocks.  Collective: every rank calls it.
 extern "C" int cup3d_grad_chi_on_tmp_over_ranks(cup3d_sim_t *h, const cup3d_grid_t *mesh_h, const int32_t *owner, double Rtol, double Ctol, int level_max_vorticity) {
-  if (!h || !mesh_h || !owner) return CUP3D_EINVAL;
+  if (!h) return CUP3D_EINVAL;
   Sim *s = reinterpret_cast<Sim *>(h);
   const Grid *gm = reinterpret_cast<const Grid *>(mesh_h);
-  if (!gm->multilevel || gm->n_local >= 0) { set_error("cup3d_grad_chi_on_tmp_over_ranks needs the GLOBAL mesh object"); return CUP3D_EINVAL; }
   const int me = s->grid->rank, nranks = s->grid->nranks;
   std::unique_ptr<Grid> tv;
-  try {
-    tv = gm->rank_view(owner, me, nranks, /*tensorial=*/true);
-    if (tv->n_local != s->nb) throw std::invalid_argument("the sim does not hold this rank's blocks of the mesh");
-  } catch (const std::exception &e) {
-    set_error("cup3d_grad_chi_on_tmp_over_ranks: %s", e.what());
-    return CUP3D_EINVAL;
-  }
-  const size_t nvis = tv->Z.size();
   DevBuf F, pack;
   DevInts d_send;
-  int rc;
-  if ((rc = F.alloc(nvis * 512 * sizeof(double))) || (rc = pack.alloc(std::max<size_t>(tv->send_blocks.size(), 1) * 512 * sizeof(double))) ||
-      (rc = d_send.upload(tv->send_blocks)))
-    return rc;
-  CUP3D_HIP(hipMemcpyAsync(F.p, s->chi, (size_t)s->nb * 512 * sizeof(double), hipMemcpyDeviceToDevice, stream()));
-  if (!tv->send_blocks.empty())
-    hipLaunchKernelGGL(k_pack_blocks, dim3((unsigned)tv->send_blocks.size()), dim3(256), 0, stream(), (const double *)F.p, d_send.p, 1, (double *)pack.p);
-  CUP3D_HIP(hipGetLastError());
+  auto local_part = [&]() -> int {  // what one rank can get wrong on its own; the ranks agree on the outcome before anything is exchanged
+    if (!mesh_h || !owner) { set_error("cup3d_grad_chi_on_tmp_over_ranks: null argument"); return CUP3D_EINVAL; }
+    if (!gm->multilevel || gm->n_local >= 0) { set_error("cup3d_grad_chi_on_tmp_over_ranks needs the GLOBAL mesh object"); return CUP3D_EINVAL; }
+    try {
+      tv = gm->rank_view(owner, me, nranks, /*tensorial=*/true);
+      if (tv->n_local != s->nb) throw std::invalid_argument("the sim does not hold this rank's blocks of the mesh");
+    } catch (const std::exception &e) {
+      set_error("cup3d_grad_chi_on_tmp_over_ranks: %s", e.what());
+      return CUP3D_EINVAL;
+    }
+    const size_t nvis = tv->Z.size();
+    int rc;
+    if ((rc = F.alloc(nvis * 512 * sizeof(double))) || (rc = pack.alloc(std::max<size_t>(tv->send_blocks.size(), 1) * 512 * sizeof(double))) ||
+        (rc = d_send.upload(tv->send_blocks)))
+      return rc;
+    CUP3D_HIP(hipMemcpyAsync(F.p, s->chi, (size_t)s->nb * 512 * sizeof(double), hipMemcpyDeviceToDevice, stream()));
+    if (!tv->send_blocks.empty())
+      hipLaunchKernelGGL(k_pack_blocks, dim3((unsigned)tv->send_blocks.size()), dim3(256), 0, stream(), (const double *)F.p, d_send.p, 1, (double *)pack.p);
+    CUP3D_HIP(hipGetLastError());
+    return CUP3D_OK;
+  };
+  int rc = agree(s, local_part(), "cup3d_grad_chi_on_tmp_over_ranks");
+  if (rc) return rc;
   if ((rc = exchange_items(s, (const double *)pack.p, tv->send_block_count, (double *)F.p + (size_t)tv->n_local * 512, tv->recv_block_count, 512))) return rc;
   CUP3D_HIP(hipStreamSynchronize(stream()));
   return grad_chi_run(tv.get(), tv->n_local, (const double *)F.p, s->tmpV, Rtol, Ctol, level_max_vorticity);
 }
 
 // TEST SUPPORT: the ghost slabs of every interface face for `field` and a w-deep stencil, [(e*nc + c)*w + gl][64]
+#ifdef CUP3D_TESTING  // test / tuning support: not in the release library at all
 extern "C" int cup3d_debug_amr_slabs(cup3d_sim_t *h, int field, int w, double *out) {
   if (!h || !out || (w != 1 && w != 3)) return CUP3D_EINVAL;
   Sim *s = reinterpret_cast<Sim *>(h);
@@ -975,3 +992,4 @@ extern "C" int cup3d_debug_amr_slabs(cup3d_sim_t *h, int field, int w, double *o
   CUP3D_HIP(hipStreamSynchronize(stream()));
   return CUP3D_OK;
 }
+#endif

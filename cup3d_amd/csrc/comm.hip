@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -37,6 +38,8 @@ struct Comm {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+  double *d_flag = nullptr;  // one double: the operand of agree()
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -46,7 +49,13 @@ struct Comm {
 };
 static Comm g_comm;
 static bool g_comm_ready = false;
+static bool g_comm_broken = false;  // an RCCL call failed and the communicator was aborted (rccl_fail)
 Comm *comm() { return g_comm_ready ? &g_comm : nullptr; }
+static int no_comm(const char *what) {
+  if (g_comm_broken) { set_error("%s: the RCCL communicator was aborted after an earlier error", what); return CUP3D_ECOMM; }
+  set_error("%s without cup3d_comm_init", what);
+  return CUP3D_ESTATE;
+}
 
 static int load_rccl() {
   if (g_comm.dl) return CUP3D_OK;
@@ -63,19 +72,27 @@ static int load_rccl() {
 #define SYM(field, name)                                                      \
   *(void **)(&g_comm.field) = dlsym(g_comm.dl, name);                         \
   if (!g_comm.field) { set_error("librccl lacks %s", name); return CUP3D_ECOMM; }
-  SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+  SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy") SYM(CommAbort, "ncclCommAbort")
   SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv")
   SYM(AllReduce, "ncclAllReduce") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
   return CUP3D_OK;
 }
+// An RCCL call that fails leaves the communicator unusable and the peers possibly inside the matching call: abort the communicator
+// (ncclCommAbort: pending operations of THIS rank end instead of spinning) and refuse every later exchange with CUP3D_ECOMM -- the
+// host then ends the run on all ranks (the C++ shim: MPI_Abort, as the reference does, main.cpp:15265, 15289; bench.py: its watchdog).
+static int rccl_fail(ncclResult_t r, const char *what) {
+  set_error("RCCL error %d (%s) in %s; communicator aborted", (int)r, g_comm.GetErrorString ? g_comm.GetErrorString(r) : "?", what);
+  if (g_comm_ready && g_comm.comm && g_comm.CommAbort) g_comm.CommAbort(g_comm.comm);
+  g_comm.comm = nullptr;
+  g_comm_ready = false;
+  g_comm_broken = true;
+  return CUP3D_ECOMM;
+}
 #define CUP3D_NCCL(call)                                                      \
   do {                                                                        \
     ncclResult_t r_ = (call);                                                 \
-    if (r_ != ncclSuccess) {                                                  \
-      set_error("RCCL error %d (%s) in %s", (int)r_, g_comm.GetErrorString ? g_comm.GetErrorString(r_) : "?", #call); \
-      return CUP3D_ECOMM;                                                     \
-    }                                                                         \
+    if (r_ != ncclSuccess) return rccl_fail(r_, #call);                       \
   } while (0)
 
 // ------------------------------------------------------------------ in-process transport (TEST SUPPORT)
@@ -92,6 +109,7 @@ struct VComm {
   std::vector<double *> ptr;
   std::vector<const std::vector<int64_t> *> counts;
   double *d_tmp = nullptr;  // [n][16]
+  std::vector<int> codes;   // agree(): the status every rank arrived with
   std::mutex m;
   std::condition_variable cv;
   int waiting = 0;
@@ -258,7 +276,7 @@ static int view_transfer(Sim *s, double *dst, size_t per, const std::vector<int6
   }
   if (g_ht_on) return ht_exchange(s->halo_send, send_count, dst, recv_count, per, -1, exchange_stream(s));
   Comm *c = comm();
-  if (!c) { set_error("multi-rank mesh without cup3d_comm_init"); return CUP3D_ESTATE; }
+  if (!c) return no_comm("multi-rank mesh");
   CUP3D_NCCL(c->GroupStart());
   size_t so = 0, ro = 0;
   for (int p = 0; p < g->nranks; ++p) {
@@ -275,12 +293,12 @@ static int view_transfer(Sim *s, double *dst, size_t per, const std::vector<int6
 // begin: pack + transfer enqueued (on the communication stream with RCCL; ev_h2 marks the arrival); finish: the compute stream waits
 static int view_exchange_blocks_begin(Sim *s, double *field, int nc) {
   const Grid *g = s->grid;
-  ProfileScope ps("ghost_block_exchange");
   hipStream_t st = exchange_stream(s);
   if (st != stream()) {
     CUP3D_HIP(hipEventRecord(s->ev_h1, stream()));
     CUP3D_HIP(hipStreamWaitEvent(st, s->ev_h1, 0));
   }
+  ProfileScope ps("comm_ghost_blocks", st);  // pack + transfer as the communication stream sees them
   const unsigned nsend = (unsigned)g->send_blocks.size();
   if (nsend) hipLaunchKernelGGL(k_pack_blocks, dim3(nsend), dim3(256), 0, st, field, s->d_send_blocks, nc, s->halo_send);
   CUP3D_HIP(hipGetLastError());
@@ -290,7 +308,10 @@ static int view_exchange_blocks_begin(Sim *s, double *field, int nc) {
   return CUP3D_OK;
 }
 static int view_exchange_blocks_finish(Sim *s) {
-  if (exchange_stream(s) != stream()) CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
+  if (exchange_stream(s) != stream()) {
+    ProfileScope ps("comm_exposed_halo_wait");  // what the compute stream idles for (zero when the inner blocks hid the transfer)
+    CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
+  }
   return CUP3D_OK;
 }
 int view_exchange_blocks(Sim *s, double *field, int nc) {
@@ -304,12 +325,12 @@ int view_exchange_blocks(Sim *s, double *field, int nc) {
 int view_exchange_flux(Sim *s, int nfc) {
   const Grid *g = s->grid;
   if (g->n_local < 0 || g->nranks == 1) return CUP3D_OK;
-  ProfileScope ps("face_flux_exchange");
   hipStream_t st = exchange_stream(s);
   if (st != stream()) {
     CUP3D_HIP(hipEventRecord(s->ev_h1, stream()));
     CUP3D_HIP(hipStreamWaitEvent(st, s->ev_h1, 0));
   }
+  ProfileScope ps("comm_face_flux", st);
   const unsigned nsend = (unsigned)g->send_flux_faces.size();
   if (nsend) hipLaunchKernelGGL(k_pack_flux, dim3(nsend), dim3(64), 0, st, s->d_flux, s->d_send_flux, nfc, s->halo_send);
   CUP3D_HIP(hipGetLastError());
@@ -335,7 +356,7 @@ int exchange_items(Sim *s, const double *sendbuf, const std::vector<int64_t> &se
   if (n == 1) return CUP3D_OK;
   stats_halo(sent_bytes(send_count, per, me));
   Comm *c = (g_vcomm || g_ht_on) ? nullptr : comm();
-  if (!g_vcomm && !g_ht_on && !c) { set_error("multi-rank mesh without cup3d_comm_init"); return CUP3D_ESTATE; }
+  if (!g_vcomm && !g_ht_on && !c) return no_comm("multi-rank mesh");
   hipStream_t st = g_vcomm ? exchange_stream(s) : (s->comm_stream ? s->comm_stream : stream());
   if (st != stream()) {
     CUP3D_HIP(hipEventRecord(s->ev_h1, stream()));
@@ -387,7 +408,7 @@ static int slab_transfer(Sim *s, size_t per_face, hipStream_t st) {
   if (g_vcomm) return vcomm_pull(s, s->halo_recv, per_face, g->recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_count; }, st);
   if (g_ht_on) return ht_exchange(s->halo_send, g->send_count, s->halo_recv, g->recv_count, per_face, -1, st);
   Comm *c = comm();
-  if (!c) { set_error("multi-rank grid without cup3d_comm_init"); return CUP3D_ESTATE; }
+  if (!c) return no_comm("multi-rank grid");
   CUP3D_NCCL(c->GroupStart());
   size_t so = 0, ro = 0;
   for (int p = 0; p < g->nranks; ++p) {
@@ -425,7 +446,7 @@ int halo_begin(Sim *s, const double *field, int nc, int w) {
     CUP3D_HIP(hipStreamWaitEvent(st, s->ev_h1, 0));
   }
   {
-    ProfileScope ps("halo_exchange");
+    ProfileScope ps("comm_halo", st);  // pack kernel + grouped send/recv, timed on the stream they run on
     int rc = launch_pack(s, field, nc, w, st);
     if (rc) return rc;
     if ((rc = slab_transfer(s, per_face, st))) return rc;
@@ -446,7 +467,10 @@ int halo_finish(Sim *s) {
     return rc;
   }
   if (s->grid->nranks == 1 || (g_virtual_ranks && !g_vcomm)) return CUP3D_OK;
-  if (exchange_stream(s) != stream()) CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
+  if (exchange_stream(s) != stream()) {
+    ProfileScope ps("comm_exposed_halo_wait");
+    CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h2, 0));
+  }
   return CUP3D_OK;
 }
 int halo_exchange(Sim *s, const double *field, int nc, int w) {
@@ -491,9 +515,48 @@ int allreduce(Sim *s, double *d_buf, int n, bool is_max, hipStream_t st) {
     return CUP3D_OK;
   }
   Comm *c = comm();
-  if (!c) { set_error("multi-rank grid without cup3d_comm_init"); return CUP3D_ESTATE; }
+  if (!c) return no_comm("multi-rank grid");
   CUP3D_NCCL(c->AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, is_max ? ncclMax : ncclSum, c->comm, st));
   return CUP3D_OK;
+}
+
+
+// Collective status agreement.  A collective entry point (mesh migration, the chi exchange of the tagging, ...) first does its
+// rank-local part -- argument checks, plan building, allocations -- and may fail there on ONE rank only; if that rank simply returned,
+// the others would block in the next send/recv for ever.  So every rank passes its local outcome here BEFORE the first exchange and
+// all ranks get the same code back: 0, or the worst (most negative) code any rank arrived with.  The reference has no return codes
+// and ends such runs with MPI_Abort on every rank (main.cpp:15265, 15289): all-or-none is the convention kept.  One MAX all-reduce of
+// one double with a host wait: for entry points that run once per mesh adaptation, not for the per-iteration halos (their only
+// rank-local failure, a missing communicator, is the same on every rank).
+int agree(Sim *s, int rc, const char *where) {
+  const Grid *g = s->grid;
+  if (g->nranks == 1 || (g_virtual_ranks && !g_vcomm)) return rc;
+  int worst = rc;
+  if (g_vcomm) {
+    VComm *vc = g_vcomm;
+    vc->codes[g->rank] = rc;
+    if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the status agreement of %s", where); return CUP3D_ECOMM; }
+    for (int q = 0; q < vc->n; ++q) worst = std::min(worst, vc->codes[q]);
+    if (!vc->barrier()) { set_error("virtual communicator: a rank is missing at the status agreement of %s", where); return CUP3D_ECOMM; }  // codes[] may be rewritten
+  } else if (g_ht_on) {
+    double v = (double)-rc;
+    if (g_ht.allreduce(g_ht.ctx, &v, 1, 1)) { set_error("host transport: status agreement of %s failed", where); return CUP3D_ECOMM; }
+    worst = -(int)v;
+  } else {
+    Comm *c = comm();
+    if (!c) return rc ? rc : no_comm(where);
+    hipStream_t st = s->comm_stream ? s->comm_stream : stream();
+    double v = (double)-rc;
+    if (!c->d_flag) CUP3D_HIP(hipMalloc((void **)&c->d_flag, sizeof(double)));
+    CUP3D_HIP(hipStreamSynchronize(stream()));  // the collective proper starts on a drained compute stream, like the reference's blocking calls
+    CUP3D_HIP(hipMemcpyAsync(c->d_flag, &v, sizeof v, hipMemcpyHostToDevice, st));
+    CUP3D_NCCL(c->AllReduce(c->d_flag, c->d_flag, 1, ncclDouble, ncclMax, c->comm, st));
+    CUP3D_HIP(hipMemcpyAsync(&v, c->d_flag, sizeof v, hipMemcpyDeviceToHost, st));
+    CUP3D_HIP(hipStreamSynchronize(st));
+    worst = -(int)v;
+  }
+  if (worst != 0 && rc == 0) set_error("%s: another rank could not take part (its status: %d); nothing was exchanged", where, worst);
+  return worst;
 }
 
 }  // namespace cup3d
@@ -522,6 +585,7 @@ int cup3d_comm_init(int rank, int nranks, const void *id128) {
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   CUP3D_NCCL(g_comm.CommInitRank(&g_comm.comm, nranks, id, rank));
+  g_comm_broken = false;
   g_comm.rank = rank;
   g_comm.nranks = nranks;
   g_comm_ready = true;
@@ -533,40 +597,35 @@ int cup3d_comm_finalize(void) {
     g_comm.CommDestroy(g_comm.comm);
     g_comm.comm = nullptr;
   }
+  if (g_comm.d_flag) { hipFree(g_comm.d_flag); g_comm.d_flag = nullptr; }
   g_comm_ready = false;
+  g_comm_broken = false;
   return CUP3D_OK;
 }
 
 // TEST SUPPORT: see cup3d_hip_testing.h
+#ifdef CUP3D_TESTING  // test / tuning support: not in the release library at all
 int cup3d_debug_host_transport(int rank, int nranks, const cup3d_host_transport *t) {
-#ifndef CUP3D_TESTING
-  (void)rank; (void)nranks;
-  return t ? not_in_release("cup3d_debug_host_transport") : CUP3D_OK;
-#else
   if (!t) { g_ht_on = false; return CUP3D_OK; }
   if (nranks < 1 || rank < 0 || rank >= nranks || !t->exchange || !t->allreduce) return CUP3D_EINVAL;
   g_ht = *t;
   g_ht_on = nranks > 1;
   return CUP3D_OK;
-#endif
 }
+#endif
 
 // TEST SUPPORT: several ranks' sims in one process on one GPU; exchanges become no-ops
+#ifdef CUP3D_TESTING  // test / tuning support: not in the release library at all
 int cup3d_debug_virtual_ranks(int on) {
-#ifdef CUP3D_TESTING
   g_virtual_ranks = on != 0;
   return CUP3D_OK;
-#else
-  return on ? not_in_release("cup3d_debug_virtual_ranks") : CUP3D_OK;
-#endif
 }
+#endif
 
 // TEST SUPPORT: in-process communicator over `nranks` host threads (see VComm above); nranks = 0 tears it down.  Create it before
 // the sims of the run (they register themselves by rank), then call the ordinary entry points from one thread per rank.
+#ifdef CUP3D_TESTING  // test / tuning support: not in the release library at all
 int cup3d_debug_virtual_comm(int nranks) {
-#ifndef CUP3D_TESTING
-  return nranks ? not_in_release("cup3d_debug_virtual_comm") : CUP3D_OK;
-#else
   if (nranks < 0 || nranks > 16) return CUP3D_EINVAL;
   if (g_vcomm) {
     if (g_vcomm->d_tmp) hipFree(g_vcomm->d_tmp);
@@ -581,21 +640,20 @@ int cup3d_debug_virtual_comm(int nranks) {
   vc->cur.assign(nranks, nullptr);
   vc->ptr.assign(nranks, nullptr);
   vc->counts.assign(nranks, nullptr);
+  vc->codes.assign(nranks, 0);
   if (hipMalloc((void **)&vc->d_tmp, (size_t)nranks * 16 * sizeof(double)) != hipSuccess) { delete vc; set_error("virtual communicator: hipMalloc failed"); return CUP3D_EDEVICE; }
   g_vcomm = vc;
   g_virtual_ranks = true;
   return CUP3D_OK;
-#endif
 }
+#endif
 
 // TEST SUPPORT: fill `dst`'s halo slabs for (field, nc, w) by packing directly from peer
 // sims living in the same process on the same GPU ("virtual ranks").  Exercises the plan
 // ordering, the pack kernel and the kernels' halo-read path on one GPU; the RCCL call
 // sequence itself is what halo_exchange() adds on top.
+#ifdef CUP3D_TESTING  // test / tuning support: not in the release library at all
 int cup3d_debug_halo_pull(cup3d_sim_t *dst_h, cup3d_sim_t *const *peers, int npeers, int field, int nc, int w) {
-#ifndef CUP3D_TESTING
-  return not_in_release("cup3d_debug_halo_pull");
-#endif
   if (!dst_h || !peers) return CUP3D_EINVAL;
   Sim *dst = reinterpret_cast<Sim *>(dst_h);
   const Grid *g = dst->grid;
@@ -621,5 +679,6 @@ int cup3d_debug_halo_pull(cup3d_sim_t *dst_h, cup3d_sim_t *const *peers, int npe
   CUP3D_HIP(hipStreamSynchronize(stream()));
   return CUP3D_OK;
 }
+#endif
 
 }  // extern "C"

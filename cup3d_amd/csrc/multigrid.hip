@@ -466,7 +466,7 @@ int mg_vcycle(Sim *s, const double *in, double *out) {
   // reduce the residual along it); there the sweeps just carry a multiple of mean(b) along, a fixed linear map like the rest.
   if (L > 0 && !mg.local) hipLaunchKernelGGL(k_mg_remove_mean, dim3(1), dim3(256), 0, stream(), mg.lev[0].b, (long)mg.lev[0].nb * 512);
   if (L > 0 && mg.local) {  // the same over all ranks: local sums, one all-reduce on the communication stream, subtraction
-    double *tot = s->d_red + 14;
+    double *tot = s->d_red + kRedMg;
     const long n = (long)mg.lev[0].nb * 512;
     hipLaunchKernelGGL(k_mg_local_sum, dim3(1), dim3(256), 0, stream(), (const double *)mg.lev[0].b, n, tot);
     hipStream_t cs = scalar_stream(s);

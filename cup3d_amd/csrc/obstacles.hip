@@ -120,10 +120,13 @@ extern "C" int cup3d_penalization(cup3d_sim_t *h, double dt, double lambda, int 
     // A rank whose share of the grid this obstacle does not touch still takes part in the all-reduce below with M = 0: the
     // reference issues MPI_Allreduce(M, 6) for every obstacle on every rank (13931), and skipping it here would pair this rank's
     // NEXT collective with the other ranks' 6-double sum.
-    double M[6] = {0, 0, 0, 0, 0, 0};
-    int rc;
-    if (o.nblocks > 0) {
-      if (!o.slots || !o.chi || !o.udef) return CUP3D_EINVAL;
+    // M[6] rides along: 0, or 1 from a rank whose local part failed -- the ranks agree on the outcome in the collective they hold
+    // anyway, so that one rank's bad obstacle returns an error everywhere instead of leaving the others inside the all-reduce
+    double M[7] = {0, 0, 0, 0, 0, 0, 0};
+    auto local_part = [&]() -> int {
+      if (o.nblocks <= 0) return CUP3D_OK;
+      int rc;
+      if (!o.slots || !o.chi || !o.udef) { set_error("cup3d_penalization: obstacle %d has blocks but no slots / chi / udef", k); return CUP3D_EINVAL; }
       DevBuf slots, geom, chi, udef, forces;
       ObstItems it;
       if ((rc = stage(s, o, slots, geom, chi, udef, &it))) return rc;
@@ -143,16 +146,25 @@ extern "C" int cup3d_penalization(cup3d_sim_t *h, double dt, double lambda, int 
       std::sort(order.begin(), order.end(), [&](long a, long b) { return o.slots[a] < o.slots[b]; });
       for (long i : order)
         for (int q = 0; q < 6; ++q) M[q] += F[(size_t)i * 6 + q];
-    }
+      return CUP3D_OK;
+    };
+    int rc = local_part();
     if (scalars_cross_ranks(s)) {  // MPI_Allreduce(M, 6), 13931; on the stream every RCCL call of the library uses
+      M[6] = rc ? 1.0 : 0.0;
       double *d = s->d_red;
       hipStream_t cs = scalar_stream(s);
+      int rc2;
       CUP3D_HIP(hipStreamSynchronize(stream()));
-      CUP3D_HIP(hipMemcpyAsync(d, M, 6 * sizeof(double), hipMemcpyHostToDevice, cs));
-      if ((rc = allreduce(s, d, 6, false, cs))) return rc;
-      CUP3D_HIP(hipMemcpyAsync(M, d, 6 * sizeof(double), hipMemcpyDeviceToHost, cs));
+      CUP3D_HIP(hipMemcpyAsync(d, M, 7 * sizeof(double), hipMemcpyHostToDevice, cs));
+      if ((rc2 = allreduce(s, d, 7, false, cs))) return rc ? rc : rc2;
+      CUP3D_HIP(hipMemcpyAsync(M, d, 7 * sizeof(double), hipMemcpyDeviceToHost, cs));
       CUP3D_HIP(hipStreamSynchronize(cs));
+      if (!rc && M[6] != 0.0) {
+        set_error("cup3d_penalization: obstacle %d failed on %d other rank(s)", k, (int)M[6]);
+        rc = CUP3D_ECOMM;
+      }
     }
+    if (rc) return rc;
     for (int d = 0; d < 3; ++d) { o.force[d] = M[d]; o.torque[d] = M[3 + d]; }
   }
   return CUP3D_OK;

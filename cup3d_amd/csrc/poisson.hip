@@ -516,7 +516,7 @@ int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
   // CG's own truncation is 1e-7, so the contraction is a tolerance-level deviation (tests bound it against the reference's z).
   // block_solver 2 = the reference's association (no contraction).
   const dim3 G(launch_groups(g)), B(64);
-  int *it = profile_on() ? cg_iters_buffer(s) : nullptr;  // for the FP64 roofline of bench.py (cup3d_debug_block_cg_iterations)
+  int *it = profile_on() ? cg_iters_buffer(s) : nullptr;  // for the FP64 roofline of bench.py (cup3d_profile_block_cg_iterations)
 #define CG(FMA_, EV_) hipLaunchKernelGGL((k_precond<FMA_, false, EV_>), G, B, 0, stream(), g, in, out, sums, 0.0, 0.0, it)
   switch (s->block_solver) {
 #ifdef CUP3D_TESTING
@@ -978,6 +978,7 @@ struct CtlThen {
 };
 template <int K, bool MEAN>
 __global__ void __launch_bounds__(256) k_sums_finish(const double *__restrict__ v, long nb, RedOut ro, const double *__restrict__ mean_src, CtlThen then) {
+  static_assert(K + (MEAN ? 1 : 0) <= kRedDotsEnd - kRedDots, "the totals of a loop must fit the kRedDots range of Sim::d_red");
   double acc[K + (MEAN ? 1 : 0)];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -1154,6 +1155,7 @@ struct Reducer {
       CUP3D_HIP(hipEventRecord(s->ev_b, stream()));
       CUP3D_HIP(hipStreamWaitEvent(cs, s->ev_b, 0));
     }
+    ProfileScope pc("comm_allreduce", cs);
     int rc = allreduce(s, s->d_red, k, false, cs);
     if (rc) return rc;
     hipLaunchKernelGGL(k_publish_totals, dim3(1), dim3(64), 0, cs, (const double *)s->d_red, k, s->h_red_dev, reinterpret_cast<unsigned *>(s->h_red_dev + 16), ++s->red_seq);
@@ -1184,11 +1186,19 @@ static int ensure_vectors(Sim *s) {
     int rc = sim_alloc(&s->d_block_dots, (size_t)7 * s->nb, s);
     if (rc) return rc;
   }
-  if (!s->d_ctl) {  // the solver's scalar struct (device) and the pinned ring its outcome reaches the host through
-    CUP3D_HIP(hipMalloc(&s->d_ctl, sizeof(SolverCtl)));
-    CUP3D_HIP(hipHostMalloc(&s->h_ctl, 4 * sizeof(CtlSlot), hipHostMallocMapped | hipHostMallocCoherent));
-    memset(s->h_ctl, 0, 4 * sizeof(CtlSlot));
-    CUP3D_HIP(hipHostGetDevicePointer(&s->h_ctl_dev, s->h_ctl, 0));
+  if (!s->h_ctl_dev) {  // the solver's scalar struct (device) and the pinned ring its outcome reaches the host through: all three or none
+    hipError_t e = s->d_ctl ? hipSuccess : hipMalloc(&s->d_ctl, sizeof(SolverCtl));
+    if (e == hipSuccess && !s->h_ctl) {
+      e = hipHostMalloc(&s->h_ctl, 4 * sizeof(CtlSlot), hipHostMallocMapped | hipHostMallocCoherent);
+      if (e == hipSuccess) memset(s->h_ctl, 0, 4 * sizeof(CtlSlot));
+    }
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&s->h_ctl_dev, s->h_ctl, 0);
+    if (e != hipSuccess) {  // leave nothing half-built behind: the next solve starts over
+      if (s->d_ctl) (void)hipFree(s->d_ctl);
+      if (s->h_ctl) (void)hipHostFree(s->h_ctl);
+      s->d_ctl = s->h_ctl = s->h_ctl_dev = nullptr;
+      return hip_fail(e, "SolverCtl allocation", __FILE__, __LINE__);
+    }
   }
   if (s->sv[0]) return CUP3D_OK;
   for (int i = 0; i < NVEC; ++i) {
@@ -1281,7 +1291,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
 
   // the mean-constraint total of `what` for the first fused loop (FLHS): d_red[7] after a fused iteration (k_sums_finish<7, true>),
   // d_red[8] after a host-driven LHS(WHAT, T_) (k_mean_finish inside launch_lhs); of `zhat` for the second loop it is d_red[2]
-  const double *what_total = s->d_red + 8;
+  const double *what_total = s->d_red + kRedMeanLhs;
   // the restart of 14567-14593 / 7096-7120 (the breakdown was detected, and counted, by ctl_step2)
   auto restart = [&]() -> int {
     { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_copy, V.v[R_], V.v[R0], N); }
@@ -1295,7 +1305,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     hs.beta = 0.0;
     hs.omega = 0.0;
     hs.state = kRun;
-    what_total = s->d_red + 8;
+    what_total = s->d_red + kRedMeanLhs;
     return CUP3D_OK;
   };
 
@@ -1334,7 +1344,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     TRY(red.wait());
     ctl_step2(hs, s->h_red);   // 14558-14566, 14594-14601 (moves xcur to the buffer just written)
     if (hs.state == kRestart) TRY(restart());
-    what_total = s->d_red + 8;  // LHS(WHAT, T_) left sum(what h^3) there (k_mean_finish)
+    what_total = s->d_red + kRedMeanLhs;  // LHS(WHAT, T_) left sum(what h^3) there (k_mean_finish)
     return CUP3D_OK;
   };
 
@@ -1361,15 +1371,21 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       CUP3D_HIP(hipEventRecord(s->ev_b, stream()));
       CUP3D_HIP(hipStreamWaitEvent(cs, s->ev_b, 0));
     }
-    TRY(allreduce(s, s->d_red, K + (want_sums ? 1 : 0), false, cs));
-    if (step == 1) hipLaunchKernelGGL(k_ctl_step<1>, dim3(1), dim3(1), 0, cs, d_ctl, (const double *)s->d_red, ring, seq);
-    else hipLaunchKernelGGL(k_ctl_step<2>, dim3(1), dim3(1), 0, cs, d_ctl, (const double *)s->d_red, ring, seq);
-    CUP3D_HIP(hipGetLastError());
+    {
+      ProfileScope pc("comm_allreduce", cs);  // the all-reduce and the recurrence step behind it, as the communication stream sees them
+      TRY(allreduce(s, s->d_red, K + (want_sums ? 1 : 0), false, cs));
+      if (step == 1) hipLaunchKernelGGL(k_ctl_step<1>, dim3(1), dim3(1), 0, cs, d_ctl, (const double *)s->d_red, ring, seq);
+      else hipLaunchKernelGGL(k_ctl_step<2>, dim3(1), dim3(1), 0, cs, d_ctl, (const double *)s->d_red, ring, seq);
+      CUP3D_HIP(hipGetLastError());
+    }
     CUP3D_HIP(hipEventRecord(s->ev_a, cs));
     return CUP3D_OK;
   };
   auto scalars_ready = [&]() -> int {  // the compute stream waits for the struct stepped on the communication stream
-    if (!direct && scalar_stream(s) != stream()) CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_a, 0));
+    if (!direct && scalar_stream(s) != stream()) {
+      ProfileScope pw("comm_exposed_scalar_wait");  // compute stream idle until the all-reduced scalars are stepped (exposed: nothing left to hide them behind)
+      CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_a, 0));
+    }
     return CUP3D_OK;
   };
   // FLHS: v = A zhat and t = A what are formed inside the loop kernels (uniform grids; on multi-level meshes the LHS needs the
@@ -1415,14 +1431,14 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, what_total, lhs_mode, s->grid->corner_slot, prio}));  // (t = A what,) loop 1, zhat = M^-1 z
     s->sums_of = want_sums ? V.v[ZHAT] : nullptr;
     TRY(finish(2, 1, seq));
-    if (want_sums) { s->mean_total_of = V.v[ZHAT]; s->mean_total = s->d_red + 2; }
+    if (want_sums) { s->mean_total_of = V.v[ZHAT]; s->mean_total = s->d_red + kRedDots + 2; }
     if (!flhs) TRY(LHS(ZHAT, V_));
     TRY(scalars_ready());
-    TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, s->d_red + 2, lhs_mode, s->grid->corner_slot, prio}));  // (v = A zhat,) loop 2, what = M^-1 w
+    TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, s->d_red + kRedDots + 2, lhs_mode, s->grid->corner_slot, prio}));  // (v = A zhat,) loop 2, what = M^-1 w
     s->sums_of = want_sums ? V.v[WHAT] : nullptr;
     TRY(finish(7, 2, seq));
-    if (want_sums) { s->mean_total_of = V.v[WHAT]; s->mean_total = s->d_red + 7; }
-    what_total = s->d_red + 7;
+    if (want_sums) { s->mean_total_of = V.v[WHAT]; s->mean_total = s->d_red + kRedDots + 7; }
+    what_total = s->d_red + kRedDots + 7;
     if (!flhs) TRY(LHS(WHAT, T_));
     TRY(scalars_ready());
     return CUP3D_OK;
@@ -1480,7 +1496,7 @@ using namespace cup3d;
 
 extern "C" {
 
-int cup3d_grad_p_update(cup3d_sim_t *h, double dt);  // stencil.hip
+__attribute__((visibility("hidden"))) int cup3d_grad_p_update(cup3d_sim_t *h, double dt);  // stencil.hip; not exported
 
 void cup3d_poisson_default_params(cup3d_poisson_params *p) {
   if (!p) return;
@@ -1488,7 +1504,7 @@ void cup3d_poisson_default_params(cup3d_poisson_params *p) {
 }
 
 // MEASUREMENT SUPPORT: CG iterations of the last block-CG launch made while cup3d_profile_enable(1) was on, summed over the blocks
-int cup3d_debug_block_cg_iterations(cup3d_sim_t *h, long *total, long *nblocks) {
+int cup3d_profile_block_cg_iterations(cup3d_sim_t *h, long *total, long *nblocks) {
   if (!h || !total || !nblocks) return CUP3D_EINVAL;
   Sim *s = reinterpret_cast<Sim *>(h);
   *total = 0;
@@ -1506,11 +1522,8 @@ int cup3d_debug_block_cg_iterations(cup3d_sim_t *h, long *total, long *nblocks) 
 // TEST SUPPORT (no GPU needed): the scalar recurrences of the solver, host side of the one pair of functions the device runs too.
 // io[16] = alpha, beta, omega, r0r_prev, norm, init_norm, min_norm, tol, tol_rel, state, restarts, max_restarts, xcur, xopt, iter, (unused);
 // step 1: totals[2] = q.y, y.y (main.cpp:14493); step 2: totals[7] = r0.r, r0.w, r0.s, r0.z, |r|^2 (norm_1), |r0|^2 (norm_2), |r|^2 (14558-14601)
+#ifdef CUP3D_TESTING  // test / tuning support: not in the release library at all
 int cup3d_debug_ctl_step(int step, double *io, const double *totals) {
-#ifndef CUP3D_TESTING
-  (void)step; (void)io; (void)totals;
-  return not_in_release("cup3d_debug_ctl_step");
-#else
   if (!io || !totals || (step != 1 && step != 2)) return CUP3D_EINVAL;
   SolverCtl c;
   c.alpha = io[0]; c.beta = io[1]; c.omega = io[2]; c.r0r_prev = io[3]; c.norm = io[4]; c.init_norm = io[5]; c.min_norm = io[6];
@@ -1520,14 +1533,12 @@ int cup3d_debug_ctl_step(int step, double *io, const double *totals) {
   io[0] = c.alpha; io[1] = c.beta; io[2] = c.omega; io[3] = c.r0r_prev; io[4] = c.norm; io[5] = c.init_norm; io[6] = c.min_norm;
   io[9] = c.state; io[10] = c.restarts; io[12] = c.xcur; io[13] = c.xopt; io[14] = c.iter;
   return CUP3D_OK;
-#endif
 }
+#endif
 
 // TEST SUPPORT: see k_debug_wave_sum (in64 -> out128, host arrays)
+#ifdef CUP3D_TESTING  // test / tuning support: not in the release library at all
 int cup3d_debug_wave_sum(const double *in64, double *out128) {
-#ifndef CUP3D_TESTING
-  return not_in_release("cup3d_debug_wave_sum");
-#else
   if (!in64 || !out128) return CUP3D_EINVAL;
   double *d = nullptr;
   CUP3D_HIP(hipMalloc((void **)&d, 192 * sizeof(double)));
@@ -1540,8 +1551,8 @@ int cup3d_debug_wave_sum(const double *in64, double *out128) {
   hipFree(d);
   if (e != hipSuccess) return hip_fail(e, "cup3d_debug_wave_sum", __FILE__, __LINE__);
   return CUP3D_OK;
-#endif
 }
+#endif
 
 int cup3d_preconditioner(cup3d_sim_t *h, int block_solver) {
   if (!h) return CUP3D_EINVAL;
@@ -1566,6 +1577,15 @@ int cup3d_pressure_project(cup3d_sim_t *h, double dt, int step, const cup3d_pois
   const long N = s->nb * 512L;
   const unsigned G = vec_groups(N), Gs = vec_groups_simple(N);
   const bool second_order = step > 2;  // sim.step > sim.step_2nd_start (= 2), main.cpp:15087, 15355
+  if (s->grid->nranks > 1) {
+    // the operator is a collective: a rank that cannot run it says so to all of them before the first exchange (comm.hip, agree)
+    int local = CUP3D_OK;
+    if (s->chi_conflict()) {
+      set_error("cup3d_pressure_project: chi was written on this rank but cup3d_sim_set_obstacles(0) says no rank holds an obstacle");
+      local = CUP3D_ESTATE;
+    }
+    TRY(agree(s, local, "cup3d_pressure_project"));
+  }
   if (second_order) { ProfileScope ps("project_pointwise"); LAUNCH_VEC_S(k_copy, s->pres, s->pold, N); }  // pOld, 15075
   // tmpV = 0 (15076-15078) matters only as the udef lab of KernelPressureRHS; without obstacles the RHS kernel does not read it
   // (adding -0*fac*0 is the identity).  With a resident chi it does: unless the caller has placed udef there since the last

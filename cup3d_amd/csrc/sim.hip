@@ -57,7 +57,8 @@ static void profile_drain() {
   }
   g_prof_open.clear();
 }
-ProfileScope::ProfileScope(const char *name) : idx(-1), start(nullptr) {
+ProfileScope::ProfileScope(const char *name) : ProfileScope(name, g_stream) {}
+ProfileScope::ProfileScope(const char *name, hipStream_t on) : idx(-1), start(nullptr), st(on) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mutex);
   for (size_t i = 0; i < g_prof_names.size(); ++i)
@@ -69,14 +70,14 @@ ProfileScope::ProfileScope(const char *name) : idx(-1), start(nullptr) {
     g_prof_ms.push_back(0);
   }
   if (!(start = pooled_event())) { idx = -1; return; }
-  hipEventRecord(start, g_stream);
+  hipEventRecord(start, st);
 }
 ProfileScope::~ProfileScope() {
   if (idx < 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mutex);
   hipEvent_t stop = pooled_event();
   if (!stop) { g_event_pool.push_back(start); return; }
-  hipEventRecord(stop, g_stream);
+  hipEventRecord(stop, st);
   g_prof_open.push_back({idx, start, stop});
   if (g_prof_open.size() > 4096) profile_drain();
 }
@@ -284,15 +285,13 @@ int cup3d_device_synchronize(void) {
 }
 
 // TEST / TUNING SUPPORT: select kernel variants (A/B timing, ablations); 0 = production
+#ifdef CUP3D_TESTING  // test / tuning support: not in the release library at all
 int cup3d_debug_set_option(const char *name, int value) {
   if (!name) return CUP3D_EINVAL;
-#ifdef CUP3D_TESTING
   g_debug_opts[name] = value;
   return CUP3D_OK;
-#else
-  return value == 0 ? CUP3D_OK : not_in_release("cup3d_debug_set_option");  // 0 = production behaviour: what this build always does
-#endif
 }
+#endif
 
 int cup3d_profile_enable(int on) { g_prof_on = on != 0; return CUP3D_OK; }
 int cup3d_profile_reset(void) {
@@ -332,7 +331,7 @@ static int sim_build(Sim *s, const Grid *g) {
   A(s->vel, nv * 1536) A(s->vel2, nv * 1536) A(s->tmpV, nv * 1536)
   A(s->pres, nv * 512) A(s->lhs, nv * 512) A(s->chi, nv * 512) A(s->pold, nv * 512)
   s->max_groups = 4096;
-  A(s->d_partials, (size_t)s->max_groups * 8 + nb) A(s->d_red, 16)
+  A(s->d_partials, (size_t)s->max_groups * 8 + nb) A(s->d_red, kRedSize)
   CUP3D_HIP(hipHostMalloc((void **)&s->h_red, 17 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));  // 16 totals + the sequence word of Reducer
   memset(s->h_red, 0, 17 * sizeof(double));
   CUP3D_HIP(hipHostGetDevicePointer((void **)&s->h_red_dev, s->h_red, 0));
@@ -700,7 +699,7 @@ int cup3d_sim_checksum(cup3d_sim_t *h, int field, unsigned long long *sum) {
   int nc;
   const double *p = s->field(field, &nc);
   if (!p) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
-  unsigned long long *d = reinterpret_cast<unsigned long long *>(s->d_red + 12);  // scratch behind the reduced scalars
+  unsigned long long *d = reinterpret_cast<unsigned long long *>(s->d_red + kRedChecksum);  // its own slot of d_red (RedSlot)
   CUP3D_HIP(hipMemsetAsync(d, 0, sizeof *d, g_stream));
   const long n = (long)s->nb * 512 * nc;  // the rank's own blocks; ghost blocks of a rank view sit behind them
   hipLaunchKernelGGL(k_checksum, dim3(stride_groups(n)), dim3(256), 0, g_stream, p, n, d);

@@ -42,10 +42,12 @@ bool profile_on();                   // cup3d_profile_enable
 
 // ---- per-kernel timing (cup3d_profile_*) ----
 struct ProfileScope {
-  explicit ProfileScope(const char *name);
+  explicit ProfileScope(const char *name);        // events on the compute stream
+  ProfileScope(const char *name, hipStream_t st);  // ... on `st` (the communication stream: "comm_*" entries)
   ~ProfileScope();
   int idx;
   hipEvent_t start;
+  hipStream_t st;
 };
 
 // ---- run statistics (cup3d_stats_*): what crossed ranks and how long the host waited for the device
@@ -76,6 +78,19 @@ struct GridDev {
 };
 __device__ __forceinline__ double block_h(const GridDev &g, int slot) { return g.hb ? g.hb[slot] : g.h; }
 
+// The 16 doubles of Sim::d_red, by user.  The ranges must stay disjoint: the solver's scalars at kRedDots are live from one loop
+// kernel to the next, and a checksum or a multigrid cycle may run in between.
+enum RedSlot : int {
+  kRedDots = 0,      // [0, 8): totals of the 2 / 7 dot products of a BiCGSTAB loop, the mean-constraint total riding along behind them
+                     //         ([2] after loop 1, [7] after loop 2); outside a solve: max|u| ([0]), the penalisation's 6 sums + status ([0, 7))
+  kRedDotsEnd = 8,
+  kRedMeanLhs = 8,   // [8]: sum(p h^3) of a stand-alone LHS application (k_mean_finish, stencil.hip)
+  kRedChecksum = 12, // [12]: cup3d_sim_checksum's 64-bit accumulator
+  kRedMg = 14,       // [14]: coarsest-level sum of the multigrid cycle over ranks (multigrid.hip)
+  kRedSize = 16
+};
+static_assert(kRedDotsEnd <= kRedMeanLhs && kRedMeanLhs < kRedChecksum && kRedChecksum < kRedMg && kRedMg < kRedSize, "Sim::d_red slots overlap");
+
 struct Sim {
   const Grid *grid = nullptr;
   int64_t nb = 0;    // local blocks: what the kernels sweep and what crosses the host boundary
@@ -92,14 +107,17 @@ struct Sim {
   // -1 = not told: several ranks then always take the chi / udef path of the pressure right-hand side, because its udef exchange is a
   // collective and chi_nonzero is per-rank state
   int obstacles_global = -1;
-  bool chi_path() const { return obstacles_global >= 0 ? obstacles_global != 0 : (chi_nonzero || grid->nranks > 1); }
+  // one rank: told "obstacles" or chi was written (a chi filled by hand after set_obstacles(0) still counts -- never silently dropped);
+  // several ranks: as told, the same on every rank (told 0 with a written chi is refused by cup3d_pressure_project, chi_conflict())
+  bool chi_path() const { return grid->nranks == 1 ? (obstacles_global == 1 || chi_nonzero) : obstacles_global != 0; }
+  bool chi_conflict() const { return grid->nranks > 1 && obstacles_global == 0 && chi_nonzero; }
   int block_solver = 0;  // cup3d_poisson_params.block_solver of the running solve
   int scalar_bc_dir = -1;  // >= 0 while a Helmholtz solve of the implicit diffusion runs: domain-face rule of the scalar tiles
   // solver vectors (allocated on first solve), each [nb][512]
   double *sv[18] = {nullptr};
   // reductions
   double *d_partials = nullptr;  // [max_groups][8]
-  double *d_red = nullptr;       // [16] final reduced scalars
+  double *d_red = nullptr;       // [kRedSize] final reduced scalars, see RedSlot
   const double *sums_of = nullptr;  // vector whose per-block sums (mean constraint) are current in d_partials' tail
   double *h_red = nullptr;       // pinned host mirror
   double *h_red_dev = nullptr;   // the same memory as the device sees it (kernels store the reduced scalars there directly)
@@ -153,6 +171,9 @@ int halo_begin(Sim *s, const double *field, int ncomp, int w);
 int halo_finish(Sim *s);
 // sum / max all-reduce of n doubles resident in device memory; no-op on one rank
 int allreduce(Sim *s, double *d_buf, int n, bool is_max, hipStream_t st);
+// collective status agreement before the first exchange of a collective entry point: every rank passes its local outcome, all get the
+// worst one back (comm.hip); no-op on one rank
+int agree(Sim *s, int rc, const char *where);
 bool scalars_cross_ranks(const Sim *s);   // does allreduce() do anything for this sim?
 hipStream_t scalar_stream(const Sim *s);  // the stream all-reduces are enqueued on (communication stream where there is one)
 // rank views of a multi-level mesh: face-flux arrays of remote fine faces -> ghost face range of d_flux (before k_flux_fix)

@@ -370,7 +370,7 @@ int launch_lhs(Sim *s, const double *p, double *out, int mc) {
   // ... and the fused solver loop has even totalled those sums (k_sums_finish<K, true>) and, over ranks, all-reduced the total
   // together with its dot products (Reducer::begin; ev_a marks the arrival)
   const bool have_total = need_sum && s->mean_total_of == p;
-  const double *total = have_total ? s->mean_total : s->d_red + 8;
+  const double *total = have_total ? s->mean_total : s->d_red + kRedMeanLhs;
   s->mean_total_of = nullptr;
   const bool across = scalars_cross_ranks(s);
   const int corner = s->grid->corner_slot;
@@ -403,26 +403,26 @@ int launch_lhs(Sim *s, const double *p, double *out, int mc) {
   } else if (need_sum) {
     ProfileScope ps("poisson_mean_sum");
     double *corner_out = (!across && mc == 1 && corner >= 0) ? out + (size_t)corner * 512 : nullptr;
-    hipLaunchKernelGGL(k_mean_finish, dim3(64), dim3(256), 0, stream(), block_sums, (int)s->nb, s->d_partials, s->d_counters + 1, s->d_red + 8, corner_out);
+    hipLaunchKernelGGL(k_mean_finish, dim3(64), dim3(256), 0, stream(), block_sums, (int)s->nb, s->d_partials, s->d_counters + 1, s->d_red + kRedMeanLhs, corner_out);
     if (across) {  // MPI_Iallreduce, main.cpp:9295 -- on the communication stream like every RCCL call; the fix-up below waits for it
       hipStream_t cs = scalar_stream(s);
       if (cs != stream()) {
         CUP3D_HIP(hipEventRecord(s->ev_b, stream()));
         CUP3D_HIP(hipStreamWaitEvent(cs, s->ev_b, 0));
       }
-      if ((rc = allreduce(s, s->d_red + 8, 1, false, cs))) return rc;
+      if ((rc = allreduce(s, s->d_red + kRedMeanLhs, 1, false, cs))) return rc;
       if (cs != stream()) {
         CUP3D_HIP(hipEventRecord(s->ev_h1, cs));
         CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_h1, 0));
       }
-      if (mc == 1 && corner >= 0) hipLaunchKernelGGL(k_lhs_corner, dim3(1), dim3(1), 0, stream(), out, p, s->d_red + 8, corner, 1);
+      if (mc == 1 && corner >= 0) hipLaunchKernelGGL(k_lhs_corner, dim3(1), dim3(1), 0, stream(), out, p, s->d_red + kRedMeanLhs, corner, 1);
     }
     if (mc == 2) {
       const double h = s->grid->h;
-      hipLaunchKernelGGL(k_lhs_add_mean, dim3(2048), dim3(256), 0, stream(), out, s->nb * 512L, s->d_red + 8, h * h * h, s->d_hb);
+      hipLaunchKernelGGL(k_lhs_add_mean, dim3(2048), dim3(256), 0, stream(), out, s->nb * 512L, s->d_red + kRedMeanLhs, h * h * h, s->d_hb);
     }
   } else if (corner >= 0) {
-    hipLaunchKernelGGL(k_lhs_corner, dim3(1), dim3(1), 0, stream(), out, p, s->d_red + 8, corner, 3);
+    hipLaunchKernelGGL(k_lhs_corner, dim3(1), dim3(1), 0, stream(), out, p, s->d_red + kRedMeanLhs, corner, 3);
   }
   CUP3D_HIP(hipGetLastError());
   return CUP3D_OK;
@@ -512,7 +512,7 @@ int cup3d_grad_p(cup3d_sim_t *h, double dt) {
   if (!h) return CUP3D_EINVAL;
   return grad_p(reinterpret_cast<Sim *>(h), dt, false);
 }
-int cup3d_grad_p_update(cup3d_sim_t *h, double dt) {  // internal to cup3d_pressure_project
+__attribute__((visibility("hidden"))) int cup3d_grad_p_update(cup3d_sim_t *h, double dt) {  // internal to cup3d_pressure_project, not exported
   return grad_p(reinterpret_cast<Sim *>(h), dt, true);
 }
 

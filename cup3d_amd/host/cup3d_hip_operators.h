@@ -512,49 +512,32 @@ inline Installed install(SimulationData &sim, int resident = -1) {
   return r;
 }
 
-// Simulation::calcMaxTimestep (main.cpp:15254-15305) with findMaxU (8603-8623, incl. its MAX all-reduce) on the device: what the
-// time loop calls instead of simulation.calcMaxTimestep() in device-led mode (DeviceMirror::device_led).  The expressions are the
-// reference's, compiled by the same host compiler; cup3d_max_u is exact (a maximum), so dt and coefU are the reference's bits.
+// Device-led replacement for simulation.calcMaxTimestep() (main.cpp:15254-15305; DeviceMirror::device_led).  Nothing of the
+// reference's function is restated here: the maximum comes from cup3d_max_u (findMaxU incl. its MAX all-reduce, 8603-8623, exact) and
+// the time-step rule and the pressure-extrapolation coefficients from the library (cup3d_calc_max_timestep2, pinned against the
+// reference by tests/test_host_indexing.py); this function only moves the results into SimulationData.
 inline Real calcMaxTimestep(Simulation &S, DeviceMirror &dev) {
   SimulationData &sim = S.sim;
-  if (!dev.dev_current) return S.calcMaxTimestep();  // the host copy is the current one (first step, after an adaptation, with obstacles)
-  const Real dt_old = sim.dt;
-  sim.dt_old = sim.dt;
-  const Real hMin = sim.hmin;
-  Real CFL = sim.CFL;
+  // host copy current (first step, after an adaptation, obstacle runs), or a fixed-dt run (CFL <= 0: nothing for the library to choose)
+  if (!dev.dev_current) return S.calcMaxTimestep();
+  if (!(sim.CFL > 0)) { dev.sync_host(); return S.calcMaxTimestep(); }
+  auto stop = [&](const char *why, double value) {
+    if (sim.rank == 0) fprintf(stderr, "cup3d_hip::calcMaxTimestep: %s (%g) at step %d -- stopping the run\n", why, value, sim.step);
+    MPI_Abort(sim.comm, 1);
+  };
   const double uinf[3] = {sim.uinf[0], sim.uinf[1], sim.uinf[2]};
-  double umax = 0;
+  double umax = 0, coef[3] = {sim.coefU[0], sim.coefU[1], sim.coefU[2]};
   CUP3D_HIP_CALL(cup3d_max_u(dev.handle(), uinf, &umax));
+  if (umax > sim.uMax_allowed) stop("velocity maximum above -uMax_allowed", umax);
+  const double previous = sim.dt;
+  const double dt = cup3d_calc_max_timestep2(sim.hmin, umax, sim.nu, sim.CFL, sim.step, sim.rampup, previous, coef, sim.implicitDiffusion ? 1 : 0);
+  if (!(dt > 0)) stop("non-positive time step", dt);
   sim.uMax_measured = umax;
-  if (sim.uMax_measured > sim.uMax_allowed) {
-    if (sim.rank == 0) fprintf(stderr, "maxU = %g exceeded uMax_allowed = %g. Aborting...\n", (double)sim.uMax_measured, (double)sim.uMax_allowed);
-    MPI_Abort(sim.comm, 1);
-  }
-  if (CFL > 0) {
-    const Real dtDiffusion = (sim.implicitDiffusion && sim.step > 10) ? 0.1 : (1.0 / 6.0) * hMin * hMin / (sim.nu + (1.0 / 6.0) * hMin * sim.uMax_measured);
-    const Real dtAdvection = hMin / (sim.uMax_measured + 1e-8);
-    if (sim.step < sim.rampup) {
-      const Real x = sim.step / (Real)sim.rampup;
-      const Real rampCFL = std::exp(std::log(1e-3) * (1 - x) + std::log(CFL) * x);
-      sim.dt = std::min(dtDiffusion, rampCFL * dtAdvection);
-    } else
-      sim.dt = std::min(dtDiffusion, CFL * dtAdvection);
-  } else {
-    CFL = (sim.uMax_measured + 1e-8) * sim.dt / hMin;
-  }
-  if (sim.dt <= 0) {
-    fprintf(stderr, "dt <= 0. CFL=%f, hMin=%f, sim.uMax_measured=%f. Aborting...\n", (double)CFL, (double)hMin, (double)sim.uMax_measured);
-    MPI_Abort(sim.comm, 1);
-  }
-  if (sim.DLM > 0) sim.lambda = sim.DLM / sim.dt;
-  if (sim.rank == 0) printf("main.cpp: step: %d, time: %f\n", sim.step, sim.time);
-  if (sim.step > sim.step_2nd_start) {
-    const Real a = dt_old, b = sim.dt;
-    const Real c1 = -(a + b) / (a * b), c2 = b / (a + b) / a;
-    sim.coefU[0] = -b * (c1 + c2);
-    sim.coefU[1] = b * c1;
-    sim.coefU[2] = b * c2;
-  }
+  sim.dt_old = previous;
+  sim.dt = dt;
+  for (int i = 0; i < 3; ++i) sim.coefU[i] = coef[i];
+  if (sim.DLM > 0) sim.lambda = sim.DLM / dt;
+  if (sim.rank == 0) printf("main.cpp: step: %d, time: %f\n", sim.step, sim.time);  // the progress line the reference's loop prints from here
   return sim.dt;
 }
 // ... and the companion of Simulation::advance (15306-15326) in that mode: adaptMesh (15314) and dump (15307-15313) read the host fields

@@ -244,6 +244,8 @@ class SimulationData:
 
     def fill(self, field, value):
         check(lib().cup3d_sim_fill(self.handle, FIELDS[field], float(value)))
+        if field == "chi":
+            self._chi_uploaded = float(value) != 0.0   # chi set (or cleared) by hand, as upload() notes
 
     def _block_ptrs(self, a):
         return (C.c_void_p * len(a))(*[a[i].ctypes.data for i in range(len(a))])

@@ -182,7 +182,9 @@ int cup3d_sim_mark_written(cup3d_sim_t *, int field);
 /* Does ANY rank hold an obstacle?  The reference's obstacle_vector is replicated on every rank (sim.obstacle_vector->nObstacles(),
  * main.cpp:15081), so the host knows without communicating; the same value on every rank (it decides whether the collective udef
  * exchange of the pressure right-hand side runs).  1: chi / udef path (KernelPressureRHS 14858-14871); 0: obstacle-free path, no udef
- * exchange, tmpV not cleared; -1 (default): not told -- one rank decides by "chi was written", several ranks always take the chi path. */
+ * exchange, tmpV not cleared; -1 (default): not told -- one rank decides by "chi was written", several ranks always take the chi path.
+ * A chi written (upload / fill / mark_written) is never dropped silently: on one rank it takes the chi path even after 0; on several
+ * ranks cup3d_pressure_project refuses the combination on EVERY rank (CUP3D_ESTATE, agreed before the first exchange). */
 int cup3d_sim_set_obstacles(cup3d_sim_t *, int any_rank_has_obstacles);
 /* Wrapping 64-bit sum of the bit patterns of every FP64 value of the rank's own blocks of `field` (ghost blocks of a rank view
  * excluded).  Integer addition commutes, so the sum of the ranks' values is independent of the partition: bench.py all-gathers it
@@ -341,6 +343,9 @@ typedef struct {
 int cup3d_stats_reset(void);
 int cup3d_stats_read(cup3d_run_stats *);
 int cup3d_profile_read(cup3d_profile_entry *entries, int max, int *n);
+/* CG iterations of the last block-CG launch made while cup3d_profile_enable(1) was on, summed over the rank's blocks (the flop count
+ * behind bench.py's FP64 roofline of the block preconditioner, getZImplParallel main.cpp:14704-14745) */
+int cup3d_profile_block_cg_iterations(cup3d_sim_t *, long *total, long *nblocks);
 
 #ifdef __cplusplus
 }

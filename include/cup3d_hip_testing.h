@@ -1,6 +1,6 @@
 /* cup3d_hip_testing.h -- TEST / TUNING SUPPORT of libcup3d_hip_testing.so (built with -DCUP3D_TESTING).  NOT part of the drop-in
- * boundary (include/cup3d_hip.h): nothing here replaces a reference interface.  The release library exports the same names, but they
- * return CUP3D_ESTATE there ("load libcup3d_hip_testing.so").
+ * boundary (include/cup3d_hip.h): nothing here replaces a reference interface.  The release library (libcup3d_hip.so) does not export any of these
+ * names (tests/test_host_indexing.py checks their absence).
  */
 #ifndef CUP3D_HIP_TESTING_H
 #define CUP3D_HIP_TESTING_H
@@ -20,7 +20,6 @@ int cup3d_debug_virtual_comm(int nranks);
 int cup3d_debug_advdiff_stage(cup3d_sim_t *, int rk, double dt, double nu, const double uinf[3]);
 int cup3d_debug_amr_slabs(cup3d_sim_t *, int field, int w, double *out);
 int cup3d_debug_wave_sum(const double *in64, double *out128);
-int cup3d_debug_block_cg_iterations(cup3d_sim_t *, long *total, long *nblocks);
 /* the solver's scalar recurrences (SolverCtl, poisson.hip) stepped on the host -- the same functions the device runs; no GPU needed.
  * io[16] = alpha, beta, omega, r0r_prev, norm, init_norm, min_norm, tol, tol_rel, state (0 run, 1 done, 2 restart), restarts,
  * max_restarts, xcur, xopt, iter; step 1 takes totals[2] (main.cpp:14493), step 2 totals[7] (14558-14601) */
