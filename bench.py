@@ -20,12 +20,21 @@ Prints ONE JSON line (rank 0): metric Mcell-updates/s = cells * steps / seconds 
 ranks (strong scaling: the grid is fixed, blocks are sharded by Hilbert ranges), plus
 `roofline` (dominant kernel by device time, algorithmic bytes / measured kernel time vs
 8 TB/s) and `cpu_baseline` (the compiled reference on this host's cores, bounded sample).
+
+A run over N > 1 ranks cannot end silently: every rank reports its stage (rendezvous, comm_init, checksum, warmup, timed, ...) to a
+progress file, a watchdog thread per rank (and the self-launching parent) ends the run when a stage stalls (--stall-timeout) or the
+whole run exceeds --timeout, and rank 0 (or the parent) then prints ONE JSON line {"valid": false, "error": ..., "stage": ...,
+"rank_progress": [...]} and exits non-zero.  torch.distributed runs on gloo (CPU tensors: bootstrap of the RCCL unique id, checksum
+gather, barriers, timing reduce), so the process holds exactly ONE RCCL communicator -- the library's own.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import signal
 import sys
+import tempfile
+import threading
 import time
 
 import numpy as np
@@ -98,32 +107,82 @@ def checksum_dt(size):
     return 0.3 * (2 * np.pi / size)
 
 
-def advdiff_checksums(sim, a, dist, world):
-    """config.checksum: one AdvectionDiffusion::operator() (fixed dt = 0.3 h, nu = 0.01) applied to (a) the exact test field, (b) the
-    Taylor-Green field of the run; the wrapping 64-bit sums of the bit patterns of `vel` afterwards, added over the ranks mod 2^64.
-    The stencil path is bit-exact with the CPU oracle under any sharding of the blocks, so both values must equal the oracle's
-    constants at every N (the reference's own multi-rank run equals its one-rank run the same way: tests/test_oracle_vs_ref.py)."""
+def gather_sum(mine, a, dist, world):
+    """sum over the ranks mod 2^64 of one (or a list of) 64-bit wrapping sums: all-gathered as signed int64 over gloo"""
     import torch
+    vals = list(mine) if isinstance(mine, (list, tuple)) else [mine]
+    if dist is None:
+        tot = [v % (1 << 64) for v in vals]
+    else:
+        signed = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in vals], dtype=torch.int64, device=a.tdev)
+        parts = [torch.zeros_like(signed) for _ in range(world)]
+        dist.all_gather(parts, signed)
+        tot = [sum(int(p[i].item()) for p in parts) % (1 << 64) for i in range(len(vals))]
+    return tot if isinstance(mine, (list, tuple)) else tot[0]
+
+
+POISSON_VECTORS = ("phat", "rhat", "shat", "what", "zhat", "qhat", "s", "w", "z", "t", "v", "q", "r", "y", "x", "r0", "b", "xopt")  # poisson.hip's order
+
+
+def advdiff_checksums(sim, a, dist, world, prog=None):
+    """config.checksum: the run's bitwise correctness signals, the same at every N (wrapping 64-bit sums of bit patterns over each rank's
+    blocks, added over the ranks mod 2^64 -- integer addition commutes, so only the BITS of every cell matter, not who owns it):
+      exact_field, taylor_green   `vel` after ONE AdvectionDiffusion::operator() (dt = 0.3 h, nu = 0.01) of the exact test field / the
+                                  Taylor-Green field: the width-3 VECTOR halo + the advect-diffuse kernels.  expected = the CPU oracle.
+      lhs_exact_field             ComputeLHS (bMeanConstraint 0) of the exact field's x component: width-1 SCALAR halo + k_lhs.  expected = the CPU oracle.
+      precond_exact_field         M^-1 of that field (cup3d_preconditioner, the block CG): block-local, so partition-independent; its
+                                  bits are the DEVICE's (tree-shaped sums, FMA), hence expected = the one-GPU run's recorded value.
+      fused_iteration             cup3d_poisson_path_checksum: ONE BiCGSTAB iteration's kernels as the solver launches them (LHS inside
+                                  the loop kernels reading the scalar face slabs in place, inner / boundary split, block CG) on hashed
+                                  vectors with alpha, beta, omega set by hand: 18 vector sums folded into one.  expected = the one-GPU run's.
+    The reference's own multi-rank run equals its one-rank run the same way (tests/test_oracle_vs_ref.py)."""
     import cup3d_amd as cu
+    from cup3d_amd.capi import check, lib
     ext = 2 * np.pi
     golden = os.path.join(ROOT, "tests", "golden", "advdiff_checksums.json")
     expected = json.load(open(golden)).get(str(a.size), {}) if os.path.exists(golden) else {}
-    out = {"what": "wrapping uint64 sum of the bit patterns of vel after ONE AdvectionDiffusion (dt = 0.3 h, nu = 0.01) on this workload's grid, "
-                   "summed over ranks mod 2^64; `expected` = the CPU oracle's value (tests/golden/advdiff_checksums.json)", "dt": checksum_dt(a.size)}
+    out = {"what": "wrapping uint64 sums of bit patterns, added over ranks mod 2^64; `expected`: the CPU oracle's value (exact_field, taylor_green, "
+                   "lhs_exact_field) or the one-GPU device run's (precond_exact_field, fused_iteration: block-local CG, device rounding) -- "
+                   "tests/golden/advdiff_checksums.json", "dt": checksum_dt(a.size)}
+
+    def record(key, value):
+        exp = expected.get(key)
+        out[key] = {"value": value, "expected": exp, "ok": (value == exp) if exp is not None else None}
+        if prog is not None:
+            prog.beat(key)
+
     adv = cu.AdvectionDiffusion(sim)
     nu0, sim.nu = sim.nu, 0.01
-    for key, field in (("exact_field", exact_test_field_blocks(sim.grid, a.size)), ("taylor_green", taylor_green_blocks(sim.grid, [ext] * 3, 1.0))):
+    exact = exact_test_field_blocks(sim.grid, a.size)
+    for key, field in (("exact_field", exact), ("taylor_green", taylor_green_blocks(sim.grid, [ext] * 3, 1.0))):
         sim.upload("vel", field)
         adv(checksum_dt(a.size))
-        mine = sim.checksum("vel")
-        if dist is not None:
-            parts = [torch.zeros(1, dtype=torch.int64, device=a.tdev) for _ in range(world)]
-            dist.all_gather(parts, torch.tensor([mine - (1 << 64) if mine >= (1 << 63) else mine], dtype=torch.int64, device=a.tdev))
-            mine = sum(int(p.item()) for p in parts) % (1 << 64)
-        exp = expected.get(key)
-        out[key] = {"value": mine, "expected": exp, "ok": (mine == exp) if exp is not None else None}
+        record(key, gather_sum(sim.checksum("vel"), a, dist, world))
     sim.nu = nu0
-    out["ok"] = all(out[k]["ok"] is not False for k in ("exact_field", "taylor_green")) and out["exact_field"]["ok"] is not None
+    # the Poisson path: A p, M^-1 p, one fused iteration
+    pres = np.ascontiguousarray(exact[..., 0])
+    sim.upload("pres", pres)
+    check(lib().cup3d_compute_lhs(sim.handle, 0))
+    record("lhs_exact_field", gather_sum(sim.checksum("lhs"), a, dist, world))
+    sim.upload("pres", pres)
+    check(lib().cup3d_preconditioner(sim.handle, 0))
+    record("precond_exact_field", gather_sum(sim.checksum("pres"), a, dist, world))
+    sums = (C.c_ulonglong * 18)()
+    check(lib().cup3d_poisson_path_checksum(sim.handle, 0, 1, sums))
+    per_vector = gather_sum([int(v) for v in sums], a, dist, world)
+    folded = 0
+    for i, v in enumerate(per_vector):   # order-sensitive fold: a swap of two vectors' sums does not cancel
+        folded = (folded * 1099511628211 + v + i) % (1 << 64)
+    record("fused_iteration", folded)
+    out["fused_iteration"]["vectors"] = dict(zip(POISSON_VECTORS, per_vector))
+    sim.fill("pres", 0.0)
+    sim.fill("lhs", 0.0)
+    keys = ("exact_field", "taylor_green", "lhs_exact_field", "precond_exact_field", "fused_iteration")
+    oks = [out[k]["ok"] for k in keys]
+    # three outcomes: False = some constant exists and differs (the run is INVALID); True = every signal has a constant and equals it;
+    # None = nothing contradicted but some signal has no recorded constant for this --size (unchecked, not wrong)
+    out["ok"] = False if any(o is False for o in oks) else (True if all(o is True for o in oks) else None)
+    out["unchecked"] = [k for k in keys if out[k]["ok"] is None]
     return out
 
 
@@ -177,7 +236,109 @@ def install_host_transport(dist, rank, world):
     return tr
 
 
-def relaunch_under_torchrun(n, need_devices=True):
+
+STAGES = ("start", "rendezvous", "comm_init", "grid", "checksum", "warmup", "timed", "alt", "report", "cpu_baseline", "done")
+
+
+def progress_dir():
+    """One directory per run, the same for every rank: handed down by the self-launching parent, else derived from the rendezvous."""
+    d = os.environ.get("CUP3D_BENCH_PROGRESS_DIR")
+    if not d:
+        d = os.path.join(tempfile.gettempdir(), "cup3d_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none")))
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def read_progress(d, world):
+    out = []
+    for r in range(world):
+        try:
+            out.append(json.load(open(os.path.join(d, f"rank{r}.json"))))
+        except Exception:
+            out.append({"rank": r, "stage": "never reported (the process did not get as far as bench.py's main)"})
+    return out
+
+
+def error_line(a_gpus, stage, error, rank_progress, steps=None, warmup=None):
+    """The ONE line a failed run prints instead of the result (same leading keys, so that a reader of BENCH/SCALE records sees it)."""
+    return json.dumps({"metric": "Mcell-updates/s (advect+diffuse+Poisson), 512^3 uniform, 1/2/4/8 GPUs", "value": None, "unit": "Mcell-updates/s",
+                       "n_gpus": a_gpus, "steps": steps, "warmup": warmup, "valid": False, "error": error, "stage": stage, "rank_progress": rank_progress})
+
+
+class Progress:
+    """Stage reporting + watchdog of one rank.  The watchdog is a daemon thread: it ends the process (os._exit) when the current stage
+    has made no progress for its stall limit, when the run exceeds its total limit, or when the launcher sends SIGTERM because another
+    rank died (signal wake-up fd: seen at once even while the main thread sits inside an RCCL call).  Rank 0 prints the error line."""
+
+    def __init__(self, rank, world, a):
+        self.rank, self.world, self.a = rank, world, a
+        self.dir = progress_dir()
+        self.path = os.path.join(self.dir, f"rank{rank}.json")
+        self.t0 = self.last = time.time()
+        self.stage, self.detail, self.limit = "start", "", a.stall_timeout
+        self.done = False
+        self.lock = threading.Lock()
+        self.rd, self.wr = os.pipe()
+        os.set_blocking(self.wr, False)
+        if world > 1 or a.watchdog:
+            try:
+                signal.signal(signal.SIGTERM, lambda *args: None)   # the watchdog thread acts on it (wake-up fd), not the blocked main thread
+                signal.set_wakeup_fd(self.wr, warn_on_full_buffer=False)
+            except ValueError:
+                pass   # not the main thread (tests importing bench): no signal hook
+            threading.Thread(target=self.watch, daemon=True).start()
+        self.set("start")
+
+    def set(self, stage, detail="", limit=None):
+        with self.lock:
+            self.stage, self.detail, self.last = stage, detail, time.time()
+            self.limit = limit if limit is not None else self.a.stall_timeout
+            rec = {"rank": self.rank, "pid": os.getpid(), "stage": stage, "detail": detail, "t": round(self.last - self.t0, 2)}
+        tmp = self.path + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump(rec, f)
+        os.replace(tmp, self.path)
+
+    def beat(self, detail):
+        self.set(self.stage, detail, self.limit)
+
+    def fail(self, error, code=4):
+        """Called by the watchdog thread or by main()'s exception handler: rank 0 prints the line; everybody leaves."""
+        self.set(self.stage, f"FAILED: {error}", 1e9)
+        if self.rank == 0:
+            time.sleep(0.5)   # the other ranks' last words
+            sys.stdout.write(error_line(self.world, self.stage, error, read_progress(self.dir, self.world), self.a.steps, self.a.warmup) + "\n")
+            sys.stdout.flush()
+        else:
+            time.sleep(3.0)   # rank 0 prints before the launcher tears the group down because this rank left
+        sys.stderr.write(f"bench.py rank {self.rank}: {error} (stage {self.stage})\n")
+        sys.stderr.flush()
+        os._exit(code)
+
+    def watch(self):
+        import select
+        while not self.done:
+            r, _, _ = select.select([self.rd], [], [], 1.0)
+            if self.done:
+                return
+            now = time.time()
+            if r:
+                sig = os.read(self.rd, 64)
+                if bytes([signal.SIGTERM]) in sig:
+                    self.fail("SIGTERM from the launcher: another rank ended (see rank_progress)", 143)
+            with self.lock:
+                stalled, total = now - self.last > self.limit, now - self.t0 > self.a.timeout
+                stage, limit = self.stage, self.limit
+            if stalled:
+                self.fail(f"no progress for {limit:.0f} s in stage '{stage}' (a hung rendezvous, communicator or collective)")
+            if total:
+                self.fail(f"run exceeded --timeout {self.a.timeout:.0f} s")
+
+    def finish(self):
+        self.set("done")
+        self.done = True
+
+def relaunch_under_torchrun(n, need_devices=True, a=None):
     """`python bench.py --gpus N` (N > 1) as the driver types it: one process per GPU via torch.distributed.run, rendezvous on
     127.0.0.1; rank 0's JSON line is the only thing on stdout."""
     import socket
@@ -190,11 +351,40 @@ def relaunch_under_torchrun(n, need_devices=True):
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
+    pdir = tempfile.mkdtemp(prefix="cup3d_bench_")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
-               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n))))
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n))), CUP3D_BENCH_PROGRESS_DIR=pdir)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.exit(subprocess.call(cmd, env=env))
+    # the parent is the last line of defence: whatever happens to the ranks (a hang the per-rank watchdogs did not end, a crash before
+    # bench.py's main, the launcher itself failing), ONE JSON line reaches stdout and the exit code says so
+    timeout = (a.timeout if a else 1500.0) + 30.0
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    lines = []
+    reader = threading.Thread(target=lambda: [lines.append(ln) for ln in proc.stdout], daemon=True)
+    reader.start()
+    try:
+        rc = proc.wait(timeout=timeout)
+        why = f"the ranks ended with exit code {rc} without a result line"
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)   # the launcher and every rank: the group this parent started, nothing else
+        except ProcessLookupError:
+            pass
+        rc = proc.wait()
+        why = f"no result within {timeout:.0f} s: process group killed"
+    reader.join(timeout=5)
+    got = [ln for ln in lines if ln.lstrip().startswith("{") and '"metric"' in ln]
+    for ln in got[:1] or []:
+        sys.stdout.write(ln if ln.endswith("\n") else ln + "\n")
+    if not got:
+        prog = read_progress(pdir, n)
+        stages = [p.get("stage") for p in prog]
+        first = min((STAGES.index(st) if st in STAGES else -1) for st in stages) if stages else -1
+        sys.stdout.write(error_line(n, STAGES[first] if first >= 0 else "launch", why, prog, a.steps if a else None, a.warmup if a else None) + "\n")
+        rc = rc or 4
+    sys.stdout.flush()
+    sys.exit(rc)
 
 
 def cpu_baseline(size_cpu, steps, threads):
@@ -325,7 +515,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=512, help="cells per side (a multiple of 8; 512 = the BASELINE workload, 768 = the largest that leaves room on one 288 GB GPU)")
     ap.add_argument("--cpu-size", type=int, default=256, help="cells per side of the CPU-baseline sample (512 needs ~35 GB and minutes per step)")
-    ap.add_argument("--cpu-steps", type=int, default=3, help="steps of the CPU-baseline sample; the median step is reported")
+    ap.add_argument("--cpu-steps", type=int, default=5, help="steps of the CPU-baseline sample; the median step is reported (SURVEY 8d: >= 5 repeats)")
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="OpenMP threads of the reference; 32 is its best on the 256-thread GPU host (see report()); 0: all host cores")
     ap.add_argument("--no-cpu", action="store_true")
@@ -336,6 +526,10 @@ def main():
                     help="what carries the library's exchanges over ranks.  rccl: production (one device per rank).  host: the library's "
                          "host-memory TEST transport over torch.distributed/gloo (libcup3d_hip_testing.so): lets --gpus N run on fewer than N "
                          "devices to check the multi-process path and config.checksum; its rate says nothing about scaling")
+    ap.add_argument("--timeout", type=float, default=1500.0, help="whole-run limit in seconds; the watchdog then prints the error line and exits 4 (the driver's own limit is 1800 s)")
+    ap.add_argument("--stall-timeout", type=float, default=300.0, help="limit for ONE stage step without progress (a hung rendezvous / collective), seconds")
+    ap.add_argument("--watchdog", action="store_true", help="run the per-rank watchdog on one rank too (it always runs when N > 1)")
+    ap.add_argument("--fail-at", default=None, help="TEST: 'stage:rank:how' with how = hang | exit | raise -- that rank misbehaves when it enters the stage")
     ap.add_argument("--no-checksum", action="store_true", help="skip config.checksum (one extra AdvectionDiffusion on two fields before the timed region)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host<->device transfer measurement behind `pcie_inclusive`")
     ap.add_argument("--debug-option", action="append", help="name=value for cup3d_debug_set_option (tuning scans)")
@@ -349,6 +543,38 @@ def main():
     ap.add_argument("--amr-levels", type=int, default=3, help="--amr: number of levels of the final mesh")
     ap.add_argument("--amr-fraction", type=float, default=0.3, help="--amr: fraction of the blocks refined per pass")
     a = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and a.gpus > 1 and not a.amr:
+        return relaunch_under_torchrun(a.gpus, a.transport == "rccl", a)
+    prog = Progress(rank, world, a)
+    try:
+        run(a, prog)
+    except SystemExit:
+        raise
+    except BaseException as e:   # a rank that raises must not leave the others inside a collective without a word
+        import traceback
+        traceback.print_exc()
+        prog.fail(f"{type(e).__name__}: {e}", 5)
+    prog.finish()
+
+
+def misbehave(a, prog, stage, rank):
+    """--fail-at stage:rank:how (tests of the watchdog): hang = sleep for ever, exit = leave at once, raise = a Python exception"""
+    if not a.fail_at:
+        return
+    st, r, how = a.fail_at.split(":")
+    if st != stage or int(r) != rank:
+        return
+    if how == "hang":
+        while True:
+            time.sleep(3600)
+    if how == "exit":
+        os._exit(7)
+    raise RuntimeError(f"--fail-at {a.fail_at}")
+
+
+def run(a, prog):
     if a.no_fuse or a.debug_option or a.block_solver in (3, 4) or a.transport == "host":
         os.environ["CUP3D_HIP_FLAVOUR"] = "testing"   # A/B switches live in libcup3d_hip_testing.so only; everything else times the release build
     if a.amr:
@@ -360,13 +586,13 @@ def main():
     # library: stdout carries the one JSON line of rank 0 and nothing else
     if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
         os.environ["NCCL_DEBUG"] = "WARN"
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, world = prog.rank, prog.world
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            return relaunch_under_torchrun(a.gpus, a.transport == "rccl")
-        a.gpus = world
+    a.gpus = world
+
+    def stage(name, detail="", limit=None):
+        prog.set(name, detail, limit)
+        misbehave(a, prog, name, rank)
 
     import torch
     import cup3d_amd as cu
@@ -385,24 +611,28 @@ def main():
         check(lib().cup3d_debug_set_option(name.encode(), int(val)))
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        stage("rendezvous", "torch.distributed on gloo")
+        # gloo with CPU tensors carries the bootstrap, the checksum gather, the barriers and the timing reduce: the process holds ONE
+        # RCCL communicator, the library's own (no second one to keep apart from it)
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=a.stall_timeout))
+        stage("comm_init", "host-memory test transport" if a.transport == "host" else "ncclCommInitRank of the library's communicator")
         if a.transport == "host":
-            dist.init_process_group(backend="gloo")
             a.host_transport = install_host_transport(dist, rank, world)   # keeps the ctypes callbacks alive
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-            # bootstrap the library's own RCCL communicator with rank 0's unique id
+            # bootstrap the library's RCCL communicator with rank 0's unique id
             idbuf = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
                 raw = (C.c_ubyte * 128)()
                 check(lib().cup3d_comm_unique_id(raw))
                 idbuf = torch.tensor(list(raw), dtype=torch.uint8)
-            idbuf = idbuf.cuda()
             dist.broadcast(idbuf, 0)
-            raw = (C.c_ubyte * 128)(*idbuf.cpu().tolist())
+            raw = (C.c_ubyte * 128)(*idbuf.tolist())
             check(lib().cup3d_comm_init(rank, world, raw))
-    a.tdev = "cpu" if a.transport == "host" else "cuda"   # where torch.distributed's own tensors live (gloo / nccl)
+    a.tdev = "cpu"   # torch.distributed's own tensors (gloo)
+    stage("grid", "topology, allocation")
 
     nb1 = a.size // 8
     assert nb1 >= 2 and 8 * nb1 == a.size, "--size must be a multiple of 8"
@@ -415,7 +645,8 @@ def main():
                             implicitDiffusion=a.implicit_diffusion)
     a.checksum = None
     if not a.stencil_only and not a.implicit_diffusion and not a.no_checksum:
-        a.checksum = advdiff_checksums(sim, a, dist, world)  # the run's correctness signal at every N (before anything is timed)
+        stage("checksum", "first exchanges over the transport: advect-diffuse, LHS, one fused iteration")
+        a.checksum = advdiff_checksums(sim, a, dist, world, prog)  # the run's correctness signal at every N (before anything is timed)
         sim.dt = 0.0
     sim.upload("vel", taylor_green_blocks(sim.grid, [ext] * 3, 1.0))
     sim.step = 21
@@ -438,21 +669,25 @@ def main():
             diff_iters.append(sum(r.iterations for r in adv.last_diffusion))
 
     def fence():
-        torch.cuda.synchronize()  # the library's RCCL kernels are done before torch's communicator is used: two communicators never overlap
+        torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier()   # gloo: host-side only
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    stage("warmup")
+    for i in range(a.warmup):
         one_step()
+        prog.beat(f"step {i + 1}/{a.warmup}")
     iters.clear()
     lib().cup3d_profile_enable(0 if a.no_profile else 1)
     lib().cup3d_profile_reset()
     lib().cup3d_stats_reset()
     fence()
+    stage("timed")
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
         one_step()
+        prog.beat(f"step {i + 1}/{a.steps}")   # (a 100-byte file write: nothing against a step)
     fence()
     sec = time.perf_counter() - t0
     main_iters = list(iters)
@@ -474,6 +709,19 @@ def main():
     lib().cup3d_profile_read(ents, 64, C.byref(n))
     lib().cup3d_profile_enable(0)
     prof = {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n.value)}
+    # device timings of the communication stream (hipEvents on that stream, rank 0's): what one iteration spends in face-slab exchanges
+    # (pack + grouped send/recv), in all-reduces (+ the recurrence step behind them), and how long the COMPUTE stream sat waiting for
+    # either -- the exposed part; the rest of the first two was hidden behind the inner blocks' pass of the loop kernels
+    cms = lambda name: prof.get(name, (0, 0.0))[1]
+    a.comm.update({"halo_ms_per_iteration": round(cms("comm_halo") / nit, 5), "allreduce_ms_per_iteration": round(cms("comm_allreduce") / nit, 5),
+                   "exposed_ms_per_iteration": round((cms("comm_exposed_halo_wait") + cms("comm_exposed_scalar_wait")) / nit, 5),
+                   "exposed_halo_wait_ms_per_iteration": round(cms("comm_exposed_halo_wait") / nit, 5),
+                   "exposed_scalar_wait_ms_per_iteration": round(cms("comm_exposed_scalar_wait") / nit, 5),
+                   "timed_by": "hipEvents on the communication stream (comm_halo, comm_allreduce) and around the compute stream's waits for it "
+                               "(comm_exposed_*), rank 0; per BiCGSTAB iteration of the timed steps (the per-step exchanges of advect-diffuse and "
+                               "the projection's one-shot kernels are included in the numerators)"})
+    a.comm_entries = {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in prof.items() if k.startswith("comm_")}
+    prof = {k: v for k, v in prof.items() if not k.startswith("comm_")}   # kernel shares are shares of the COMPUTE stream's time
     tot, nblk = C.c_long(0), C.c_long(0)
     lib().cup3d_profile_block_cg_iterations(sim.handle, C.byref(tot), C.byref(nblk))
     a.cg_iters_per_block = tot.value / nblk.value if nblk.value else None
@@ -514,8 +762,11 @@ def main():
         # the same workload once more with the preconditioner M^-1 evaluated / chosen differently (cup3d_poisson_params.block_solver),
         # reported NEXT to the headline, never instead of it: the direct block solve (the reference's M, exact instead of by CG) and,
         # a multigrid V-cycle in M's place (what BASELINE.json's north_star wording describes; the reference has none; over several
-        # GPUs every rank cycles on its own blocks -- additive Schwarz, no message inside the preconditioner)
-        for solver in ([1, 5] if a.block_solver == 0 else [1 - a.block_solver] if a.block_solver in (0, 1) else []):
+        # GPUs it is ONE cycle coupled over the ranks: face slabs of every level's iterate cross ranks, multigrid.hip), and the block CG in
+        # the reference's own association (block_solver 2: no FMA contraction) -- the price of the faithful rounding, five steps
+        stage("alt", "the same workload with the other block preconditioners (never `value`)")
+        for solver in ([1, 5, 2] if a.block_solver == 0 else [1 - a.block_solver] if a.block_solver in (0, 1) else []):
+            nsteps = a.steps if solver != 2 else min(a.steps, 5)   # the reference-association block CG: five steps say what it costs
             sim.blockSolver = solver
             sim.upload("vel", taylor_green_blocks(sim.grid, [ext] * 3, 1.0))
             sim.fill("pres", 0.0)
@@ -525,19 +776,24 @@ def main():
             iters.clear()
             fence()
             t0 = time.perf_counter()
-            for _ in range(a.steps):
+            for _ in range(nsteps):
                 one_step()
+                prog.beat(f"block_solver {solver}")
             fence()
             sec2 = time.perf_counter() - t0
             if dist is not None:
                 t = torch.tensor([sec2], dtype=torch.float64, device=a.tdev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 sec2 = float(t.item())
-            alts[solver] = {"block_preconditioner": SOLVERS[solver], "value": round(float(a.size) ** 3 * a.steps / sec2 / 1e6, 2), "unit": "Mcell-updates/s",
-                            "ms_per_step": round(sec2 / a.steps * 1e3, 3), "bicgstab_iters_per_step": round(float(np.mean(iters)), 2), "warmup": 1, "steps": a.steps}
+            alts[solver] = {"block_preconditioner": SOLVERS[solver], "value": round(float(a.size) ** 3 * nsteps / sec2 / 1e6, 2), "unit": "Mcell-updates/s",
+                            "ms_per_step": round(sec2 / nsteps * 1e3, 3), "bicgstab_iters_per_step": round(float(np.mean(iters)), 2),
+                            "ms_per_bicgstab_iteration": round(sec2 * 1e3 / max(1, sum(iters)), 4), "warmup": 1, "steps": nsteps}
         alt = alts.get(1, alts.get(0))
         a.alt_multigrid = alts.get(5)
-    invalid = a.checksum is not None and not a.checksum["ok"]  # the same on every rank (all-gathered)
+        a.alt_reference_association = alts.get(2)
+        sim.blockSolver = a.block_solver
+    invalid = a.checksum is not None and a.checksum["ok"] is False  # the same on every rank (all-gathered); None = unchecked, not wrong
+    stage("report", "rank 0: JSON line (+ the CPU baseline on one rank)", limit=max(a.stall_timeout, 900.0))
     if rank == 0:
         report(a, sim, prof, sec, main_iters, world, alt)
     if dist is not None:
@@ -622,6 +878,9 @@ def report(a, sim, prof, sec, iters, world, alt=None):
         "value": round(value, 2), "unit": "Mcell-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(sec / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
+        # the stable figure of this workload: `value` moves with the (erratic, rounding-dependent) iteration count of the solver, the
+        # time of ONE BiCGSTAB iteration does not -- whole timed region / iterations, so advect-diffuse and the projection's passes are inside
+        "ms_per_bicgstab_iteration": round(sec * 1e3 / max(1, sum(iters)), 4) if iters else None,
         "config": {"workload": (f"taylor-green {a.size}^3 uniform, all-wall box (reference has no lid BC), nu=0.01, CFL=0.3, rampup=0, "
                                 f"poissonTol 1e-6/1e-4, bMeanConstraint 1, steps from 21") if not a.stencil_only
                    else f"taylor-green {a.size}^3 uniform periodic, advect-diffuse RK3 only",
@@ -649,12 +908,16 @@ def report(a, sim, prof, sec, iters, world, alt=None):
         out["alt"] = alt
     if getattr(a, "alt_multigrid", None):
         out["alt_multigrid"] = a.alt_multigrid
+    if getattr(a, "alt_reference_association", None):
+        out["alt_reference_association"] = a.alt_reference_association
+    if getattr(a, "comm_entries", None):
+        out["communication_stream"] = a.comm_entries
     if getattr(a, "pcie", None):
         out["pcie_inclusive"] = a.pcie
     if not a.no_cpu and world == 1:
         # SURVEY 8d asks for the reference on all host cores at 512^3, else 256^3.  A 512^3 step of the reference takes 4.5 minutes
-        # (268 s for the projection alone on 64 threads, profiles/r02/reference_step_512.json) and ~35 GB: the sample is ONE step at
-        # 256^3.  "All cores" would be a strawman on this host: the reference's OpenMP regions (one lab per thread, master-polled halo
+        # (268 s for the projection alone on 64 threads, profiles/r02/reference_step_512.json) and ~35 GB: the sample is the MEDIAN of
+        # --cpu-steps (5) separate steps at 256^3.  "All cores" would be a strawman on this host: the reference's OpenMP regions (one lab per thread, master-polled halo
         # loop, 5594-5640) ANTI-scale -- one 256^3 step takes 18 s on 32 threads, 30 s on 64 and 338 s on all 256
         # (profiles/r02/probe_reference_threads_256cubed.txt) -- so the baseline runs at the reference's best setting, 32 threads,
         # and `cores` says so.  Round 1's sample (128^3, 10 steps) stays beside it as cpu_baseline_128.
@@ -668,8 +931,10 @@ def report(a, sim, prof, sec, iters, world, alt=None):
         if a.cpu_size != 128:
             out["cpu_baseline_128"] = cpu_baseline(128, 10, min(32, os.cpu_count() or 1))
     ck = getattr(a, "checksum", None)
-    if ck is not None and not ck["ok"]:
-        out["valid"] = False  # the stencil path did not reproduce the oracle's bits on this partition: the rate above measures a wrong program
+    if ck is not None and ck["ok"] is False:
+        out["valid"] = False  # a bitwise signal did not reproduce its constant on this partition: the rate above measures a wrong program
+    elif ck is not None and ck["ok"] is None:
+        sys.stderr.write(f"bench: no recorded checksum constant for {ck['unchecked']} at --size {a.size}: unchecked, not invalid\n")
     print(json.dumps(out))
     sys.stdout.flush()
     if out.get("valid") is False:

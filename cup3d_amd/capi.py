@@ -144,6 +144,7 @@ SIGNATURES = {
     "cup3d_profile_enable": (C.c_int, [C.c_int]),
     "cup3d_profile_reset": (C.c_int, []),
     "cup3d_profile_read": (C.c_int, [C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),
+    "cup3d_poisson_path_checksum": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]),
     "cup3d_profile_block_cg_iterations": (C.c_int, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
 }
 # test-support symbols (not part of the drop-in surface)

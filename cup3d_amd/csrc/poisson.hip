@@ -944,16 +944,18 @@ __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, c
   if constexpr (FLHS) __syncthreads();
   cg_block<FMA, false, EV>(g, slot, r, V.v[WHAT], block_sums, 0.0, 0.0, iters_out, P);  // what = M^-1 w, 14548
 }
-// Production: held to 96 registers (2 of the 122 the body asks for are spilled, outside the CG loop) -> 5 wavefronts per SIMD like the
-// first fused kernel: 3.63-3.70 ms instead of 3.75 at 512^3, 0.457-0.461 instead of 0.497 at 256^3
-// (profiles/r02/probe_fused_kernel_occupancy.jsonl).  The same test on the other side -- the first kernel or the stand-alone block
+// WITHOUT the LHS inside (FLHS = false: multi-level meshes, the no_fuse_lhs A/B): held to 96 registers (2 of the 122 the body asks for
+// are spilled, outside the CG loop) -> 5 wavefronts per SIMD: 3.63-3.70 ms instead of 3.75 at 512^3, 0.457-0.461 instead of 0.497 at
+// 256^3 (profiles/r02/probe_fused_kernel_occupancy.jsonl).  The same test on the other side -- the first kernel or the stand-alone block
 // CG held to 80 registers for 6 wavefronts -- loses (12-14 spills inside the loops: 5.3 ms instead of 3.88; CG 0.43 instead of 0.40).
+// (With FLHS held to 96 it spills 30 registers inside the plane loop: the production kernel of uniform grids is k_loop2_cg_w4 below.)
 template <bool FMA, int EV, bool FLHS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
 k_loop2_cg(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums, int *__restrict__ iters_out, LhsIn L) {
   loop2_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L);
 }
-// A/B (debug option "loop2_four_waves"): the register allocation the compiler picks on its own -> 4 wavefronts per SIMD
+// PRODUCTION on uniform grids (FLHS = true; what bench.py's `value` runs): the register allocation the compiler picks on its own, 128
+// registers -> 4 wavefronts per SIMD, no spills.  (Also the "loop2_four_waves" A/B of the FLHS = false form.)
 template <bool FMA, int EV, bool FLHS>
 __global__ void __launch_bounds__(64) k_loop2_cg_w4(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
                                                     int *__restrict__ iters_out, LhsIn L) {
@@ -1089,6 +1091,20 @@ __global__ void __launch_bounds__(256) k_copy(const double *__restrict__ src, do
   GRID_STRIDE(j, n) dst[j] = src[j];
 }
 __global__ void k_set_one(double *p, size_t i, double v) { p[i] = v; }
+// cup3d_poisson_path_checksum: vector `vec` of block blockIdx.x, a function of (vec, level, global cell index) -- integer hashing and one
+// exact scaling, so the bits are the same on every device and under every sharding; values in [-1, 1)
+__global__ void __launch_bounds__(256) k_selfcheck_fill(double *__restrict__ v, int vec, const int32_t *__restrict__ index, const int32_t *__restrict__ level, int level0) {
+  const int b = blockIdx.x;
+  const unsigned lv = (unsigned)(level ? level[b] : level0);
+  for (int c = threadIdx.x; c < 512; c += 256) {
+    const unsigned gx = (unsigned)index[3 * b] * 8u + (c & 7), gy = (unsigned)index[3 * b + 1] * 8u + ((c >> 3) & 7), gz = (unsigned)index[3 * b + 2] * 8u + (c >> 6);
+    unsigned hsh = gx * 73856093u ^ gy * 19349663u ^ gz * 83492791u ^ (unsigned)(vec + 1) * 2654435761u ^ (lv + 1u) * 40503u;
+    hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13; hsh *= 3266489917u; hsh ^= hsh >> 16;
+    // a smooth part (so that the block solve sees a right-hand side like the solver's) + the hashed part
+    const double smooth = (double)((int)((gx + 2 * gy + 3 * gz + 5u * (unsigned)vec) & 63u) - 32) * (1.0 / 64.0);
+    v[(size_t)b * 512 + c] = 0.5 * smooth + (double)((int)(hsh & 0xfffffu) - 0x80000) * (1.0 / 2097152.0);
+  }
+}
 // lhs -= tmpV.u[0] ; pres = 0   (main.cpp:15090-15099)
 __global__ void __launch_bounds__(256) k_sub_divp(double *__restrict__ lhs, const double *__restrict__ tmpV, double *__restrict__ pres, long n) {
   GRID_STRIDE(j, n) { lhs[j] -= tmpV[(j >> 9) * 1536 + (j & 511)]; pres[j] = 0; }
@@ -1239,7 +1255,9 @@ static int wait_status(Sim *s, unsigned seq, SolverCtl *out) {
 
 // helm != nullptr: DiffusionSolver::solve (main.cpp:6896-7146) -- the same routine on the Helmholtz operator of one velocity
 // component, with no mean constraint and no cap on the breakdown restarts
-static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *res, const HelmholtzOp *helm = nullptr) {
+// sc != nullptr: cup3d_poisson_path_checksum -- no solve; the work vectors are filled with a function of the global cell index, the
+// scalars are set by hand and ONE iteration's kernels run as they do inside a solve; sc[NVEC] receives the vectors' wrapping sums
+static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *res, const HelmholtzOp *helm = nullptr, unsigned long long *sc = nullptr) {
   TRY(ensure_vectors(s));
   s->block_solver = P.block_solver;
   Vecs V;
@@ -1277,17 +1295,19 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   auto x_ptrs = [&]() { const int xw = ctl_xwrite(hs); V.v[X_] = XB[xw]; V.v[XOPT] = XB[1 - xw]; V.xin = XB[hs.xcur]; };
   x_ptrs();
 
-  if ((mc == 1 || mc > 2) && s->grid->corner_slot >= 0)  // rhs(0,0,0) = 0, 14404-14407
-    hipLaunchKernelGGL(k_set_one, dim3(1), dim3(1), 0, stream(), s->lhs, (size_t)s->grid->corner_slot * 512, 0.0);
-  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_solver_init, V, s->lhs, s->pres, N); }
-  TRY(LHS(X_, R0));
-  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_resid0, V, N); }
-  TRY(PRE(R0, RHAT)); TRY(LHS(RHAT, W_)); TRY(PRE(W_, WHAT)); TRY(LHS(WHAT, T_));
-  { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots_r0, V, N, red.out()); }
-  TRY(red.begin(2)); TRY(red.wait());
-  hs.alpha = s->h_red[0] / (s->h_red[1] + eps);  // 14443
-  hs.r0r_prev = s->h_red[0];
-  hs.norm = hs.init_norm = std::sqrt(s->h_red[0]);
+  if (!sc) {
+    if ((mc == 1 || mc > 2) && s->grid->corner_slot >= 0)  // rhs(0,0,0) = 0, 14404-14407
+      hipLaunchKernelGGL(k_set_one, dim3(1), dim3(1), 0, stream(), s->lhs, (size_t)s->grid->corner_slot * 512, 0.0);
+    { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_solver_init, V, s->lhs, s->pres, N); }
+    TRY(LHS(X_, R0));
+    { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_resid0, V, N); }
+    TRY(PRE(R0, RHAT)); TRY(LHS(RHAT, W_)); TRY(PRE(W_, WHAT)); TRY(LHS(WHAT, T_));
+    { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC(k_dots_r0, V, N, red.out()); }
+    TRY(red.begin(2)); TRY(red.wait());
+    hs.alpha = s->h_red[0] / (s->h_red[1] + eps);  // 14443
+    hs.r0r_prev = s->h_red[0];
+    hs.norm = hs.init_norm = std::sqrt(s->h_red[0]);
+  }
 
   // the mean-constraint total of `what` for the first fused loop (FLHS): d_red[7] after a fused iteration (k_sums_finish<7, true>),
   // d_red[8] after a host-driven LHS(WHAT, T_) (k_mean_finish inside launch_lhs); of `zhat` for the second loop it is d_red[2]
@@ -1424,6 +1444,45 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     }
     return CUP3D_OK;
   };
+  if (sc) {
+    if (!fuse) { set_error("cup3d_poisson_path_checksum: block_solver %d has no fused loop kernels (0 and 2 do)", P.block_solver); return CUP3D_EINVAL; }
+    // every vector = a function of (vector, level, global cell index): the same cells hold the same bits however the blocks are
+    // spread over ranks.  alpha, beta, omega by hand: no dot product (whose rounding depends on the partition) enters the update.
+    int32_t *d_index = nullptr, *d_level = nullptr;
+    const size_t nidx = (size_t)s->nb * 3;
+    CUP3D_HIP(hipMalloc((void **)&d_index, nidx * sizeof(int32_t)));
+    hipError_t e = hipMemcpyAsync(d_index, s->grid->index.data(), nidx * sizeof(int32_t), hipMemcpyHostToDevice, stream());
+    if (e == hipSuccess && s->grid->multilevel) {
+      e = hipMalloc((void **)&d_level, (size_t)s->nb * sizeof(int32_t));
+      if (e == hipSuccess) e = hipMemcpyAsync(d_level, s->grid->blevel.data(), (size_t)s->nb * sizeof(int32_t), hipMemcpyHostToDevice, stream());
+    }
+    auto body = [&]() -> int {
+      if (e != hipSuccess) return hip_fail(e, "cup3d_poisson_path_checksum tables", __FILE__, __LINE__);
+      for (int i = 0; i < NVEC; ++i) hipLaunchKernelGGL(k_selfcheck_fill, dim3((unsigned)s->nb), dim3(256), 0, stream(), s->sv[i], i, (const int32_t *)d_index, (const int32_t *)d_level, s->grid->level);
+      hs.alpha = 0.75; hs.beta = 0.5; hs.omega = 0.625;  // exact in binary
+      hs.xcur = 0; hs.xopt = -1; hs.state = kRun;
+      hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, stream(), d_ctl, hs);
+      hipLaunchKernelGGL(k_set_one, dim3(1), dim3(1), 0, stream(), s->d_red, (size_t)kRedMeanLhs, 0.375);  // the mean-constraint total, by hand as well
+      CUP3D_HIP(hipGetLastError());
+      V.v[X_] = XB[0]; V.v[XOPT] = XB[1]; V.xin = XB[0];
+      // with the LHS inside the loop kernels the mean-constraint row takes the hand-set total; the stand-alone LHS would reduce the
+      // field for it (partition-dependent rounding), so there the row is left out: mode 0 gives the same bits on both routes
+      const int lhs_mode = !flhs ? -1 : (mc > 2 ? 3 : mc);
+      const double *total = s->d_red + kRedMeanLhs;
+      auto LHS0 = [&](int in, int out) { return launch_lhs(s, V.v[in], V.v[out], 0); };
+      if (!flhs) TRY(LHS0(WHAT, T_));
+      TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, total, lhs_mode, s->grid->corner_slot, kLoopPrio}));
+      if (!flhs) TRY(LHS0(ZHAT, V_));
+      TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, total, lhs_mode, s->grid->corner_slot, kLoopPrio}));
+      for (int i = 0; i < NVEC; ++i) TRY(checksum_array(s, s->sv[i], N, &sc[i]));
+      return CUP3D_OK;
+    };
+    const int rc = body();
+    (void)hipStreamSynchronize(stream());
+    if (d_index) (void)hipFree(d_index);
+    if (d_level) (void)hipFree(d_level);
+    return rc;
+  }
   auto enqueue_fused = [&](unsigned seq) -> int {
     V.v[X_] = XB[0]; V.v[XOPT] = XB[1];  // fixed roles: the kernels pick by SolverCtl::xcur / xopt
     const int lhs_mode = !flhs ? -1 : (mc > 2 ? 3 : mc);
@@ -1559,6 +1618,15 @@ int cup3d_preconditioner(cup3d_sim_t *h, int block_solver) {
   Sim *s = reinterpret_cast<Sim *>(h);
   s->block_solver = block_solver;
   return launch_precond(s, s->pres, s->pres, false);  // in place: each wavefront reads its block before writing it
+}
+
+int cup3d_poisson_path_checksum(cup3d_sim_t *h, int block_solver, int mean_constraint, unsigned long long *sums) {
+  if (!h || !sums) return CUP3D_EINVAL;
+  cup3d_poisson_params d;
+  cup3d_poisson_default_params(&d);
+  d.block_solver = block_solver;
+  d.mean_constraint = mean_constraint;
+  return solve(reinterpret_cast<Sim *>(h), d, nullptr, nullptr, sums);
 }
 
 int cup3d_poisson_solve(cup3d_sim_t *h, const cup3d_poisson_params *p, cup3d_poisson_result *r) {

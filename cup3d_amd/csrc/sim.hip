@@ -193,6 +193,16 @@ __global__ void __launch_bounds__(256) k_checksum(const double *__restrict__ p, 
   }
   if (threadIdx.x == 0) atomicAdd(out, part[0]);
 }
+static unsigned stride_groups(long n);
+int checksum_array(Sim *s, const double *p, long n, unsigned long long *sum) {
+  unsigned long long *d = reinterpret_cast<unsigned long long *>(s->d_red + kRedChecksum);  // its own slot of d_red (RedSlot)
+  CUP3D_HIP(hipMemsetAsync(d, 0, sizeof *d, g_stream));
+  hipLaunchKernelGGL(k_checksum, dim3(stride_groups(n)), dim3(256), 0, g_stream, p, n, d);
+  CUP3D_HIP(hipGetLastError());
+  CUP3D_HIP(hipMemcpyAsync(sum, d, sizeof *d, hipMemcpyDeviceToHost, g_stream));
+  CUP3D_HIP(hipStreamSynchronize(g_stream));
+  return CUP3D_OK;
+}
 __global__ void __launch_bounds__(256) k_fill(double *__restrict__ p, long n, double v) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
 }
@@ -699,14 +709,7 @@ int cup3d_sim_checksum(cup3d_sim_t *h, int field, unsigned long long *sum) {
   int nc;
   const double *p = s->field(field, &nc);
   if (!p) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
-  unsigned long long *d = reinterpret_cast<unsigned long long *>(s->d_red + kRedChecksum);  // its own slot of d_red (RedSlot)
-  CUP3D_HIP(hipMemsetAsync(d, 0, sizeof *d, g_stream));
-  const long n = (long)s->nb * 512 * nc;  // the rank's own blocks; ghost blocks of a rank view sit behind them
-  hipLaunchKernelGGL(k_checksum, dim3(stride_groups(n)), dim3(256), 0, g_stream, p, n, d);
-  CUP3D_HIP(hipGetLastError());
-  CUP3D_HIP(hipMemcpyAsync(sum, d, sizeof *d, hipMemcpyDeviceToHost, g_stream));
-  CUP3D_HIP(hipStreamSynchronize(g_stream));
-  return CUP3D_OK;
+  return checksum_array(s, p, (long)s->nb * 512 * nc, sum);  // the rank's own blocks; ghost blocks of a rank view sit behind them
 }
 
 int cup3d_sim_fill(cup3d_sim_t *h, int field, double value) {

@@ -161,6 +161,8 @@ struct Sim {
 };
 
 int sim_alloc(double **p, size_t n_doubles, Sim *s);
+// wrapping 64-bit sum of the bit patterns of n doubles (independent of launch geometry and of the sharding); synchronises
+int checksum_array(Sim *s, const double *p, long n, unsigned long long *sum);
 Sim *sim_comm_only(const Grid *g, hipStream_t comm_stream);  // exchange-only Sim of a coarse multigrid level (sim.hip)
 void sim_comm_only_destroy(Sim *s);
 

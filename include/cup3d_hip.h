@@ -217,8 +217,9 @@ typedef struct {
                           5 = NOT the reference's preconditioner: one geometric-multigrid V(2,2)-cycle (red-black Gauss-Seidel in LDS,
                               summed-residual restriction, piecewise-constant prolongation) on the hierarchy of uniform block grids --
                               same operator, same stopping rule, same converged pressure to solver tolerance, O(10) instead of O(150)
-                              iterations; uniform grids (over several ranks each rank cycles on its own blocks with zero ghosts behind
-                              the faces other ranks own: additive Schwarz, no message inside M^-1); bench.py: `alt_multigrid` only */
+                              iterations; uniform grids (over several ranks ONE cycle coupled over the ranks: every level is partitioned
+                              like the solver's grid and its iterate crosses ranks as face slabs before each launch that reads
+                              ghosts) and multi-level meshes on one rank (the octree's levels); bench.py: `alt_multigrid` only */
 } cup3d_poisson_params;
 typedef struct {
   int iterations; /* BiCGSTAB iterations performed (= 7-double reductions, main.cpp:14546) */
@@ -343,6 +344,15 @@ typedef struct {
 int cup3d_stats_reset(void);
 int cup3d_stats_read(cup3d_run_stats *);
 int cup3d_profile_read(cup3d_profile_entry *entries, int max, int *n);
+/* VERIFICATION SUPPORT: the bits of the Poisson path under any sharding of the blocks (bench.py's config.checksum at every N).
+ * Fills PoissonSolverAMR's 18 work vectors (main.cpp:14382-14399) with a function of (vector, level, global cell index) only, sets
+ * alpha, beta, omega (and the mean-constraint total) BY HAND and runs the kernels of ONE BiCGSTAB iteration exactly as
+ * cup3d_poisson_solve launches them -- t = A what (14549), loop 1 (14453-14464), zhat = M^-1 z (14488, getZImplParallel 14704-14745),
+ * v = A zhat (14489), loop 2 (14502-14515), what = M^-1 w (14548): the fused kernels, the width-1 scalar halo exchanges, the
+ * inner / boundary split -- with no dot product feeding back.  The stencil and the block-local solve do not see the partition, so
+ * sums[18] (wrapping 64-bit sums of each vector's bit patterns over the rank's blocks, vector order of poisson.hip), added over the
+ * ranks mod 2^64, are the same at every N.  block_solver 0 or 2 (the solvers with fused kernels); clobbers the work vectors only. */
+int cup3d_poisson_path_checksum(cup3d_sim_t *, int block_solver, int mean_constraint, unsigned long long *sums18);
 /* CG iterations of the last block-CG launch made while cup3d_profile_enable(1) was on, summed over the rank's blocks (the flop count
  * behind bench.py's FP64 roofline of the block preconditioner, getZImplParallel main.cpp:14704-14745) */
 int cup3d_profile_block_cg_iterations(cup3d_sim_t *, long *total, long *nblocks);

@@ -41,6 +41,11 @@ def main():
         for key, vel in (("exact_field", exact_test_field_blocks(G, size)), ("taylor_green", taylor_green_blocks(G, [ext] * 3, 1.0))):
             g.advect_diffuse(vel, np.zeros_like(vel), checksum_dt(size), 0.01, (0.0, 0.0, 0.0))
             rec[key] = int(vel.view(np.uint64).sum(dtype=np.uint64))
+        # the Poisson path's stencil: ONE ComputeLHS (KernelLHSPoisson, main.cpp:9205-9215; bMeanConstraint 0) of the x component of the
+        # exact test field taken as a pressure -- bit-exact on the device under any sharding, like the advect-diffuse stage
+        pres = np.ascontiguousarray(exact_test_field_blocks(G, size)[..., 0])
+        rec["lhs_exact_field"] = int(g.lhs(pres, 0).view(np.uint64).sum(dtype=np.uint64))
+        rec = {**out.get(str(size), {}), **rec}   # keep what other generators recorded for this size (scripts/make_poisson_checksums.py)
         out[str(size)] = rec
         print(size, rec)
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)

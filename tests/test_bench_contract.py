@@ -94,6 +94,37 @@ def test_report_carries_the_checksum_and_marks_a_mismatch_invalid():
         assert r.get("valid", True) is valid and r["n_gpus"] == 2
 
 
+def test_a_size_without_recorded_constants_is_unchecked_not_invalid(capsys):
+    """`no golden constant for this --size` is not a mismatch -- ok = None, no `valid: false`, exit code 0."""
+    prof = {"bicgstab_loop2_cg": (10, 39.0)}
+    ck = {"ok": None, "unchecked": ["exact_field"], "exact_field": {"value": 1, "expected": None, "ok": None}}
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.report(_args(checksum=ck, comm={"rccl_ranks": 1}), _Sim(), prof, 7.4, [156, 150], 1)
+    r = json.loads(buf.getvalue().strip())
+    assert "valid" not in r and r["config"]["checksum"]["ok"] is None
+    assert r["ms_per_bicgstab_iteration"] == round(7.4e3 / 306, 4)
+
+
+def test_multi_rank_run_that_cannot_start_prints_one_error_line():
+    """`python bench.py --gpus 2 --transport host` on a box WITHOUT a GPU: every rank fails at device initialisation.  The run must
+    end quickly with ONE JSON line {"valid": false, "error", "stage", "rank_progress"} on stdout and a non-zero exit code (the
+    watchdog / failure path of N > 1 runs, exercised where no device exists)."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host", "--size", "64", "--steps", "1", "--warmup", "0",
+                          "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode != 0
+    lines = [l for l in out.stdout.decode().strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (out.stdout.decode()[-1000:], out.stderr.decode()[-1000:])
+    r = json.loads(lines[0])
+    assert r["valid"] is False and r["value"] is None and r["n_gpus"] == 2 and r["stage"] and len(r["rank_progress"]) == 2
+    assert "rror" in r["error"] or "device" in r["error"].lower(), r["error"]
+
+
 def test_checksum_fixture_is_what_the_oracle_produces():
     """tests/golden/advdiff_checksums.json (the constants bench.py compares the device with at every N) regenerated for the small sizes."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -15,6 +15,7 @@ Stated bounds
     iteration / restart counts on all ranks of a run; at the default tolerance the returned iterate satisfies the reference's
     stopping rule.
 """
+import ctypes as C
 import os
 import threading
 
@@ -351,6 +352,57 @@ def test_block_migration_equals_one_rank_adaptation(golden_dir, case):
     for r in range(nranks):
         assert np.array_equal(tabs[r][:, :2], new[ow_new == r][:, :2]), r   # the reference's block list of that rank
     assert np.array_equal(got_v, vel_ref) and np.array_equal(got_p, pres_ref)
+
+
+@pytest.mark.parametrize("bad_rank", [0, 2])
+def test_a_bad_call_on_one_rank_fails_on_every_rank_at_once(golden_dir, bad_rank):
+    """Collective status agreement (comm.hip, agree): cup3d_adapt_migrate is a collective; when ONE rank's call is invalid -- here an
+    unknown field id, found by that rank's local checks -- every rank must get an error back before anything is exchanged, within
+    seconds, instead of the valid ranks blocking in the exchange for ever (the reference ends such runs with MPI_Abort on all ranks,
+    main.cpp:15265, 15289).  The communicator stays usable: the same ranks then complete a correct migration."""
+    import time
+    z = np.load(os.path.join(golden_dir, "adapt_mpi.npz"))
+    case = 1
+    bx, by, bz, lmax, b0, b1, b2, nranks = (int(v) for v in z[f"t{case}_meta"])
+    old, new, ow_old = z[f"t{case}_old"], z[f"t{case}_new"], z[f"t{case}_old_owner"].astype(np.int32)
+    assert bad_rank < nranks
+    st = _states_from_tables(old, new)
+    g_old = cu.operators.Grid((bx, by, bz), lmax, 0, EXT, (b0, b1, b2), leaves=(old[:, 0].astype(np.int32), old[:, 1].copy()))
+    bcn = {0: "freespace", 1: "periodic", 2: "wall"}
+    kw = dict(bpdx=bx, bpdy=by, bpdz=bz, levelMax=lmax, levelStart=0, extent=EXT, BC_x=bcn[b0], BC_y=bcn[b1], BC_z=bcn[b2])
+    lv, zs = g_old.adapted_leaves(st)
+    new_mesh = cu.operators.Grid((bx, by, bz), lmax, 0, EXT, (b0, b1, b2), leaves=(lv, zs))
+    new_owner = g_old.adapted_owners(ow_old, st, nranks, new_mesh)
+    codes, texts, took = [None] * nranks, [None] * nranks, [None] * nranks
+    with VirtualComm(nranks):
+        views = [g_old.rank_view(ow_old, r, nranks) for r in range(nranks)]
+        sims = [cu.SimulationData(view=views[r], **kw) for r in range(nranks)]
+        dsts = [sims[r]._like(view=new_mesh.rank_view(new_owner, r, nranks)) for r in range(nranks)]
+
+        def migrate(r, field):
+            return lib().cup3d_adapt_migrate(g_old.handle, ow_old.ctypes.data_as(C.c_void_p), sims[r].handle, new_mesh.handle,
+                                             new_owner.ctypes.data_as(C.c_void_p), dsts[r].handle, field)
+
+        def rank(r):
+            t0 = time.time()
+            codes[r] = migrate(r, 99 if r == bad_rank else cu.operators.FIELDS["vel"])
+            texts[r] = lib().cup3d_last_error().decode()
+            took[r] = time.time() - t0
+
+        run_ranks(rank, nranks)
+        assert all(c == -1 for c in codes), codes                       # CUP3D_EINVAL everywhere: the worst code any rank arrived with
+        assert max(took) < 5.0, took
+        assert "unknown field id" in texts[bad_rank]
+        assert all("another rank could not take part" in texts[r] for r in range(nranks) if r != bad_rank), texts
+        # ... and the communicator is not left half-way through an exchange: a correct collective call works right after
+        ok = [None] * nranks
+
+        def again(r):
+            ok[r] = migrate(r, cu.operators.FIELDS["vel"])
+
+        run_ranks(again, nranks)
+        assert ok == [0] * nranks, ok
+        del sims, views, dsts
 
 
 def test_adaptive_loop_on_three_ranks_equals_one_rank():

@@ -204,8 +204,9 @@ def test_advect_diffuse_kernel_variants_bit_exact(golden_dir, name, variant):
 
 
 def test_wave_sum_on_the_matrix_pipe():
-    """The wave-wide sum the production block CG uses (two v_mfma_f64_16x16x4_f64 with a ones matrix + three adds): exact on
-    integers (every lane receives the total), and to rounding on random data, like the DPP form it replaces."""
+    """The wave-wide sum of the block CG's A/B variant on the matrix pipe (two v_mfma_f64_16x16x4_f64 with a ones matrix + three adds;
+    production sums by DPP row reductions, kCgProduction = 0 -- the matrix form measured 12-20 % slower): exact on integers (every
+    lane receives the total), and to rounding on random data, like the DPP form."""
     import math
     rng = np.random.default_rng(3)
     for v in (np.arange(64, dtype=np.float64) * 3 - 17, np.float64(2) ** rng.integers(-20, 20, 64), rng.uniform(-1, 1, 64), rng.normal(size=64) * 1e8):

@@ -18,6 +18,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+POISSON_KEYS = ("lhs_exact_field", "precond_exact_field", "fused_iteration")
+ALL_KEYS = ("exact_field", "taylor_green") + POISSON_KEYS
+
+
+def same_bits_at_every_n(ck1, ckn):
+    """every bitwise signal of config.checksum: the N-rank value equals the one-process value (and the recorded constant where one exists)"""
+    assert ckn["ok"] is not False and ck1["ok"] is not False, (ck1, ckn)
+    for k in ALL_KEYS:
+        assert ckn[k]["value"] == ck1[k]["value"], (k, ck1[k], ckn[k])
+        assert ckn[k]["ok"] is not False, (k, ckn[k])
+    assert ckn["fused_iteration"]["vectors"] == ck1["fused_iteration"]["vectors"]
+
+
 def run_bench(*args, timeout=900):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
@@ -32,8 +45,13 @@ def test_one_process_bench_carries_a_matching_checksum():
     ck = r["config"]["checksum"]
     assert ck["ok"] is True and ck["exact_field"]["ok"] is True and ck["exact_field"]["value"] == ck["exact_field"]["expected"]
     assert ck["taylor_green"]["value"] == ck["taylor_green"]["expected"]   # holds as long as numpy's sin / cos equal the build container's
+    # the Poisson path: A p against the CPU oracle's constant; M^-1 p and one fused iteration against the recorded one-GPU values
+    for k in POISSON_KEYS:
+        assert ck[k]["ok"] is True and ck[k]["value"] == ck[k]["expected"], (k, ck[k])
+    assert len(ck["fused_iteration"]["vectors"]) == 18
     assert r["config"]["communication"]["rccl_ranks"] == 1 and r.get("valid", True) is True
     assert len(r["config"]["bicgstab_iters_by_step"]) == 2
+    assert r["ms_per_bicgstab_iteration"] > 0
 
 
 def test_more_gpus_than_devices_is_refused_clearly():
@@ -55,16 +73,17 @@ def test_bench_over_rccl_matches_the_one_process_run(n):
     assert len(lines) == 1, lines
     r1, rn = json.loads(one.stdout.decode().strip()), json.loads(lines[0])
     assert rn["n_gpus"] == n and rn["config"]["communication"]["rccl_ranks"] == n
+    # the bits: vector halo (advect-diffuse), scalar halo read in place by the fused kernels, block CG -- equal at every N
+    same_bits_at_every_n(r1["config"]["checksum"], rn["config"]["checksum"])
     assert rn["config"]["checksum"]["ok"] is True
-    assert rn["config"]["checksum"]["exact_field"]["value"] == r1["config"]["checksum"]["exact_field"]["value"]
-    assert rn["config"]["checksum"]["taylor_green"]["value"] == r1["config"]["checksum"]["taylor_green"]["value"]
-    # the all-reduces change the order of the dot-product sums: on this all-wall workload BiCGSTAB's count moves by tens of per cent with
-    # the rounding alone (tests/test_gpu_parity.py::iters_band) -- a factor of 1.5 either way per step, 25 % on the sum
-    i1, im = r1["config"]["bicgstab_iters_by_step"], rn["config"]["bicgstab_iters_by_step"]
+    # the solver over ranks: the all-reduces only reorder the dot-product sums, both runs project to the same stopping tolerance
     u1, un = r1["config"]["umax_by_step"], rn["config"]["umax_by_step"]
-    assert max(abs(a - b) / a for a, b in zip(u1, un)) <= 2e-3, (u1, un)   # the projections agree to their stopping tolerance
-    assert all(5 < b < 400 for b in im), (i1, im)                            # (the count itself is erratic on this workload)
-    assert rn["config"]["communication"]["halo_exchanges_per_iteration"] > 0
+    assert max(abs(a - b) / a for a, b in zip(u1, un)) <= 2e-3, (u1, un)
+    com = rn["config"]["communication"]
+    assert com["halo_exchanges_per_iteration"] > 0
+    for k in ("halo_ms_per_iteration", "allreduce_ms_per_iteration", "exposed_ms_per_iteration"):
+        assert com[k] >= 0, (k, com)
+    assert com["halo_ms_per_iteration"] > 0 and com["allreduce_ms_per_iteration"] > 0
 
 
 @pytest.mark.timeout(900)
@@ -86,13 +105,42 @@ def test_bench_multi_process_path_over_the_host_transport(n):
     assert rn["n_gpus"] == n and rn["config"]["communication"]["rccl_ranks"] == n and "host-memory" in rn["config"]["transport"]
     ck1, ckn = r1["config"]["checksum"], rn["config"]["checksum"]
     assert ckn["ok"] is True and ckn["exact_field"]["value"] == ck1["exact_field"]["value"] == ckn["exact_field"]["expected"]
-    assert ckn["taylor_green"]["value"] == ck1["taylor_green"]["value"]
+    # every bitwise signal -- incl. A p over the scalar halo, the block CG and ONE fused iteration's 18 vectors -- equal on 1, 2, 3 ranks
+    same_bits_at_every_n(ck1, ckn)
     # the solver over ranks: both runs project to the same stopping tolerance, so max|u| along the run agrees to ~1e-4; the iteration
     # COUNT of this all-wall workload is not a usable signal at 128^3 (131 / 105 on one rank, 93 / 53 on two: the count at which the
     # residual first dips below the tolerance moves by a factor of two with the order of the sums)
     u1, un = r1["config"]["umax_by_step"], rn["config"]["umax_by_step"]
     assert len(u1) == len(un) == 3 and max(abs(a - b) / a for a, b in zip(u1, un)) <= 2e-3, (u1, un)
     i1, im = r1["config"]["bicgstab_iters_by_step"], rn["config"]["bicgstab_iters_by_step"]
-    assert all(5 < b < 400 for b in im), (i1, im)
     print(f"{n} ranks over the host transport: iterations {im} (one process: {i1}); max|u| {un} vs {u1}")
     assert rn["config"]["communication"]["halo_exchanges_per_iteration"] >= 2 and rn["config"]["communication"]["allreduces_per_iteration"] >= 2
+    com = rn["config"]["communication"]
+    for k in ("halo_ms_per_iteration", "allreduce_ms_per_iteration", "exposed_ms_per_iteration"):   # the keys a SCALE run is read by
+        assert k in com and com[k] >= 0, (k, com)
+
+
+def parse_error_line(out):
+    lines = [l for l in out.stdout.decode().strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (out.stdout.decode()[-1500:], out.stderr.decode()[-1500:])
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("how, stage", [("hang", "timed"), ("exit", "warmup"), ("raise", "checksum"), ("hang", "comm_init")])
+def test_a_rank_that_hangs_or_dies_yields_one_diagnostic_line(how, stage):
+    """First contact with N > 1 must not be able to fail silently: when ONE rank hangs (a stuck collective), leaves (a crash) or raises
+    in any stage, the run ends within the stall limit with ONE JSON line {"valid": false, "error", "stage", "rank_progress"} and a
+    non-zero exit code -- never a result line, never the launcher's 1800 s."""
+    import time
+    t0 = time.time()
+    out = run_bench("--gpus", "2", "--transport", "host", "--size", "64", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-alt", "--no-pcie",
+                    "--stall-timeout", "25", "--fail-at", f"{stage}:1:{how}", timeout=400)
+    took = time.time() - t0
+    assert out.returncode != 0
+    r = parse_error_line(out)
+    assert r["valid"] is False and r["value"] is None and r["n_gpus"] == 2 and r["error"], r
+    assert len(r["rank_progress"]) == 2
+    stages = [p["stage"] for p in r["rank_progress"]]
+    assert stage in stages, r      # the line says where the run was
+    assert took < 200, took        # (25 s stall limit + start-up; a silent hang would sit here for the launcher's half hour)
