@@ -41,7 +41,7 @@ class PoissonResult(C.Structure):
 class RunStats(C.Structure):
     """cup3d_run_stats"""
     _fields_ = [("halo_exchanges", C.c_long), ("halo_bytes_sent", C.c_double), ("allreduces", C.c_long), ("host_waits", C.c_long),
-                ("host_wait_seconds", C.c_double), ("solver_iterations", C.c_long)]
+                ("host_wait_seconds", C.c_double), ("solver_iterations", C.c_long), ("field_bytes_uploaded", C.c_double), ("field_bytes_downloaded", C.c_double)]
 
 
 class ProfileEntry(C.Structure):

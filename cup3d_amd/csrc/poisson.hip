@@ -391,19 +391,17 @@ __device__ __forceinline__ void sine_transform8(const double (&v)[8], double (&o
   }
 }
 
-__global__ void __launch_bounds__(64) k_precond_fdm(GridDev g, const double *in, double *out, const double *__restrict__ invD,
-                                                    double *__restrict__ block_sums) {
-  __shared__ double T[64 * 9];  // transposes; pitch 9 doubles keeps every ds_read/write_b64 conflict-free
-  const int slot = block_slot(g);
-  if (slot < 0) return;
+constexpr int kFdmLds = 64 * 9;  // transposes; pitch 9 doubles keeps every ds_read/write_b64 conflict-free
+// the direct solve of one block by its wavefront: v[z] = (right-hand side / h) of cell (x = lane & 7, y = lane >> 3, z) on entry;
+// out receives M^-1, block_sums[slot] (if any) sum(z h^3).  T: kFdmLds doubles of LDS nobody else is using.
+__device__ __forceinline__ void fdm_block(const GridDev &g, int slot, double (&v)[8], double *__restrict__ out, const double *__restrict__ invD,
+                                          double *__restrict__ block_sums, double *T) {
   const int l = threadIdx.x, lo = l & 7, hi = l >> 3;
-  const double invh = 1 / block_h(g, slot);
-  double v[8], w[8], scale[8];
+  double w[8], scale[8];
   double rr = 0;
 #pragma unroll
   for (int z = 0; z < 8; ++z) {
     scale[z] = invD[z * 64 + l];
-    v[z] = invh * in[(size_t)slot * 512 + z * 64 + l];
     rr = __builtin_fma(v[z], v[z], rr);
   }
   rr = wave_sum(rr);
@@ -453,6 +451,18 @@ __global__ void __launch_bounds__(64) k_precond_fdm(GridDev g, const double *in,
     sx = wave_sum(sx * h3);
     if (l == 0) block_sums[slot] = sx;
   }
+}
+__global__ void __launch_bounds__(64) k_precond_fdm(GridDev g, const double *in, double *out, const double *__restrict__ invD,
+                                                    double *__restrict__ block_sums) {
+  __shared__ double T[kFdmLds];
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  const int l = threadIdx.x;
+  const double invh = 1 / block_h(g, slot);
+  double v[8];
+#pragma unroll
+  for (int z = 0; z < 8; ++z) v[z] = invh * in[(size_t)slot * 512 + z * 64 + l];
+  fdm_block(g, slot, v, out, invD, block_sums, T);
 }
 
 #ifdef CUP3D_TESTING
@@ -708,13 +718,14 @@ struct Loop2Args { double alpha, omega; };
 // + 8 x-plus ghosts.  960 doubles; the block CG's LDS (zeroed again when the CG starts) is inside it.  Every stencil operand is one
 // ds_read_b64 with an immediate plane offset: nothing is carried in registers from plane to plane.
 constexpr int kTilePitch = 96, kTileLds = 10 * kTilePitch;
-static_assert(kTileLds >= kCgLds, "the block CG reuses the tile's LDS");
+static_assert(kTileLds >= kCgLds && kTileLds >= kFdmLds, "the block solve reuses the tile's LDS");
 struct LhsIn {
   const double *halo;   // face slabs received from other ranks (Sim::halo_recv)
   const double *total;  // sum(u h^3) over all ranks, for the mean-constraint row (9283-9326); device memory
   int mode;             // bMeanConstraint as ComputeLHS uses it: 0 none, 1 corner row = total, 2 += total h^3 everywhere, 3 corner row = u
   int corner_slot;      // slot of the block with index (0,0,0) on this rank, or -1
   int prio;             // wave priority (s_setprio) while the wavefront streams its block; back to 0 when the block CG starts
+  const double *invD;   // DIRECT form of the block solve (block_solver 1): 1 / (lam_kx + lam_ky + lam_kz), [ky][kz][kx]; else unused
 };
 struct TileRegs { double c[8], gv[6]; };
 // the 14 loads of a tile in two groups: the block's own column (needs nothing but the slot) and the six face slabs (need the
@@ -792,10 +803,12 @@ __device__ __forceinline__ double tile_lhs(const double *T, const TileIdx &ix, d
   return f.add_mean ? t2 : t;
 }
 
-template <bool FMA, int EV, bool FLHS>
+// DIRECT: the block solve behind the loop is the fast diagonalisation (fdm_block: the same M^-1, exact instead of by CG -- block_solver 1,
+// bench.py's `alt`), not the reference's CG: no iteration, no reductions, so the kernel is what the streams alone allow
+template <bool FMA, int EV, bool FLHS, bool DIRECT = false>
 __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb,
                                               double *__restrict__ block_sums, int *__restrict__ iters_out, const LhsIn &L) {
-  __shared__ double P[FLHS ? kTileLds : kCgLds];
+  __shared__ double P[FLHS ? kTileLds : (DIRECT ? kFdmLds : kCgLds)];
   const int slot = block_slot(g);
   if (slot < 0) return;
   if (ctl->state != kRun) return;  // enqueued ahead of a stop or a restart (see SolverCtl)
@@ -860,8 +873,9 @@ __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, c
   d1 = wave_sum(d1);
   if (l == 0) { block_dots[slot] = d0; block_dots[nb + slot] = d1; }
   if (L.prio) __builtin_amdgcn_s_setprio(0);
-  if constexpr (FLHS) __syncthreads();  // the tile is read no more: the block CG takes over its LDS
-  cg_block<FMA, false, EV>(g, slot, r, V.v[ZHAT], block_sums, 0.0, 0.0, iters_out, P);  // zhat = M^-1 z, 14488
+  if constexpr (FLHS) __syncthreads();  // the tile is read no more: the block solve takes over its LDS
+  if constexpr (DIRECT) fdm_block(g, slot, r, V.v[ZHAT], L.invD, block_sums, P);
+  else cg_block<FMA, false, EV>(g, slot, r, V.v[ZHAT], block_sums, 0.0, 0.0, iters_out, P);  // zhat = M^-1 z, 14488
 }
 // (with the LHS inside the compiler takes 110 registers -> 4 wavefronts per SIMD; held to 5 wavefronts it fits 94 without a spill and is
 //  SLOWER: 0.54 instead of 0.51 ms at 256^3, 3.96 instead of 3.93 at 512^3 -- gpurun_out r03c / r03d, profiles/r03)
@@ -870,11 +884,17 @@ __global__ void __launch_bounds__(64) k_loop1_cg(GridDev g, Vecs V, const Solver
                                                  int *__restrict__ iters_out, LhsIn L) {
   loop1_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L);
 }
+// block_solver 1: first loop + the direct block solve (`alt`)
+template <bool FLHS>
+__global__ void __launch_bounds__(64) k_loop1_fdm(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
+                                                  LhsIn L) {
+  loop1_cg_body<true, 0, FLHS, true>(g, V, ctl, block_dots, nb, block_sums, nullptr, L);
+}
 
-template <bool FMA, int EV, bool FLHS>
+template <bool FMA, int EV, bool FLHS, bool DIRECT = false>
 __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb,
                                               double *__restrict__ block_sums, int *__restrict__ iters_out, const LhsIn &L) {
-  __shared__ double P[FLHS ? kTileLds : kCgLds];
+  __shared__ double P[FLHS ? kTileLds : (DIRECT ? kFdmLds : kCgLds)];
   const int slot = block_slot(g);
   if (slot < 0) return;
   if (ctl->state != kRun) return;
@@ -942,7 +962,8 @@ __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, c
   }
   if (L.prio) __builtin_amdgcn_s_setprio(0);
   if constexpr (FLHS) __syncthreads();
-  cg_block<FMA, false, EV>(g, slot, r, V.v[WHAT], block_sums, 0.0, 0.0, iters_out, P);  // what = M^-1 w, 14548
+  if constexpr (DIRECT) fdm_block(g, slot, r, V.v[WHAT], L.invD, block_sums, P);
+  else cg_block<FMA, false, EV>(g, slot, r, V.v[WHAT], block_sums, 0.0, 0.0, iters_out, P);  // what = M^-1 w, 14548
 }
 // WITHOUT the LHS inside (FLHS = false: multi-level meshes, the no_fuse_lhs A/B): held to 96 registers (2 of the 122 the body asks for
 // are spilled, outside the CG loop) -> 5 wavefronts per SIMD: 3.63-3.70 ms instead of 3.75 at 512^3, 0.457-0.461 instead of 0.497 at
@@ -960,6 +981,13 @@ template <bool FMA, int EV, bool FLHS>
 __global__ void __launch_bounds__(64) k_loop2_cg_w4(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
                                                     int *__restrict__ iters_out, LhsIn L) {
   loop2_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L);
+}
+
+// block_solver 1: second loop + the direct block solve (`alt`)
+template <bool FLHS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_loop2_fdm(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
+                                                  LhsIn L) {
+  loop2_cg_body<true, 0, FLHS, true>(g, V, ctl, block_dots, nb, block_sums, nullptr, L);
 }
 
 // K sums of nb per-block values each ([K][nb]) finished in one launch: 64 workgroups, the last one to arrive totals the partials.
@@ -1275,7 +1303,10 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     return helm ? launch_precond_diffusion(s, V.v[in], V.v[out], *helm) : launch_precond(s, V.v[in], V.v[out], mc > 0 && mc <= 2);
   };
   // vector loop + block CG in one launch (k_loop1_cg / k_loop2_cg): the production path of the pressure solver with the block CG
-  const bool fuse = !helm && (P.block_solver == 0 || P.block_solver == 2) && !debug_option("no_fuse");
+  // block_solver 1 (the direct block solve, `alt`): the same two kernels with fdm_block behind the loops ("no_fuse_fdm": A/B, round 3's launches)
+  const bool fuse = !helm && (P.block_solver == 0 || P.block_solver == 2 || (P.block_solver == 1 && !debug_option("no_fuse_fdm"))) && !debug_option("no_fuse");
+  const bool direct_solve = P.block_solver == 1;
+  if (fuse && direct_solve) TRY(fdm_setup());
   const bool want_sums = mc > 0 && mc <= 2;
   const bool four_waves = debug_option("loop2_four_waves") != 0;  // A/B of the second fused kernel's occupancy
   double *const sums = want_sums ? s->d_partials + (size_t)s->max_groups * 8 : nullptr;
@@ -1418,10 +1449,17 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       const GridDev gp = flhs && split ? s->gdev(pass == 1, pass == 0) : gd;
       if (pass == 1) TRY(halo_finish(s));
       if (gp.nblocks == 0) continue;
-      ProfileScope ps(which == 1 ? "bicgstab_loop1_cg" : "bicgstab_loop2_cg");
+      ProfileScope ps(direct_solve ? (which == 1 ? "bicgstab_loop1_fdm" : "bicgstab_loop2_fdm") : (which == 1 ? "bicgstab_loop1_cg" : "bicgstab_loop2_cg"));
       const dim3 GG(launch_groups(gp)), BB(64);
 #define LOOP_ARGS gp, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, cg_it, L
-      if (which == 1) {
+      if (direct_solve) {
+#define FDM_ARGS gp, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, L
+        if (which == 1 && flhs) hipLaunchKernelGGL(k_loop1_fdm<true>, GG, BB, 0, stream(), FDM_ARGS);
+        else if (which == 1) hipLaunchKernelGGL(k_loop1_fdm<false>, GG, BB, 0, stream(), FDM_ARGS);
+        else if (flhs) hipLaunchKernelGGL(k_loop2_fdm<true>, GG, BB, 0, stream(), FDM_ARGS);
+        else hipLaunchKernelGGL(k_loop2_fdm<false>, GG, BB, 0, stream(), FDM_ARGS);
+#undef FDM_ARGS
+      } else if (which == 1) {
         if (P.block_solver == 0 && flhs) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (flhs) hipLaunchKernelGGL((k_loop1_cg<false, 0, true>), GG, BB, 0, stream(), LOOP_ARGS);
@@ -1445,7 +1483,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     return CUP3D_OK;
   };
   if (sc) {
-    if (!fuse) { set_error("cup3d_poisson_path_checksum: block_solver %d has no fused loop kernels (0 and 2 do)", P.block_solver); return CUP3D_EINVAL; }
+    if (!fuse) { set_error("cup3d_poisson_path_checksum: block_solver %d has no fused loop kernels (0, 1 and 2 do)", P.block_solver); return CUP3D_EINVAL; }
     // every vector = a function of (vector, level, global cell index): the same cells hold the same bits however the blocks are
     // spread over ranks.  alpha, beta, omega by hand: no dot product (whose rounding depends on the partition) enters the update.
     int32_t *d_index = nullptr, *d_level = nullptr;
@@ -1471,9 +1509,9 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       const double *total = s->d_red + kRedMeanLhs;
       auto LHS0 = [&](int in, int out) { return launch_lhs(s, V.v[in], V.v[out], 0); };
       if (!flhs) TRY(LHS0(WHAT, T_));
-      TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, total, lhs_mode, s->grid->corner_slot, kLoopPrio}));
+      TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, total, lhs_mode, s->grid->corner_slot, kLoopPrio, g_invD}));
       if (!flhs) TRY(LHS0(ZHAT, V_));
-      TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, total, lhs_mode, s->grid->corner_slot, kLoopPrio}));
+      TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, total, lhs_mode, s->grid->corner_slot, kLoopPrio, g_invD}));
       for (int i = 0; i < NVEC; ++i) TRY(checksum_array(s, s->sv[i], N, &sc[i]));
       return CUP3D_OK;
     };
@@ -1487,13 +1525,13 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     V.v[X_] = XB[0]; V.v[XOPT] = XB[1];  // fixed roles: the kernels pick by SolverCtl::xcur / xopt
     const int lhs_mode = !flhs ? -1 : (mc > 2 ? 3 : mc);
     const int prio = debug_option("loop_prio") ? debug_option("loop_prio") - 1 : kLoopPrio;  // tuning: option value = priority + 1
-    TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, what_total, lhs_mode, s->grid->corner_slot, prio}));  // (t = A what,) loop 1, zhat = M^-1 z
+    TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, what_total, lhs_mode, s->grid->corner_slot, prio, g_invD}));  // (t = A what,) loop 1, zhat = M^-1 z
     s->sums_of = want_sums ? V.v[ZHAT] : nullptr;
     TRY(finish(2, 1, seq));
     if (want_sums) { s->mean_total_of = V.v[ZHAT]; s->mean_total = s->d_red + kRedDots + 2; }
     if (!flhs) TRY(LHS(ZHAT, V_));
     TRY(scalars_ready());
-    TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, s->d_red + kRedDots + 2, lhs_mode, s->grid->corner_slot, prio}));  // (v = A zhat,) loop 2, what = M^-1 w
+    TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, s->d_red + kRedDots + 2, lhs_mode, s->grid->corner_slot, prio, g_invD}));  // (v = A zhat,) loop 2, what = M^-1 w
     s->sums_of = want_sums ? V.v[WHAT] : nullptr;
     TRY(finish(7, 2, seq));
     if (want_sums) { s->mean_total_of = V.v[WHAT]; s->mean_total = s->d_red + kRedDots + 7; }

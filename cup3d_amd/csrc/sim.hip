@@ -90,7 +90,8 @@ int not_in_release(const char *what) {
   return CUP3D_ESTATE;
 }
 // ---- cup3d_stats_*: process-wide counters (the ranks of the in-process test communicator are threads, hence atomics)
-static std::atomic<long> g_st_halo{0}, g_st_halo_bytes{0}, g_st_allreduce{0}, g_st_waits{0}, g_st_wait_ns{0}, g_st_iters{0};
+static std::atomic<long> g_st_halo{0}, g_st_halo_bytes{0}, g_st_allreduce{0}, g_st_waits{0}, g_st_wait_ns{0}, g_st_iters{0}, g_st_h2d{0}, g_st_d2h{0};
+static void stats_field_transfer(bool up, size_t bytes) { (up ? g_st_h2d : g_st_d2h) += (long)bytes; }
 void stats_host_wait(double seconds) { g_st_waits++; g_st_wait_ns += (long)(seconds * 1e9); }
 void stats_solver_iterations(long n) { g_st_iters += n; }
 void stats_halo(size_t bytes_sent) { g_st_halo++; g_st_halo_bytes += (long)bytes_sent; }
@@ -350,7 +351,12 @@ static int sim_build(Sim *s, const Grid *g) {
   if ((rc = up(&s->d_nbr, g->nbr))) return rc;
   if (g->nranks > 1) {
     if ((rc = up(&s->d_inner, g->inner)) || (rc = up(&s->d_boundary, g->boundary)) || (rc = up(&s->d_send_faces, g->send_faces))) return rc;
-    CUP3D_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+    // the communication stream outranks the compute stream: its pack kernels, RCCL's send / receive kernels and the one-thread
+    // recurrence steps are dispatched ahead of the tens of thousands of loop-kernel workgroups queued on the compute stream, so an
+    // exchange started with the inner blocks' pass really runs beside it instead of behind it
+    int prio_least = 0, prio_greatest = 0;
+    CUP3D_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    CUP3D_HIP(hipStreamCreateWithPriority(&s->comm_stream, hipStreamNonBlocking, prio_greatest));
   }
   if (g->nranks > 1 && !g->multilevel) {
     const size_t slab = 3 * 3 * 64;  // widest exchange: 3 components x 3 layers
@@ -593,6 +599,7 @@ int cup3d_sim_upload_blocks(cup3d_sim_t *h, int field, const void *const *ptrs) 
   if (!dst) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
   if ((rc = ensure_stage(s))) return rc;
   const size_t per = 512 * (size_t)nc, cap = s->stage_blocks * 1536;
+  stats_field_transfer(true, (size_t)s->nb * per * sizeof(double));
   int k = 0;
   for (size_t b0 = 0; b0 < (size_t)s->nb; b0 += s->stage_blocks, ++k) {
     const size_t n = std::min(s->stage_blocks, (size_t)s->nb - b0);
@@ -617,6 +624,7 @@ int cup3d_sim_download_blocks(cup3d_sim_t *h, int field, void *const *ptrs) {
   if (!src) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
   if ((rc = ensure_stage(s))) return rc;
   const size_t per = 512 * (size_t)nc, cap = s->stage_blocks * 1536;
+  stats_field_transfer(false, (size_t)s->nb * per * sizeof(double));
   const size_t nchunks = ((size_t)s->nb + s->stage_blocks - 1) / s->stage_blocks;
   auto issue = [&](size_t c) -> int {  // layout kernel + copy of chunk c into pinned buffer c & 1
     const size_t b0 = c * s->stage_blocks, n = std::min(s->stage_blocks, (size_t)s->nb - b0);
@@ -657,6 +665,7 @@ int cup3d_sim_upload_block_list(cup3d_sim_t *h, int field, long nlist, const int
   if (!dst) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
   if ((rc = check_list(s, nlist, slots)) || (rc = ensure_stage(s))) return rc;
   const size_t per = 512 * (size_t)nc;
+  stats_field_transfer(true, (size_t)nlist * per * sizeof(double));
   for (size_t b0 = 0; b0 < (size_t)nlist; b0 += s->stage_blocks) {
     const size_t n = std::min(s->stage_blocks, (size_t)nlist - b0);
     for (size_t i = 0; i < n; ++i) {
@@ -679,6 +688,7 @@ int cup3d_sim_download_block_list(cup3d_sim_t *h, int field, long nlist, const i
   if (!src) { set_error("unknown field id %d", field); return CUP3D_EINVAL; }
   if ((rc = check_list(s, nlist, slots)) || (rc = ensure_stage(s))) return rc;
   const size_t per = 512 * (size_t)nc;
+  stats_field_transfer(false, (size_t)nlist * per * sizeof(double));
   for (size_t b0 = 0; b0 < (size_t)nlist; b0 += s->stage_blocks) {
     const size_t n = std::min(s->stage_blocks, (size_t)nlist - b0);
     for (size_t i = 0; i < n; ++i) s->h_stage_slots[i] = slots[b0 + i];
@@ -693,13 +703,14 @@ int cup3d_sim_download_block_list(cup3d_sim_t *h, int field, long nlist, const i
 }
 
 int cup3d_stats_reset(void) {
-  g_st_halo = 0; g_st_halo_bytes = 0; g_st_allreduce = 0; g_st_waits = 0; g_st_wait_ns = 0; g_st_iters = 0;
+  g_st_halo = 0; g_st_halo_bytes = 0; g_st_allreduce = 0; g_st_waits = 0; g_st_wait_ns = 0; g_st_iters = 0; g_st_h2d = 0; g_st_d2h = 0;
   return CUP3D_OK;
 }
 int cup3d_stats_read(cup3d_run_stats *o) {
   if (!o) return CUP3D_EINVAL;
   o->halo_exchanges = g_st_halo; o->halo_bytes_sent = (double)g_st_halo_bytes; o->allreduces = g_st_allreduce;
   o->host_waits = g_st_waits; o->host_wait_seconds = g_st_wait_ns * 1e-9; o->solver_iterations = g_st_iters;
+  o->field_bytes_uploaded = (double)g_st_h2d; o->field_bytes_downloaded = (double)g_st_d2h;
   return CUP3D_OK;
 }
 

@@ -340,6 +340,8 @@ typedef struct {
   long host_waits;          /* times the host waited for scalars of the device */
   double host_wait_seconds; /* ... and for how long in total */
   long solver_iterations;   /* BiCGSTAB iterations (Poisson and Helmholtz solves) */
+  double field_bytes_uploaded;   /* field data that crossed the host boundary (cup3d_sim_upload*, PCIe host -> device) ... */
+  double field_bytes_downloaded; /* ... and back (cup3d_sim_download*): what the drop-in adds to a step of the host's time loop */
 } cup3d_run_stats;
 int cup3d_stats_reset(void);
 int cup3d_stats_read(cup3d_run_stats *);

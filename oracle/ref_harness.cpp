@@ -36,10 +36,14 @@
  *   lab <field> <s> <e> <tensorial> <file>   ghosted tiles of every block (BlockLab::load)
  *   loadb <field> <file>   block-order load (multi-level meshes)
  *   amrtol <rt> <ct> | adapt | tagvel <rt> <ct> <file>   mesh-adaptation hooks (refine/compress everything)
+ *   timeops                wrap every entry of sim.pipeline in a wall-clock timer (after `hip ...`, if any); `op steps` then prints
+ *                          `REF optime name=<class> calls=<n> seconds=<t>` per operator, plus calcMaxTimestep / adaptMesh (= the rest
+ *                          of the step) -- the Amdahl split of a step with and without the drop-in (scripts/configs4_measure.py)
  *   rep <n>                repeat every following `op` n times when timing
  * Every `op` prints one line `REF <op> seconds=<t> iters=<k> value=<v>`.
  */
 #include <chrono>
+#include <cxxabi.h>
 /* every header the reference TU includes is pulled in FIRST, so that the access-specifier
    override below (needed to reach MeshAdaptation's tolerances, main.cpp:5037-5038) touches the
    reference's own classes only, not the standard library */
@@ -120,6 +124,32 @@ Field field_of(SimulationData &s, const std::string &name) {
 double now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+/* `timeops`: a pipeline entry that times the operator it wraps (the HIP operators enqueue work and return: the device is drained
+   before the clock is read, so that the time lands on the operator that caused it) */
+struct TimedOp : public Operator {
+  std::shared_ptr<Operator> inner;
+  std::string name;
+  double seconds = 0;
+  long calls = 0;
+  bool drain_device;
+  TimedOp(SimulationData &s, std::shared_ptr<Operator> in, bool drain) : Operator(s), inner(in), drain_device(drain) {
+    Operator &ref = *in;
+    int status = 0;
+    char *d = abi::__cxa_demangle(typeid(ref).name(), nullptr, nullptr, &status);
+    name = (status == 0 && d) ? d : typeid(ref).name();
+    free(d);
+    for (char &c : name) if (c == ' ') c = '_';
+  }
+  void operator()(Real dt) override {
+    const double t0 = now();
+    (*inner)(dt);
+#ifdef CUP3D_WITH_HIP
+    if (drain_device) cup3d_device_synchronize();
+#endif
+    seconds += now() - t0;
+    calls++;
+  }
+};
 void write_file(const std::string &path0, const void *p, size_t bytes) {
   /* several ranks (ref_tool_mpi, linked against a real MPI): one file per rank, <path>.r<rank> */
   const std::string path = ::sim.size > 1 ? path0 + ".r" + std::to_string(::sim.rank) : path0;
@@ -278,6 +308,13 @@ int main(int argc, char **argv) {
 #else
       fprintf(stderr, "ref_tool: built without CUP3D_WITH_HIP\n"); exit(2);
 #endif
+    } else if (cmd == "timeops") {
+      bool drain = false;
+#ifdef CUP3D_WITH_HIP
+      drain = (bool)hip_mirror;
+#endif
+      for (auto &op : sd.pipeline)
+        if (!std::dynamic_pointer_cast<TimedOp>(op)) op = std::make_shared<TimedOp>(sd, op, drain);
     } else if (cmd == "hipsolver") {
       /* `hipsolver <key>`: sim.poissonSolver = key; sim.pressureSolver = cup3d_hip::makePoissonSolver(sim) -- the reference's factory
          (main.cpp:14747-14758) with the GPU slot it reserves ("cuda_iterative") filled in; `op solve` then runs through it */
@@ -466,18 +503,48 @@ int main(int argc, char **argv) {
         else if (op == "maxu") value = findMaxU(sd);
         else if (op == "forcing") { ExternalForcing f(sd); f(arg); }
         else if (op == "steps") {
+          double t_dt = 0, t_adv = 0;
           for (int n = 0; n < (int)arg; n++) {
 #ifdef CUP3D_WITH_HIP
             if (hip_mirror && hip_mirror->device_led) {  /* the time loop of the one-edit integration */
+              const double a0 = now();
               const Real dt = cup3d_hip::calcMaxTimestep(*S, *hip_mirror);
+              const double a1 = now();
               cup3d_hip::advance(*S, *hip_mirror, dt);
+              t_dt += a1 - a0; t_adv += now() - a1;
               value = dt;
               continue;
             }
 #endif
+            const double a0 = now();
             const Real dt = S->calcMaxTimestep();
+            const double a1 = now();
             S->advance(dt);
+            t_dt += a1 - a0; t_adv += now() - a1;
             value = dt;
+          }
+          { /* `timeops`: where the steps' time went, operator by operator; what is left of advance() is adaptMesh (+ dump) */
+            double in_ops = 0;
+            bool any = false;
+            for (auto &pop : sd.pipeline)
+              if (auto t = std::dynamic_pointer_cast<TimedOp>(pop)) {
+                printf("REF optime name=%s calls=%ld seconds=%.6f\n", t->name.c_str(), t->calls, t->seconds);
+                in_ops += t->seconds; t->seconds = 0; t->calls = 0; any = true;
+              }
+            if (any) {
+              printf("REF optime name=calcMaxTimestep calls=%d seconds=%.6f\n", (int)arg, t_dt);
+              printf("REF optime name=adaptMesh_and_rest calls=%d seconds=%.6f\n", (int)arg, t_adv - in_ops);
+              printf("REF optime name=blocks calls=%ld seconds=0\n", (long)sd.velInfo().size());
+#ifdef CUP3D_WITH_HIP
+              cup3d_run_stats st;
+              if (hip_mirror && cup3d_stats_read(&st) == 0) {  /* PCIe traffic of the drop-in over these steps (then reset) */
+                printf("REF optime name=pcie_MB_up calls=%ld seconds=0\n", (long)(st.field_bytes_uploaded / 1e6));
+                printf("REF optime name=pcie_MB_down calls=%ld seconds=0\n", (long)(st.field_bytes_downloaded / 1e6));
+                printf("REF optime name=bicgstab_iterations calls=%ld seconds=0\n", st.solver_iterations);
+                cup3d_stats_reset();
+              }
+#endif
+            }
           }
 #ifdef CUP3D_WITH_HIP
           if (hip_mirror) hip_mirror->sync_host();  /* whatever the script does next (dump, tables, another op) sees the host fields */

@@ -1,0 +1,68 @@
+#!/bin/bash
+# One gpurun call of round 4.  Usage: gpurun --timeout 1500 -- 'bash scripts/gpu_round4.sh <tag> [stages...]'
+TAG=${1:-r04a}; shift
+STAGES=${@:-smoke constants newtests}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd "$(dirname "$0")/.."
+has() { [[ " $STAGES " == *" $1 "* ]]; }
+echo "== host: $(nproc) cpus, $(free -g | awk '/Mem:/{print $2}') GB, devices: $(python -c 'import cup3d_amd.capi as c; print(c.device_count())' 2>/dev/null)"
+if has smoke; then echo "== smoke (release build)"
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1 ; echo "smoke rc=$?" ; tail -3 $OUT/smoke.log; fi
+if has constants; then echo "== device-side checksum constants (release build, one GPU)"
+  timeout 600 python scripts/make_poisson_checksums.py ${CONST_SIZES:-64 128 256 512} --out $OUT/poisson_checksums.json --merge > $OUT/constants.log 2>&1 ; echo "constants rc=$?" ; tail -6 $OUT/constants.log; fi
+if has newtests; then echo "== pytest: round-4 tests first"
+  timeout 1200 python -m pytest tests/test_gpu_rccl.py tests/test_gpu_release_flavour.py "tests/test_gpu_multirank.py::test_a_bad_call_on_one_rank_fails_on_every_rank_at_once" ${NEW_TESTS} -m gpu -q --durations=8 -s > $OUT/pytest_new.log 2>&1 ; echo "pytest rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert|ranks over" $OUT/pytest_new.log | tail -60 | cut -c1-600; fi
+if has tests; then echo "== pytest -m gpu (everything)"
+  timeout 1800 python -m pytest tests -m gpu -q --durations=10 > $OUT/pytest_gpu.log 2>&1 ; echo "pytest rc=$?" ; grep -E "passed|failed|FAILED|Error" $OUT/pytest_gpu.log | tail -40 | cut -c1-300; tail -12 $OUT/pytest_gpu.log | cut -c1-300; fi
+if has resttests; then echo "== pytest -m gpu (all but the files of newtests)"
+  timeout 1800 python -m pytest tests -m gpu -q --durations=10 --ignore=tests/test_gpu_rccl.py --ignore=tests/test_gpu_release_flavour.py > $OUT/pytest_rest.log 2>&1 ; echo "pytest rc=$?" ; grep -E "passed|failed|FAILED|Error" $OUT/pytest_rest.log | tail -40 | cut -c1-300; tail -12 $OUT/pytest_rest.log | cut -c1-300; fi
+summ() { python - "$1" <<'PY'
+import json, sys
+try:
+    r = json.loads([l for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith("{")][-1])
+except Exception as e:
+    print("  (no JSON)", e); sys.exit(0)
+if r.get("valid") is False and r.get("value") is None:
+    print("  ERROR LINE:", json.dumps(r)[:1500]); sys.exit(0)
+c = r["config"]
+print("  value", r["value"], "ms/step", r["ms_per_step"], "its/step", c.get("bicgstab_iters_per_step"), "ms/iteration", r.get("ms_per_bicgstab_iteration"), "lib", c.get("library"))
+ck = c.get("checksum") or {}
+print("  checksum", ck.get("ok"), {k: ck[k].get("ok") for k in ck if isinstance(ck[k], dict)}, "unchecked", ck.get("unchecked"))
+print("  comm", c.get("communication"))
+print("  comm stream", r.get("communication_stream"))
+for k in ("alt", "alt_multigrid", "alt_reference_association"):
+    if r.get(k): print("  ", k, r[k].get("value"), r[k].get("bicgstab_iters_per_step"), r[k].get("ms_per_bicgstab_iteration"))
+for k in r.get("kernels", [])[:7]:
+    print("   ", k["kernel"], k["launches"], k["avg_ms"], k.get("frac"))
+PY
+}
+for S in 128 256 512; do
+  if has bench$S; then echo "== bench $S (release build, no cpu baseline, no alt)"
+    timeout 900 python bench.py --size $S --no-cpu --no-alt --no-pcie --steps ${BENCH_STEPS:-10} --warmup ${BENCH_WARMUP:-3} ${BENCH_ARGS} > $OUT/bench_$S.json 2> $OUT/bench_$S.err ; echo "bench rc=$?" ; summ $OUT/bench_$S.json ; tail -2 $OUT/bench_$S.err
+  fi
+  for N in 2 4 8; do
+    if has host$S.$N; then echo "== bench $S on $N ranks over the host-memory TEST transport"
+      timeout 1200 python bench.py --gpus $N --transport host --size $S --no-cpu --no-alt --no-pcie --steps ${BENCH_STEPS:-5} --warmup ${BENCH_WARMUP:-2} > $OUT/bench_${S}_host_${N}ranks.json 2> $OUT/bench_${S}_host_${N}ranks.err ; echo "bench rc=$?" ; summ $OUT/bench_${S}_host_${N}ranks.json ; tail -2 $OUT/bench_${S}_host_${N}ranks.err
+    fi
+  done
+done
+if has driver; then echo "== the driver's command: python bench.py --gpus 1 --steps 20 --warmup 5"
+  timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_512_fullstep.json 2> $OUT/bench_512_fullstep.err ; echo "bench rc=$?" ; summ $OUT/bench_512_fullstep.json ; tail -3 $OUT/bench_512_fullstep.err
+fi
+if has amr; then echo "== bench --amr (3 levels)"
+  timeout 900 python bench.py --amr --steps ${AMR_STEPS:-10} --warmup 3 ${AMR_ARGS} > $OUT/bench_amr.json 2> $OUT/bench_amr.err ; echo "rc=$?" ; python - $OUT/bench_amr.json <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("  value", r["value"], "ms/step", r["ms_per_step"], r["config"]["blocks"], r["config"]["bicgstab_iters_per_step"])
+for k in r["kernels"][:10]: print("   ", k["kernel"], k["launches"], k["avg_ms"], k["share"])
+PY
+fi
+if has trace; then echo "== rocprofv3 kernel trace of the driver's bench"
+  cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/trace -o fullstep -- python $OLDPWD/bench.py --steps ${TRACE_STEPS:-20} --warmup 5 --no-cpu --no-alt --no-pcie > $OLDPWD/$OUT/trace_bench.json 2> $OLDPWD/$OUT/trace.err ; echo "trace rc=$?"; cd $OLDPWD
+  find $OUT/trace -name "*kernel_stats.csv" | head -2 | while read f; do head -12 "$f" | cut -c1-220; done
+  find $OUT/trace -name "*kernel_trace.csv" -delete; find $OUT/trace -name "*.db" -delete
+fi
+ls -la $OUT | head -30

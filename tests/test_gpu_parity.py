@@ -903,24 +903,26 @@ def test_udef_written_through_the_device_pointer_survives_the_projection(golden_
     assert np.abs(res["upload"] - res["pointer_unmarked"]).max() > 1e-6   # unmarked: cleared like the reference's tmpV = 0 (15076-15078)
 
 
+@pytest.mark.parametrize("block_solver", [0, 1])
 @pytest.mark.parametrize("mc", [0, 1, 2, 3])
 @pytest.mark.parametrize("bpd,lmax,level,bc", [
     ((1, 1, 1), 4, 3, ("wall", "wall", "wall")),
     ((2, 1, 3), 2, 1, ("periodic", "freespace", "wall")),
     ((1, 1, 2), 1, 0, ("periodic", "periodic", "periodic")),   # a block that is its own neighbour
 ])
-def test_lhs_inside_the_loop_kernels_is_bit_identical(bpd, lmax, level, bc, mc):
+def test_lhs_inside_the_loop_kernels_is_bit_identical(bpd, lmax, level, bc, mc, block_solver):
     """v = A zhat and t = A what formed inside the fused loop kernels (one wavefront per block, ghosted tile in LDS, poisson.hip FLHS)
     against the same solve with k_lhs launches (`no_fuse_lhs`): the stencil keeps k_lhs's association and the mean-constraint rows
     (main.cpp:9299-9326) are applied to the same cells, so t and v -- hence every iterate, the iteration count and the returned
-    pressure -- are the same BITS.  Every bMeanConstraint mode."""
+    pressure -- are the same BITS.  Every bMeanConstraint mode; with the block CG and with the direct block solve behind the loops
+    (block_solver 1: k_loop1_fdm / k_loop2_fdm)."""
     rng = np.random.default_rng(31 + mc)
     res = {}
     for opt in (0, 1):
         cu.capi.check(cu.lib().cup3d_debug_set_option(b"no_fuse_lhs", opt))
         try:
             sim = cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=level, extent=2 * np.pi,
-                                    BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], bMeanConstraint=mc, poissonTol=1e-9, poissonTolRel=1e-7)
+                                    BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], bMeanConstraint=mc, poissonTol=1e-9, poissonTolRel=1e-7, blockSolver=block_solver)
             if opt == 0:
                 rhs = rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8))
                 rhs -= rhs.mean()
@@ -933,3 +935,33 @@ def test_lhs_inside_the_loop_kernels_is_bit_identical(bpd, lmax, level, bc, mc):
     assert res[0][0] > 3
     assert res[0][:3] == res[1][:3], (res[0][:3], res[1][:3])
     assert np.array_equal(res[0][3], res[1][3])
+
+
+@pytest.mark.parametrize("bpd,lmax,level,bc", [((1, 1, 1), 4, 3, ("wall", "wall", "wall")), ((2, 1, 3), 3, 2, ("periodic", "freespace", "wall"))])
+def test_direct_block_solve_inside_the_loop_kernels(bpd, lmax, level, bc):
+    """block_solver = 1 with the fast diagonalisation running BEHIND the vector loops in the same launch (k_loop1_fdm / k_loop2_fdm,
+    bench.py's `alt`) against the same solver with round 3's separate launches (`no_fuse_fdm`: k_loop1 / k_loop2 + k_precond_fdm + k_lhs).
+    fdm_block is one function, so zhat / what are the same map; what differs is the order of the dot-product sums (per block, then over
+    blocks -- instead of grid-stride partials).  Tight tolerance: the pressures agree to 1e-7 of the pressure, the iteration counts to
+    a few; and the direct solve itself equals the stand-alone kernel bit for bit (cup3d_preconditioner on the same input)."""
+    rng = np.random.default_rng(77)
+    res = {}
+    for opt in (0, 1):
+        cu.capi.check(cu.lib().cup3d_debug_set_option(b"no_fuse_fdm", opt))
+        try:
+            sim = cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=level, extent=2 * np.pi,
+                                    BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], poissonTol=1e-11, poissonTolRel=1e-10, blockSolver=1)
+            if opt == 0:
+                rhs = rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8))
+                rhs -= rhs.mean()
+            sim.upload("lhs", rhs)
+            sim.fill("pres", 0.0)
+            r = cu.makePoissonSolver(sim).solve()
+            res[opt] = (r.iterations, sim.download("pres"))
+        finally:
+            cu.capi.check(cu.lib().cup3d_debug_set_option(b"no_fuse_fdm", 0))
+    (i0, p0), (i1, p1) = res[0], res[1]
+    print(f"direct block solve fused / unfused: {i0} / {i1} iterations")
+    assert i0 > 3 and abs(i0 - i1) <= max(3, 0.15 * i1), (i0, i1)
+    p0, p1 = p0 - p0.mean(), p1 - p1.mean()
+    assert np.abs(p0 - p1).max() <= 1e-7 * np.abs(p1).max()

@@ -1,7 +1,8 @@
 """The RELEASE build of the library (libcup3d_hip.so: no debug-option map, no in-process communicator, no A/B kernel variants) in
 subprocesses -- the rest of the suite loads libcup3d_hip_testing.so (tests/conftest.py).  Same sources, same kernels: the smoke
-check (advect-diffuse bit-exact against the oracle, projection to solver round-off) and a 64^3 solve must behave the same, and the
-test-support entry points must refuse to work instead of silently doing nothing."""
+check (advect-diffuse bit-exact against the oracle, projection to solver round-off) and a cross-section of the paths whose launch code
+differs between the builds (solves in every mean-constraint mode, a multi-level mesh, implicit diffusion, the fused iteration) must give
+the same bits, and the test-support entry points must be ABSENT from the release library."""
 import os
 import subprocess
 import sys
@@ -23,26 +24,60 @@ def test_smoke_on_the_release_build():
     assert b"smoke ok" in out.stdout and b"libcup3d_hip.so" in out.stdout and b"testing" not in out.stdout.split(b"LIB")[-1]
 
 
-SOLVE = r"""
+# A cross-section of the paths whose dispatch differs between the two builds (#ifndef CUP3D_TESTING launchers: advdiff_stage, the
+# launch_precond switch, launch_loop, the constexpr-folded communicator branches): every line printed must be the same in both builds
+CROSS_SECTION = r"""
+import sys, os
 import numpy as np, cup3d_amd as cu
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import oracle_lib as O
+import ctypes as C
 cu.device_init(0)
-sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=4, levelStart=3, extent=1.0, BC_x="wall", BC_y="wall", BC_z="wall")
-rhs = np.random.default_rng(3).uniform(-1, 1, (sim.nblocks, 8, 8, 8))
-sim.upload("lhs", rhs)
-r = cu.makePoissonSolver(sim).solve()
-print("RESULT", r.iterations, r.restarts, repr(float(r.norm)), sim.checksum("pres"))
-rc = cu.lib().cup3d_debug_set_option(b"no_fuse", 1)
-print("DEBUG_RC", rc, cu.lib().cup3d_debug_virtual_comm(2))
+rng = np.random.default_rng(3)
+ext = 2 * np.pi
+# uniform 64^3: the pressure solve for every mean-constraint mode, both block solvers with a stand-alone kernel
+for mc in (0, 1, 2, 3):
+    for bs in (0, 1):
+        sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=4, levelStart=3, extent=1.0, BC_x="wall", BC_y="periodic", BC_z="freespace",
+                                bMeanConstraint=mc, blockSolver=bs)
+        sim.upload("lhs", rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8)))
+        r = cu.makePoissonSolver(sim).solve()
+        print("RESULT solve", mc, bs, r.iterations, r.restarts, repr(float(r.norm)), sim.checksum("pres"))
+sums = (C.c_ulonglong * 18)()
+for mc in (0, 1, 2, 3):
+    cu.capi.check(cu.lib().cup3d_poisson_path_checksum(sim.handle, 0, mc, sums))
+    print("RESULT fused_iteration", mc, [int(v) for v in sums])
+# a three-level mesh: advect-diffuse (ghost reconstruction + flux correction), the full projection
+bc = ("wall", "freespace", "periodic")
+lv, zs = O.build_balanced_mesh((2, 2, 2), 3, bc, [(0, 0, 0, 0), (1, 0, 0, 0), (0, 1, 1, 1)])
+sim = cu.SimulationData(bpdx=2, bpdy=2, bpdz=2, levelMax=3, levelStart=0, extent=ext, nu=0.02, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], leaves=(lv, zs))
+sim.upload("vel", rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8, 3)))
+cu.AdvectionDiffusion(sim)(0.01)
+print("RESULT amr advdiff", sim.nblocks, sim.checksum("vel"))
+sim.step = 5
+r = cu.PressureProjection(sim)(0.01)
+print("RESULT amr project", r.iterations, sim.checksum("vel"), sim.checksum("pres"))
+cu.capi.check(cu.lib().cup3d_poisson_path_checksum(sim.handle, 0, 1, sums))
+print("RESULT amr fused_iteration", [int(v) for v in sums])
+# implicit diffusion: upwind advection + three Helmholtz solves
+sim = cu.SimulationData(bpdx=2, bpdy=2, bpdz=2, levelMax=3, levelStart=0, extent=ext, nu=2.0, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], leaves=(lv, zs),
+                        implicitDiffusion=True)
+sim.upload("vel", rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8, 3)))
+res = cu.AdvectionDiffusionImplicit(sim)(0.05)
+print("RESULT implicit", [x.iterations for x in res], sim.checksum("vel"))
+print("HAS_DEBUG", hasattr(cu.lib(), "cup3d_debug_set_option"), hasattr(cu.lib(), "cup3d_debug_virtual_comm"))
 """
 
 
 def test_release_and_testing_builds_compute_the_same_bits():
     res = {}
     for flavour in ("release", "testing"):
-        out = run(SOLVE, flavour)
+        out = run(CROSS_SECTION, flavour)
         assert out.returncode == 0, out.stderr.decode()[-2000:]
         lines = out.stdout.decode().splitlines()
-        res[flavour] = ([l for l in lines if l.startswith("RESULT")][0], [l for l in lines if l.startswith("DEBUG_RC")][0])
-    assert res["release"][0] == res["testing"][0]            # iterations, restarts, final norm and the pressure's checksum
-    assert res["release"][1] == "DEBUG_RC -5 -5"             # CUP3D_ESTATE: test support is not in this build
-    assert res["testing"][1] == "DEBUG_RC 0 0"
+        res[flavour] = ([l for l in lines if l.startswith("RESULT")], [l for l in lines if l.startswith("HAS_DEBUG")][0])
+    assert len(res["release"][0]) == 8 + 4 + 4 + 1
+    for a, b in zip(res["release"][0], res["testing"][0]):   # iterations, restarts, final norms and every checksum
+        assert a == b, (a, b)
+    assert res["release"][1] == "HAS_DEBUG False False"      # test support is not in this build at all
+    assert res["testing"][1] == "HAS_DEBUG True True"
