@@ -55,6 +55,8 @@ ALGO_BYTES = {
     "advdiff_stage1": 72.0,    # RK stage 1 reads no tmpV (it is zero there)
     "bicgstab_loop1_cg": 152.0,  # loop 1 fused with the block CG on z: 11 reads + 7 writes + zhat out (z never re-read)
     "bicgstab_loop2_cg": 136.0,  # loop 2 fused with the block CG on w: 12 reads + 4 writes + what out
+    "bicgstab_loop1_fdm": 152.0,  # the same two kernels with the direct block solve behind the loops (`alt`, block_solver 1)
+    "bicgstab_loop2_fdm": 136.0,
     "bicgstab_loop1": 144.0,   # 11 reads + 7 writes
     "bicgstab_loop2": 128.0,   # 12 reads + 4 writes
     "poisson_lhs": 16.0,       # p in, Ap out
@@ -428,8 +430,11 @@ def run_amr(a):
     Simulation.adaptMesh (vorticity tags -> ValidStates -> refine/compress on the device) refine around it; then K steps on the
     frozen mesh are timed.  One GPU.  Reported beside the headline, not instead of it."""
     import cup3d_amd as cu
-    from cup3d_amd.capi import ProfileEntry, lib
+    from cup3d_amd.capi import ProfileEntry, check, lib
     cu.device_init(0)
+    for opt in (a.debug_option or []):   # A/B switches (libcup3d_hip_testing.so): --debug-option name=value
+        name, val = opt.split("=")
+        check(lib().cup3d_debug_set_option(name.encode(), int(val)))
     ext, lmax, lstart = 2 * np.pi, a.amr_levels + a.amr_base, a.amr_base
     sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=lmax, levelStart=lstart, extent=ext, nu=0.002, CFL=0.3, BC_x="wall", BC_y="wall",
                             BC_z="wall", rampup=0, blockSolver=a.block_solver)
@@ -774,6 +779,9 @@ def run(a, prog):
             lib().cup3d_profile_enable(0)
             one_step()
             iters.clear()
+            if solver == 1 and not a.no_profile:   # the kernels of the direct-solve iteration: what the streams alone allow
+                lib().cup3d_profile_enable(1)
+                lib().cup3d_profile_reset()
             fence()
             t0 = time.perf_counter()
             for _ in range(nsteps):
@@ -788,6 +796,18 @@ def run(a, prog):
             alts[solver] = {"block_preconditioner": SOLVERS[solver], "value": round(float(a.size) ** 3 * nsteps / sec2 / 1e6, 2), "unit": "Mcell-updates/s",
                             "ms_per_step": round(sec2 / nsteps * 1e3, 3), "bicgstab_iters_per_step": round(float(np.mean(iters)), 2),
                             "ms_per_bicgstab_iteration": round(sec2 * 1e3 / max(1, sum(iters)), 4), "warmup": 1, "steps": nsteps}
+            if solver == 1 and not a.no_profile:
+                n2 = C.c_int(0)
+                lib().cup3d_profile_read(ents, 64, C.byref(n2))
+                lib().cup3d_profile_enable(0)
+                ks = []
+                for i in range(n2.value):
+                    nm, ln, ms = ents[i].name.decode(), ents[i].launches, ents[i].total_ms
+                    if nm in ALGO_BYTES and ln and nm.endswith("_fdm"):
+                        ach = ALGO_BYTES[nm] * sim.nblocks * 512.0 / (ms / ln * 1e-3) / 1e9
+                        ks.append({"kernel": nm, "launches": ln, "avg_ms": round(ms / ln, 5), "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)})
+                alts[solver]["kernels"] = ks
         alt = alts.get(1, alts.get(0))
         a.alt_multigrid = alts.get(5)
         a.alt_reference_association = alts.get(2)

@@ -1442,39 +1442,44 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   // FLHS: v = A zhat and t = A what are formed inside the loop kernels (uniform grids; on multi-level meshes the LHS needs the
   // coarse/fine ghost slabs and the flux correction, so it stays a launch of its own)
   const bool flhs = fuse && !s->grid->multilevel && !debug_option("no_fuse_lhs");
+  // ... except for the blocks none of whose six faces is a coarse/fine interface (one rank): those take the FLHS kernels too, and only
+  // the interface blocks keep k_lhs + ghost slabs + flux correction (launch_lhs on the interface list).  Bit-identical t and v.
+  const bool flhs_ml = fuse && s->grid->multilevel && s->grid->nranks == 1 && s->n_plain > 0 && !debug_option("no_fuse_lhs") && !debug_option("no_fuse_lhs_ml");
   const bool split = s->grid->nranks > 1;
   auto launch_loop = [&](int which, const double *u, const LhsIn &L) -> int {  // one loop kernel; over ranks: inner blocks while u's face slabs travel, then the rest
     if (flhs && split) TRY(halo_begin(s, u, 1, 1));
-    for (int pass = 0; pass < (flhs && split ? 2 : 1); ++pass) {
-      const GridDev gp = flhs && split ? s->gdev(pass == 1, pass == 0) : gd;
-      if (pass == 1) TRY(halo_finish(s));
+    for (int pass = 0; pass < ((flhs && split) || flhs_ml ? 2 : 1); ++pass) {
+      const GridDev gp = flhs_ml ? (pass == 0 ? s->gdev_list(s->d_plain_list, s->n_plain) : s->gdev_list(s->d_iface_list, s->n_iface))
+                                 : (flhs && split ? s->gdev(pass == 1, pass == 0) : gd);
+      const bool fl = flhs || (flhs_ml && pass == 0);  // does this launch form the LHS itself?
+      if (pass == 1 && !flhs_ml) TRY(halo_finish(s));
       if (gp.nblocks == 0) continue;
       ProfileScope ps(direct_solve ? (which == 1 ? "bicgstab_loop1_fdm" : "bicgstab_loop2_fdm") : (which == 1 ? "bicgstab_loop1_cg" : "bicgstab_loop2_cg"));
       const dim3 GG(launch_groups(gp)), BB(64);
 #define LOOP_ARGS gp, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, cg_it, L
       if (direct_solve) {
 #define FDM_ARGS gp, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, L
-        if (which == 1 && flhs) hipLaunchKernelGGL(k_loop1_fdm<true>, GG, BB, 0, stream(), FDM_ARGS);
+        if (which == 1 && fl) hipLaunchKernelGGL(k_loop1_fdm<true>, GG, BB, 0, stream(), FDM_ARGS);
         else if (which == 1) hipLaunchKernelGGL(k_loop1_fdm<false>, GG, BB, 0, stream(), FDM_ARGS);
-        else if (flhs) hipLaunchKernelGGL(k_loop2_fdm<true>, GG, BB, 0, stream(), FDM_ARGS);
+        else if (fl) hipLaunchKernelGGL(k_loop2_fdm<true>, GG, BB, 0, stream(), FDM_ARGS);
         else hipLaunchKernelGGL(k_loop2_fdm<false>, GG, BB, 0, stream(), FDM_ARGS);
 #undef FDM_ARGS
       } else if (which == 1) {
-        if (P.block_solver == 0 && flhs) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        if (P.block_solver == 0 && fl) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
-        else if (flhs) hipLaunchKernelGGL((k_loop1_cg<false, 0, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (fl) hipLaunchKernelGGL((k_loop1_cg<false, 0, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else hipLaunchKernelGGL((k_loop1_cg<false, 0, false>), GG, BB, 0, stream(), LOOP_ARGS);
       } else {
         // with the LHS inside, the second loop asks for 128 registers: 4 wavefronts per SIMD without spills (k_loop2_cg_w4; held to 96 it
         // spills 30 registers inside the plane loop), and the 7.5 KB tile needs 16 wavefronts per CU or fewer anyway
 #ifdef CUP3D_TESTING  // A/B of the occupancy, test builds only: with the LHS inside at 96 registers (30 spilled); without it at 4 wavefronts
-        if (P.block_solver == 0 && flhs && debug_option("loop2_flhs_five_waves")) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
-        else if (P.block_solver == 0 && !flhs && four_waves) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
+        if (P.block_solver == 0 && fl && debug_option("loop2_flhs_five_waves")) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (P.block_solver == 0 && !fl && four_waves) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
         else
 #endif
-        if (P.block_solver == 0 && flhs) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        if (P.block_solver == 0 && fl) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
-        else if (flhs) hipLaunchKernelGGL((k_loop2_cg_w4<false, 0, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (fl) hipLaunchKernelGGL((k_loop2_cg_w4<false, 0, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else hipLaunchKernelGGL((k_loop2_cg<false, 0, false>), GG, BB, 0, stream(), LOOP_ARGS);
       }
 #undef LOOP_ARGS
@@ -1505,9 +1510,11 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       V.v[X_] = XB[0]; V.v[XOPT] = XB[1]; V.xin = XB[0];
       // with the LHS inside the loop kernels the mean-constraint row takes the hand-set total; the stand-alone LHS would reduce the
       // field for it (partition-dependent rounding), so there the row is left out: mode 0 gives the same bits on both routes
-      const int lhs_mode = !flhs ? -1 : (mc > 2 ? 3 : mc);
+      const int lhs_mode = flhs ? (mc > 2 ? 3 : mc) : (flhs_ml ? 0 : -1);
       const double *total = s->d_red + kRedMeanLhs;
-      auto LHS0 = [&](int in, int out) { return launch_lhs(s, V.v[in], V.v[out], 0); };
+      auto LHS0 = [&](int in, int out) {  // (multi-level, one rank: the interface blocks only -- the plain ones form theirs in the loop kernels)
+        return flhs_ml ? launch_lhs(s, V.v[in], V.v[out], 0, s->d_iface_list, s->n_iface) : launch_lhs(s, V.v[in], V.v[out], 0);
+      };
       if (!flhs) TRY(LHS0(WHAT, T_));
       TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, total, lhs_mode, s->grid->corner_slot, kLoopPrio, g_invD}));
       if (!flhs) TRY(LHS0(ZHAT, V_));
@@ -1523,20 +1530,25 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   }
   auto enqueue_fused = [&](unsigned seq) -> int {
     V.v[X_] = XB[0]; V.v[XOPT] = XB[1];  // fixed roles: the kernels pick by SolverCtl::xcur / xopt
-    const int lhs_mode = !flhs ? -1 : (mc > 2 ? 3 : mc);
+    const int lhs_mode = !(flhs || flhs_ml) ? -1 : (mc > 2 ? 3 : mc);
     const int prio = debug_option("loop_prio") ? debug_option("loop_prio") - 1 : kLoopPrio;  // tuning: option value = priority + 1
-    TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, what_total, lhs_mode, s->grid->corner_slot, prio, g_invD}));  // (t = A what,) loop 1, zhat = M^-1 z
+    // the mean-constraint row inside the kernels belongs to the corner block only if that block forms its own LHS
+    const int corner_in = (flhs || (flhs_ml && s->corner_is_plain)) ? s->grid->corner_slot : -1;
+    auto LHS_IFACE = [&](int in, int out) { return launch_lhs(s, V.v[in], V.v[out], mc, s->d_iface_list, s->n_iface); };
+    TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, what_total, lhs_mode, corner_in, prio, g_invD}));  // (t = A what,) loop 1, zhat = M^-1 z
     s->sums_of = want_sums ? V.v[ZHAT] : nullptr;
     TRY(finish(2, 1, seq));
     if (want_sums) { s->mean_total_of = V.v[ZHAT]; s->mean_total = s->d_red + kRedDots + 2; }
-    if (!flhs) TRY(LHS(ZHAT, V_));
+    if (flhs_ml) TRY(LHS_IFACE(ZHAT, V_));
+    else if (!flhs) TRY(LHS(ZHAT, V_));
     TRY(scalars_ready());
-    TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, s->d_red + kRedDots + 2, lhs_mode, s->grid->corner_slot, prio, g_invD}));  // (v = A zhat,) loop 2, what = M^-1 w
+    TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, s->d_red + kRedDots + 2, lhs_mode, corner_in, prio, g_invD}));  // (v = A zhat,) loop 2, what = M^-1 w
     s->sums_of = want_sums ? V.v[WHAT] : nullptr;
     TRY(finish(7, 2, seq));
     if (want_sums) { s->mean_total_of = V.v[WHAT]; s->mean_total = s->d_red + kRedDots + 7; }
     what_total = s->d_red + kRedDots + 7;
-    if (!flhs) TRY(LHS(WHAT, T_));
+    if (flhs_ml) TRY(LHS_IFACE(WHAT, T_));  // t of the interface blocks for the next first loop; the others form theirs in that kernel
+    else if (!flhs) TRY(LHS(WHAT, T_));
     TRY(scalars_ready());
     return CUP3D_OK;
   };

@@ -125,6 +125,13 @@ GridDev Sim::gdev(bool boundary_only, bool inner_only) const {
   g.chunk = (g.nblocks + 7) / 8;
   return g;
 }
+GridDev Sim::gdev_list(const int32_t *l, unsigned n) const {
+  GridDev g = gdev();
+  g.list = l;
+  g.nblocks = (int)n;
+  g.chunk = (g.nblocks + 7) / 8;
+  return g;
+}
 double *Sim::field(int id, int *ncomp) const {
   switch (id) {
     case CUP3D_FIELD_CHI: *ncomp = 1; return chi;
@@ -395,6 +402,18 @@ static int sim_build(Sim *s, const Grid *g) {
       CUP3D_HIP(hipMemcpy(s->d_raw_mask, mask.data(), mask.size(), hipMemcpyHostToDevice));
       if ((rc = up(&s->d_raw_list, raw))) return rc;
     }
+    if (!view) {  // one rank: which blocks have an interface face, which have none
+      std::vector<int32_t> iface, plain;
+      for (size_t b = 0; b < nb; ++b) {
+        bool any = false;
+        for (int f = 0; f < 6; ++f) any = any || g->nbr[6 * b + f] >= kNbrHalo;
+        (any ? iface : plain).push_back((int32_t)b);
+        if ((int32_t)b == g->corner_slot) s->corner_is_plain = !any;
+      }
+      s->n_iface = (unsigned)iface.size();
+      s->n_plain = (unsigned)plain.size();
+      if ((rc = up(&s->d_iface_list, iface)) || (rc = up(&s->d_plain_list, plain))) return rc;
+    }
     const size_t ne = (size_t)std::max<int64_t>(g->n_amr_faces(), 1);
     // ghost slabs: widest use = 3 components x 3 layers; the pressure RHS keeps a second set (udef) behind the first
     A(s->halo_recv, ne * 9 * 64)
@@ -491,7 +510,7 @@ void cup3d_sim_destroy(cup3d_sim_t *h) {
   if (s->d_cg_iters) hipFree(s->d_cg_iters);
   release_stage(s);
   int32_t *ip[] = {s->d_nbr, s->d_inner, s->d_boundary, s->d_send_faces, s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_index,
-                   s->d_restrict_list, s->d_prolong_list, s->d_fix_list[0], s->d_fix_list[1], s->d_fix_list[2], s->d_send_blocks, s->d_send_flux, s->d_raw_list};
+                   s->d_restrict_list, s->d_prolong_list, s->d_fix_list[0], s->d_fix_list[1], s->d_fix_list[2], s->d_send_blocks, s->d_send_flux, s->d_raw_list, s->d_iface_list, s->d_plain_list};
   if (s->d_raw_mask) hipFree(s->d_raw_mask);
   for (int32_t *p : ip) if (p) hipFree(p);
   if (s->comm_stream) hipStreamDestroy(s->comm_stream);

@@ -147,6 +147,11 @@ struct Sim {
   int32_t *d_send_blocks = nullptr, *d_send_flux = nullptr;  // rank views: exchange plans (comm.hip)
   unsigned char *d_raw_mask = nullptr;  // [nb], see GridDev::raw
   int32_t *d_raw_list = nullptr;        // the blocks with raw_mask set
+  // multi-level mesh on one rank: blocks with an interface face (coarse/fine: ghost slabs, face fluxes, flux correction) and the rest,
+  // whose six faces are same-level blocks or domain faces -- for those the LHS application lives inside the fused loop kernels (poisson.hip)
+  int32_t *d_iface_list = nullptr, *d_plain_list = nullptr;
+  unsigned n_iface = 0, n_plain = 0;
+  bool corner_is_plain = false;  // the block of the mean-constraint row (grid->corner_slot) is in the plain list
   unsigned n_raw = 0;
   double *d_hb = nullptr, *d_flux = nullptr;
   // halo buffers (multi-rank)
@@ -157,6 +162,7 @@ struct Sim {
   hipEvent_t ev_vc_pack = nullptr, ev_vc_done = nullptr;  // virtual communicator (tests): "my send buffer is packed" / "my copies are enqueued"
 
   GridDev gdev(bool boundary_only = false, bool inner_only = false) const;
+  GridDev gdev_list(const int32_t *list, unsigned n) const;  // the same over an explicit block list
   double *field(int id, int *ncomp) const;
 };
 
@@ -193,7 +199,9 @@ int amr_fill_ghosts(Sim *s, const double *field, int ncomp, int w, double *slabs
 int amr_flux_fix(Sim *s, int nfc, double *out, int out_nc);
 
 // kernels' launchers shared across translation units
-int launch_lhs(Sim *s, const double *p, double *out, int mean_constraint);
+// list != nullptr: only the `nlist` blocks listed (and the mean-constraint fix-ups of those blocks only; needs the total of p to be known
+// already, Sim::mean_total_of == p) -- the interface blocks of a multi-level mesh, while the loop kernels form the LHS of all others
+int launch_lhs(Sim *s, const double *p, double *out, int mean_constraint, const int32_t *list = nullptr, unsigned nlist = 0);
 int launch_precond(Sim *s, const double *in, double *out, bool want_sums);
 // block_solver 5: one multigrid V-cycle from a zero guess as M^-1 (multigrid.hip; an alternative, not the reference's algorithm)
 int mg_vcycle(Sim *s, const double *in, double *out);

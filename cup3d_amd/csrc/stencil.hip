@@ -359,7 +359,39 @@ int launch_diffusion_rhs(Sim *s) {
   return CUP3D_OK;
 }
 
-int launch_lhs(Sim *s, const double *p, double *out, int mc) {
+__global__ void __launch_bounds__(256) k_lhs_add_mean_list(double *__restrict__ out, const int32_t *__restrict__ list, const double *__restrict__ avg,
+                                                           const double *__restrict__ hb) {
+  const int slot = list[blockIdx.x];
+  const double h = hb[slot], v = h * h * h;
+  for (int i = threadIdx.x; i < 512; i += 256) out[(size_t)slot * 512 + i] += avg[0] * v;  // 9314
+}
+
+int launch_lhs(Sim *s, const double *p, double *out, int mc, const int32_t *list, unsigned nlist) {
+  if (list) {
+    // the interface blocks of a multi-level mesh on one rank (the loop kernels form the LHS of all other blocks): ghost slabs of every
+    // interface face, k_lhs on the list (it fills the face fluxes of the list's faces = all of them), flux correction, then the
+    // mean-constraint fix-ups of 9299-9326 for the list's blocks from the total the fused iteration has already formed
+    const bool need_sum = mc > 0 && mc <= 2;
+    if (!s->grid->multilevel || s->grid->nranks != 1 || (need_sum && s->mean_total_of != p)) { set_error("launch_lhs: block list without a known total"); return CUP3D_ESTATE; }
+    const double *total = s->mean_total;
+    s->mean_total_of = nullptr;
+    s->sums_of = nullptr;
+    int rc = amr_fill_ghosts(s, p, 1, 1, s->halo_recv);
+    if (rc) return rc;
+    if (nlist) {
+      ProfileScope ps("poisson_lhs");
+      const GridDev g = s->gdev_list(list, nlist);
+      hipLaunchKernelGGL(k_lhs<false>, dim3(launch_groups(g)), dim3(256), 0, stream(), g, p, s->halo_recv, out, (double *)nullptr, (const double *)nullptr, -1);
+    }
+    CUP3D_HIP(hipGetLastError());
+    if ((rc = amr_flux_fix(s, 1, out, 1))) return rc;
+    const int corner = s->corner_is_plain ? -1 : s->grid->corner_slot;
+    if (mc == 1 && corner >= 0) hipLaunchKernelGGL(k_lhs_corner, dim3(1), dim3(1), 0, stream(), out, p, total, corner, 1);
+    if (mc == 2 && nlist) hipLaunchKernelGGL(k_lhs_add_mean_list, dim3(nlist), dim3(256), 0, stream(), out, list, total, s->d_hb);
+    if (mc > 2 && corner >= 0) hipLaunchKernelGGL(k_lhs_corner, dim3(1), dim3(1), 0, stream(), out, p, total, corner, 3);
+    CUP3D_HIP(hipGetLastError());
+    return CUP3D_OK;
+  }
   int rc = halo_begin(s, p, 1, 1);  // overlapped with the inner blocks, as compute<>() does (main.cpp:5598-5618)
   if (rc) return rc;
   const bool need_sum = mc > 0 && mc <= 2;

@@ -178,6 +178,7 @@ int main(int argc, char **argv) {
     fprintf(stderr, "usage: ref_tool <script> -- <reference args>\n");
     return 2;
   }
+  setvbuf(stdout, nullptr, _IOLBF, 0); /* the reference's progress line per step reaches a pipe at once: tests tell slow from hung by it */
   int provided;
   MPI_Init_thread(&argc, &argv, MPI_THREAD_FUNNELED, &provided);
   MPI_Comm_rank(MPI_COMM_WORLD, &::sim.rank);

@@ -60,6 +60,21 @@ print("  value", r["value"], "ms/step", r["ms_per_step"], r["config"]["blocks"],
 for k in r["kernels"][:10]: print("   ", k["kernel"], k["launches"], k["avg_ms"], k["share"])
 PY
 fi
+if has configs4; then echo "== configs[4] at its stated size: reference CPU operators vs the drop-in (one rank)"
+  timeout 1500 python scripts/configs4_measure.py --level-max ${C4_LEVEL:-7} --steps ${C4_STEPS:-5} --threads ${C4_THREADS:-32} --out $OUT/configs4_1024_effective.json > $OUT/configs4.log 2>&1 ; echo "configs4 rc=$?"
+  python - $OUT/configs4_1024_effective.json <<'PY'
+import json, sys
+try:
+    r = json.load(open(sys.argv[1]))
+except Exception as e:
+    print("  (no record)", e); sys.exit(0)
+for k in ("blocks", "blocks_per_level", "hot_path_fraction_cpu", "hot_path_fraction_hip", "end_to_end_speedup", "hot_path_speedup", "pcie_MB_per_step", "block_lists_identical", "max_abs_dvel", "max_abs_vel"):
+    print("  ", k, r.get(k))
+print("   cpu", r["cpu"]["seconds_per_step"], r["cpu"]["per_operator_seconds_per_step"])
+if "hip" in r: print("   hip", r["hip"]["seconds_per_step"], r["hip"]["per_operator_seconds_per_step"])
+PY
+  tail -3 $OUT/configs4.log | cut -c1-300
+fi
 if has trace; then echo "== rocprofv3 kernel trace of the driver's bench"
   cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/trace -o fullstep -- python $OLDPWD/bench.py --steps ${TRACE_STEPS:-20} --warmup 5 --no-cpu --no-alt --no-pcie > $OLDPWD/$OUT/trace_bench.json 2> $OLDPWD/$OUT/trace.err ; echo "trace rc=$?"; cd $OLDPWD
   find $OUT/trace -name "*kernel_stats.csv" | head -2 | while read f; do head -12 "$f" | cut -c1-220; done

@@ -42,6 +42,7 @@ ENV = dict(os.environ, OMP_NUM_THREADS="1", LD_LIBRARY_PATH="/usr/lib/x86_64-lin
 for k in ("OMP_PROC_BIND", "GOMP_CPU_AFFINITY", "OMP_PLACES"):
     ENV.pop(k, None)
 RUN_LIMIT = 240   # seconds per launch of the harness; the longest one takes 10-40 s when the GPU switches between the ranks quickly
+STALL_LIMIT = 90  # ... and seconds without a single line of output before the launch counts as HUNG (a failure, not a skip)
 
 
 def _all_cpus():   # the ranks must not inherit a narrowed affinity mask from whatever ran in this process before
@@ -87,12 +88,35 @@ def run(tool, nranks, pre, args, wd, extra_env=None, nsteps=30):
         f.write("\n".join(pre + script(nsteps)) + "\n")
     proc = subprocess.Popen((launcher() + ["-n", str(nranks)] if nranks > 1 else []) + [tool, "script.txt", "--"] + args, cwd=wd, env=dict(ENV, **(extra_env or {})),
                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, preexec_fn=_all_cpus)
-    try:
-        so, se = proc.communicate(timeout=RUN_LIMIT)
-    except subprocess.TimeoutExpired:
-        os.killpg(proc.pid, signal.SIGKILL)   # mpiexec and every rank (own session, see _all_cpus)
-        proc.communicate()
-        raise HarnessTimeout(f"{os.path.basename(tool)} on {nranks} ranks did not finish within {RUN_LIMIT} s")
+    # SLOW and HUNG are told apart: the reference prints "main.cpp: step: N" from every calcMaxTimestep (rank 0), so a run that is
+    # merely slow keeps producing lines; one that produced nothing for STALL_LIMIT seconds is hung and FAILS (never a skip)
+    import threading
+    import time
+    out_chunks, err_chunks, last = [], [], [time.time()]
+
+    def pump(stream, sink):
+        for line in iter(stream.readline, b""):
+            sink.append(line)
+            last[0] = time.time()
+
+    pumps = [threading.Thread(target=pump, args=(proc.stdout, out_chunks), daemon=True), threading.Thread(target=pump, args=(proc.stderr, err_chunks), daemon=True)]
+    for t in pumps:
+        t.start()
+    t0 = time.time()
+    while proc.poll() is None:
+        time.sleep(0.5)
+        now = time.time()
+        stalled, late = now - last[0] > STALL_LIMIT, now - t0 > RUN_LIMIT
+        if stalled or late:
+            os.killpg(proc.pid, signal.SIGKILL)   # mpiexec and every rank (own session, see _all_cpus)
+            proc.wait()
+            tail = b"".join(out_chunks[-5:]).decode()[-400:]
+            if stalled:
+                raise AssertionError(f"{os.path.basename(tool)} on {nranks} ranks produced no output for {STALL_LIMIT} s: HUNG, not slow.  Last output: {tail}")
+            raise HarnessTimeout(f"{os.path.basename(tool)} on {nranks} ranks was still making progress after {RUN_LIMIT} s (slow box).  Last output: {tail}")
+    for t in pumps:
+        t.join(timeout=10)
+    so, se = b"".join(out_chunks), b"".join(err_chunks)
     assert proc.returncode == 0, (so.decode()[-1500:], se.decode()[-3000:])
     res = []
     for r in range(nranks):

@@ -672,3 +672,37 @@ def test_implicit_time_loop(golden_dir):
         assert np.abs(sim.download("vel") - v).max() <= 1e-6 * np.abs(v).max(), step
     sim.step = 11
     assert S.calcMaxTimestep() <= 0.1
+
+
+@pytest.mark.parametrize("block_solver", [0, 1])
+@pytest.mark.parametrize("mc", [0, 1, 2, 3])
+@pytest.mark.parametrize("bc", [("wall", "freespace", "wall"), ("periodic", "periodic", "wall")])
+def test_lhs_inside_the_loop_kernels_on_a_multilevel_mesh_is_bit_identical(bc, mc, block_solver):
+    """On a multi-level mesh (one rank) the blocks none of whose six faces is a coarse/fine interface form v = A zhat and t = A what inside
+    the fused loop kernels, like every block of a uniform grid; only the interface blocks keep k_lhs + ghost slabs + flux correction
+    (launch_lhs on the interface list).  Against the same solve with every LHS a launch of its own (`no_fuse_lhs_ml`): t and v are the
+    same bits -- same stencil association, same mean-constraint rows (9299-9326) on the same cells -- hence every iterate, the iteration
+    count and the returned pressure.  512 level-2 blocks of which a few are refined: most blocks are plain, the corner block too."""
+    bpd, lmax = (2, 2, 2), 4
+    refine = [(0, i, j, k) for k in range(2) for j in range(2) for i in range(2)] + [(1, i, j, k) for k in range(4) for j in range(4) for i in range(4)]
+    refine += [(2, 3, 3, 3), (2, 4, 4, 4), (2, 6, 1, 2)]
+    lv, zs = O.build_balanced_mesh(bpd, lmax, bc, refine)
+    assert len(set(lv.tolist())) >= 2 and len(lv) > 500
+    rng = np.random.default_rng(17 + mc)
+    res = {}
+    for opt in (0, 1):
+        check(lib().cup3d_debug_set_option(b"no_fuse_lhs_ml", opt))
+        try:
+            sim = cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=0, extent=EXT, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2],
+                                    leaves=(lv, zs), bMeanConstraint=mc, poissonTol=1e-9, poissonTolRel=1e-7, blockSolver=block_solver)
+            if opt == 0:
+                rhs = rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8))
+            sim.upload("lhs", rhs)
+            sim.fill("pres", 0.0)
+            r = cu.makePoissonSolver(sim).solve()
+            res[opt] = (r.iterations, r.restarts, r.norm, sim.download("pres"))
+        finally:
+            check(lib().cup3d_debug_set_option(b"no_fuse_lhs_ml", 0))
+    assert res[0][0] > 3
+    assert res[0][:3] == res[1][:3], (res[0][:3], res[1][:3])
+    assert np.array_equal(res[0][3], res[1][3])

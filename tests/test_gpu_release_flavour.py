@@ -76,7 +76,7 @@ def test_release_and_testing_builds_compute_the_same_bits():
         assert out.returncode == 0, out.stderr.decode()[-2000:]
         lines = out.stdout.decode().splitlines()
         res[flavour] = ([l for l in lines if l.startswith("RESULT")], [l for l in lines if l.startswith("HAS_DEBUG")][0])
-    assert len(res["release"][0]) == 8 + 4 + 4 + 1
+    assert len(res["release"][0]) == 8 + 4 + 3 + 1   # solves, fused iterations, the multi-level mesh, implicit diffusion
     for a, b in zip(res["release"][0], res["testing"][0]):   # iterations, restarts, final norms and every checksum
         assert a == b, (a, b)
     assert res["release"][1] == "HAS_DEBUG False False"      # test support is not in this build at all
