@@ -1442,9 +1442,12 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   // FLHS: v = A zhat and t = A what are formed inside the loop kernels (uniform grids; on multi-level meshes the LHS needs the
   // coarse/fine ghost slabs and the flux correction, so it stays a launch of its own)
   const bool flhs = fuse && !s->grid->multilevel && !debug_option("no_fuse_lhs");
-  // ... except for the blocks none of whose six faces is a coarse/fine interface (one rank): those take the FLHS kernels too, and only
-  // the interface blocks keep k_lhs + ghost slabs + flux correction (launch_lhs on the interface list).  Bit-identical t and v.
-  const bool flhs_ml = fuse && s->grid->multilevel && s->grid->nranks == 1 && s->n_plain > 0 && !debug_option("no_fuse_lhs") && !debug_option("no_fuse_lhs_ml");
+  // A/B, test builds only ("fuse_lhs_ml"): on a multi-level mesh (one rank) the blocks none of whose six faces is a coarse/fine interface
+  // take the FLHS kernels too, and only the interface blocks keep k_lhs + ghost slabs + flux correction (launch_lhs on the interface
+  // list).  Bit-identical t and v -- and NOT faster: each loop kernel becomes two launches (plain list, interface list), which costs what
+  // the smaller k_lhs saves (1.574 -> 1.567 ms per iteration on the 39 369-block mesh of bench.py --amr, profiles/r04).  Measured, kept
+  // out of the production path.
+  const bool flhs_ml = fuse && s->grid->multilevel && s->grid->nranks == 1 && s->n_plain > 0 && !debug_option("no_fuse_lhs") && debug_option("fuse_lhs_ml");
   const bool split = s->grid->nranks > 1;
   auto launch_loop = [&](int which, const double *u, const LhsIn &L) -> int {  // one loop kernel; over ranks: inner blocks while u's face slabs travel, then the rest
     if (flhs && split) TRY(halo_begin(s, u, 1, 1));

@@ -75,6 +75,36 @@ if "hip" in r: print("   hip", r["hip"]["seconds_per_step"], r["hip"]["per_opera
 PY
   tail -3 $OUT/configs4.log | cut -c1-300
 fi
+if has amrab; then echo "== bench --amr A/B: every LHS a launch of its own (no_fuse_lhs_ml=1)"
+  timeout 900 python bench.py --amr --steps ${AMR_STEPS:-10} --warmup 3 --debug-option no_fuse_lhs_ml=1 > $OUT/bench_amr_no_fuse_lhs_ml.json 2> $OUT/bench_amr_ab.err ; echo "rc=$?" ; python - $OUT/bench_amr_no_fuse_lhs_ml.json <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+its = r["config"]["bicgstab_iters_per_step"]
+print("  value", r["value"], "ms/step", r["ms_per_step"], r["config"]["blocks"], its, "ms/iteration", round(r["ms_per_step"] / its, 4))
+for k in r["kernels"][:8]: print("   ", k["kernel"], k["launches"], k["avg_ms"], k["share"])
+PY
+  echo "== the same with the testing build and the option off"
+  timeout 900 python bench.py --amr --steps ${AMR_STEPS:-10} --warmup 3 --debug-option no_fuse_lhs_ml=0 > $OUT/bench_amr_fuse_lhs_ml.json 2>> $OUT/bench_amr_ab.err ; echo "rc=$?" ; python - $OUT/bench_amr_fuse_lhs_ml.json <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+its = r["config"]["bicgstab_iters_per_step"]
+print("  value", r["value"], "ms/step", r["ms_per_step"], r["config"]["blocks"], its, "ms/iteration", round(r["ms_per_step"] / its, 4))
+for k in r["kernels"][:8]: print("   ", k["kernel"], k["launches"], k["avg_ms"], k["share"])
+PY
+fi
+if has amrbig; then echo "== bench --amr, four levels, >= 300 k blocks"
+  timeout 1200 python bench.py --amr --amr-base ${AMRBIG_BASE:-4} --amr-levels 4 --amr-fraction ${AMRBIG_FRACTION:-0.45} --steps 5 --warmup 2 > $OUT/bench_amr_4level.json 2> $OUT/bench_amr_4level.err ; echo "rc=$?" ; python - $OUT/bench_amr_4level.json <<'PY'
+import json, sys
+try:
+    r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+except Exception as e:
+    print("  (no JSON)", e); sys.exit(0)
+its = r["config"]["bicgstab_iters_per_step"]
+print("  value", r["value"], "ms/step", r["ms_per_step"], r["config"]["blocks"], r["config"]["blocks_per_level"], its, "ms/iteration", round(r["ms_per_step"] / its, 4), "mesh build s", r["config"]["mesh_build_seconds"])
+for k in r["kernels"][:10]: print("   ", k["kernel"], k["launches"], k["avg_ms"], k["share"])
+PY
+  tail -3 $OUT/bench_amr_4level.err
+fi
 if has trace; then echo "== rocprofv3 kernel trace of the driver's bench"
   cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/trace -o fullstep -- python $OLDPWD/bench.py --steps ${TRACE_STEPS:-20} --warmup 5 --no-cpu --no-alt --no-pcie > $OLDPWD/$OUT/trace_bench.json 2> $OLDPWD/$OUT/trace.err ; echo "trace rc=$?"; cd $OLDPWD
   find $OUT/trace -name "*kernel_stats.csv" | head -2 | while read f; do head -12 "$f" | cut -c1-220; done

@@ -678,10 +678,10 @@ def test_implicit_time_loop(golden_dir):
 @pytest.mark.parametrize("mc", [0, 1, 2, 3])
 @pytest.mark.parametrize("bc", [("wall", "freespace", "wall"), ("periodic", "periodic", "wall")])
 def test_lhs_inside_the_loop_kernels_on_a_multilevel_mesh_is_bit_identical(bc, mc, block_solver):
-    """On a multi-level mesh (one rank) the blocks none of whose six faces is a coarse/fine interface form v = A zhat and t = A what inside
-    the fused loop kernels, like every block of a uniform grid; only the interface blocks keep k_lhs + ghost slabs + flux correction
-    (launch_lhs on the interface list).  Against the same solve with every LHS a launch of its own (`no_fuse_lhs_ml`): t and v are the
-    same bits -- same stencil association, same mean-constraint rows (9299-9326) on the same cells -- hence every iterate, the iteration
+    """The `fuse_lhs_ml` A/B (test builds; measured no faster, so production keeps one k_lhs launch per LHS on multi-level meshes): the
+    blocks none of whose six faces is a coarse/fine interface form v = A zhat and t = A what inside the fused loop kernels, like every block
+    of a uniform grid; only the interface blocks keep k_lhs + ghost slabs + flux correction (launch_lhs on the interface list).  Against
+    the production solve: t and v are the same bits -- same stencil association, same mean-constraint rows (9299-9326) on the same cells -- hence every iterate, the iteration
     count and the returned pressure.  512 level-2 blocks of which a few are refined: most blocks are plain, the corner block too."""
     bpd, lmax = (2, 2, 2), 4
     refine = [(0, i, j, k) for k in range(2) for j in range(2) for i in range(2)] + [(1, i, j, k) for k in range(4) for j in range(4) for i in range(4)]
@@ -691,7 +691,7 @@ def test_lhs_inside_the_loop_kernels_on_a_multilevel_mesh_is_bit_identical(bc, m
     rng = np.random.default_rng(17 + mc)
     res = {}
     for opt in (0, 1):
-        check(lib().cup3d_debug_set_option(b"no_fuse_lhs_ml", opt))
+        check(lib().cup3d_debug_set_option(b"fuse_lhs_ml", opt))
         try:
             sim = cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=0, extent=EXT, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2],
                                     leaves=(lv, zs), bMeanConstraint=mc, poissonTol=1e-9, poissonTolRel=1e-7, blockSolver=block_solver)
@@ -702,7 +702,7 @@ def test_lhs_inside_the_loop_kernels_on_a_multilevel_mesh_is_bit_identical(bc, m
             r = cu.makePoissonSolver(sim).solve()
             res[opt] = (r.iterations, r.restarts, r.norm, sim.download("pres"))
         finally:
-            check(lib().cup3d_debug_set_option(b"no_fuse_lhs_ml", 0))
+            check(lib().cup3d_debug_set_option(b"fuse_lhs_ml", 0))
     assert res[0][0] > 3
     assert res[0][:3] == res[1][:3], (res[0][:3], res[1][:3])
     assert np.array_equal(res[0][3], res[1][3])
