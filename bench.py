@@ -105,6 +105,51 @@ def exact_test_field_blocks(grid, size):
     return vel
 
 
+def _mt19937_64(seeds, ndraws):
+    """std::mt19937_64 (the C++ standard's 64-bit Mersenne twister), one engine per entry of `seeds`, vectorised over the engines:
+    uint64 [len(seeds)][ndraws].  (Its 10000th output for the default seed 5489 is 9981545732273789042, the standard's check value:
+    tests/test_bench_contract.py.)"""
+    u = np.uint64
+    with np.errstate(over="ignore"):
+        s = np.empty((len(seeds), 312), dtype=np.uint64)
+        s[:, 0] = seeds
+        for i in range(1, 312):
+            p = s[:, i - 1]
+            s[:, i] = u(6364136223846793005) * (p ^ (p >> u(62))) + u(i)
+        out = np.empty((len(seeds), 0), dtype=np.uint64)
+        UM, LM, A = u(0xFFFFFFFF80000000), u(0x7FFFFFFF), u(0xB5026F5AA96619E9)
+
+        def mix(hi, lo, m):
+            x = (hi & UM) | (lo & LM)
+            return m ^ (x >> u(1)) ^ np.where((x & u(1)) != 0, A, u(0))
+
+        while out.shape[1] < ndraws:
+            n = s.copy()
+            n[:, :156] = mix(s[:, :156], s[:, 1:157], s[:, 156:312])
+            n[:, 156:311] = mix(s[:, 156:311], s[:, 157:312], n[:, :155])
+            n[:, 311] = mix(s[:, 311], n[:, 0], n[:, 155])
+            s = n
+            x = s ^ ((s >> u(29)) & u(0x5555555555555555))
+            x = x ^ ((x << u(17)) & u(0x71D67FFFEDA60000))
+            x = x ^ ((x << u(37)) & u(0xFFF7EEE000000000))
+            out = np.concatenate([out, x ^ (x >> u(43))], axis=1)
+    return out[:, :ndraws]
+
+
+def random_velocity_blocks(grid, seed=12345, chunk=8192):
+    """SURVEY 8(d)'s solver-stress input: a seeded uniform[-1, 1) velocity, discretely divergence-full (every cell independent).  One
+    std::mt19937_64 per block, seeded with `seed + Z` (Z = the block's Hilbert index), 1536 draws in the block's memory order
+    [z][y][x][component] mapped like std::uniform_real_distribution<double>(-1, 1): -1 + 2 * (x / 2^64) -- so the field does not depend
+    on how the blocks are spread over ranks, and a C++ host can produce the same bits."""
+    Z = grid.tables[:, 1].astype(np.uint64)
+    vel = np.empty((grid.nblocks, 8, 8, 8, 3))
+    for b0 in range(0, grid.nblocks, chunk):
+        x = _mt19937_64(Z[b0:b0 + chunk] + np.uint64(seed), 1536)
+        r = np.minimum(x.astype(np.float64) * 2.0 ** -64, np.nextafter(1.0, 0.0))   # generate_canonical<double, 53> of a 64-bit engine
+        vel[b0:b0 + chunk] = (-1.0 + 2.0 * r).reshape(-1, 8, 8, 8, 3)
+    return vel
+
+
 def checksum_dt(size):
     return 0.3 * (2 * np.pi / size)
 
@@ -513,6 +558,57 @@ def run_amr(a):
     sys.stdout.flush()
 
 
+def run_micro(a, sim, prog):
+    """--micro: SURVEY 8(d)'s micro-benchmarks on the workload's grid, one rank: ComputeLHS (main.cpp:9273-9327), the block preconditioner
+    (getZImplParallel 14704-14745: the block CG and its direct evaluation) and the two fused vector updates (14453-14464 + 14502-14515 with
+    the LHS and the block solve inside, as the solver launches them: cup3d_poisson_path_checksum), each timed by hipEvents over `--steps`
+    repetitions on a random p (std::mt19937_64 seeded 1 + block index)."""
+    import cup3d_amd as cu
+    from cup3d_amd.capi import ProfileEntry, check, lib
+    Z = sim.grid.tables[:, 1].astype(np.uint64)
+    p = np.empty((sim.nblocks, 8, 8, 8))
+    for b0 in range(0, sim.nblocks, 16384):
+        x = _mt19937_64(Z[b0:b0 + 16384] + np.uint64(1), 512)
+        p[b0:b0 + 16384] = (-1.0 + 2.0 * np.minimum(x.astype(np.float64) * 2.0 ** -64, np.nextafter(1.0, 0.0))).reshape(-1, 8, 8, 8)
+    reps = max(3, a.steps)
+    sums = (C.c_ulonglong * 18)()
+    prog.set("timed", "micro-benchmarks")
+    lib().cup3d_profile_enable(1)
+    lib().cup3d_profile_reset()
+    for i in range(reps + 1):
+        if i == 1:
+            lib().cup3d_profile_reset()   # the first round warms up (allocations, constant tables)
+        sim.upload("pres", p)
+        check(lib().cup3d_compute_lhs(sim.handle, 1))
+        for bs in (0, 1):
+            sim.upload("pres", p)
+            check(lib().cup3d_preconditioner(sim.handle, bs))
+        for bs in (0, 1):
+            check(lib().cup3d_poisson_path_checksum(sim.handle, bs, 1, sums))
+    lib().cup3d_device_synchronize()
+    ents = (ProfileEntry * 64)()
+    n = C.c_int(0)
+    lib().cup3d_profile_read(ents, 64, C.byref(n))
+    lib().cup3d_profile_enable(0)
+    cells = sim.nblocks * 512.0
+    names = {"poisson_lhs": "one LHS apply (ComputeLHS, bMeanConstraint 1)", "poisson_block_cg": "one preconditioner apply (block CG)",
+             "poisson_block_fdm": "one preconditioner apply (direct block solve)", "bicgstab_loop1_cg": "fused vector update 1 (+ LHS + block CG)",
+             "bicgstab_loop2_cg": "fused vector update 2 (+ LHS + block CG)", "bicgstab_loop1_fdm": "fused vector update 1 (+ LHS + direct block solve)",
+             "bicgstab_loop2_fdm": "fused vector update 2 (+ LHS + direct block solve)"}
+    out = []
+    for i in range(n.value):
+        nm, ln, ms = ents[i].name.decode(), ents[i].launches, ents[i].total_ms
+        if nm in names and ln:
+            ach = ALGO_BYTES[nm] * cells / (ms / ln * 1e-3) / 1e9
+            out.append({"kernel": nm, "what": names[nm], "launches": ln, "avg_ms": round(ms / ln, 5), "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_cell": ALGO_BYTES[nm]})
+    print(json.dumps({"metric": "micro-benchmarks of the Poisson path (SURVEY 8d)", "n_gpus": 1, "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": f"{a.size}^3 uniform all-wall grid, random p (std::mt19937_64, 1 + block index)", "blocks": int(sim.nblocks), "repetitions": reps,
+                                 "note": "the random field makes the block CG run its full course (more CG iterations than on solver inputs)"},
+                      "kernels": sorted(out, key=lambda k: k["kernel"])}))
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -535,6 +631,12 @@ def main():
     ap.add_argument("--stall-timeout", type=float, default=300.0, help="limit for ONE stage step without progress (a hung rendezvous / collective), seconds")
     ap.add_argument("--watchdog", action="store_true", help="run the per-rank watchdog on one rank too (it always runs when N > 1)")
     ap.add_argument("--fail-at", default=None, help="TEST: 'stage:rank:how' with how = hang | exit | raise -- that rank misbehaves when it enters the stage")
+    ap.add_argument("--input", choices=["taylor_green", "random"], default="taylor_green",
+                    help="initial velocity.  taylor_green: the BASELINE workload.  random: SURVEY 8(d)'s solver-stress input, a seeded "
+                         "(std::mt19937_64, 12345 + block index) uniform[-1,1) divergence-full field -- reported beside the headline, never as it")
+    ap.add_argument("--micro", action="store_true",
+                    help="SURVEY 8(d)'s micro-benchmarks instead of the step: one LHS apply, one preconditioner apply (block CG, direct), the two "
+                         "fused vector updates, on a random p (seed 1 + block index) of the workload's grid; one JSON line")
     ap.add_argument("--no-checksum", action="store_true", help="skip config.checksum (one extra AdvectionDiffusion on two fields before the timed region)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host<->device transfer measurement behind `pcie_inclusive`")
     ap.add_argument("--debug-option", action="append", help="name=value for cup3d_debug_set_option (tuning scans)")
@@ -649,11 +751,14 @@ def run(a, prog):
                             BC_x=bc, BC_y=bc, BC_z=bc, uMax_forced=1.0, rampup=0, rank=rank, nranks=world, blockSolver=a.block_solver,
                             implicitDiffusion=a.implicit_diffusion)
     a.checksum = None
-    if not a.stencil_only and not a.implicit_diffusion and not a.no_checksum:
+    if not a.stencil_only and not a.implicit_diffusion and not a.no_checksum and not a.micro:
         stage("checksum", "first exchanges over the transport: advect-diffuse, LHS, one fused iteration")
         a.checksum = advdiff_checksums(sim, a, dist, world, prog)  # the run's correctness signal at every N (before anything is timed)
         sim.dt = 0.0
-    sim.upload("vel", taylor_green_blocks(sim.grid, [ext] * 3, 1.0))
+    if a.micro:
+        return run_micro(a, sim, prog)
+    initial = (lambda: random_velocity_blocks(sim.grid)) if a.input == "random" else (lambda: taylor_green_blocks(sim.grid, [ext] * 3, 1.0))
+    sim.upload("vel", initial())
     sim.step = 21
     S = cu.Simulation(sim)
     adv = S.pipeline[0]  # AdvectionDiffusion, or AdvectionDiffusionImplicit with --implicit-diffusion
@@ -773,7 +878,7 @@ def run(a, prog):
         for solver in ([1, 5, 2] if a.block_solver == 0 else [1 - a.block_solver] if a.block_solver in (0, 1) else []):
             nsteps = a.steps if solver != 2 else min(a.steps, 5)   # the reference-association block CG: five steps say what it costs
             sim.blockSolver = solver
-            sim.upload("vel", taylor_green_blocks(sim.grid, [ext] * 3, 1.0))
+            sim.upload("vel", initial())
             sim.fill("pres", 0.0)
             sim.step, sim.dt = 21, 0.0
             lib().cup3d_profile_enable(0)
@@ -901,7 +1006,9 @@ def report(a, sim, prof, sec, iters, world, alt=None):
         # the stable figure of this workload: `value` moves with the (erratic, rounding-dependent) iteration count of the solver, the
         # time of ONE BiCGSTAB iteration does not -- whole timed region / iterations, so advect-diffuse and the projection's passes are inside
         "ms_per_bicgstab_iteration": round(sec * 1e3 / max(1, sum(iters)), 4) if iters else None,
-        "config": {"workload": (f"taylor-green {a.size}^3 uniform, all-wall box (reference has no lid BC), nu=0.01, CFL=0.3, rampup=0, "
+        "config": {"workload": ((f"taylor-green {a.size}^3 uniform" if getattr(a, "input", "taylor_green") == "taylor_green" else
+                                 f"SOLVER-STRESS INPUT (not the headline): seeded random velocity (std::mt19937_64, 12345 + block index, uniform[-1,1)), {a.size}^3 uniform") +
+                                f", all-wall box (reference has no lid BC), nu=0.01, CFL=0.3, rampup=0, "
                                 f"poissonTol 1e-6/1e-4, bMeanConstraint 1, steps from 21") if not a.stencil_only
                    else f"taylor-green {a.size}^3 uniform periodic, advect-diffuse RK3 only",
                    "cells": int(cells), "blocks": int(cells // 512), "block": "8^3", "partition": f"hilbert-range x{world}",

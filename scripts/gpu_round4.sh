@@ -105,6 +105,36 @@ for k in r["kernels"][:10]: print("   ", k["kernel"], k["launches"], k["avg_ms"]
 PY
   tail -3 $OUT/bench_amr_4level.err
 fi
+if has micro; then echo "== SURVEY 8(d) micro-benchmarks at 512^3 (release build)"
+  timeout 600 python bench.py --micro --steps 5 --no-cpu > $OUT/bench_512_micro.json 2> $OUT/bench_512_micro.err ; echo "rc=$?"
+  python - $OUT/bench_512_micro.json <<'PY'
+import json, sys
+try:
+    r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    for k in r["kernels"]: print("   ", k["kernel"], k["launches"], k["avg_ms"], k["frac"], "|", k["what"])
+except Exception as e:
+    print("  (no JSON)", e)
+PY
+  tail -2 $OUT/bench_512_micro.err; fi
+if has stress; then echo "== SURVEY 8(d) solver-stress input (seeded random velocity) at 512^3"
+  timeout 900 python bench.py --input random --steps 5 --warmup 2 --no-cpu --no-pcie > $OUT/bench_512_random_input.json 2> $OUT/bench_512_random_input.err ; echo "rc=$?" ; summ $OUT/bench_512_random_input.json ; tail -2 $OUT/bench_512_random_input.err; fi
+if has pmc; then echo "== rocprofv3 PMC passes over the micro-benchmarks at 512^3: FETCH_SIZE, WRITE_SIZE in separate runs"
+  ROOT=$(pwd); rm -f $OUT/pmc_poisson_kernels_512cubed.txt
+  for CN in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && timeout 900 rocprofv3 --pmc $CN --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_$CN -o p -- python $ROOT/bench.py --micro --steps 3 --no-cpu > $ROOT/$OUT/pmc_$CN.log 2>&1 )
+    for f in $(find $OUT/pmc_$CN -name "*counter_collection.csv" | head -1); do python - "$f" $CN <<'PY' | tee -a $OUT/pmc_poisson_kernels_512cubed.txt
+import csv, sys, collections
+f, c = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if r.get("Counter_Name") == c:
+        acc[r["Kernel_Name"][:70]].append(float(r["Counter_Value"]))
+for k, v in sorted(acc.items()):
+    if any(t in k for t in ("k_loop", "k_lhs", "k_precond")): print(c, k, "launches", len(v), "mean_KB", round(sum(v) / len(v), 1))
+PY
+    done
+    rm -rf $OUT/pmc_$CN
+  done; fi
 if has trace; then echo "== rocprofv3 kernel trace of the driver's bench"
   cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/trace -o fullstep -- python $OLDPWD/bench.py --steps ${TRACE_STEPS:-20} --warmup 5 --no-cpu --no-alt --no-pcie > $OLDPWD/$OUT/trace_bench.json 2> $OLDPWD/$OUT/trace.err ; echo "trace rc=$?"; cd $OLDPWD
   find $OUT/trace -name "*kernel_stats.csv" | head -2 | while read f; do head -12 "$f" | cut -c1-220; done

@@ -125,6 +125,26 @@ def test_multi_rank_run_that_cannot_start_prints_one_error_line():
     assert "rror" in r["error"] or "device" in r["error"].lower(), r["error"]
 
 
+def test_solver_stress_input_is_the_standard_generator_and_partition_independent():
+    """bench.py --input random (SURVEY 8d's second input): std::mt19937_64 restated in numpy gives the C++ standard's check value (the
+    10000th output of the default-seeded engine), and the field -- one engine per block, seeded 12345 + Hilbert index -- is the same
+    bits whether one rank builds it or three."""
+    import numpy as np
+    import cup3d_amd as cu
+    x = bench._mt19937_64(np.array([5489, 5489 + 1], dtype=np.uint64), 10000)
+    assert int(x[0, 9999]) == 9981545732273789042 and int(x[1, 9999]) != int(x[0, 9999])
+    ext, bc = 2 * np.pi, ("wall",) * 3
+    whole = cu.Grid((1, 1, 1), 3, 2, ext, bc)
+    v = bench.random_velocity_blocks(whole)
+    assert v.shape == (64, 8, 8, 8, 3) and -1.0 <= v.min() < -0.99 and 0.99 < v.max() < 1.0 and abs(v.mean()) < 0.01
+    by_z = {int(z): v[i] for i, z in enumerate(whole.tables[:, 1])}
+    for r in range(3):
+        part = cu.Grid((1, 1, 1), 3, 2, ext, bc, rank=r, nranks=3)
+        vr = bench.random_velocity_blocks(part)
+        for i, z in enumerate(part.tables[:, 1]):
+            assert np.array_equal(vr[i], by_z[int(z)])
+
+
 def test_checksum_fixture_is_what_the_oracle_produces():
     """tests/golden/advdiff_checksums.json (the constants bench.py compares the device with at every N) regenerated for the small sizes."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
