@@ -42,6 +42,18 @@ def test_fused_solver_kernels(release):
     assert LDS_PER_CU // l1["lds_bytes"] >= 4 * 4
 
 
+def test_fused_solver_kernels_with_the_direct_block_solve(release):
+    """k_loop1_fdm / k_loop2_fdm <FLHS = true> (`alt`, block_solver 1): the same kernels with the fast diagonalisation behind the loops.  They
+    are the HBM-bound form of the iteration (0.76 / 0.79 of the roof, profiles/r04), which only holds while nothing spills: the second one
+    is held to 128 registers (amdgpu_waves_per_eu(4, 8); the compiler would take 136 -> 3 wavefronts per SIMD)."""
+    for name in ("k_loop1_fdm<b1>", "k_loop2_fdm<b1>"):
+        k = release[name]
+        assert k["scratch_bytes"] == 0 and k["vgpr_spills"] == 0 and k["waves_per_simd"] == 4 and k["lds_bytes"] == 10 * 96 * 8 and k["vgpr"] <= 128, k
+    for name in ("k_loop1_fdm<b0>", "k_loop2_fdm<b0>"):   # multi-level meshes: no tile, the transposes' 4.5 KB only
+        k = release[name]
+        assert k["scratch_bytes"] == 0 and k["waves_per_simd"] >= 4 and k["lds_bytes"] == 64 * 9 * 8, k
+
+
 def test_fused_solver_kernels_without_the_lhs(release):
     """<FMA, 0, FLHS = false>: multi-level meshes (the LHS needs coarse/fine ghosts there) -- 5 wavefronts per SIMD; the second kernel is HELD
     to 96 registers at the price of two spills outside the CG loop (measured faster than 122 registers at 4 wavefronts, profiles/README.md)"""
