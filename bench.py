@@ -323,7 +323,7 @@ class Progress:
         self.path = os.path.join(self.dir, f"rank{rank}.json")
         self.t0 = self.last = time.time()
         self.stage, self.detail, self.limit = "start", "", a.stall_timeout
-        self.done = False
+        self.done = self.failing = False
         self.lock = threading.Lock()
         self.rd, self.wr = os.pipe()
         os.set_blocking(self.wr, False)
@@ -351,6 +351,11 @@ class Progress:
 
     def fail(self, error, code=4):
         """Called by the watchdog thread or by main()'s exception handler: rank 0 prints the line; everybody leaves."""
+        with self.lock:
+            second, self.failing = self.failing, True
+        if second:                    # the other thread is already on its way out with its own diagnosis: one line, not two
+            time.sleep(30)
+            os._exit(code)
         self.set(self.stage, f"FAILED: {error}", 1e9)
         if self.rank == 0:
             time.sleep(0.5)   # the other ranks' last words
