@@ -135,6 +135,9 @@ PY
     done
     rm -rf $OUT/pmc_$CN
   done; fi
+if has configs4mpi; then echo "== configs[4] at its stated size on 8 real MPI ranks through the shim (host-memory transport, one GPU)"
+  CUP3D_CONFIGS4_LEVELMAX=7 timeout 2400 python -m pytest "tests/test_gpu_00_dropin_mpi.py" -m gpu -q -s -k configs4 > $OUT/pytest_configs4_levelmax7_8ranks.log 2>&1 ; echo "pytest rc=$?"
+  grep -E "configs4|passed|failed|skipped|HUNG|Timeout" $OUT/pytest_configs4_levelmax7_8ranks.log | tail -8 | cut -c1-600; fi
 if has trace; then echo "== rocprofv3 kernel trace of the driver's bench"
   cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/trace -o fullstep -- python $OLDPWD/bench.py --steps ${TRACE_STEPS:-20} --warmup 5 --no-cpu --no-alt --no-pcie > $OLDPWD/$OUT/trace_bench.json 2> $OLDPWD/$OUT/trace.err ; echo "trace rc=$?"; cd $OLDPWD
   find $OUT/trace -name "*kernel_stats.csv" | head -2 | while read f; do head -12 "$f" | cut -c1-220; done
