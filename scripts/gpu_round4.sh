@@ -138,6 +138,10 @@ PY
 if has configs4mpi; then echo "== configs[4] at its stated size on 8 real MPI ranks through the shim (host-memory transport, one GPU)"
   CUP3D_CONFIGS4_LEVELMAX=7 timeout 2400 python -m pytest "tests/test_gpu_00_dropin_mpi.py" -m gpu -q -s -k configs4 > $OUT/pytest_configs4_levelmax7_8ranks.log 2>&1 ; echo "pytest rc=$?"
   grep -E "configs4|passed|failed|skipped|HUNG|Timeout" $OUT/pytest_configs4_levelmax7_8ranks.log | tail -8 | cut -c1-600; fi
+if has ref256; then echo "== device vs the COMPILED REFERENCE at 256^3 periodic, three steps, default and tight tolerances"
+  timeout 1500 python scripts/campaigns/baseline_sizes_vs_reference.py --size 256 --bc periodic --steps 3 --tight --threads ${REF_THREADS:-32} --out $OUT/reference_steps_256_periodic.json > $OUT/campaign256.log 2>&1 ; echo "rc=$?"; tail -c 1500 $OUT/campaign256.log; fi
+if has ref512; then echo "== device vs the COMPILED REFERENCE at 512^3 all-wall, one step (minutes of host time)"
+  timeout 2400 python scripts/campaigns/baseline_sizes_vs_reference.py --size 512 --bc wall --threads ${REF_THREADS:-32} --out $OUT/reference_step_512.json > $OUT/campaign512.log 2>&1 ; echo "rc=$?"; tail -c 1500 $OUT/campaign512.log; fi
 if has trace; then echo "== rocprofv3 kernel trace of the driver's bench"
   cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/trace -o fullstep -- python $OLDPWD/bench.py --steps ${TRACE_STEPS:-20} --warmup 5 --no-cpu --no-alt --no-pcie > $OLDPWD/$OUT/trace_bench.json 2> $OLDPWD/$OUT/trace.err ; echo "trace rc=$?"; cd $OLDPWD
   find $OUT/trace -name "*kernel_stats.csv" | head -2 | while read f; do head -12 "$f" | cut -c1-220; done
