@@ -96,6 +96,102 @@ __global__ void __launch_bounds__(256) k_mg_smooth(GridDev g, const double *__re
   xout[(size_t)slot * 512 + 256 + cell0] = tile[i1];
 }
 
+// The same smoother by ONE WAVEFRONT per block, the form BASELINE.json's north_star names ("wavefront shuffles for the red-black
+// Gauss-Seidel smoother").  Lane l owns the z-column of cell (x = l & 7, y = l >> 3) in registers, split by colour: with p = (x + y) & 1,
+// R[k] is the cell at z = 2k + p ((x + y + z) even: red) and B[k] the one at z = 2k + 1 - p.  A red cell's x / y neighbours are the
+// BLACK cells of the adjacent lanes at the same z -- and since those lanes have the other parity, that is their B[k] for the very same
+// k: one wavefront shuffle (ds_bpermute: the LDS crossbar, no LDS memory) per neighbour, no index arithmetic.  Its z neighbours are the
+// lane's own B registers.  No LDS tile, no barrier: the four wavefronts of the workgroup form met at 2 x sweeps barriers per launch.
+// Ghost values (neighbour blocks' face cells, the zero-gradient domain face, coarse/fine or other ranks' slabs) live in registers of
+// the lanes on the block's faces and stay frozen during the launch, as in k_mg_smooth.  Same expression, same association: BIT-IDENTICAL
+// iterates (tests/test_gpu_parity.py::test_multigrid_smoother_forms_agree).
+__device__ __forceinline__ double shfl_f64(double v, int src_lane) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)b), hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b >> 32));
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <bool ZERO>
+__global__ void __launch_bounds__(64) k_mg_smooth_wave(GridDev g, const double *__restrict__ xin, const double *__restrict__ halo, const double *__restrict__ b,
+                                                       double *__restrict__ xout, int sweeps) {
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  const int l = threadIdx.x, x = l & 7, y = l >> 3;
+  const bool p = ((x + y) & 1) != 0;
+  const size_t bo = (size_t)slot * 512;
+  const double invh = 1.0 / g.h;
+  double R[4], B[4], rR[4], rB[4];       // iterate and right-hand side / h, by colour
+  double gxR[4], gxB[4], gyR[4], gyB[4];  // lateral ghosts of the face lanes at the z of R[k] / B[k]
+  double gzm = 0.0, gzp = 0.0;            // ghosts below z = 0 and above z = 7
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double b0 = invh * b[bo + (2 * k) * 64 + l], b1 = invh * b[bo + (2 * k + 1) * 64 + l];
+    rR[k] = p ? b1 : b0;
+    rB[k] = p ? b0 : b1;
+    R[k] = B[k] = gxR[k] = gxB[k] = gyR[k] = gyB[k] = 0.0;
+  }
+  if constexpr (!ZERO) {
+    const double *own = xin + bo;
+    double v[8];
+#pragma unroll
+    for (int z = 0; z < 8; ++z) v[z] = own[z * 64 + l];
+    // ghosts: the lanes on a face fetch their column of the neighbour's face layer (strided for the x and y faces: 8 lanes x 8 loads)
+    const int fx = x == 0 ? 0 : 1, fy = y == 0 ? 2 : 3;
+    const bool onx = x == 0 || x == 7, ony = y == 0 || y == 7;
+    const int nx = onx ? g.nbr[slot * 6 + fx] : -1, ny = ony ? g.nbr[slot * 6 + fy] : -1, nzm = g.nbr[slot * 6 + 4], nzp = g.nbr[slot * 6 + 5];
+    // every ghost is ONE load from a selected global address -- the neighbour's face cell, the slab element, or (zero-gradient domain
+    // face) the own face cell once more -- never "a register or a load": the compiler turns that into a select of addresses with the
+    // register parked in scratch
+    double gx[8], gy[8];
+    const double *px = nx >= kNbrHalo ? halo + (size_t)(nx - kNbrHalo) * 64 + y           // slab order: face1(), (a1, a2) = (y, z): + z * 8
+                                      : (nx >= 0 ? xin + (size_t)nx * 512 + y * 8 + (x == 0 ? 7 : 0) : own + l);
+    const double *py = ny >= kNbrHalo ? halo + (size_t)(ny - kNbrHalo) * 64 + x           // (a1, a2) = (x, z)
+                                      : (ny >= 0 ? xin + (size_t)ny * 512 + (y == 0 ? 7 : 0) * 8 + x : own + l);
+    const int sx = nx >= kNbrHalo ? 8 : 64, sy = ny >= kNbrHalo ? 8 : 64;
+#pragma unroll
+    for (int z = 0; z < 8; ++z) {
+      gx[z] = px[z * sx];
+      gy[z] = py[z * sy];
+    }
+    gzm = *(nzm >= kNbrHalo ? halo + (size_t)(nzm - kNbrHalo) * 64 + l : (nzm >= 0 ? xin + (size_t)nzm * 512 + 7 * 64 + l : own + l));  // (a1, a2) = (x, y)
+    gzp = *(nzp >= kNbrHalo ? halo + (size_t)(nzp - kNbrHalo) * 64 + l : (nzp >= 0 ? xin + (size_t)nzp * 512 + l : own + 7 * 64 + l));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      R[k] = p ? v[2 * k + 1] : v[2 * k];
+      B[k] = p ? v[2 * k] : v[2 * k + 1];
+      gxR[k] = p ? gx[2 * k + 1] : gx[2 * k];
+      gxB[k] = p ? gx[2 * k] : gx[2 * k + 1];
+      gyR[k] = p ? gy[2 * k + 1] : gy[2 * k];
+      gyB[k] = p ? gy[2 * k] : gy[2 * k + 1];
+    }
+  }
+  const int lxm = l - 1, lxp = l + 1, lym = l - 8, lyp = l + 8;  // (the face lanes' out-of-block sources are replaced by their ghosts)
+  for (int s = 0; s < sweeps; ++s) {
+    // red: R[k] at z = 2k + p; lateral neighbours = the adjacent lanes' B[k]; z neighbours = own B[k - 1 + p], B[k + p]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double sxm = shfl_f64(B[k], lxm), sxp = shfl_f64(B[k], lxp), sym = shfl_f64(B[k], lym), syp = shfl_f64(B[k], lyp);
+      const double xm = x == 0 ? gxR[k] : sxm, xp = x == 7 ? gxR[k] : sxp, ym = y == 0 ? gyR[k] : sym, yp = y == 7 ? gyR[k] : syp;
+      const double below = k > 0 ? B[k > 0 ? k - 1 : 0] : gzm, above = k < 3 ? B[k < 3 ? k + 1 : 3] : gzp;
+      const double zm = p ? B[k] : below, zp = p ? above : B[k];
+      R[k] = (1.0 / 6.0) * ((xm + xp) + (ym + yp) + (zm + zp) - rR[k]);
+    }
+    // black: B[k] at z = 2k + 1 - p; lateral neighbours = the adjacent lanes' R[k]; z neighbours = own R[k - p], R[k + 1 - p]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double sxm = shfl_f64(R[k], lxm), sxp = shfl_f64(R[k], lxp), sym = shfl_f64(R[k], lym), syp = shfl_f64(R[k], lyp);
+      const double xm = x == 0 ? gxB[k] : sxm, xp = x == 7 ? gxB[k] : sxp, ym = y == 0 ? gyB[k] : sym, yp = y == 7 ? gyB[k] : syp;
+      const double below = k > 0 ? R[k > 0 ? k - 1 : 0] : gzm, above = k < 3 ? R[k < 3 ? k + 1 : 3] : gzp;
+      const double zm = p ? below : R[k], zp = p ? R[k] : above;
+      B[k] = (1.0 / 6.0) * ((xm + xp) + (ym + yp) + (zm + zp) - rB[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    xout[bo + (2 * k) * 64 + l] = p ? B[k] : R[k];
+    xout[bo + (2 * k + 1) * 64 + l] = p ? R[k] : B[k];
+  }
+}
+
 // coarse b (parent block, this block's octant) <- sum over 2x2x2 of the fine residual b - A x
 __global__ void __launch_bounds__(256) k_mg_residual_restrict(GridDev g, const double *__restrict__ x, const double *__restrict__ halo, const double *__restrict__ b,
                                                               const int32_t *__restrict__ parent, double *__restrict__ bc) {
@@ -366,13 +462,16 @@ void mg_destroy(Sim *s) {
 static int mg_smooth(const MGLevel &M, const double *zeros, double **xa, double **xb, const double *rhs, int launches, int sweeps, bool from_zero) {
   const GridDev g = level_gdev(M);
   const dim3 G(launch_groups(g)), B(256);
+  const bool wave = !debug_option("mg_smooth_workgroup");  // production: one wavefront per block, shuffles (k_mg_smooth_wave); A/B: the LDS-tile form
   for (int i = 0; i < launches; ++i) {
     const bool zero = from_zero && i == 0;
     if (M.xch && !zero) { int rc = halo_exchange(M.xch, *xa, 1, 1); if (rc) return rc; }
     const double *halo = M.xch ? (const double *)M.xch->halo_recv : (zeros ? zeros : (const double *)*xa);
     if (!halo) halo = *xa;  // a rank without remote faces
     ProfileScope ps("mg_smooth");
-    if (zero) hipLaunchKernelGGL(k_mg_smooth<true>, G, B, 0, stream(), g, (const double *)nullptr, halo, rhs, *xb, sweeps);
+    if (wave && zero) hipLaunchKernelGGL(k_mg_smooth_wave<true>, G, dim3(64), 0, stream(), g, (const double *)nullptr, halo, rhs, *xb, sweeps);
+    else if (wave) hipLaunchKernelGGL(k_mg_smooth_wave<false>, G, dim3(64), 0, stream(), g, (const double *)*xa, halo, rhs, *xb, sweeps);
+    else if (zero) hipLaunchKernelGGL(k_mg_smooth<true>, G, B, 0, stream(), g, (const double *)nullptr, halo, rhs, *xb, sweeps);
     else hipLaunchKernelGGL(k_mg_smooth<false>, G, B, 0, stream(), g, (const double *)*xa, halo, rhs, *xb, sweeps);
     double *t = *xa;
     *xa = *xb;

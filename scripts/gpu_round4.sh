@@ -142,6 +142,16 @@ if has ref256; then echo "== device vs the COMPILED REFERENCE at 256^3 periodic,
   timeout 1500 python scripts/campaigns/baseline_sizes_vs_reference.py --size 256 --bc periodic --steps 3 --tight --threads ${REF_THREADS:-32} --out $OUT/reference_steps_256_periodic.json > $OUT/campaign256.log 2>&1 ; echo "rc=$?"; tail -c 1500 $OUT/campaign256.log; fi
 if has ref512; then echo "== device vs the COMPILED REFERENCE at 512^3 all-wall, one step (minutes of host time)"
   timeout 2400 python scripts/campaigns/baseline_sizes_vs_reference.py --size 512 --bc wall --threads ${REF_THREADS:-32} --out $OUT/reference_step_512.json > $OUT/campaign512.log 2>&1 ; echo "rc=$?"; tail -c 1500 $OUT/campaign512.log; fi
+if has mgab; then echo "== multigrid option at 512^3: smoother by one wavefront per block (production) vs workgroup per block (A/B), testing build"
+  for V in 0 1; do
+    timeout 600 python bench.py --block-solver 5 --steps 5 --warmup 2 --no-cpu --no-pcie --no-alt --debug-option mg_smooth_workgroup=$V > $OUT/bench_512_multigrid_smoother_$V.json 2> $OUT/bench_512_multigrid_smoother_$V.err ; echo "rc=$? (mg_smooth_workgroup=$V)"
+    python - $OUT/bench_512_multigrid_smoother_$V.json <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("  value", r["value"], "ms/step", r["ms_per_step"], "its/step", r["config"]["bicgstab_iters_per_step"])
+for k in r["kernels"][:6]: print("   ", k["kernel"], k["launches"], k["avg_ms"], k["share"])
+PY
+  done; fi
 if has trace; then echo "== rocprofv3 kernel trace of the driver's bench"
   cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/trace -o fullstep -- python $OLDPWD/bench.py --steps ${TRACE_STEPS:-20} --warmup 5 --no-cpu --no-alt --no-pcie > $OLDPWD/$OUT/trace_bench.json 2> $OLDPWD/$OUT/trace.err ; echo "trace rc=$?"; cd $OLDPWD
   find $OUT/trace -name "*kernel_stats.csv" | head -2 | while read f; do head -12 "$f" | cut -c1-220; done

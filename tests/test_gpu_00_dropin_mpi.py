@@ -156,7 +156,7 @@ def test_fish_with_amr_over_mpi_ranks_through_the_shim(tmp_path, name, nranks, l
         nblocks += len(c[1])
         vmax, pmax, wet = max(vmax, np.abs(c[2]).max()), max(pmax, np.abs(c[3]).max()), wet + int((c[4] > 0).sum())
     assert len(levels) >= min_levels and nblocks > 100 * nranks // 2      # the mesh the config names, spread over the ranks
-    assert wet > 100 and vmax > 1e-3                                      # there IS a fish, and it moves the fluid
+    assert wet > 100 and vmax > (1e-3 if level_max <= 5 else 1e-4)        # there IS a fish, and it moves the fluid (finer mesh, smaller dt: less after 8 steps)
     # the one-rank run holds the same leaves (the mesh does not depend on the number of ranks): match blocks by (level, Z)
     where = {(int(l), int(z)): i for i, (l, z) in enumerate(one[0][1][:, :2])}
     noise_v = noise_p = 0.0

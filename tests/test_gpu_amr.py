@@ -706,3 +706,21 @@ def test_lhs_inside_the_loop_kernels_on_a_multilevel_mesh_is_bit_identical(bc, m
     assert res[0][0] > 3
     assert res[0][:3] == res[1][:3], (res[0][:3], res[1][:3])
     assert np.array_equal(res[0][3], res[1][3])
+
+
+@pytest.mark.parametrize("name", MESHES)
+def test_multigrid_smoother_forms_agree_on_multilevel_meshes(golden_dir, name):
+    """The wavefront-per-block smoother (k_mg_smooth_wave: shuffles, no LDS tile) against the workgroup-per-block form on the octree's
+    levels -- coarse/fine ghost slabs behind interface faces included: same bits, same iteration count."""
+    res = {}
+    for opt in (0, 1):
+        check(lib().cup3d_debug_set_option(b"mg_smooth_workgroup", opt))
+        try:
+            m, sim, f = make(golden_dir, name, blockSolver=5, poissonTol=1e-10, poissonTolRel=1e-9)
+            sim.upload("lhs", f["rhs"]); sim.upload("pres", f["pres"])
+            r = cu.makePoissonSolver(sim).solve()
+            res[opt] = (r.iterations, r.norm, sim.download("pres"))
+        finally:
+            check(lib().cup3d_debug_set_option(b"mg_smooth_workgroup", 0))
+    assert res[0][0] >= 2 and res[0][:2] == res[1][:2], (res[0][:2], res[1][:2])
+    assert np.array_equal(res[0][2], res[1][2])

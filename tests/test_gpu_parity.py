@@ -965,3 +965,32 @@ def test_direct_block_solve_inside_the_loop_kernels(bpd, lmax, level, bc):
     assert i0 > 3 and abs(i0 - i1) <= max(3, 0.15 * i1), (i0, i1)
     p0, p1 = p0 - p0.mean(), p1 - p1.mean()
     assert np.abs(p0 - p1).max() <= 1e-7 * np.abs(p1).max()
+
+
+@pytest.mark.parametrize("bpd,lmax,level,bc", [((1, 1, 1), 4, 3, ("wall", "wall", "wall")), ((2, 1, 3), 3, 2, ("periodic", "freespace", "wall")),
+                                               ((1, 1, 2), 1, 0, ("periodic", "periodic", "periodic"))])
+def test_multigrid_smoother_forms_agree(bpd, lmax, level, bc):
+    """The red-black Gauss-Seidel smoother of the multigrid option by ONE WAVEFRONT per block -- the z-column of a cell in the lane's
+    registers split by colour, x / y neighbours by wavefront shuffles, no LDS tile, no barrier (k_mg_smooth_wave; BASELINE.json's
+    north_star names this form) -- against the workgroup-per-block LDS-tile form it replaces (`mg_smooth_workgroup`): the same expression
+    in the same association on the same frozen ghosts, so every V-cycle, every BiCGSTAB iterate, the iteration count and the returned
+    pressure are the same BITS."""
+    rng = np.random.default_rng(5)
+    res = {}
+    for opt in (0, 1):
+        cu.capi.check(cu.lib().cup3d_debug_set_option(b"mg_smooth_workgroup", opt))
+        try:
+            sim = cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=level, extent=2 * np.pi,
+                                    BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], poissonTol=1e-9, poissonTolRel=1e-8, blockSolver=5)
+            if opt == 0:
+                rhs = rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8))
+                rhs -= rhs.mean()
+            sim.upload("lhs", rhs)
+            sim.fill("pres", 0.0)
+            r = cu.makePoissonSolver(sim).solve()
+            res[opt] = (r.iterations, r.restarts, r.norm, sim.download("pres"))
+        finally:
+            cu.capi.check(cu.lib().cup3d_debug_set_option(b"mg_smooth_workgroup", 0))
+    assert res[0][0] >= 2
+    assert res[0][:3] == res[1][:3], (res[0][:3], res[1][:3])
+    assert np.array_equal(res[0][3], res[1][3])
