@@ -761,6 +761,8 @@ def run(a, prog):
         a.checksum = advdiff_checksums(sim, a, dist, world, prog)  # the run's correctness signal at every N (before anything is timed)
         sim.dt = 0.0
     if a.micro:
+        if world > 1:
+            sys.exit("bench.py --micro runs on one rank")
         return run_micro(a, sim, prog)
     initial = (lambda: random_velocity_blocks(sim.grid)) if a.input == "random" else (lambda: taylor_green_blocks(sim.grid, [ext] * 3, 1.0))
     sim.upload("vel", initial())

@@ -162,6 +162,9 @@ def test_checksum_fixture_is_what_the_oracle_produces():
         for key, vel in (("exact_field", bench.exact_test_field_blocks(G, size)), ("taylor_green", bench.taylor_green_blocks(G, [ext] * 3, 1.0))):
             g.advect_diffuse(vel, np.zeros_like(vel), bench.checksum_dt(size), 0.01, (0.0, 0.0, 0.0))
             assert int(vel.view(np.uint64).sum(dtype=np.uint64)) == gold[str(size)][key], (size, key)
+        pres = np.ascontiguousarray(bench.exact_test_field_blocks(G, size)[..., 0])        # the Poisson path's oracle-side constant: A p
+        assert int(g.lhs(pres, 0).view(np.uint64).sum(dtype=np.uint64)) == gold[str(size)]["lhs_exact_field"], size
+        assert {"precond_exact_field", "fused_iteration"} <= set(gold[str(size)])             # the device-side ones: recorded on one GPU
 
 
 def _checksum_worker(rank, world, port, size, q):
@@ -174,10 +177,13 @@ def _checksum_worker(rank, world, port, size, q):
     try:
         level = (size // 8).bit_length() - 1
         G = cu.Grid((1, 1, 1), level + 1, level, 2 * np.pi, ("wall",) * 3, rank, world)   # this rank's Hilbert range (main.cpp:2970-2986)
-        mine = int(bench.exact_test_field_blocks(G, size).view(np.uint64).sum(dtype=np.uint64))
-        parts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]                  # bench.advdiff_checksums' gather, gloo for RCCL
-        dist.all_gather(parts, torch.tensor([mine - (1 << 64) if mine >= (1 << 63) else mine], dtype=torch.int64))
-        q.put((rank, sum(int(p.item()) for p in parts) % (1 << 64), int(G.nblocks)))
+        f = bench.exact_test_field_blocks(G, size)
+        mine = int(f.view(np.uint64).sum(dtype=np.uint64))
+        # bench.py's own gather (gloo, CPU tensors -- what every N > 1 run of the bench uses): one value, and a list of values at once
+        a = argparse.Namespace(tdev="cpu")
+        one = bench.gather_sum(mine, a, dist, world)
+        per_comp = bench.gather_sum([int(np.ascontiguousarray(f[..., c]).view(np.uint64).sum(dtype=np.uint64)) for c in range(3)], a, dist, world)
+        q.put((rank, one, int(G.nblocks), per_comp))
     finally:
         dist.destroy_process_group()
 
@@ -191,7 +197,10 @@ def test_checksum_is_independent_of_the_partition_over_gloo():
     import cup3d_amd as cu
     size = 64
     G = cu.Grid((1, 1, 1), 4, 3, 2 * np.pi, ("wall",) * 3)
-    want = int(bench.exact_test_field_blocks(G, size).view(np.uint64).sum(dtype=np.uint64))
+    whole = bench.exact_test_field_blocks(G, size)
+    want = int(whole.view(np.uint64).sum(dtype=np.uint64))
+    want_comp = [int(np.ascontiguousarray(whole[..., c]).view(np.uint64).sum(dtype=np.uint64)) for c in range(3)]
+    assert bench.gather_sum(want, argparse.Namespace(tdev="cpu"), None, 1) == want
     for world in (2, 3):
         with socket.socket() as so:
             so.bind(("127.0.0.1", 0))
@@ -206,3 +215,4 @@ def test_checksum_is_independent_of_the_partition_over_gloo():
             p.join(60)
         assert sum(g[2] for g in got) == G.nblocks
         assert all(g[1] == want for g in got), (world, got, want)
+        assert all(g[3] == want_comp for g in got), (world, got, want_comp)
