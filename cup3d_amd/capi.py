@@ -158,6 +158,7 @@ DEBUG_SIGNATURES = {
     "cup3d_debug_host_transport": (C.c_int, [C.c_int, C.c_int, _vp]),
     "cup3d_debug_wave_sum": (C.c_int, [_dp, _dp]),
     "cup3d_debug_ctl_step": (C.c_int, [C.c_int, _dp, _dp]),
+    "cup3d_debug_mg_plan_check": (C.c_int, [_vp, _vp, C.c_int]),
 }
 
 _lib = None

@@ -210,6 +210,88 @@ int cup3d_grid_halo_plan(const cup3d_grid_t *gh, long *send_count, long *recv_co
   return CUP3D_OK;
 }
 
+#ifdef CUP3D_TESTING
+// TEST SUPPORT (no GPU): the multigrid hierarchies of ALL ranks for the given ownership, checked against each other -- every table
+// entry resolves to an owned or a ghost slot; what rank r sends to rank p is, node for node, what p expects from r (ghost exchange and
+// restriction octants); every owned ancestor receives each of its eight octants exactly once (from a local child or from a message)
+int cup3d_debug_mg_plan_check(const cup3d_grid_t *gh, const int32_t *owner, int nranks) {
+  if (!gh || nranks < 1) return CUP3D_EINVAL;
+  const Grid *g = reinterpret_cast<const Grid *>(gh);
+  try {
+    std::vector<std::shared_ptr<MGHierarchy>> H(nranks);
+    for (int r = 0; r < nranks; ++r) H[r] = g->mg_hierarchy(nranks > 1 ? owner : nullptr, r, nranks, nullptr);
+    const size_t nlev = H[0]->lev.size();
+    for (size_t l = 0; l < nlev; ++l) {
+      int64_t owned_total = 0;
+      for (int r = 0; r < nranks; ++r) {
+        const MGLevelPlan &P = H[r]->lev[l];
+        owned_total += P.n_owned;
+        const int64_t nvis = P.n_owned + P.n_ghost, nvis_c = l > 0 ? H[r]->lev[l - 1].n_owned + H[r]->lev[l - 1].n_ghost : 0;
+        if ((int64_t)P.gid.size() != nvis) throw std::logic_error("gid size");
+        for (int64_t i = 0; i < P.n_owned; ++i) {
+          for (int f = 0; f < 6; ++f) {
+            const int32_t v = P.nbr[6 * i + f];
+            if (v >= kNbrHalo) { if ((size_t)(v - kNbrHalo) >= P.cf.size() / 4) throw std::logic_error("cf index out of range"); }
+            else if (v >= 0) { if (v >= nvis) throw std::logic_error("neighbour slot out of range"); }
+            else if (v != -1) throw std::logic_error("bad neighbour code");
+          }
+          if (l > 0 && (P.parent[2 * i] < 0 || P.parent[2 * i] >= nvis_c || P.parent[2 * i + 1] < 0 || P.parent[2 * i + 1] > 7)) throw std::logic_error("parent out of range");
+        }
+        for (size_t e = 0; e < P.cf.size() / 4; ++e)
+          if (P.cf[4 * e] < 0 || P.cf[4 * e] >= nvis_c) throw std::logic_error("coarse neighbour slot out of range");
+        // ghost exchange: my receive from p == p's send to me, node for node
+        int64_t ghost_at = P.n_owned;
+        for (int p = 0; p < nranks; ++p) {
+          const MGLevelPlan &Q = H[p]->lev[l];
+          if (P.recv_count[p] != Q.send_count[r]) throw std::logic_error("ghost exchange counts differ");
+          int64_t off = 0;
+          for (int q = 0; q < r; ++q) off += Q.send_count[q];
+          for (int64_t k = 0; k < P.recv_count[p]; ++k)
+            if (Q.gid[Q.send_slots[off + k]] != P.gid[ghost_at + k]) throw std::logic_error("ghost exchange order differs");
+          ghost_at += P.recv_count[p];
+        }
+        if (ghost_at != nvis) throw std::logic_error("ghost counts do not add up");
+        // restriction octants
+        if (l > 0) {
+          const MGLevelPlan &C = H[r]->lev[l - 1];
+          int64_t at = 0;
+          for (int p = 0; p < nranks; ++p) {
+            const MGLevelPlan &Q = H[p]->lev[l];
+            if (P.rrecv_count[p] != Q.rsend_count[r]) throw std::logic_error("restriction counts differ");
+            int64_t off = 0;
+            for (int q = 0; q < r; ++q) off += Q.rsend_count[q];
+            const MGLevelPlan &QC = H[p]->lev[l - 1];
+            for (int64_t k = 0; k < P.rrecv_count[p]; ++k) {
+              const int32_t mine = P.rrecv[2 * (at + k)], theirs = Q.rsend[2 * (off + k)];
+              if (mine >= C.n_owned) throw std::logic_error("a received octant goes into a ghost parent");
+              if (theirs < QC.n_owned) throw std::logic_error("a sent octant comes from an owned parent");
+              if (C.gid[mine] != QC.gid[theirs] || P.rrecv[2 * (at + k) + 1] != Q.rsend[2 * (off + k) + 1]) throw std::logic_error("restriction order differs");
+            }
+            at += P.rrecv_count[p];
+          }
+          // every owned ancestor of level l - 1 gets each octant exactly once
+          std::vector<unsigned char> seen((size_t)C.n_owned, 0);
+          for (int64_t i = 0; i < P.n_owned; ++i)
+            if (P.parent[2 * i] < C.n_owned) seen[P.parent[2 * i]] |= (unsigned char)(1u << P.parent[2 * i + 1]);
+          for (size_t k = 0; k < P.rrecv.size() / 2; ++k) {
+            unsigned char &m = seen[P.rrecv[2 * k]];
+            if (m & (1u << P.rrecv[2 * k + 1])) throw std::logic_error("an octant arrives twice");
+            m |= (unsigned char)(1u << P.rrecv[2 * k + 1]);
+          }
+          for (int64_t i = 0; i < C.n_owned; ++i)
+            if (C.leaf[i] < 0 ? seen[i] != 0xff : seen[i] != 0) throw std::logic_error("an ancestor misses an octant (or a leaf receives one)");
+        }
+      }
+      if (owned_total != H[0]->lev[l].n_global) throw std::logic_error("the ranks' owned nodes do not add up to the level");
+    }
+  } catch (const std::exception &e) {
+    set_error("cup3d_debug_mg_plan_check: %s", e.what());
+    return CUP3D_ESTATE;
+  }
+  return CUP3D_OK;
+}
+#endif
+
 double cup3d_calc_max_timestep(double hmin, double umax, double nu, double cfl, int step, int rampup, double dt_old, double coefU[3]) {
   return cup3d_calc_max_timestep2(hmin, umax, nu, cfl, step, rampup, dt_old, coefU, 0);
 }

@@ -1,4 +1,5 @@
 // See grid.hpp.
+#include <memory>
 #include "grid.hpp"
 
 #include <algorithm>
@@ -414,7 +415,162 @@ std::unique_ptr<Grid> Grid::rank_view(const int32_t *owner, int rank_, int nrank
     for (int32_t g : pg) if (owner[g] == rank_) { V.send_blocks.push_back(to_view[g]); V.send_block_count[p]++; }
     for (int32_t e : pf) if (owner[amr_faces[2 * e] / 6] == rank_) { V.send_flux_faces.push_back(face_to_view[e]); V.send_flux_count[p]++; }
   }
+  // the multigrid option's hierarchy of this rank (it needs the global mesh, which the view does not keep)
+  if (!tensorial) {
+    try {
+      V.mg_plan = mg_hierarchy(owner, rank_, nranks_, &to_view);
+    } catch (const std::exception &) {
+      V.mg_plan = nullptr;  // (a mesh the hierarchy cannot be built on: block_solver 5 says so when it is asked for; everything else does not care)
+    }
+  }
   return v;
+}
+
+std::shared_ptr<MGHierarchy> Grid::mg_hierarchy(const int32_t *owner, int rank_, int nranks_, const std::vector<int32_t> *leaf_slot) const {
+  if (!multilevel || n_local >= 0) throw std::invalid_argument("mg_hierarchy needs a global multi-level mesh");
+  const int64_t nb = nblocks();
+  int lmax = 0;
+  for (int64_t b = 0; b < nb; ++b) lmax = std::max(lmax, (int)blevel[(size_t)b]);
+  const int nlev = lmax + 1;
+  struct Node { int c[3]; int32_t leaf; int32_t owner; };
+  std::vector<std::vector<Node>> nodes(nlev);
+  std::vector<std::vector<int32_t>> map(nlev);
+  auto dim = [&](int l, int d) { return bpd[d] << l; };
+  auto at = [&](int l, const int c[3]) -> int32_t & { return map[l][((size_t)c[2] * dim(l, 1) + c[1]) * dim(l, 0) + c[0]]; };
+  for (int l = 0; l < nlev; ++l) map[l].assign((size_t)dim(l, 0) * dim(l, 1) * dim(l, 2), -1);
+  for (int64_t b = 0; b < nb; ++b) {
+    const int l = blevel[(size_t)b];
+    Node n{{index[3 * b], index[3 * b + 1], index[3 * b + 2]}, (int32_t)b, owner ? owner[b] : 0};
+    if (n.owner < 0 || n.owner >= nranks_) throw std::invalid_argument("owner out of range");
+    at(l, n.c) = (int32_t)nodes[l].size();
+    nodes[l].push_back(n);
+  }
+  for (int l = lmax; l >= 1; --l)  // ancestors: nodes[l] is complete when level l is visited
+    for (size_t i = 0; i < nodes[l].size(); ++i) {
+      const int pc[3] = {nodes[l][i].c[0] >> 1, nodes[l][i].c[1] >> 1, nodes[l][i].c[2] >> 1};
+      if (at(l - 1, pc) < 0) {
+        at(l - 1, pc) = (int32_t)nodes[l - 1].size();
+        nodes[l - 1].push_back(Node{{pc[0], pc[1], pc[2]}, -1, -1});
+      }
+    }
+  for (int l = lmax - 1; l >= 0; --l)  // an ancestor lives where its first child lives (the children of level l + 1 have their owners by now)
+    for (Node &n : nodes[l]) {
+      if (n.leaf >= 0) continue;
+      const int cc[3] = {2 * n.c[0], 2 * n.c[1], 2 * n.c[2]};
+      const int32_t ch = at(l + 1, cc);
+      if (ch < 0) throw std::logic_error("multigrid: an ancestor without its first child");
+      n.owner = nodes[l + 1][ch].owner;
+    }
+  // face neighbour of node (l, i) across face f: >= 0 same-level node; -1 domain face; -2 - cs: only the coarse node cs of level l - 1 exists
+  auto neighbour = [&](int l, const Node &nd, int f) -> int32_t {
+    const int d = f >> 1, side = f & 1;
+    int c[3] = {nd.c[0], nd.c[1], nd.c[2]};
+    c[d] += side ? 1 : -1;
+    if (c[d] < 0 || c[d] >= dim(l, d)) {
+      if (bc[d] != 1) return -1;  // zero-gradient pressure tile behind every non-periodic domain face
+      c[d] = (c[d] + dim(l, d)) % dim(l, d);
+    }
+    const int32_t m = at(l, c);
+    if (m >= 0) return m;
+    const int cc[3] = {c[0] >> 1, c[1] >> 1, c[2] >> 1};
+    const int32_t cs = l > 0 ? at(l - 1, cc) : -1;
+    if (cs < 0) throw std::invalid_argument("multigrid: the mesh is not 2:1 balanced");
+    return -2 - cs;
+  };
+  // ghost lists of EVERY rank (a rank's send list is the part of the others' ghost lists it owns): want[l][r] = global node numbers
+  std::vector<std::vector<std::vector<int32_t>>> want(nlev, std::vector<std::vector<int32_t>>(nranks_));
+  if (nranks_ > 1)
+    for (int l = 0; l < nlev; ++l)
+      for (size_t i = 0; i < nodes[l].size(); ++i) {
+        const Node &nd = nodes[l][i];
+        const int r = nd.owner;
+        for (int f = 0; f < 6; ++f) {
+          const int32_t m = neighbour(l, nd, f);
+          if (m >= 0) { if (nodes[l][m].owner != r) want[l][r].push_back(m); }
+          else if (m <= -2) { const int32_t cs = -2 - m; if (nodes[l - 1][cs].owner != r) want[l - 1][r].push_back(cs); }
+        }
+        if (l > 0) {
+          const int pc[3] = {nd.c[0] >> 1, nd.c[1] >> 1, nd.c[2] >> 1};
+          const int32_t pn = at(l - 1, pc);
+          if (nodes[l - 1][pn].owner != r) want[l - 1][r].push_back(pn);
+        }
+      }
+  for (int l = 0; l < nlev; ++l)
+    for (int r = 0; r < nranks_; ++r) {
+      auto &w = want[l][r];
+      std::sort(w.begin(), w.end(), [&](int32_t a, int32_t b) { return nodes[l][a].owner != nodes[l][b].owner ? nodes[l][a].owner < nodes[l][b].owner : a < b; });
+      w.erase(std::unique(w.begin(), w.end()), w.end());
+    }
+  auto H = std::make_shared<MGHierarchy>();
+  H->rank = rank_;
+  H->nranks = nranks_;
+  H->lev.resize(nlev);
+  std::vector<std::vector<int32_t>> loc(nlev);  // global node -> slot in rank_'s arrays, -1 invisible
+  for (int l = 0; l < nlev; ++l) {
+    MGLevelPlan &P = H->lev[l];
+    loc[l].assign(nodes[l].size(), -1);
+    for (size_t i = 0; i < nodes[l].size(); ++i)
+      if (nodes[l][i].owner == rank_) { loc[l][i] = (int32_t)P.gid.size(); P.gid.push_back((int32_t)i); }
+    P.n_owned = (int64_t)P.gid.size();
+    for (int32_t gnode : want[l][rank_]) { loc[l][gnode] = (int32_t)P.gid.size(); P.gid.push_back(gnode); }
+    P.n_ghost = (int64_t)P.gid.size() - P.n_owned;
+    P.n_global = (int64_t)nodes[l].size();
+    P.h = maxextent / (8.0 * std::max(std::max(dim(l, 0), dim(l, 1)), dim(l, 2)));  // Info::h of level l (h_gridpoint, main.cpp:15405-15415)
+  }
+  for (int l = 0; l < nlev; ++l) {
+    MGLevelPlan &P = H->lev[l];
+    const size_t n = (size_t)P.n_owned;
+    P.nbr.assign(6 * n, -1);
+    P.parent.assign(2 * n, 0);
+    P.leaf.assign(n, -1);
+    for (size_t i = 0; i < n; ++i) {
+      const Node &nd = nodes[l][P.gid[i]];
+      P.leaf[i] = nd.leaf < 0 ? -1 : (leaf_slot ? (*leaf_slot)[nd.leaf] : nd.leaf);
+      if (nd.leaf >= 0 && P.leaf[i] < 0) throw std::logic_error("multigrid: an owned leaf without a local slot");
+      if (l > 0) {
+        const int pc[3] = {nd.c[0] >> 1, nd.c[1] >> 1, nd.c[2] >> 1};
+        P.parent[2 * i] = loc[l - 1][at(l - 1, pc)];
+        P.parent[2 * i + 1] = (nd.c[0] & 1) + 2 * (nd.c[1] & 1) + 4 * (nd.c[2] & 1);
+        if (P.parent[2 * i] < 0) throw std::logic_error("multigrid: an owned node's parent is not visible");
+      }
+      for (int f = 0; f < 6; ++f) {
+        const int32_t m = neighbour(l, nd, f);
+        if (m >= 0) {
+          if (loc[l][m] < 0) throw std::logic_error("multigrid: an owned node's neighbour is not visible");
+          P.nbr[6 * i + f] = loc[l][m];
+        } else if (m <= -2) {
+          const int32_t cs = loc[l - 1][-2 - m];
+          if (cs < 0) throw std::logic_error("multigrid: an owned node's coarse neighbour is not visible");
+          const int d = f >> 1, t1 = d == 0 ? 1 : 0, t2 = d == 2 ? 1 : 2;  // the slab's (a1, a2) directions, face1()
+          P.nbr[6 * i + f] = kNbrHalo + (int32_t)(P.cf.size() / 4);
+          P.cf.push_back(cs); P.cf.push_back(d); P.cf.push_back(f & 1); P.cf.push_back((nd.c[t1] & 1) | ((nd.c[t2] & 1) << 1));
+        }
+      }
+    }
+    // exchange plans
+    P.send_count.assign(nranks_, 0); P.recv_count.assign(nranks_, 0);
+    P.rsend_count.assign(nranks_, 0); P.rrecv_count.assign(nranks_, 0);
+    for (int32_t gnode : want[l][rank_]) P.recv_count[nodes[l][gnode].owner]++;
+    for (int p = 0; p < nranks_; ++p) {
+      if (p == rank_) continue;
+      for (int32_t gnode : want[l][p])
+        if (nodes[l][gnode].owner == rank_) { P.send_slots.push_back(loc[l][gnode]); P.send_count[p]++; }
+    }
+    if (l > 0 && nranks_ > 1) {
+      for (int p = 0; p < nranks_; ++p) {  // peer-major, children in global order -- on both sides
+        if (p == rank_) continue;
+        for (size_t i = 0; i < nodes[l].size(); ++i) {
+          const Node &nd = nodes[l][i];
+          const int pc[3] = {nd.c[0] >> 1, nd.c[1] >> 1, nd.c[2] >> 1};
+          const int32_t pn = at(l - 1, pc);
+          const int po = nodes[l - 1][pn].owner, oct = (nd.c[0] & 1) + 2 * (nd.c[1] & 1) + 4 * (nd.c[2] & 1);
+          if (nd.owner == rank_ && po == p) { P.rsend.push_back(loc[l - 1][pn]); P.rsend.push_back(oct); P.rsend_count[p]++; }
+          if (nd.owner == p && po == rank_) { P.rrecv.push_back(loc[l - 1][pn]); P.rrecv.push_back(oct); P.rrecv_count[p]++; }
+        }
+      }
+    }
+  }
+  return H;
 }
 
 int32_t Grid::leaf(int l, const int c[3]) const {

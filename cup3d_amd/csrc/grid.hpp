@@ -24,6 +24,32 @@ constexpr int32_t kNbrHalo = 0x40000000;
 constexpr int32_t kNbrCoarser = 0x20000000;
 constexpr int32_t kNbrSkipped = -1, kNbrFiner = -3;
 
+// ---- the level hierarchy of the multigrid option on a multi-level mesh (multigrid.hip), for one rank.  Level l holds, as NODES, the leaves of
+// level l and the ancestors (at level l) of every finer leaf.  A leaf node belongs to the leaf's owner, an ancestor to the owner of its
+// first child (octant 0), recursively.  A rank's arrays of level l hold its OWNED nodes (global order) followed by GHOST nodes, ordered by
+// (owner, global order): every remote node an owned node's tables name -- same-level face neighbours, the parent and the coarse neighbours
+// behind coarse/fine faces of the owned nodes one level up.  All slots below are slots of those arrays.
+struct MGLevelPlan {
+  int64_t n_owned = 0, n_ghost = 0, n_global = 0;
+  double h = 0;
+  std::vector<int32_t> nbr;     // [n_owned][6]: slot | -1 zero-gradient domain face | kNbrHalo + index into cf
+  std::vector<int32_t> parent;  // [n_owned][2]: slot on level l - 1, octant (x + 2y + 4z)
+  std::vector<int32_t> leaf;    // [n_owned]: slot of the leaf in the rank's field arrays, -1 for an ancestor
+  std::vector<int32_t> cf;      // [ncf][4]: coarse node's slot on level l - 1, direction, side, tangential parities
+  std::vector<int32_t> gid;     // [n_owned + n_ghost]: global node number (checks only)
+  // ghost exchange of an array of this level: what I send to p = the nodes of p's ghost list that I own, in p's ghost order
+  std::vector<int64_t> send_count, recv_count;  // [nranks]
+  std::vector<int32_t> send_slots;
+  // restriction into level l - 1: octants of REMOTE parents that my owned nodes of this level produce (sent to the parent's owner,
+  // peer-major, children in global order), and the octants of my owned parents that arrive (sender-major, the same order)
+  std::vector<int64_t> rsend_count, rrecv_count;  // [nranks]
+  std::vector<int32_t> rsend, rrecv;              // pairs: slot on level l - 1 (a ghost slot when sending, an owned one when receiving), octant
+};
+struct MGHierarchy {
+  int rank = 0, nranks = 1;
+  std::vector<MGLevelPlan> lev;  // [0] coarsest ... finest level present
+};
+
 struct Grid {
   Grid(const int bpd[3], int level_max, int level, double maxextent, const int bc[3], int rank, int nranks);
   // multi-level (AMR) mesh on one rank: the leaves (level, Z) in any order -- what Grid::m_vInfo holds after
@@ -104,6 +130,10 @@ struct Grid {
   // tensorial: also the finer leaves behind EDGE and CORNER positions become ghosts -- what the tensorial [-1,2) tile of mesh adaptation
   // (refine_1 / RefineBlocks) averages down; the star-shaped stencils of the time step never read them
   std::unique_ptr<Grid> rank_view(const int32_t *owner, int rank, int nranks, bool tensorial = false) const;
+  // the multigrid hierarchy of rank `rank` when the leaves of this (global, multi-level) mesh are owned as `owner` says (nullptr: one
+  // rank owns everything); leaf_slot[global leaf] = slot of the leaf in that rank's field arrays (nullptr: the global slot itself)
+  std::shared_ptr<MGHierarchy> mg_hierarchy(const int32_t *owner, int rank, int nranks, const std::vector<int32_t> *leaf_slot) const;
+  std::shared_ptr<const MGHierarchy> mg_plan;  // views: built by rank_view (it needs the global mesh); else built on first use
   Grid(const Grid &proto, int basics_only);  // box, curve and spacing of `proto`, no blocks (used by rank_view)
   int owner_of(int64_t z) const;
   static void partition(int64_t total, int rank, int nranks, int64_t *begin, int64_t *count);

@@ -42,19 +42,25 @@ struct MGLevel {
   double *slabs = nullptr;      // [ncf][64] ghost values behind those faces, injected from the coarse iterate
   Sim *xch = nullptr;           // several ranks: what halo_exchange() needs for this level's iterate (the solver's Sim on the finest level)
   bool own_xch = false;
+  // multi-level meshes over ranks (Grid::mg_hierarchy): the arrays hold nb owned nodes + nghost ghost nodes; the exchange plans
+  const MGLevelPlan *plan = nullptr;
+  int64_t nghost = 0;
+  int32_t *d_send_slots = nullptr, *d_rsend = nullptr, *d_rrecv = nullptr;
+  double *pack = nullptr, *rpack = nullptr, *runpack = nullptr;  // send buffer of the ghost exchange; octant buffers of the restriction (64 doubles per item)
 };
 struct Multigrid {
   std::vector<MGLevel> lev;  // [0] coarsest ... [L] finest
   double *zeros = nullptr;   // ghost values behind faces owned by other ranks (see mg_setup); the x pointer itself on one rank
   bool local = false;        // a rank-local hierarchy (several ranks)
   bool amr = false;          // hierarchy of a multi-level mesh (mg_setup_amr)
+  std::shared_ptr<const MGHierarchy> plan;  // ... its tables (kept alive: the exchange plans are read at every cycle)
   ~Multigrid() {
     if (zeros) hipFree(zeros);
     for (size_t i = 0; i < lev.size(); ++i) {
       MGLevel &l = lev[i];
       if ((l.grid || l.own_nbr) && l.d_nbr) hipFree(l.d_nbr);
       if (l.own_xch) sim_comm_only_destroy(l.xch);
-      void *p[] = {l.d_parent, l.x, l.x2, l.b, l.d_leaf, l.d_cf, l.slabs};
+      void *p[] = {l.d_parent, l.x, l.x2, l.b, l.d_leaf, l.d_cf, l.slabs, l.d_send_slots, l.d_rsend, l.d_rrecv, l.pack, l.rpack, l.runpack};
       for (void *q : p) if (q) hipFree(q);
     }
   }
@@ -295,34 +301,26 @@ static GridDev level_gdev(const MGLevel &L) {
 // preconditioner it only has to be close.
 static int mg_setup_amr(Sim *s) {
   const Grid *g = s->grid;
-  if (g->nranks > 1 || g->n_local >= 0) { set_error("the multigrid preconditioner on a multi-level mesh runs on one rank"); return CUP3D_EINVAL; }
   std::unique_ptr<Multigrid> mg(new Multigrid());
   mg->amr = true;
-  const int64_t nb = g->nblocks();
-  int lmax = 0;
-  for (int64_t b = 0; b < nb; ++b) lmax = std::max(lmax, (int)g->blevel[(size_t)b]);
-  const int nlev = lmax + 1;
-  mg->lev.resize(nlev);
-  struct Node { int c[3]; int32_t leaf; };
-  std::vector<std::vector<Node>> nodes(nlev);
-  std::vector<std::vector<int32_t>> map(nlev);
-  auto dim = [&](int l, int d) { return g->bpd[d] << l; };
-  auto at = [&](int l, const int c[3]) -> int32_t & { return map[l][((size_t)c[2] * dim(l, 1) + c[1]) * dim(l, 0) + c[0]]; };
-  for (int l = 0; l < nlev; ++l) map[l].assign((size_t)dim(l, 0) * dim(l, 1) * dim(l, 2), -1);
-  for (int64_t b = 0; b < nb; ++b) {
-    const int l = g->blevel[(size_t)b];
-    Node n{{g->index[3 * b], g->index[3 * b + 1], g->index[3 * b + 2]}, (int32_t)b};
-    at(l, n.c) = (int32_t)nodes[l].size();
-    nodes[l].push_back(n);
-  }
-  for (int l = lmax; l >= 1; --l)  // ancestors: nodes[l] is complete when level l is visited
-    for (size_t i = 0; i < nodes[l].size(); ++i) {
-      const int pc[3] = {nodes[l][i].c[0] >> 1, nodes[l][i].c[1] >> 1, nodes[l][i].c[2] >> 1};
-      if (at(l - 1, pc) < 0) {
-        at(l - 1, pc) = (int32_t)nodes[l - 1].size();
-        nodes[l - 1].push_back(Node{{pc[0], pc[1], pc[2]}, -1});
-      }
+  // the tables of this rank's share of every level: Grid::mg_hierarchy (grid.cpp) -- built with the rank view where the mesh is spread over
+  // ranks (the view does not keep the global mesh), here for a mesh on one rank
+  try {
+    if (g->n_local >= 0) {
+      if (!g->mg_plan) { set_error("multigrid: this rank view carries no level hierarchy (a tensorial view, or a mesh that is not 2:1 balanced)"); return CUP3D_EINVAL; }
+      mg->plan = g->mg_plan;
+    } else {
+      if (g->nranks > 1) { set_error("multigrid on a multi-level mesh over ranks needs rank views (cup3d_grid_rank_view)"); return CUP3D_EINVAL; }
+      mg->plan = g->mg_hierarchy(nullptr, 0, 1, nullptr);
     }
+  } catch (const std::exception &e) {
+    set_error("multigrid: %s", e.what());
+    return CUP3D_EINVAL;
+  }
+  const MGHierarchy &H = *mg->plan;
+  mg->local = H.nranks > 1;
+  const int nlev = (int)H.lev.size();
+  mg->lev.resize(nlev);
   auto up = [&](int32_t **d, const std::vector<int32_t> &v) -> int {
     CUP3D_HIP(hipMalloc((void **)d, std::max<size_t>(v.size(), 1) * sizeof(int32_t)));
     if (!v.empty()) CUP3D_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -331,46 +329,34 @@ static int mg_setup_amr(Sim *s) {
   int rc;
   for (int l = 0; l < nlev; ++l) {
     MGLevel &M = mg->lev[l];
-    const size_t n = nodes[l].size();
-    M.nb = (int64_t)n;
-    M.h = g->maxextent / (8.0 * std::max(std::max(dim(l, 0), dim(l, 1)), dim(l, 2)));  // Info::h of level l (h_gridpoint, main.cpp:15405-15415)
-    std::vector<int32_t> nbr(6 * n), par(2 * n, 0), leaf(n), cf;
-    for (size_t i = 0; i < n; ++i) {
-      const Node &nd = nodes[l][i];
-      leaf[i] = nd.leaf;
-      if (l > 0) {
-        const int pc[3] = {nd.c[0] >> 1, nd.c[1] >> 1, nd.c[2] >> 1};
-        par[2 * i] = at(l - 1, pc);
-        par[2 * i + 1] = (nd.c[0] & 1) + 2 * (nd.c[1] & 1) + 4 * (nd.c[2] & 1);
-      }
-      for (int f = 0; f < 6; ++f) {
-        const int d = f >> 1, side = f & 1;
-        int c[3] = {nd.c[0], nd.c[1], nd.c[2]};
-        c[d] += side ? 1 : -1;
-        if (c[d] < 0 || c[d] >= dim(l, d)) {
-          if (g->bc[d] != 1) { nbr[6 * i + f] = -1; continue; }  // zero-gradient pressure tile behind every non-periodic domain face
-          c[d] = (c[d] + dim(l, d)) % dim(l, d);
-        }
-        const int32_t m = at(l, c);
-        if (m >= 0) { nbr[6 * i + f] = m; continue; }
-        const int cc[3] = {c[0] >> 1, c[1] >> 1, c[2] >> 1};
-        const int32_t cs = l > 0 ? at(l - 1, cc) : -1;
-        if (cs < 0) { set_error("multigrid: mesh is not 2:1 balanced at level %d", l); return CUP3D_EINVAL; }
-        const int t1 = d == 0 ? 1 : 0, t2 = d == 2 ? 1 : 2;  // the slab's (a1, a2) directions, face1()
-        nbr[6 * i + f] = kNbrHalo + (int32_t)(cf.size() / 4);
-        cf.push_back(cs); cf.push_back(d); cf.push_back(side); cf.push_back((nd.c[t1] & 1) | ((nd.c[t2] & 1) << 1));
-      }
-    }
+    const MGLevelPlan &P = H.lev[l];
+    M.plan = &P;
+    M.nb = P.n_owned;
+    M.nghost = P.n_ghost;
+    M.h = P.h;
     M.own_nbr = true;
-    M.ncf = (int64_t)cf.size() / 4;
-    if ((rc = up(&M.d_nbr, nbr)) || (rc = up(&M.d_parent, par)) || (rc = up(&M.d_leaf, leaf)) || (rc = up(&M.d_cf, cf))) return rc;
-    const size_t bytes = n * 512 * sizeof(double), sb = (size_t)std::max<int64_t>(M.ncf, 1) * 64 * sizeof(double);
+    M.ncf = (int64_t)P.cf.size() / 4;
+    if ((rc = up(&M.d_nbr, P.nbr)) || (rc = up(&M.d_parent, P.parent)) || (rc = up(&M.d_leaf, P.leaf)) || (rc = up(&M.d_cf, P.cf))) return rc;
+    const size_t nvis = (size_t)std::max<int64_t>(P.n_owned + P.n_ghost, 1);
+    const size_t bytes = nvis * 512 * sizeof(double), sb = (size_t)std::max<int64_t>(M.ncf, 1) * 64 * sizeof(double);
     CUP3D_HIP(hipMalloc((void **)&M.x, bytes));
     CUP3D_HIP(hipMalloc((void **)&M.x2, bytes));
     CUP3D_HIP(hipMalloc((void **)&M.b, bytes));
     CUP3D_HIP(hipMalloc((void **)&M.slabs, sb));
     CUP3D_HIP(hipMemset(M.slabs, 0, sb));
+    CUP3D_HIP(hipMemset(M.x, 0, bytes));
+    CUP3D_HIP(hipMemset(M.x2, 0, bytes));
+    CUP3D_HIP(hipMemset(M.b, 0, bytes));
     s->bytes += 3 * bytes + sb;
+    if (H.nranks > 1) {
+      if ((rc = up(&M.d_send_slots, P.send_slots)) || (rc = up(&M.d_rsend, P.rsend)) || (rc = up(&M.d_rrecv, P.rrecv))) return rc;
+      const size_t ps = std::max<size_t>(P.send_slots.size(), 1) * 512 * sizeof(double);
+      const size_t rs = std::max<size_t>(P.rsend.size() / 2, 1) * 64 * sizeof(double), rr = std::max<size_t>(P.rrecv.size() / 2, 1) * 64 * sizeof(double);
+      CUP3D_HIP(hipMalloc((void **)&M.pack, ps));
+      CUP3D_HIP(hipMalloc((void **)&M.rpack, rs));
+      CUP3D_HIP(hipMalloc((void **)&M.runpack, rr));
+      s->bytes += ps + rs + rr;
+    }
   }
   s->mg = mg.release();
   return CUP3D_OK;
@@ -459,17 +445,21 @@ void mg_destroy(Sim *s) {
 // `launches` smoothing launches of `sweeps` sweeps each on one level; the iterate alternates between *xa and *xb and ends in *xa.
 // Several ranks: the face slabs of the iterate travel before every launch that reads them (not before the first one of a cycle, whose
 // iterate is zero everywhere).
-static int mg_smooth(const MGLevel &M, const double *zeros, double **xa, double **xb, const double *rhs, int launches, int sweeps, bool from_zero) {
+static int mg_ghosts(Sim *s, const MGLevel &M, double *x);
+// amr_sim != nullptr: a level of a multi-level mesh spread over ranks -- its ghost NODES are refreshed before every launch that reads them
+static int mg_smooth(const MGLevel &M, const double *zeros, double **xa, double **xb, const double *rhs, int launches, int sweeps, bool from_zero, Sim *amr_sim = nullptr) {
   const GridDev g = level_gdev(M);
   const dim3 G(launch_groups(g)), B(256);
   const bool wave = !debug_option("mg_smooth_workgroup");  // production: one wavefront per block, shuffles (k_mg_smooth_wave); A/B: the LDS-tile form
   for (int i = 0; i < launches; ++i) {
     const bool zero = from_zero && i == 0;
     if (M.xch && !zero) { int rc = halo_exchange(M.xch, *xa, 1, 1); if (rc) return rc; }
+    if (amr_sim && !zero) { int rc = mg_ghosts(amr_sim, M, *xa); if (rc) return rc; }
     const double *halo = M.xch ? (const double *)M.xch->halo_recv : (zeros ? zeros : (const double *)*xa);
     if (!halo) halo = *xa;  // a rank without remote faces
     ProfileScope ps("mg_smooth");
-    if (wave && zero) hipLaunchKernelGGL(k_mg_smooth_wave<true>, G, dim3(64), 0, stream(), g, (const double *)nullptr, halo, rhs, *xb, sweeps);
+    if (M.nb == 0) { /* a rank that owns no node of this level still took part in the exchange above */ }
+    else if (wave && zero) hipLaunchKernelGGL(k_mg_smooth_wave<true>, G, dim3(64), 0, stream(), g, (const double *)nullptr, halo, rhs, *xb, sweeps);
     else if (wave) hipLaunchKernelGGL(k_mg_smooth_wave<false>, G, dim3(64), 0, stream(), g, (const double *)*xa, halo, rhs, *xb, sweeps);
     else if (zero) hipLaunchKernelGGL(k_mg_smooth<true>, G, B, 0, stream(), g, (const double *)nullptr, halo, rhs, *xb, sweeps);
     else hipLaunchKernelGGL(k_mg_smooth<false>, G, B, 0, stream(), g, (const double *)*xa, halo, rhs, *xb, sweeps);
@@ -493,40 +483,100 @@ __global__ void __launch_bounds__(256) k_mg_sub(double *__restrict__ b, long n, 
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) b[i] -= m;
 }
 
-static int mg_vcycle_amr(Multigrid &mg, const double *in, double *out, int nu, int sw) {
+// ---- multi-level meshes over ranks: the two exchanges of a level (plans: MGLevelPlan, grid.hpp)
+__global__ void __launch_bounds__(256) k_mg_pack_nodes(const double *__restrict__ x, const int32_t *__restrict__ slots, double *__restrict__ out) {
+  const double *src = x + (size_t)slots[blockIdx.x] * 512;
+  for (int i = threadIdx.x; i < 512; i += 256) out[(size_t)blockIdx.x * 512 + i] = src[i];
+}
+// octant `oct` of block `slot` of b <-> 64 contiguous doubles
+__global__ void __launch_bounds__(64) k_mg_pack_octants(const double *__restrict__ b, const int32_t *__restrict__ items, double *__restrict__ out) {
+  const int slot = items[2 * blockIdx.x], oct = items[2 * blockIdx.x + 1], t = threadIdx.x;
+  const int cx = 4 * (oct & 1) + (t & 3), cy = 4 * ((oct >> 1) & 1) + ((t >> 2) & 3), cz = 4 * (oct >> 2) + (t >> 4);
+  out[(size_t)blockIdx.x * 64 + t] = b[(size_t)slot * 512 + cz * 64 + cy * 8 + cx];
+}
+__global__ void __launch_bounds__(64) k_mg_unpack_octants(double *__restrict__ b, const int32_t *__restrict__ items, const double *__restrict__ in) {
+  const int slot = items[2 * blockIdx.x], oct = items[2 * blockIdx.x + 1], t = threadIdx.x;
+  const int cx = 4 * (oct & 1) + (t & 3), cy = 4 * ((oct >> 1) & 1) + ((t >> 2) & 3), cz = 4 * (oct >> 2) + (t >> 4);
+  b[(size_t)slot * 512 + cz * 64 + cy * 8 + cx] = in[(size_t)blockIdx.x * 64 + t];
+}
+// the ghost nodes of `x` (an array of level M) <- their owners' current values.  Collective; no-op on one rank.
+static int mg_ghosts(Sim *s, const MGLevel &M, double *x) {
+  const MGLevelPlan &P = *M.plan;
+  if (P.send_count.size() <= 1) return CUP3D_OK;
+  ProfileScope ps("mg_exchange");
+  const unsigned ns = (unsigned)P.send_slots.size();
+  if (ns) hipLaunchKernelGGL(k_mg_pack_nodes, dim3(ns), dim3(256), 0, stream(), (const double *)x, (const int32_t *)M.d_send_slots, M.pack);
+  CUP3D_HIP(hipGetLastError());
+  return exchange_items(s, M.pack, P.send_count, x + (size_t)M.nb * 512, P.recv_count, 512);
+}
+// after the residual of level M was restricted into bc (level below): the octants that landed in GHOST parents travel to the parents' owners
+static int mg_restrict_exchange(Sim *s, const MGLevel &M, double *bc) {
+  const MGLevelPlan &P = *M.plan;
+  if (P.rsend_count.size() <= 1) return CUP3D_OK;
+  ProfileScope ps("mg_exchange");
+  const unsigned ns = (unsigned)(P.rsend.size() / 2), nr = (unsigned)(P.rrecv.size() / 2);
+  if (ns) hipLaunchKernelGGL(k_mg_pack_octants, dim3(ns), dim3(64), 0, stream(), (const double *)bc, (const int32_t *)M.d_rsend, M.rpack);
+  CUP3D_HIP(hipGetLastError());
+  int rc = exchange_items(s, M.rpack, P.rsend_count, M.runpack, P.rrecv_count, 64);
+  if (rc) return rc;
+  if (nr) hipLaunchKernelGGL(k_mg_unpack_octants, dim3(nr), dim3(64), 0, stream(), bc, (const int32_t *)M.d_rrecv, (const double *)M.runpack);
+  CUP3D_HIP(hipGetLastError());
+  return CUP3D_OK;
+}
+
+static int mg_vcycle_amr(Sim *s, Multigrid &mg, const double *in, double *out, int nu, int sw) {
   const int L = (int)mg.lev.size() - 1;
+  Sim *xs = mg.local ? s : nullptr;  // several ranks: ghost nodes are exchanged (mg_ghosts), restricted octants travel to remote parents
+  int rc;
   std::vector<double *> xa(L + 1), xb(L + 1);
   for (int l = 0; l <= L; ++l) {
     MGLevel &M = mg.lev[l];
     xa[l] = M.x;
     xb[l] = M.x2;
     ProfileScope ps("mg_gather");
-    hipLaunchKernelGGL(k_mg_gather, dim3((unsigned)M.nb), dim3(256), 0, stream(), (const int32_t *)M.d_leaf, in, M.b);
+    if (M.nb) hipLaunchKernelGGL(k_mg_gather, dim3((unsigned)M.nb), dim3(256), 0, stream(), (const int32_t *)M.d_leaf, in, M.b);
     if (M.ncf) CUP3D_HIP(hipMemsetAsync(M.slabs, 0, (size_t)M.ncf * 64 * sizeof(double), stream()));  // the coarse iterate is zero on the way down
   }
   for (int l = L; l >= 1; --l) {
     MGLevel &M = mg.lev[l];
-    mg_smooth(M, M.slabs, &xa[l], &xb[l], M.b, nu, sw, true);
+    if ((rc = mg_smooth(M, M.slabs, &xa[l], &xb[l], M.b, nu, sw, true, xs))) return rc;
+    if (xs && (rc = mg_ghosts(xs, M, xa[l]))) return rc;  // the residual reads the neighbours' final iterate
     const GridDev g = level_gdev(M);
-    ProfileScope ps("mg_residual_restrict");
-    hipLaunchKernelGGL(k_mg_residual_restrict, dim3(launch_groups(g)), dim3(256), 0, stream(), g, (const double *)xa[l], (const double *)M.slabs, (const double *)M.b,
-                       (const int32_t *)M.d_parent, mg.lev[l - 1].b);
+    {
+      ProfileScope ps("mg_residual_restrict");
+      if (M.nb) hipLaunchKernelGGL(k_mg_residual_restrict, dim3(launch_groups(g)), dim3(256), 0, stream(), g, (const double *)xa[l], (const double *)M.slabs, (const double *)M.b,
+                                   (const int32_t *)M.d_parent, mg.lev[l - 1].b);
+    }
+    if (xs && (rc = mg_restrict_exchange(xs, M, mg.lev[l - 1].b))) return rc;
   }
-  if (L > 0) hipLaunchKernelGGL(k_mg_remove_mean, dim3(1), dim3(256), 0, stream(), mg.lev[0].b, (long)mg.lev[0].nb * 512);
-  if (mg.lev[0].nb == 1) mg_smooth(mg.lev[0], mg.lev[0].slabs, &xa[0], &xb[0], mg.lev[0].b, 1, 64, true);
-  else mg_smooth(mg.lev[0], mg.lev[0].slabs, &xa[0], &xb[0], mg.lev[0].b, 16, 4, true);
+  MGLevel &C = mg.lev[0];
+  if (L > 0 && !xs) hipLaunchKernelGGL(k_mg_remove_mean, dim3(1), dim3(256), 0, stream(), C.b, (long)C.nb * 512);
+  if (L > 0 && xs) {  // the same over all ranks: local sums, one all-reduce on the communication stream, subtraction
+    double *tot = s->d_red + kRedMg;
+    const long n = (long)C.nb * 512;
+    hipLaunchKernelGGL(k_mg_local_sum, dim3(1), dim3(256), 0, stream(), (const double *)C.b, n, tot);
+    hipStream_t cs = scalar_stream(s);
+    if (cs != stream()) { CUP3D_HIP(hipEventRecord(s->ev_b, stream())); CUP3D_HIP(hipStreamWaitEvent(cs, s->ev_b, 0)); }
+    if ((rc = allreduce(s, tot, 1, false, cs))) return rc;
+    if (cs != stream()) { CUP3D_HIP(hipEventRecord(s->ev_a, cs)); CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_a, 0)); }
+    if (n) hipLaunchKernelGGL(k_mg_sub, dim3(64), dim3(256), 0, stream(), C.b, n, (const double *)tot, 1.0 / (512.0 * (double)C.plan->n_global));
+  }
+  if (C.plan->n_global == 1) rc = mg_smooth(C, C.slabs, &xa[0], &xb[0], C.b, 1, 64, true, xs);
+  else rc = mg_smooth(C, C.slabs, &xa[0], &xb[0], C.b, 16, 4, true, xs);
+  if (rc) return rc;
   for (int l = 1; l <= L; ++l) {
     MGLevel &M = mg.lev[l];
+    if (xs && (rc = mg_ghosts(xs, mg.lev[l - 1], xa[l - 1]))) return rc;  // remote parents and coarse neighbours: their final iterate
     {
       ProfileScope ps("mg_prolong_add");
-      hipLaunchKernelGGL(k_mg_prolong_add, dim3((unsigned)M.nb), dim3(256), 0, stream(), (int)M.nb, xa[l], (const int32_t *)M.d_parent, (const double *)xa[l - 1]);
+      if (M.nb) hipLaunchKernelGGL(k_mg_prolong_add, dim3((unsigned)M.nb), dim3(256), 0, stream(), (int)M.nb, xa[l], (const int32_t *)M.d_parent, (const double *)xa[l - 1]);
       if (M.ncf) hipLaunchKernelGGL(k_mg_cf_ghosts, dim3((unsigned)M.ncf), dim3(64), 0, stream(), (const int32_t *)M.d_cf, (const double *)xa[l - 1], M.slabs);
     }
-    mg_smooth(M, M.slabs, &xa[l], &xb[l], M.b, nu, sw, false);
+    if ((rc = mg_smooth(M, M.slabs, &xa[l], &xb[l], M.b, nu, sw, false, xs))) return rc;
   }
   for (int l = 0; l <= L; ++l) {
     ProfileScope ps("mg_gather");
-    hipLaunchKernelGGL(k_mg_scatter, dim3((unsigned)mg.lev[l].nb), dim3(256), 0, stream(), (const int32_t *)mg.lev[l].d_leaf, (const double *)xa[l], out);
+    if (mg.lev[l].nb) hipLaunchKernelGGL(k_mg_scatter, dim3((unsigned)mg.lev[l].nb), dim3(256), 0, stream(), (const int32_t *)mg.lev[l].d_leaf, (const double *)xa[l], out);
   }
   CUP3D_HIP(hipGetLastError());
   return CUP3D_OK;
@@ -537,7 +587,7 @@ int mg_vcycle(Sim *s, const double *in, double *out) {
   int rc = mg_setup(s);
   if (rc) return rc;
   Multigrid &mg = *reinterpret_cast<Multigrid *>(s->mg);
-  if (mg.amr) return mg_vcycle_amr(mg, in, out, debug_option("mg_launches") > 0 ? debug_option("mg_launches") : 2, debug_option("mg_sweeps") > 0 ? debug_option("mg_sweeps") : 2);
+  if (mg.amr) return mg_vcycle_amr(s, mg, in, out, debug_option("mg_launches") > 0 ? debug_option("mg_launches") : 2, debug_option("mg_sweeps") > 0 ? debug_option("mg_sweeps") : 2);
   const int L = (int)mg.lev.size() - 1;
   // smoothing launches before / after the coarse-grid correction, sweeps per launch (ghosts are frozen within a launch);
   // cup3d_debug_set_option("mg_launches" / "mg_sweeps") for tuning scans

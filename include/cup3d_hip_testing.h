@@ -24,6 +24,9 @@ int cup3d_debug_wave_sum(const double *in64, double *out128);
  * io[16] = alpha, beta, omega, r0r_prev, norm, init_norm, min_norm, tol, tol_rel, state (0 run, 1 done, 2 restart), restarts,
  * max_restarts, xcur, xopt, iter; step 1 takes totals[2] (main.cpp:14493), step 2 totals[7] (14558-14601) */
 int cup3d_debug_ctl_step(int step, double *io, const double *totals);
+/* the multigrid option's level hierarchies of all `nranks` ranks for the leaf ownership `owner[nblocks]` of a global multi-level mesh,
+ * checked against each other (tables in range, exchange plans symmetric node for node, every ancestor's octants complete); no GPU */
+int cup3d_debug_mg_plan_check(const cup3d_grid_t *mesh, const int32_t *owner, int nranks);
 
 /* HOST-MEMORY TRANSPORT in RCCL's place: one process per rank as in production, but every exchange of the library (face slabs, ghost
  * blocks, face fluxes, block migration, scalar all-reduces) is staged through host memory and carried by the CALLER's transport --

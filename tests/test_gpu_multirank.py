@@ -293,6 +293,63 @@ def test_multilevel_mesh_over_ranks_projection(name, nranks, kind):
     assert np.abs(got_v2 - v2).max() <= 1e-6 * max(corr, np.abs(v2 - v).max())
 
 
+@pytest.mark.parametrize("nranks,kind", [(2, "ranges"), (3, "ranges"), (3, "scattered"), (5, "scattered")])
+@pytest.mark.parametrize("name", ["l012_wall", "l012_periodic", "l012_box322"])
+def test_multigrid_on_a_multilevel_mesh_over_ranks(name, nranks, kind):
+    """block_solver 5 on a multi-level mesh SPREAD OVER RANKS: one V-cycle over all ranks on the octree's levels.  Every rank holds its
+    owned nodes of every level (leaves + ancestors; an ancestor lives with its first child) plus ghost nodes; the iterate's ghost nodes are
+    refreshed before every launch that reads them, restricted octants travel to remote parents, prolongation and coarse/fine ghosts read
+    the remote parent's final iterate (Grid::mg_hierarchy, multigrid.hip).  Below the level-0 mean (one all-reduce instead of one
+    workgroup's sum) the distributed cycle computes what the one-rank cycle computes:
+      * ONE application M^-1 r (cup3d_preconditioner) equals the one-rank application to rounding of that mean (1e-13 of the result);
+      * the projection with it: the same pressure as the one-rank multigrid run to 1e-8, the same iteration count (+-1), every rank on the
+        same path."""
+    bpd, lmax, bc, lv, zs = _mesh_case(name)
+    mesh = cu.operators.Grid(bpd, lmax, 0, EXT, bc, leaves=(lv, zs))
+    nb = mesh.nblocks
+    owner = _owners(nb, nranks, kind, seed=3 + len(name))
+    rng = np.random.default_rng(21)
+    r0 = rng.uniform(-1, 1, (nb, 8, 8, 8))
+    vel0, pres0 = rng.uniform(-1, 1, (nb, 8, 8, 8, 3)), rng.uniform(-1, 1, (nb, 8, 8, 8))
+    dt = 0.01
+    kw = dict(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=0, extent=EXT, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], nu=0.02,
+              poissonTol=1e-11, poissonTolRel=1e-10, blockSolver=5)
+    one = cu.SimulationData(leaves=(lv, zs), **kw)
+    one.upload("pres", r0)
+    check(lib().cup3d_preconditioner(one.handle, 5))
+    z_one = one.download("pres")
+    one.upload("vel", vel0); one.upload("pres", pres0)
+    one.step = 5
+    res_one = cu.PressureProjection(one)(dt)
+    v_one, p_one = one.download("vel"), one.download("pres")
+    z, v, p = np.zeros_like(z_one), np.zeros_like(v_one), np.zeros_like(p_one)
+    its = [None] * nranks
+    with VirtualComm(nranks):
+        views = [mesh.rank_view(owner, r, nranks) for r in range(nranks)]
+        sims = [cu.SimulationData(view=views[r], **kw) for r in range(nranks)]
+
+        def rank(r):
+            s, vw = sims[r], views[r]
+            mine = vw.global_slot[:vw.nlocal]
+            s.upload("pres", r0[mine])
+            check(lib().cup3d_preconditioner(s.handle, 5))
+            z[mine] = s.download("pres")
+            s.upload("vel", vel0[mine]); s.upload("pres", pres0[mine])
+            s.step = 5
+            res = cu.PressureProjection(s)(dt)
+            its[r] = (res.iterations, res.restarts)
+            v[mine], p[mine] = s.download("vel"), s.download("pres")
+
+        run_ranks(rank, nranks)
+        del sims, views
+    assert np.abs(z - z_one).max() <= 1e-12 * np.abs(z_one).max(), np.abs(z - z_one).max() / np.abs(z_one).max()
+    assert len(set(its)) == 1, its
+    print(f"{name} on {nranks} ranks ({kind}): {its[0][0]} iterations, one rank {res_one.iterations}")
+    assert abs(its[0][0] - res_one.iterations) <= 1, (its, res_one.iterations)
+    assert np.abs(p - p_one).max() <= 1e-8 * np.abs(p_one).max()
+    assert np.abs(v - v_one).max() <= 1e-8 * np.abs(v_one - vel0).max()
+
+
 # ------------------------------------------------------------------ mesh adaptation over ranks: the LoadBalancer's block traffic
 def _states_from_tables(old, new):
     """valid states of the old leaves that turn the old block list into the new one"""

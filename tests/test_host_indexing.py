@@ -479,3 +479,40 @@ def test_rank_views_of_a_multilevel_mesh(golden_dir, nranks):
                 got_f[pos_f:pos_f + len(sentf)] = sentf
                 pos_f += len(sentf)
             assert np.array_equal(got_b, v.global_slot) and np.array_equal(got_f, v.global_face), (name, r)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_multigrid_hierarchies_of_all_ranks_fit_together(seed):
+    """The multigrid option on a multi-level mesh spread over ranks (multigrid.hip on rank views): every rank's level hierarchy -- owned
+    nodes (leaves + ancestors, an ancestor living with its first child), ghost nodes, neighbour / parent / coarse-fine tables, the ghost
+    exchange plan and the restriction-octant plan -- built by Grid::mg_hierarchy and cross-checked by cup3d_debug_mg_plan_check: tables
+    in range, what r sends to p is node for node what p expects from r, every owned ancestor receives each of its eight octants exactly
+    once.  Random balanced meshes (2-4 levels, mixed boundary conditions, non-cubic boxes) under contiguous (Hilbert-range-like) AND
+    scattered ownership on 1-7 ranks."""
+    rng = np.random.default_rng(1000 + seed)
+    bpd = tuple(int(v) for v in rng.choice([1, 2, 3], 3))
+    if bpd == (1, 1, 1):
+        bpd = (2, 1, 2)
+    lmax = int(rng.choice([3, 4]))
+    bc = tuple(str(b) for b in rng.choice(["periodic", "wall", "freespace"], 3))
+    refine = []
+    for l in range(lmax - 1):          # refine a few random blocks per level (build_balanced_mesh keeps the 2:1 balance)
+        n = [b << l for b in bpd]
+        for _ in range(int(rng.integers(1, 4))):
+            refine.append((l, int(rng.integers(0, n[0])), int(rng.integers(0, n[1])), int(rng.integers(0, n[2]))))
+    try:
+        lv, zs = O.build_balanced_mesh(bpd, lmax, bc, refine)
+    except Exception:
+        pytest.skip("the random refinement list named a block that no longer exists")
+    g = cu.operators.Grid(bpd, lmax, 0, 2 * np.pi, bc, leaves=(lv, zs))
+    nb = g.nblocks
+    assert L.cup3d_debug_mg_plan_check(g.handle, None, 1) == 0, L.cup3d_last_error().decode()
+    for nranks in (2, 3, 7):
+        if nranks > nb:
+            continue
+        contiguous = (np.arange(nb) * nranks // nb).astype(np.int32)
+        scattered = rng.integers(0, nranks, nb).astype(np.int32)
+        scattered[:nranks] = np.arange(nranks)       # every rank owns something
+        for owner in (contiguous, scattered):
+            ow = np.ascontiguousarray(owner)
+            assert L.cup3d_debug_mg_plan_check(g.handle, ow.ctypes.data_as(C.c_void_p), nranks) == 0, (nranks, L.cup3d_last_error().decode())
