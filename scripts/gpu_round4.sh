@@ -152,6 +152,9 @@ print("  value", r["value"], "ms/step", r["ms_per_step"], "its/step", r["config"
 for k in r["kernels"][:6]: print("   ", k["kernel"], k["launches"], k["avg_ms"], k["share"])
 PY
   done; fi
+if has mgtests; then echo "== pytest: the multigrid tests (one rank, over ranks, multi-level)"
+  timeout 1200 python -m pytest tests/test_gpu_multirank.py tests/test_gpu_amr.py tests/test_gpu_parity.py -m gpu -q -s -k "multigrid" --durations=5 > $OUT/pytest_multigrid.log 2>&1 ; echo "pytest rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert|iterations" $OUT/pytest_multigrid.log | tail -40 | cut -c1-400; fi
 if has trace; then echo "== rocprofv3 kernel trace of the driver's bench"
   cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/trace -o fullstep -- python $OLDPWD/bench.py --steps ${TRACE_STEPS:-20} --warmup 5 --no-cpu --no-alt --no-pcie > $OLDPWD/$OUT/trace_bench.json 2> $OLDPWD/$OUT/trace.err ; echo "trace rc=$?"; cd $OLDPWD
   find $OUT/trace -name "*kernel_stats.csv" | head -2 | while read f; do head -12 "$f" | cut -c1-220; done
