@@ -5,8 +5,10 @@
 // BiCGSTAB driver, the same operator A = h (sum6 - 6 p) (KernelLHSPoisson, 9205-9215), the same mean constraint and the same
 // stopping rule -- so the CONVERGED pressure is the reference's to solver tolerance (tests), while the iteration count drops
 // from O(150) to O(10) at 512^3.  bench.py reports it under `alt_multigrid`, never as `value`.  Uniform grids (over several ranks the
-// levels exchange face slabs before every launch, see mg_setup) and multi-level meshes on one rank (mg_setup_amr: the octree's own
-// levels are the hierarchy; restriction / prolongation across the refinement levels, AverageDown / TestInterp's place, main.cpp:3877-3906).
+// levels exchange face slabs before every launch, see mg_setup) and multi-level meshes (mg_setup_amr: the octree's own levels are the
+// hierarchy; restriction / prolongation across the refinement levels, AverageDown / TestInterp's place, main.cpp:3877-3906) -- on one rank
+// and spread over ranks (rank views: every rank holds its owned nodes of every level + ghost nodes, Grid::mg_hierarchy; mg_ghosts /
+// mg_restrict_exchange carry the iterate and the restricted octants between ranks).
 //
 // One application M^-1 r = one V(2,2)-cycle from a zero guess on the hierarchy of uniform block grids, level L (the solver's grid)
 // down to level 0 (the bpd[0] x bpd[1] x bpd[2] box of 8^3 blocks):

@@ -219,7 +219,8 @@ typedef struct {
                               same operator, same stopping rule, same converged pressure to solver tolerance, O(10) instead of O(150)
                               iterations; uniform grids (over several ranks ONE cycle coupled over the ranks: every level is partitioned
                               like the solver's grid and its iterate crosses ranks as face slabs before each launch that reads
-                              ghosts) and multi-level meshes on one rank (the octree's levels); bench.py: `alt_multigrid` only */
+                              ghosts) and multi-level meshes (the octree's levels; over ranks: rank views, ghost nodes exchanged before
+                              every launch that reads them); bench.py: `alt_multigrid` only */
 } cup3d_poisson_params;
 typedef struct {
   int iterations; /* BiCGSTAB iterations performed (= 7-double reductions, main.cpp:14546) */
