@@ -45,7 +45,7 @@ for k in ("OMP_PROC_BIND", "GOMP_CPU_AFFINITY", "OMP_PLACES"):
 # instead of the 256^3-effective one the suite runs by default (820 blocks); the limits scale with it
 BIG = int(os.environ.get("CUP3D_CONFIGS4_LEVELMAX", "5"))
 RUN_LIMIT = 240 if BIG <= 5 else 1500   # seconds per launch of the harness; the longest one takes 10-40 s when the GPU switches between the ranks quickly
-STALL_LIMIT = 90 if BIG <= 5 else 600  # ... and seconds without a single line of output before the launch counts as HUNG (a failure, not a skip)
+STALL_LIMIT = 150 if BIG <= 5 else 600  # ... and seconds without a single line of output before the launch counts as HUNG (a failure, not a skip)
 
 
 def _all_cpus():   # the ranks must not inherit a narrowed affinity mask from whatever ran in this process before

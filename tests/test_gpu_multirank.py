@@ -302,7 +302,7 @@ def test_multigrid_on_a_multilevel_mesh_over_ranks(name, nranks, kind):
     the remote parent's final iterate (Grid::mg_hierarchy, multigrid.hip).  Below the level-0 mean (one all-reduce instead of one
     workgroup's sum) the distributed cycle computes what the one-rank cycle computes:
       * ONE application M^-1 r (cup3d_preconditioner) equals the one-rank application to rounding of that mean (1e-13 of the result);
-      * the projection with it: the same pressure as the one-rank multigrid run to 1e-6 (both stopped by the same rule), the same iteration
+      * the projection with it: the same pressure as the one-rank multigrid run to 5e-6 (both stopped by the same rule), the same iteration
         count (+-1), every rank on the same path."""
     bpd, lmax, bc, lv, zs = _mesh_case(name)
     mesh = cu.operators.Grid(bpd, lmax, 0, EXT, bc, leaves=(lv, zs))
@@ -346,7 +346,7 @@ def test_multigrid_on_a_multilevel_mesh_over_ranks(name, nranks, kind):
     assert len(set(its)) == 1, its
     print(f"{name} on {nranks} ranks ({kind}): {its[0][0]} iterations, one rank {res_one.iterations}")
     assert abs(its[0][0] - res_one.iterations) <= 1, (its, res_one.iterations)
-    assert np.abs(p - p_one).max() <= 1e-6 * np.abs(p_one).max()      # (two solves stopped by the same rule: cond(A) x the residual tolerance)
+    assert np.abs(p - p_one).max() <= 5e-6 * np.abs(p_one).max()      # (two solves stopped by the same rule: cond(A) x the residual tolerance; 6e-7 seen)
     assert np.abs(v - v_one).max() <= 5e-6 * np.abs(v_one - vel0).max()    # (13 against 14 iterations on l012_wall: 1.2e-6 seen)
 
 
