@@ -691,7 +691,7 @@ def run(a, prog):
         os.environ["CUP3D_HIP_FLAVOUR"] = "testing"   # A/B switches live in libcup3d_hip_testing.so only; everything else times the release build
     if a.amr:
         if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-            sys.exit("bench.py --amr runs on one GPU (multi-level meshes are single-rank this round)")
+            sys.exit("bench.py --amr runs on one GPU: it builds its mesh there (multi-level meshes over ranks are covered by tests/test_gpu_multirank.py and the MPI drop-in tests)")
         return run_amr(a)
 
     # RCCL prints a version banner to STDOUT under NCCL_DEBUG=VERSION (the image's default), once per process and communicator
