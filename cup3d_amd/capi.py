@@ -131,6 +131,7 @@ SIGNATURES = {
     "cup3d_grid_rank_view": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "cup3d_grid_view_sizes": (C.c_int, [_vp, _vp]),
     "cup3d_grid_view_plan": (C.c_int, [_vp] * 9),
+    "cup3d_grid_view_boxes": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "cup3d_sim_upload_block_list": (C.c_int, [_vp, C.c_int, C.c_long, _vp, _vp]),
     "cup3d_sim_download_block_list": (C.c_int, [_vp, C.c_int, C.c_long, _vp, _vp]),
     "cup3d_advect_diffuse_implicit": (C.c_int, [_vp, C.c_double, C.c_double, _dp, C.POINTER(PoissonParams), C.POINTER(PoissonResult)]),

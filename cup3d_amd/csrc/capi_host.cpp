@@ -128,6 +128,18 @@ int cup3d_grid_view_plan(const cup3d_grid_t *gh, int32_t *global_slot, int32_t *
   }
   return CUP3D_OK;
 }
+int cup3d_grid_view_boxes(const cup3d_grid_t *gh, int k, unsigned char *ghost_box, unsigned char *send_box, long *send_cells, long *recv_cells) {
+  if (!gh || k < 0 || k > 1) return CUP3D_EINVAL;
+  const Grid *g = reinterpret_cast<const Grid *>(gh);
+  if (g->n_local < 0 || g->send_cells[k].empty()) { set_error("cup3d_grid_view_boxes: not a rank view with a sub-box plan"); return CUP3D_EINVAL; }
+  if (ghost_box && !g->ghost_box[k].empty()) memcpy(ghost_box, g->ghost_box[k].data(), g->ghost_box[k].size());
+  if (send_box && !g->send_box[k].empty()) memcpy(send_box, g->send_box[k].data(), g->send_box[k].size());
+  for (int p = 0; p < g->nranks; ++p) {
+    if (send_cells) send_cells[p] = (long)g->send_cells[k][p];
+    if (recv_cells) recv_cells[p] = (long)g->recv_cells[k][p];
+  }
+  return CUP3D_OK;
+}
 int cup3d_grid_valid_states(const cup3d_grid_t *gh, signed char *states) {
   if (!gh || !states) return CUP3D_EINVAL;
   const Grid *g = reinterpret_cast<const Grid *>(gh);

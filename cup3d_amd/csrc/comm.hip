@@ -260,6 +260,38 @@ __global__ void __launch_bounds__(64) k_pack_flux(const double *__restrict__ flu
   for (int c = 0; c < nfc; ++c) dst[c * 64 + threadIdx.x] = src[c * 64 + threadIdx.x];
 }
 
+// sub-box form: block i of the list contributes the cells of its box ([c][z][y][x] over the box) at offset off[i] * nc of the message
+__global__ void __launch_bounds__(256) k_pack_boxes(const double *__restrict__ field, const int32_t *__restrict__ slots, const unsigned char *__restrict__ box,
+                                                    const long long *__restrict__ off, int nc, double *__restrict__ out) {
+  const int i = blockIdx.x;
+  const unsigned char *b = box + 6 * i;
+  const int nx = b[3] - b[0], ny = b[4] - b[1], nz = b[5] - b[2], vol = nx * ny * nz;
+  if (vol == 0) return;
+  const double *src = field + (size_t)slots[i] * nc * 512;
+  double *dst = out + (size_t)off[i] * nc;
+  for (int j = threadIdx.x; j < vol * nc; j += 256) {
+    const int c = j / vol, q = j - c * vol, x = q % nx, y = (q / nx) % ny, z = q / (nx * ny);
+    dst[j] = src[c * 512 + (b[2] + z) * 64 + (b[1] + y) * 8 + (b[0] + x)];
+  }
+}
+// ... and arrives in the box of ghost block i (slots first_ghost + i of the field)
+__global__ void __launch_bounds__(256) k_unpack_boxes(double *__restrict__ ghosts, const unsigned char *__restrict__ box, const long long *__restrict__ off, int nc,
+                                                      const double *__restrict__ in) {
+  const int i = blockIdx.x;
+  const unsigned char *b = box + 6 * i;
+  const int nx = b[3] - b[0], ny = b[4] - b[1], nz = b[5] - b[2], vol = nx * ny * nz;
+  if (vol == 0) return;
+  double *dst = ghosts + (size_t)i * nc * 512;
+  const double *src = in + (size_t)off[i] * nc;
+  for (int j = threadIdx.x; j < vol * nc; j += 256) {
+    const int c = j / vol, q = j - c * vol, x = q % nx, y = (q / nx) % ny, z = q / (nx * ny);
+    dst[c * 512 + (b[2] + z) * 64 + (b[1] + y) * 8 + (b[0] + x)] = src[j];
+  }
+}
+__global__ void __launch_bounds__(256) k_poison(double *__restrict__ p, size_t n) {  // TEST SUPPORT ("poison_ghosts"): quiet NaNs
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = __builtin_nan("");
+}
+
 // items of `per` doubles: packed send buffer -> peers; received runs land contiguously at dst.  RCCL on the communication stream
 // (compute stream <-> communication stream hand-off by events), or the in-process transport.
 static size_t sent_bytes(const std::vector<int64_t> &send_count, size_t per, int skip = -1) {
@@ -267,11 +299,15 @@ static size_t sent_bytes(const std::vector<int64_t> &send_count, size_t per, int
   for (size_t p = 0; p < send_count.size(); ++p) if ((int)p != skip) n += (size_t)send_count[p];
   return n * per * sizeof(double);
 }
-static int view_transfer(Sim *s, double *dst, size_t per, const std::vector<int64_t> &send_count, const std::vector<int64_t> &recv_count, bool flux) {
+// kind: which of the view's plans the counts belong to (the in-process test transport looks the SENDER's counts up by it)
+enum ViewPlan { kPlanBlocks = 0, kPlanFlux = 1, kPlanBoxes1 = 2, kPlanBoxes3 = 3 };
+static int view_transfer(Sim *s, double *dst, size_t per, const std::vector<int64_t> &send_count, const std::vector<int64_t> &recv_count, ViewPlan kind) {
   const Grid *g = s->grid;
   stats_halo(sent_bytes(send_count, per));
   if (g_vcomm) {
-    if (flux) return vcomm_pull(s, dst, per, recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_flux_count; }, exchange_stream(s));
+    if (kind == kPlanFlux) return vcomm_pull(s, dst, per, recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_flux_count; }, exchange_stream(s));
+    if (kind == kPlanBoxes1) return vcomm_pull(s, dst, per, recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_cells[0]; }, exchange_stream(s));
+    if (kind == kPlanBoxes3) return vcomm_pull(s, dst, per, recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_cells[1]; }, exchange_stream(s));
     return vcomm_pull(s, dst, per, recv_count, [](const Grid *q) -> const std::vector<int64_t> & { return q->send_block_count; }, exchange_stream(s));
   }
   if (g_ht_on) return ht_exchange(s->halo_send, send_count, dst, recv_count, per, -1, exchange_stream(s));
@@ -291,7 +327,7 @@ static int view_transfer(Sim *s, double *dst, size_t per, const std::vector<int6
 }
 
 // begin: pack + transfer enqueued (on the communication stream with RCCL; ev_h2 marks the arrival); finish: the compute stream waits
-static int view_exchange_blocks_begin(Sim *s, double *field, int nc) {
+static int view_exchange_blocks_begin(Sim *s, double *field, int nc, int w) {
   const Grid *g = s->grid;
   hipStream_t st = exchange_stream(s);
   if (st != stream()) {
@@ -299,11 +335,27 @@ static int view_exchange_blocks_begin(Sim *s, double *field, int nc) {
     CUP3D_HIP(hipStreamWaitEvent(st, s->ev_h1, 0));
   }
   ProfileScope ps("comm_ghost_blocks", st);  // pack + transfer as the communication stream sees them
-  const unsigned nsend = (unsigned)g->send_blocks.size();
-  if (nsend) hipLaunchKernelGGL(k_pack_blocks, dim3(nsend), dim3(256), 0, st, field, s->d_send_blocks, nc, s->halo_send);
-  CUP3D_HIP(hipGetLastError());
-  int rc = view_transfer(s, field + (size_t)g->n_local * nc * 512, (size_t)nc * 512, g->send_block_count, g->recv_block_count, false);
-  if (rc) return rc;
+  const unsigned nsend = (unsigned)g->send_blocks.size(), nghost = (unsigned)g->nghost();
+  const int k = w == 3 ? 1 : 0;
+  int rc;
+  if (!g->send_cells[k].empty() && s->d_send_box[k] && !debug_option("whole_ghost_blocks")) {
+    // sub-box form (what the reference ships: SynchronizerMPI_AMR's face sub-boxes and coarse shadow cells, main.cpp:1832-1966,
+    // 2423-2544): of every ghost block only the box of cells the width-w star consumers read (Grid::ghost_box) -- packed, sent, scattered
+    if (nsend) hipLaunchKernelGGL(k_pack_boxes, dim3(nsend), dim3(256), 0, st, (const double *)field, (const int32_t *)s->d_send_blocks, (const unsigned char *)s->d_send_box[k],
+                                  (const long long *)s->d_send_off[k], nc, s->halo_send);
+    CUP3D_HIP(hipGetLastError());
+    if ((rc = view_transfer(s, s->box_recv, (size_t)nc, g->send_cells[k], g->recv_cells[k], k ? kPlanBoxes3 : kPlanBoxes1))) return rc;
+    double *ghosts = field + (size_t)g->n_local * nc * 512;
+    if (debug_option("poison_ghosts") && nghost)  // tests: whatever is NOT shipped reads as NaN, so a consumer outside its box cannot go unnoticed
+      hipLaunchKernelGGL(k_poison, dim3(256), dim3(256), 0, st, ghosts, (size_t)nghost * nc * 512);
+    if (nghost) hipLaunchKernelGGL(k_unpack_boxes, dim3(nghost), dim3(256), 0, st, ghosts, (const unsigned char *)s->d_ghost_box[k], (const long long *)s->d_ghost_off[k], nc,
+                                   (const double *)s->box_recv);
+    CUP3D_HIP(hipGetLastError());
+  } else {
+    if (nsend) hipLaunchKernelGGL(k_pack_blocks, dim3(nsend), dim3(256), 0, st, field, s->d_send_blocks, nc, s->halo_send);
+    CUP3D_HIP(hipGetLastError());
+    if ((rc = view_transfer(s, field + (size_t)g->n_local * nc * 512, (size_t)nc * 512, g->send_block_count, g->recv_block_count, kPlanBlocks))) return rc;
+  }
   if (st != stream()) CUP3D_HIP(hipEventRecord(s->ev_h2, st));
   return CUP3D_OK;
 }
@@ -314,10 +366,10 @@ static int view_exchange_blocks_finish(Sim *s) {
   }
   return CUP3D_OK;
 }
-int view_exchange_blocks(Sim *s, double *field, int nc) {
+int view_exchange_blocks(Sim *s, double *field, int nc, int w) {
   const Grid *g = s->grid;
   if (g->n_local < 0 || g->nranks == 1) return CUP3D_OK;
-  int rc = view_exchange_blocks_begin(s, field, nc);
+  int rc = view_exchange_blocks_begin(s, field, nc, w);
   if (rc) return rc;
   return view_exchange_blocks_finish(s);
 }
@@ -334,7 +386,7 @@ int view_exchange_flux(Sim *s, int nfc) {
   const unsigned nsend = (unsigned)g->send_flux_faces.size();
   if (nsend) hipLaunchKernelGGL(k_pack_flux, dim3(nsend), dim3(64), 0, st, s->d_flux, s->d_send_flux, nfc, s->halo_send);
   CUP3D_HIP(hipGetLastError());
-  int rc = view_transfer(s, s->d_flux + (size_t)g->n_local_faces * nfc * 64, (size_t)nfc * 64, g->send_flux_count, g->recv_flux_count, true);
+  int rc = view_transfer(s, s->d_flux + (size_t)g->n_local_faces * nfc * 64, (size_t)nfc * 64, g->send_flux_count, g->recv_flux_count, kPlanFlux);
   if (rc) return rc;
   if (st != stream()) {
     CUP3D_HIP(hipEventRecord(s->ev_h2, st));
@@ -432,7 +484,7 @@ int halo_begin(Sim *s, const double *field, int nc, int w) {
     if (g->n_local < 0 || g->nranks == 1) return amr_fill_ghosts(s, field, nc, w, s->halo_recv);
     // a rank view: the ghost blocks travel on the communication stream while the slabs of the inner blocks' faces are produced and
     // the caller launches its kernel on the inner blocks (gdev(inner_only)); halo_finish() waits and produces the rest
-    int rc = view_exchange_blocks_begin(s, const_cast<double *>(field), nc);
+    int rc = view_exchange_blocks_begin(s, const_cast<double *>(field), nc, w);
     if (rc) return rc;
     s->pending_fill.field = field; s->pending_fill.nc = nc; s->pending_fill.w = w; s->pending_fill.slabs = s->halo_recv; s->pending_fill.bc_dir = s->scalar_bc_dir; s->pending_fill.open = true;
     return amr_fill_ghosts(s, field, nc, w, s->halo_recv, 1);

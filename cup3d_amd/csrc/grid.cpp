@@ -1,4 +1,5 @@
 // See grid.hpp.
+#include <map>
 #include <memory>
 #include "grid.hpp"
 
@@ -257,6 +258,78 @@ Grid::Grid(const Grid &p, int)
 // reads through them on rank r is what it reads on one rank -- provided the ghost blocks / ghost face fluxes hold the owners' data,
 // which is what the two exchange plans are for.  (In the reference every rank keeps the whole octree too: Grid::Octree with the
 // owner in TreePosition, main.cpp:815-855; SynchronizerMPI_AMR::_Setup 1979-2286 derives its messages from it.)
+// The cells of REMOTE blocks that the star-stencil consumers of rank r's blocks read, for a stencil of width W (1 or 3), as one bounding
+// box per remote block (global slot -> lo[3], hi[3]).  Each consumer's index arithmetic is replayed here exactly:
+//   * a stencil kernel's tile: the W layers of a same-level face neighbour behind the shared face;
+//   * k_ghost_restrict (amr.hip): the 2W layers of the four finer leaves behind a face;
+//   * k_ghost_prolong (amr.hip): the coarse shadow patch of W layers x 6 x 6 behind a face whose neighbour is coarser -- cells of coarser
+//     leaves, and 2x2x2 averages over cells of same-level edge / corner neighbours; domain faces clamp the patch as the kernel does.
+namespace {
+struct CellBox { uint8_t lo[3] = {8, 8, 8}, hi[3] = {0, 0, 0}; };
+}
+static void star_boxes(const Grid &G, const int32_t *owner, int r, int W, std::map<int32_t, CellBox> &boxes) {
+  auto mark = [&](int32_t slot, const int lo[3], const int hi[3]) {
+    if (owner[slot] == r) return;
+    CellBox &b = boxes[slot];
+    for (int d = 0; d < 3; ++d) {
+      if (lo[d] < 0 || hi[d] > 8 || lo[d] >= hi[d]) throw std::logic_error("star_boxes: a consumer's cell range leaves the block");
+      b.lo[d] = (uint8_t)std::min<int>(b.lo[d], lo[d]);
+      b.hi[d] = (uint8_t)std::max<int>(b.hi[d], hi[d]);
+    }
+  };
+  const int64_t nb = G.nblocks();
+  for (int64_t s = 0; s < nb; ++s) {
+    if (owner[s] != r) continue;
+    for (int f = 0; f < 6; ++f) {
+      const int32_t n = G.nbr[6 * s + f];
+      const int ax = f >> 1, side = f & 1;
+      if (n >= 0 && n < kNbrHalo) {  // same-level face neighbour: the W layers behind the shared face
+        int lo[3] = {0, 0, 0}, hi[3] = {8, 8, 8};
+        if (side) hi[ax] = W; else lo[ax] = 8 - W;
+        mark(n, lo, hi);
+      } else if (n >= kNbrHalo) {
+        const int32_t e = n - kNbrHalo;
+        if (G.amr_faces[2 * e + 1] == 1) {  // neighbour finer: k_ghost_restrict, layers n0 = side ? 2 gl : 6 - 2 gl (+1), gl < W
+          for (int B = 0; B < 4; ++B) {
+            const int32_t fe = G.amr_fine[4 * e + B];
+            if (fe < 0) continue;
+            int lo[3] = {0, 0, 0}, hi[3] = {8, 8, 8};
+            if (side) hi[ax] = 2 * W; else lo[ax] = 8 - 2 * W;
+            mark(G.amr_faces[2 * fe] / 6, lo, hi);
+          }
+        } else {  // neighbour coarser: the patch of k_ghost_prolong
+          const int ax1 = ax == 0 ? 1 : 0, ax2 = ax == 2 ? 1 : 2;
+          const int par[3] = {G.index[3 * s] & 1, G.index[3 * s + 1] & 1, G.index[3 * s + 2] & 1};
+          for (int L = 0; L < W; ++L)
+            for (int q = 0; q < 36; ++q) {
+              int P[3], code[3];
+              P[ax] = side ? 4 + L : -1 - L;
+              P[ax1] = q % 6 - 1;
+              P[ax2] = q / 6 - 1;
+              code[ax] = side ? 1 : -1;
+              for (int k = 0; k < 2; ++k) {
+                const int t = k ? ax2 : ax1;
+                int rg = P[t] < 0 ? -1 : (P[t] > 3 ? 1 : 0);
+                if (rg != 0 && G.nbr[6 * s + 2 * t + (rg > 0)] < 0) { P[t] = rg < 0 ? 0 : 3; rg = 0; }  // domain face: the face cell
+                code[t] = rg;
+              }
+              const int32_t v = G.nbr27[27 * s + (code[0] + 1) + 3 * (code[1] + 1) + 9 * (code[2] + 1)];
+              if (v >= kNbrCoarser) {
+                int lo[3], hi[3];
+                for (int d = 0; d < 3; ++d) { lo[d] = (par[d] * 4 + P[d] + 8) & 7; hi[d] = lo[d] + 1; }
+                mark(v - kNbrCoarser, lo, hi);
+              } else if (v >= 0) {  // avg_block(blk, 2 P - 8 code): a 2 x 2 x 2 cube
+                int lo[3], hi[3];
+                for (int d = 0; d < 3; ++d) { lo[d] = 2 * P[d] - 8 * code[d]; hi[d] = lo[d] + 2; }
+                mark(v, lo, hi);
+              }
+            }
+        }
+      }
+    }
+  }
+}
+
 std::unique_ptr<Grid> Grid::rank_view(const int32_t *owner, int rank_, int nranks_, bool tensorial) const {
   if (!multilevel || n_local >= 0) throw std::invalid_argument("rank_view needs a global multi-level mesh");
   if (!owner || nranks_ < 1 || rank_ < 0 || rank_ >= nranks_) throw std::invalid_argument("bad rank / nranks");
@@ -414,6 +487,45 @@ std::unique_ptr<Grid> Grid::rank_view(const int32_t *owner, int rank_, int nrank
     view_of(p, pg, pf);
     for (int32_t g : pg) if (owner[g] == rank_) { V.send_blocks.push_back(to_view[g]); V.send_block_count[p]++; }
     for (int32_t e : pf) if (owner[amr_faces[2 * e] / 6] == rank_) { V.send_flux_faces.push_back(face_to_view[e]); V.send_flux_count[p]++; }
+  }
+  // sub-box form of the ghost-block exchange: the boxes of my ghosts, and -- replaying every peer's consumers -- of what I send
+  if (!tensorial) {
+    for (int k = 0; k < 2; ++k) {
+      const int W = k ? 3 : 1;
+      std::map<int32_t, CellBox> mine;
+      star_boxes(*this, owner, rank_, W, mine);
+      V.ghost_box[k].assign(6 * ghost.size(), 0);
+      V.recv_cells[k].assign(nranks_, 0);
+      V.send_cells[k].assign(nranks_, 0);
+      for (size_t i = 0; i < ghost.size(); ++i) {
+        auto it = mine.find(ghost[i]);
+        if (it == mine.end()) continue;  // a ghost only the tensorial consumers or the tables name: nothing of it is read here
+        int64_t vol = 1;
+        for (int d = 0; d < 3; ++d) { V.ghost_box[k][6 * i + d] = it->second.lo[d]; V.ghost_box[k][6 * i + 3 + d] = it->second.hi[d]; vol *= it->second.hi[d] - it->second.lo[d]; }
+        V.recv_cells[k][owner[ghost[i]]] += vol;
+      }
+      for (auto &kv : mine)  // every block a consumer reads must be in the ghost list
+        if (to_view[kv.first] < 0) throw std::logic_error("rank_view: a star-stencil consumer reads a block that is not a ghost");
+      V.send_box[k].clear();
+      for (int p = 0; p < nranks_; ++p) {
+        if (p == rank_) continue;
+        std::map<int32_t, CellBox> theirs;
+        star_boxes(*this, owner, p, W, theirs);
+        view_of(p, pg, pf);
+        for (int32_t g : pg) {
+          if (owner[g] != rank_) continue;
+          uint8_t bx[6] = {0, 0, 0, 0, 0, 0};
+          auto it = theirs.find(g);
+          int64_t vol = 0;
+          if (it != theirs.end()) {
+            vol = 1;
+            for (int d = 0; d < 3; ++d) { bx[d] = it->second.lo[d]; bx[3 + d] = it->second.hi[d]; vol *= it->second.hi[d] - it->second.lo[d]; }
+          }
+          V.send_box[k].insert(V.send_box[k].end(), bx, bx + 6);
+          V.send_cells[k][p] += vol;
+        }
+      }
+    }
   }
   // the multigrid option's hierarchy of this rank (it needs the global mesh, which the view does not keep)
   if (!tensorial) {

@@ -8,6 +8,7 @@
 //     all the star-shaped hot-path stencils read; inner/halo block split (2196-2199).
 #pragma once
 #include <cstdint>
+#include <map>
 #include <memory>
 #include <vector>
 
@@ -127,6 +128,14 @@ struct Grid {
   std::vector<int64_t> send_block_count, recv_block_count;   // [nranks]
   std::vector<int32_t> send_flux_faces;   // local interface faces (fine side), in the receiver's ghost-face order
   std::vector<int64_t> send_flux_count, recv_flux_count;     // [nranks]
+  // Sub-box form of the ghost-block exchange (comm.hip): of a ghost block only the cells the rank's STAR-stencil consumers read travel
+  // -- the w layers behind a shared face (same-level neighbour), the 2w layers a restriction averages (finer leaf), the cells the coarse
+  // shadow patch of an interpolation takes (coarser leaves; same-level edge / corner neighbours averaged down).  Per stencil-width class
+  // k (0: w = 1, 1: w = 3) the bounding box of those cells, found by replaying the consumers' index arithmetic (grid.cpp, star_boxes):
+  // lo x, y, z, hi x, y, z (hi exclusive; lo = hi = 0: nothing is read).  Empty for tensorial views (mesh adaptation ships whole blocks).
+  std::vector<uint8_t> ghost_box[2];                  // [nghost][6], ghost order
+  std::vector<uint8_t> send_box[2];                   // [send_blocks.size()][6], send order
+  std::vector<int64_t> send_cells[2], recv_cells[2];  // [nranks]: cells (per component) to / from each peer
   // tensorial: also the finer leaves behind EDGE and CORNER positions become ghosts -- what the tensorial [-1,2) tile of mesh adaptation
   // (refine_1 / RefineBlocks) averages down; the star-shaped stencils of the time step never read them
   std::unique_ptr<Grid> rank_view(const int32_t *owner, int rank, int nranks, bool tensorial = false) const;

@@ -422,6 +422,25 @@ static int sim_build(Sim *s, const Grid *g) {
       if ((rc = up(&s->d_send_blocks, g->send_blocks)) || (rc = up(&s->d_send_flux, g->send_flux_faces))) return rc;
       const size_t need = std::max(g->send_blocks.size() * 1536, g->send_flux_faces.size() * 3 * 64);
       if (need) A(s->halo_send, need)
+      // sub-box form of the ghost-block exchange: boxes + packed-message offsets of both width classes, one staging buffer
+      size_t most = 0;
+      for (int k = 0; k < 2 && !g->send_cells[k].empty(); ++k) {
+        auto upload = [&](const std::vector<uint8_t> &box, unsigned char **d_box, long long **d_off, size_t *total) -> int {
+          std::vector<long long> off(box.size() / 6 + 1, 0);
+          for (size_t i = 0; i < box.size() / 6; ++i)
+            off[i + 1] = off[i] + (long long)(box[6 * i + 3] - box[6 * i]) * (box[6 * i + 4] - box[6 * i + 1]) * (box[6 * i + 5] - box[6 * i + 2]);
+          *total = (size_t)off.back();
+          CUP3D_HIP(hipMalloc((void **)d_box, std::max<size_t>(box.size(), 1)));
+          CUP3D_HIP(hipMalloc((void **)d_off, off.size() * sizeof(long long)));
+          if (!box.empty()) CUP3D_HIP(hipMemcpy(*d_box, box.data(), box.size(), hipMemcpyHostToDevice));
+          CUP3D_HIP(hipMemcpy(*d_off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice));
+          return CUP3D_OK;
+        };
+        size_t ts = 0, tr = 0;
+        if ((rc = upload(g->send_box[k], &s->d_send_box[k], &s->d_send_off[k], &ts)) || (rc = upload(g->ghost_box[k], &s->d_ghost_box[k], &s->d_ghost_off[k], &tr))) return rc;
+        most = std::max(most, tr);
+      }
+      if (most) A(s->box_recv, most * 3)
     }
   }
 #undef A
@@ -512,6 +531,11 @@ void cup3d_sim_destroy(cup3d_sim_t *h) {
   int32_t *ip[] = {s->d_nbr, s->d_inner, s->d_boundary, s->d_send_faces, s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_index,
                    s->d_restrict_list, s->d_prolong_list, s->d_fix_list[0], s->d_fix_list[1], s->d_fix_list[2], s->d_send_blocks, s->d_send_flux, s->d_raw_list, s->d_iface_list, s->d_plain_list};
   if (s->d_raw_mask) hipFree(s->d_raw_mask);
+  for (int k = 0; k < 2; ++k) {
+    void *bp[] = {s->d_send_box[k], s->d_ghost_box[k], s->d_send_off[k], s->d_ghost_off[k]};
+    for (void *p : bp) if (p) hipFree(p);
+  }
+  if (s->box_recv) hipFree(s->box_recv);
   for (int32_t *p : ip) if (p) hipFree(p);
   if (s->comm_stream) hipStreamDestroy(s->comm_stream);
   if (s->ev_a) hipEventDestroy(s->ev_a);

@@ -145,6 +145,11 @@ struct Sim {
   unsigned n_restrict_inner = 0, n_prolong_inner = 0;  // leading entries of the two lists that belong to inner blocks (rank views)
   struct { const double *field = nullptr; int nc = 0, w = 0, bc_dir = -1; double *slabs = nullptr; bool open = false; } pending_fill;  // halo_begin -> halo_finish
   int32_t *d_send_blocks = nullptr, *d_send_flux = nullptr;  // rank views: exchange plans (comm.hip)
+  // ... and the sub-box form of the ghost-block exchange (Grid::ghost_box / send_box), per stencil-width class: boxes, the offset (in cells
+  // per component) of every block's cells in the packed message, the staging buffer the messages arrive in before they are scattered
+  unsigned char *d_send_box[2] = {nullptr, nullptr}, *d_ghost_box[2] = {nullptr, nullptr};
+  long long *d_send_off[2] = {nullptr, nullptr}, *d_ghost_off[2] = {nullptr, nullptr};
+  double *box_recv = nullptr;
   unsigned char *d_raw_mask = nullptr;  // [nb], see GridDev::raw
   int32_t *d_raw_list = nullptr;        // the blocks with raw_mask set
   // multi-level mesh on one rank: blocks with an interface face (coarse/fine: ghost slabs, face fluxes, flux correction) and the rest,
@@ -187,7 +192,7 @@ hipStream_t scalar_stream(const Sim *s);  // the stream all-reduces are enqueued
 // rank views of a multi-level mesh: face-flux arrays of remote fine faces -> ghost face range of d_flux (before k_flux_fix)
 int view_exchange_flux(Sim *s, int nfc);
 // ... and whole blocks of `field` -> ghost slot range, before the ghost slabs of a stencil kernel are built (no-op elsewhere)
-int view_exchange_blocks(Sim *s, double *field, int nc);
+int view_exchange_blocks(Sim *s, double *field, int nc, int w);  // w: width of the star stencil that will read them (1 or 3)
 // generic exchange of `per`-double items between ranks (own rank included), peer-major buffers; compute stream
 int exchange_items(Sim *s, const double *sendbuf, const std::vector<int64_t> &send_count, double *recvbuf, const std::vector<int64_t> &recv_count, size_t per);
 void vcomm_register(Sim *s);    // in-process test communicator (comm.hip)

@@ -483,7 +483,7 @@ int cup3d_pressure_rhs(cup3d_sim_t *h, double dt) {
   double *halo_u = nullptr;
   if (obst && s->grid->multilevel) {
     halo_u = s->halo_recv + (size_t)s->grid->n_amr_faces() * 3 * 64;
-    if ((rc = view_exchange_blocks(s, s->tmpV, 3))) return rc;  // rank views: udef of the ghost blocks
+    if ((rc = view_exchange_blocks(s, s->tmpV, 3, 1))) return rc;  // rank views: udef of the ghost blocks
     if ((rc = amr_fill_ghosts(s, s->tmpV, 3, 1, halo_u))) return rc;
   } else if (obst && s->grid->nranks > 1) {
     // udef slabs go to the second half of the receive buffer (each exchange uses <= 3*64 per face of 9*64)

@@ -161,6 +161,13 @@ class RankView:
         self.nbr27 = np.zeros((self.nlocal, 27), dtype=np.int32)
         check(lib().cup3d_grid_interface(h, p(self.faces), p(self.fine), p(self.nbr27)))
         self.faces, self.fine = self.faces[:nf], self.fine[:nf]
+        # sub-box form of the ghost-block exchange, per stencil-width class (0: w = 1, 1: w = 3): boxes lo x,y,z / hi x,y,z and cells per rank
+        self.ghost_box, self.send_box, self.send_cells, self.recv_cells = [], [], [], []
+        for k in (0, 1):
+            gb, sb = np.zeros((max(self.nghost, 1), 6), dtype=np.uint8), np.zeros((max(nsb, 1), 6), dtype=np.uint8)
+            sc, rc = np.zeros(nranks, dtype=np.int64), np.zeros(nranks, dtype=np.int64)
+            check(lib().cup3d_grid_view_boxes(h, k, p(gb), p(sb), p(sc), p(rc)))
+            self.ghost_box.append(gb[:self.nghost]); self.send_box.append(sb[:nsb]); self.send_cells.append(sc); self.recv_cells.append(rc)
 
     def __del__(self):
         try:

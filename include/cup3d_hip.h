@@ -107,6 +107,12 @@ int cup3d_grid_view_sizes(const cup3d_grid_t *view, long out[6]);
  * peer-major order (each peer's run in that peer's ghost order), counts per rank; the same for the face-flux arrays */
 int cup3d_grid_view_plan(const cup3d_grid_t *view, int32_t *global_slot, int32_t *global_face, int32_t *send_blocks, long *send_block_count,
                          long *recv_block_count, int32_t *send_flux_faces, long *send_flux_count, long *recv_flux_count);
+/* The sub-box form of the ghost-block exchange (what SynchronizerMPI_AMR ships: face sub-boxes and coarse shadow cells, main.cpp:1832-1966,
+ * 2423-2544): of every ghost block only the bounding box of the cells the rank's star-stencil consumers read travels -- the w layers behind
+ * a shared face, the 2w layers a restriction averages, the cells of the coarse shadow patch of an interpolation.  width_class 0: stencil
+ * width 1, 1: width 3.  ghost_box[nghost][6], send_box[blocks sent][6] = lo x, y, z, hi x, y, z (hi exclusive; all zero: nothing of the
+ * block is read); send_cells[nranks] / recv_cells[nranks]: cells per component to / from every rank.  Any pointer may be NULL. */
+int cup3d_grid_view_boxes(const cup3d_grid_t *view, int width_class, unsigned char *ghost_box, unsigned char *send_box, long *send_cells, long *recv_cells);
 void cup3d_grid_destroy(cup3d_grid_t *);
 long cup3d_grid_nblocks(const cup3d_grid_t *);        /* local blocks = m_vInfo.size() */
 long cup3d_grid_nblocks_global(const cup3d_grid_t *);

@@ -158,6 +158,9 @@ if has mgtests; then echo "== pytest: the multigrid tests (one rank, over ranks,
 if has mgmpi; then echo "== configs[3] / configs[4] over real MPI ranks with the MULTIGRID preconditioner in the shim (CUP3D_HIP_BLOCK_SOLVER=5)"
   CUP3D_HIP_BLOCK_SOLVER=5 timeout 1500 python -m pytest tests/test_gpu_00_dropin_mpi.py -m gpu -q -s > $OUT/pytest_dropin_mpi_multigrid.log 2>&1 ; echo "pytest rc=$?"
   grep -E "configs|passed|failed|skipped|HUNG|Timeout|Error" $OUT/pytest_dropin_mpi_multigrid.log | tail -8 | cut -c1-600; fi
+if has viewtests; then echo "== pytest: everything on rank views (thread ranks with poisoned ghost cells; real MPI ranks)"
+  timeout 1500 python -m pytest tests/test_gpu_multirank.py tests/test_gpu_00_dropin_mpi.py -m gpu -q -s --durations=5 > $OUT/pytest_views.log 2>&1 ; echo "pytest rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert|sub-boxes|configs" $OUT/pytest_views.log | tail -30 | cut -c1-400; fi
 if has trace; then echo "== rocprofv3 kernel trace of the driver's bench"
   cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/trace -o fullstep -- python $OLDPWD/bench.py --steps ${TRACE_STEPS:-20} --warmup 5 --no-cpu --no-alt --no-pcie > $OLDPWD/$OUT/trace_bench.json 2> $OLDPWD/$OUT/trace.err ; echo "trace rc=$?"; cd $OLDPWD
   find $OUT/trace -name "*kernel_stats.csv" | head -2 | while read f; do head -12 "$f" | cut -c1-220; done

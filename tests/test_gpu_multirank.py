@@ -31,6 +31,16 @@ EXT = 2 * np.pi
 
 
 @pytest.fixture(scope="module", autouse=True)
+def _poison_the_cells_that_are_not_shipped():
+    """Every test of this file runs with `poison_ghosts`: after each sub-box ghost exchange of a rank view the ghost blocks hold NaN in every
+    cell that did not travel.  The tests compare with the one-rank oracle bit for bit, so a consumer that read a cell outside the box the
+    exchange plan gives its block (Grid::ghost_box) would turn them red."""
+    check(lib().cup3d_debug_set_option(b"poison_ghosts", 1))
+    yield
+    check(lib().cup3d_debug_set_option(b"poison_ghosts", 0))
+
+
+@pytest.fixture(scope="module", autouse=True)
 def _device():
     cu.device_init(0)
 
@@ -348,6 +358,66 @@ def test_multigrid_on_a_multilevel_mesh_over_ranks(name, nranks, kind):
     assert abs(its[0][0] - res_one.iterations) <= 1, (its, res_one.iterations)
     assert np.abs(p - p_one).max() <= 5e-6 * np.abs(p_one).max()      # (two solves stopped by the same rule: cond(A) x the residual tolerance; 6e-7 seen)
     assert np.abs(v - v_one).max() <= 5e-6 * np.abs(v_one - vel0).max()    # (13 against 14 iterations on l012_wall: 1.2e-6 seen)
+
+
+@pytest.mark.parametrize("name,nranks,kind", [("l012_wall", 3, "ranges"), ("l012_box322", 5, "scattered"), ("l012_periodic", 2, "ranges")])
+def test_sub_box_ghost_exchange_same_bits_fewer_bytes(name, nranks, kind):
+    """The ghost-block exchange of rank views in its sub-box form (only the box of cells the star-stencil consumers read: the w layers
+    behind a shared face, the 2w layers a restriction averages, the coarse shadow patch of an interpolation -- comm.hip, Grid::ghost_box)
+    against whole 8^3 ghost blocks (`whole_ghost_blocks`): advect-diffuse (width 3, vector), LHS, pressure RHS with chi / udef, gradP,
+    vorticity (width 1) give the SAME BITS -- with every cell that is not shipped poisoned with NaN (the module-wide `poison_ghosts`), so a
+    consumer reading outside its box could not go unnoticed -- and fewer bytes cross ranks."""
+    bpd, lmax, bc, lv, zs = _mesh_case(name)
+    mesh = cu.operators.Grid(bpd, lmax, 0, EXT, bc, leaves=(lv, zs))
+    nb = mesh.nblocks
+    owner = _owners(nb, nranks, kind, seed=11)
+    rng = np.random.default_rng(8)
+    f = dict(vel=rng.uniform(-1, 1, (nb, 8, 8, 8, 3)), pres=rng.uniform(-1, 1, (nb, 8, 8, 8)), udef=rng.uniform(-1, 1, (nb, 8, 8, 8, 3)),
+             chi=(rng.uniform(0, 1, (nb, 8, 8, 8)) > 0.7) * rng.uniform(0, 1, (nb, 8, 8, 8)))
+    dt, nu, uinf = 0.01, 0.02, (0.1, -0.2, 0.3)
+    kw = dict(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=0, extent=EXT, BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], nu=nu, uinf=uinf)
+    res, sent = {}, {}
+    for whole in (0, 1):
+        check(lib().cup3d_debug_set_option(b"whole_ghost_blocks", whole))
+        try:
+            got = {k: np.zeros((nb, 8, 8, 8, 3)) for k in ("adv", "gradp", "vort")}
+            got.update({k: np.zeros((nb, 8, 8, 8)) for k in ("lhs", "rhs")})
+            with VirtualComm(nranks):
+                views = [mesh.rank_view(owner, r, nranks) for r in range(nranks)]
+                sims = [cu.SimulationData(view=views[r], **kw) for r in range(nranks)]
+                lib().cup3d_stats_reset()
+
+                def rank(r):
+                    s, v = sims[r], views[r]
+                    mine = v.global_slot[:v.nlocal]
+                    s.upload("vel", f["vel"][mine])
+                    cu.AdvectionDiffusion(s)(dt)
+                    got["adv"][mine] = s.download("vel")
+                    s.upload("pres", f["pres"][mine])
+                    s.bMeanConstraint = 0
+                    cu.ComputeLHS(s)(0)
+                    got["lhs"][mine] = s.download("lhs")
+                    s.upload("vel", f["vel"][mine]); s.upload("tmpV", f["udef"][mine]); s.upload("chi", f["chi"][mine])
+                    check(lib().cup3d_pressure_rhs(s.handle, dt))
+                    got["rhs"][mine] = s.download("lhs")
+                    check(lib().cup3d_grad_p(s.handle, dt))
+                    got["gradp"][mine] = s.download("tmpV")
+                    cu.ComputeVorticity(s)(0)
+                    got["vort"][mine] = s.download("tmpV")
+
+                run_ranks(rank, nranks)
+                st = cu.capi.RunStats()
+                lib().cup3d_stats_read(C.byref(st))
+                sent[whole] = st.halo_bytes_sent
+                del sims, views
+            res[whole] = got
+        finally:
+            check(lib().cup3d_debug_set_option(b"whole_ghost_blocks", 0))
+    for k in res[0]:
+        assert not np.isnan(res[0][k]).any(), k
+        assert np.array_equal(res[0][k], res[1][k]), (name, nranks, kind, k)
+    print(f"{name} on {nranks} ranks ({kind}): {sent[0] / 1e6:.2f} MB in sub-boxes, {sent[1] / 1e6:.2f} MB as whole blocks (x{sent[1] / sent[0]:.2f})")
+    assert sent[0] < sent[1]
 
 
 # ------------------------------------------------------------------ mesh adaptation over ranks: the LoadBalancer's block traffic
