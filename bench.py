@@ -475,16 +475,14 @@ def cpu_baseline(size_cpu, steps, threads):
                       f"{sec:.2f} s, {its / steps:.1f} BiCGSTAB its/step"}
 
 
-def run_amr(a):
+def run_amr(a, prog=None, dist=None, rank=0, world=1):
     """--amr: the same step on a multi-level mesh the device builds itself.  A compact vortex on a uniform level; a few passes of
     Simulation.adaptMesh (vorticity tags -> ValidStates -> refine/compress on the device) refine around it; then K steps on the
-    frozen mesh are timed.  One GPU.  Reported beside the headline, not instead of it."""
+    frozen mesh are timed.  Reported beside the headline, not instead of it.  With --gpus N every rank builds the same mesh (the
+    adaptation is deterministic), takes its contiguous run of the block order (GridMPI's rule) as a RANK VIEW -- ghost blocks exchanged
+    in sub-boxes, face fluxes, all-reduced scalars -- and the line carries what crossed ranks per BiCGSTAB iteration."""
     import cup3d_amd as cu
-    from cup3d_amd.capi import ProfileEntry, check, lib
-    cu.device_init(0)
-    for opt in (a.debug_option or []):   # A/B switches (libcup3d_hip_testing.so): --debug-option name=value
-        name, val = opt.split("=")
-        check(lib().cup3d_debug_set_option(name.encode(), int(val)))
+    from cup3d_amd.capi import ProfileEntry, RunStats, check, lib
     ext, lmax, lstart = 2 * np.pi, a.amr_levels + a.amr_base, a.amr_base
     sim = cu.SimulationData(bpdx=1, bpdy=1, bpdz=1, levelMax=lmax, levelStart=lstart, extent=ext, nu=0.002, CFL=0.3, BC_x="wall", BC_y="wall",
                             BC_z="wall", rampup=0, blockSolver=a.block_solver)
@@ -509,50 +507,101 @@ def run_amr(a):
     lib().cup3d_device_synchronize()
     adapt_s = time.perf_counter() - t0
     sim = S.sim
+    nblocks_global = int(sim.nblocks)
+    tables = sim.grid.tables.copy()
+    nfaces = int(lib().cup3d_grid_ninterface_faces(sim.grid.handle))
+    comm = None
+    if world > 1:   # this rank's view of the mesh: its contiguous run of the block order + ghost blocks; the fields of its blocks
+        if prog is not None:
+            prog.set("grid", "rank views of the multi-level mesh")
+        owner = (np.arange(nblocks_global) * world // nblocks_global).astype(np.int32)
+        mesh = sim.grid
+        view = mesh.rank_view(owner, rank, world)
+        mine = view.global_slot[:view.nlocal]
+        vel = sim.download("vel")[mine]
+        vs = sim._like(view=view)
+        vs.upload("vel", vel)
+        a.view_sizes = {"local_blocks": int(view.nlocal), "ghost_blocks": int(view.nghost),
+                        "cells_received_per_exchange": {"width_1_sub_boxes": int(view.recv_cells[0].sum()), "width_3_sub_boxes": int(view.recv_cells[1].sum()),
+                                                        "whole_blocks": int(view.nghost) * 512}}
+        del S, sim, vel
+        sim = vs
+        S = cu.Simulation(sim)
     sim.step = 21
-    iters = []
+    iters, umax = [], []
 
     def one_step():
-        S.advance(S.calcMaxTimestep())
+        dt = S.calcMaxTimestep()
+        umax.append(float(sim.uMax_measured))
+        S.advance(dt)
         iters.append(sim.last_poisson.iterations)
+        if prog is not None:
+            prog.beat(f"step {len(iters)}")
 
+    def fence():
+        lib().cup3d_device_synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    if prog is not None:
+        prog.set("warmup")
     for _ in range(a.warmup):
         one_step()
     iters.clear()
     lib().cup3d_profile_enable(1)
     lib().cup3d_profile_reset()
-    lib().cup3d_device_synchronize()
+    lib().cup3d_stats_reset()
+    fence()
+    if prog is not None:
+        prog.set("timed")
     t0 = time.perf_counter()
     for _ in range(a.steps):
         one_step()
-    lib().cup3d_device_synchronize()
+    fence()
     sec = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([sec], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sec = float(t.item())
+        st = RunStats()
+        lib().cup3d_stats_read(C.byref(st))
+        nit = max(1, st.solver_iterations)
+        comm = {"ranks": world, "ghost_and_flux_exchanges_per_iteration": round(st.halo_exchanges / nit, 2),
+                "MB_sent_per_iteration (rank 0)": round(st.halo_bytes_sent / nit / 1e6, 4), "allreduces_per_iteration": round(st.allreduces / nit, 2),
+                "rank_0_view": getattr(a, "view_sizes", None),
+                "ghost_blocks_travel_as": "whole 8^3 blocks (A/B)" if any(o.startswith("whole_ghost_blocks=1") for o in (a.debug_option or [])) else "sub-boxes (Grid::ghost_box)",
+                "transport": "rccl" if a.transport == "rccl" else "host-memory TEST transport over gloo (a correctness run: bytes and counts are meaningful, the rate is not)"}
+    if rank != 0:
+        return None
     ents = (ProfileEntry * 64)()
     n = C.c_int(0)
     lib().cup3d_profile_read(ents, 64, C.byref(n))
     prof = {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n.value)}
-    total_ms = sum(ms for _, ms in prof.values()) or 1.0
-    cells = sim.nblocks * 512.0
-    t = sim.grid.tables
+    total_ms = sum(ms for k, (_, ms) in prof.items() if not k.startswith("comm_")) or 1.0   # shares of the compute stream's time
+    cells = nblocks_global * 512.0
+    cells_local = sim.nblocks * 512.0
+    t = tables
     kernels = []
     for name, (launches, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
-        if not launches:
+        if not launches or name.startswith("comm_"):
             continue
         e = {"kernel": name, "launches": launches, "avg_ms": round(ms / launches, 5), "share": round(ms / total_ms, 4)}
         if name in ALGO_BYTES:
             # the unfused AMR advect-diffuse stage reads vel and tmpV and writes tmpV only (72 B/cell); k_rk_update is its own entry
             bpc = 72.0 if name == "advdiff_stage" else ALGO_BYTES[name]
-            ach = bpc * cells / (ms / launches * 1e-3) / 1e9
+            ach = bpc * cells_local / (ms / launches * 1e-3) / 1e9
             e.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None})
         kernels.append(e)
     with_roof = [k for k in kernels if "achieved" in k]
     out = {"metric": "Mcell-updates/s (advect+diffuse+Poisson), multi-level AMR mesh", "value": round(cells * a.steps / sec / 1e6, 2),
-           "unit": "Mcell-updates/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(sec / a.steps * 1e3, 3),
+           "unit": "Mcell-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(sec / a.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"compact vortex in an all-wall box, uniform level {lstart} refined {a.amr_levels - 1}x around it by Simulation.adaptMesh "
                                   f"(top {a.amr_fraction:.0%} of the blocks by vorticity each pass), frozen mesh while timing",
-                      "blocks": int(sim.nblocks), "cells": int(cells), "blocks_per_level": {int(l): int((t[:, 0] == l).sum()) for l in sorted(set(t[:, 0].tolist()))},
-                      "interface_faces": int(lib().cup3d_grid_ninterface_faces(sim.grid.handle)), "block_history": history,
+                      "blocks": nblocks_global, "cells": int(cells), "blocks_per_level": {int(l): int((t[:, 0] == l).sum()) for l in sorted(set(t[:, 0].tolist()))},
+                      "interface_faces": nfaces, "block_history": history, "umax_by_step": umax[-a.steps:], "communication": comm,
+                      "bicgstab_iters_by_step": [int(i) for i in iters],
                       "finest_uniform_equivalent_cells": int((8 << (lmax - 1)) ** 3), "mesh_build_seconds": round(adapt_s, 3),
                       "bicgstab_iters_per_step": round(float(np.mean(iters)), 2),
                       "block_preconditioner": {0: "block CG (reference algorithm)", 1: "direct block solve (fast diagonalisation)",
@@ -657,7 +706,7 @@ def main():
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 and a.gpus > 1 and not a.amr:
+    if world == 1 and a.gpus > 1:
         return relaunch_under_torchrun(a.gpus, a.transport == "rccl", a)
     prog = Progress(rank, world, a)
     try:
@@ -689,11 +738,6 @@ def misbehave(a, prog, stage, rank):
 def run(a, prog):
     if a.no_fuse or a.debug_option or a.block_solver in (3, 4) or a.transport == "host":
         os.environ["CUP3D_HIP_FLAVOUR"] = "testing"   # A/B switches live in libcup3d_hip_testing.so only; everything else times the release build
-    if a.amr:
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-            sys.exit("bench.py --amr runs on one GPU: it builds its mesh there (multi-level meshes over ranks are covered by tests/test_gpu_multirank.py and the MPI drop-in tests)")
-        return run_amr(a)
-
     # RCCL prints a version banner to STDOUT under NCCL_DEBUG=VERSION (the image's default), once per process and communicator
     # library: stdout carries the one JSON line of rank 0 and nothing else
     if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
@@ -745,6 +789,14 @@ def run(a, prog):
             check(lib().cup3d_comm_init(rank, world, raw))
     a.tdev = "cpu"   # torch.distributed's own tensors (gloo)
     stage("grid", "topology, allocation")
+    if a.amr:
+        out = run_amr(a, prog, dist, rank, world)
+        if dist is not None:
+            if a.transport == "host":
+                lib().cup3d_debug_host_transport(0, 1, None)
+            lib().cup3d_comm_finalize()
+            dist.destroy_process_group()
+        return out
 
     nb1 = a.size // 8
     assert nb1 >= 2 and 8 * nb1 == a.size, "--size must be a multiple of 8"

@@ -161,6 +161,29 @@ if has mgmpi; then echo "== configs[3] / configs[4] over real MPI ranks with the
 if has viewtests; then echo "== pytest: everything on rank views (thread ranks with poisoned ghost cells; real MPI ranks)"
   timeout 1500 python -m pytest tests/test_gpu_multirank.py tests/test_gpu_00_dropin_mpi.py -m gpu -q -s --durations=5 > $OUT/pytest_views.log 2>&1 ; echo "pytest rc=$?"
   grep -E "passed|failed|FAILED|Error|assert|sub-boxes|configs" $OUT/pytest_views.log | tail -30 | cut -c1-400; fi
+if has amrranks; then echo "== bench --amr over ranks (host-memory TEST transport, one GPU): sub-boxes vs whole ghost blocks; block CG and multigrid"
+  for TAG2 in "subbox:" "whole:--debug-option whole_ghost_blocks=1" "multigrid:--block-solver 5"; do
+    NAME=${TAG2%%:*}; EXTRA=${TAG2#*:}
+    timeout 900 python bench.py --amr --gpus ${AMR_RANKS:-4} --transport host --steps 3 --warmup 1 $EXTRA > $OUT/bench_amr_${AMR_RANKS:-4}ranks_$NAME.json 2> $OUT/bench_amr_ranks_$NAME.err ; echo "rc=$? ($NAME)"
+    python - $OUT/bench_amr_${AMR_RANKS:-4}ranks_$NAME.json <<'PY'
+import json, sys
+try:
+    r = json.loads([l for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith("{")][-1])
+    c = r["config"]
+    print("  value", r.get("value"), "blocks", c.get("blocks"), "its", c.get("bicgstab_iters_by_step"), "umax", [round(u, 9) for u in c.get("umax_by_step", [])])
+    print("  comm", c.get("communication"))
+except Exception as e:
+    print("  (no JSON)", e, open(sys.argv[1]).read()[-600:])
+PY
+    tail -2 $OUT/bench_amr_ranks_$NAME.err | cut -c1-300
+  done
+  echo "-- the same on one rank"
+  timeout 600 python bench.py --amr --steps 3 --warmup 1 > $OUT/bench_amr_1rank.json 2>/dev/null; python - $OUT/bench_amr_1rank.json <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c = r["config"]
+print("  value", r["value"], "blocks", c["blocks"], "its", c.get("bicgstab_iters_by_step"), "umax", [round(u, 9) for u in c.get("umax_by_step", [])])
+PY
+fi
 if has trace; then echo "== rocprofv3 kernel trace of the driver's bench"
   cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/trace -o fullstep -- python $OLDPWD/bench.py --steps ${TRACE_STEPS:-20} --warmup 5 --no-cpu --no-alt --no-pcie > $OLDPWD/$OUT/trace_bench.json 2> $OLDPWD/$OUT/trace.err ; echo "trace rc=$?"; cd $OLDPWD
   find $OUT/trace -name "*kernel_stats.csv" | head -2 | while read f; do head -12 "$f" | cut -c1-220; done
