@@ -144,3 +144,28 @@ def test_a_rank_that_hangs_or_dies_yields_one_diagnostic_line(how, stage):
     stages = [p["stage"] for p in r["rank_progress"]]
     assert stage in stages, r      # the line says where the run was
     assert took < 200, took        # (25 s stall limit + start-up; a silent hang would sit here for the launcher's half hour)
+
+
+@pytest.mark.timeout(600)
+def test_bench_on_a_multilevel_mesh_over_rank_views():
+    """`bench.py --amr --gpus 2 --transport host`: every rank builds the multi-level mesh, takes its contiguous run of the block order as a
+    rank view (ghost blocks in sub-boxes, face fluxes, all-reduced scalars) and steps it.  Sub-boxes against whole ghost blocks
+    (`whole_ghost_blocks=1`): the same BiCGSTAB iteration counts and the same max|u| to the last bit -- the exchange form changes which
+    cells travel, not what is read -- with several times fewer bytes per iteration; the line says how the ghost blocks travelled."""
+    args = ("--amr", "--amr-base", "3", "--amr-levels", "3", "--gpus", "2", "--transport", "host", "--steps", "2", "--warmup", "1")
+    runs = {}
+    for name, extra in (("subbox", ()), ("whole", ("--debug-option", "whole_ghost_blocks=1"))):
+        out = run_bench(*args, *extra, timeout=500)
+        assert out.returncode == 0, out.stderr.decode()[-3000:]
+        lines = [l for l in out.stdout.decode().strip().splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout.decode()[-2000:]
+        runs[name] = json.loads(lines[0])
+    a, b = runs["subbox"]["config"], runs["whole"]["config"]
+    assert runs["subbox"]["n_gpus"] == 2 and a["blocks"] == b["blocks"] > 1000 and len(a["blocks_per_level"]) == 3
+    assert a["bicgstab_iters_by_step"] == b["bicgstab_iters_by_step"] and a["umax_by_step"] == b["umax_by_step"]
+    ca, cb = a["communication"], b["communication"]
+    assert "sub-boxes" in ca["ghost_blocks_travel_as"] and "whole" in cb["ghost_blocks_travel_as"]
+    assert ca["ghost_and_flux_exchanges_per_iteration"] == cb["ghost_and_flux_exchanges_per_iteration"] > 2
+    ratio = cb["MB_sent_per_iteration (rank 0)"] / ca["MB_sent_per_iteration (rank 0)"]
+    print(f"bench --amr on 2 rank views: {a['blocks']} blocks, {ca['MB_sent_per_iteration (rank 0)']} MB per iteration in sub-boxes, x{ratio:.2f} as whole blocks")
+    assert ratio > 2.5
