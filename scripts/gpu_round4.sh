@@ -184,6 +184,12 @@ r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c = r["config
 print("  value", r["value"], "blocks", c["blocks"], "its", c.get("bicgstab_iters_by_step"), "umax", [round(u, 9) for u in c.get("umax_by_step", [])])
 PY
 fi
+if has tracealt; then echo "== rocprofv3 kernel trace of the direct-solve iteration (block_solver 1, the `alt` of the bench)"
+  cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/tracealt -o alt -- python $OLDPWD/bench.py --block-solver 1 --steps 5 --warmup 2 --no-cpu --no-alt --no-pcie > $OLDPWD/$OUT/tracealt_bench.json 2> $OLDPWD/$OUT/tracealt.err ; echo "trace rc=$?"; cd $OLDPWD
+  find $OUT/tracealt -name "*kernel_stats.csv" | head -1 | while read f; do head -6 "$f" | cut -c1-200; done
+  find $OUT/tracealt -name "*kernel_trace.csv" -delete; find $OUT/tracealt -name "*.db" -delete
+  summ $OUT/tracealt_bench.json
+fi
 if has trace; then echo "== rocprofv3 kernel trace of the driver's bench"
   cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/trace -o fullstep -- python $OLDPWD/bench.py --steps ${TRACE_STEPS:-20} --warmup 5 --no-cpu --no-alt --no-pcie > $OLDPWD/$OUT/trace_bench.json 2> $OLDPWD/$OUT/trace.err ; echo "trace rc=$?"; cd $OLDPWD
   find $OUT/trace -name "*kernel_stats.csv" | head -2 | while read f; do head -12 "$f" | cut -c1-220; done
