@@ -397,6 +397,8 @@ def relaunch_under_torchrun(n, need_devices=True, a=None):
     import subprocess
     import torch
     have = torch.cuda.device_count()
+    if os.environ.get("CUP3D_BENCH_SHARE_DEVICE"):   # TEST hook (with CUP3D_RCCL_LIBRARY = the stand-in of tests/fake_rccl): ranks may share a device
+        need_devices = False
     if have < n and need_devices:
         sys.stderr.write(f"bench.py --gpus {n} needs {n} devices; {have} visible on this host\n")
         sys.exit(2)
@@ -755,7 +757,7 @@ def run(a, prog):
     from cup3d_amd.capi import ProfileEntry, RunStats, check, lib
 
     ndev = max(1, torch.cuda.device_count())
-    if a.transport == "rccl" and local_rank >= ndev:
+    if a.transport == "rccl" and local_rank >= ndev and not os.environ.get("CUP3D_BENCH_SHARE_DEVICE"):
         sys.exit(f"bench.py: rank {rank} has no device (RCCL wants one per rank; {ndev} visible)")
     local_dev = local_rank % ndev   # host transport: ranks may share a device
     torch.cuda.set_device(local_dev)

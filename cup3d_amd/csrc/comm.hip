@@ -60,10 +60,18 @@ static int no_comm(const char *what) {
 static int load_rccl() {
   if (g_comm.dl) return CUP3D_OK;
   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // CUP3D_RCCL_LIBRARY=<path>: this library and no other (a site's own RCCL build; tests: the stand-in of tests/fake_rccl, which lets
+  // every line below run on a box where RCCL itself cannot -- two ranks on one device).  RTLD_LOCAL + dlsym on the handle: its symbols,
+  // not those of an RCCL the process has loaded already.
+  if (const char *path = getenv("CUP3D_RCCL_LIBRARY")) {
+    if (!(g_comm.dl = dlopen(path, RTLD_NOW | RTLD_LOCAL))) { set_error("CUP3D_RCCL_LIBRARY: cannot dlopen %s: %s", path, dlerror()); return CUP3D_ECOMM; }
+  }
   // an RCCL the process has loaded already (torch.distributed brings its own copy) is the one to use: two copies of the library in
   // one process corrupt each other's teardown.  Hosts that load RCCL themselves do so before cup3d_comm_init (bench.py imports torch first).
-  for (const char *n : names)
-    if ((g_comm.dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD))) break;
+  for (const char *n : names) {
+    if (g_comm.dl) break;
+    g_comm.dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+  }
   for (const char *n : names) {
     if (g_comm.dl) break;
     g_comm.dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL);

@@ -190,6 +190,9 @@ if has tracealt; then echo "== rocprofv3 kernel trace of the direct-solve iterat
   find $OUT/tracealt -name "*kernel_trace.csv" -delete; find $OUT/tracealt -name "*.db" -delete
   summ $OUT/tracealt_bench.json
 fi
+if has fakerccl; then echo "== pytest: the RCCL code path with the stand-in library (bench over 2 / 3 processes; configs[3] through the shim on 2 MPI ranks)"
+  timeout 1500 python -m pytest tests/test_gpu_rccl.py tests/test_gpu_00_dropin_mpi.py -m gpu -q -s -k "stand_in" --durations=5 > $OUT/pytest_rccl_stand_in.log 2>&1 ; echo "pytest rc=$?"
+  grep -E "passed|failed|FAILED|Error|assert|ranks through|configs|fake_rccl" $OUT/pytest_rccl_stand_in.log | tail -30 | cut -c1-500; fi
 if has trace; then echo "== rocprofv3 kernel trace of the driver's bench"
   cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/trace -o fullstep -- python $OLDPWD/bench.py --steps ${TRACE_STEPS:-20} --warmup 5 --no-cpu --no-alt --no-pcie > $OLDPWD/$OUT/trace_bench.json 2> $OLDPWD/$OUT/trace.err ; echo "trace rc=$?"; cd $OLDPWD
   find $OUT/trace -name "*kernel_stats.csv" | head -2 | while read f; do head -12 "$f" | cut -c1-220; done

@@ -131,17 +131,28 @@ def run(tool, nranks, pre, args, wd, extra_env=None, nsteps=30):
     return res
 
 
+FAKE_RCCL = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "fake_rccl", "librccl_fake.so")
+
+
 @pytest.mark.timeout(1800)
-@pytest.mark.parametrize("name,nranks,level_max,fish,min_levels,nsteps", [("configs3_one_fish_3_levels_2_ranks", 2, 4, ONE_FISH, 3, 30),
-                                                                          ("configs4_two_fish_4_levels_8_ranks", 8, BIG, TWO_FISH, 4, 8)])
-def test_fish_with_amr_over_mpi_ranks_through_the_shim(tmp_path, name, nranks, level_max, fish, min_levels, nsteps):
+@pytest.mark.parametrize("name,nranks,level_max,fish,min_levels,nsteps,transport", [
+    ("configs3_one_fish_3_levels_2_ranks", 2, 4, ONE_FISH, 3, 30, "host"),
+    # the same through the PRODUCTION branch of the shim and of comm.hip -- unique id by MPI_Bcast, cup3d_comm_init, grouped ncclSend /
+    # ncclRecv of sub-boxes, face fluxes and migrating blocks, ncclAllReduce, the status agreement -- with librccl replaced at its own API by
+    # tests/fake_rccl (RCCL refuses two ranks on one device): everything but RCCL's internals executes
+    ("configs3_one_fish_3_levels_2_ranks", 2, 4, ONE_FISH, 3, 30, "rccl_stand_in"),
+    ("configs4_two_fish_4_levels_8_ranks", 8, BIG, TWO_FISH, 4, 8, "host")])
+def test_fish_with_amr_over_mpi_ranks_through_the_shim(tmp_path, name, nranks, level_max, fish, min_levels, nsteps, transport):
     if not (os.path.exists(REF_MPI) and os.path.exists(REF_HIP_MPI) and os.path.exists(O.MPIEXEC)):
         pytest.skip("needs oracle/_ref/ref_tool_mpi, ref_tool_hip_mpi_testing (built where /root/reference exists) and an mpiexec")
     if not launcher():
         pytest.skip("mpiexec cannot start local ranks on this box")
     args = COMMON + ["-levelMax", str(level_max), "-factory-content", fish]
+    if transport == "rccl_stand_in" and not os.path.exists(FAKE_RCCL):
+        pytest.skip("tests/fake_rccl/librccl_fake.so is not built")
+    hip_env = {"CUP3D_HIP_HOST_TRANSPORT": "1"} if transport == "host" else {"CUP3D_RCCL_LIBRARY": FAKE_RCCL}
     try:
-        hip = run(REF_HIP_MPI, nranks, ["hip on"], args, str(tmp_path / "hip"), {"CUP3D_HIP_HOST_TRANSPORT": "1"}, nsteps=nsteps)
+        hip = run(REF_HIP_MPI, nranks, ["hip on"], args, str(tmp_path / "hip"), hip_env, nsteps=nsteps)
         cpu = run(REF_MPI, nranks, [], args, str(tmp_path / "cpu"), nsteps=nsteps)
         one = run(O.REF_TOOL, 1, [], args, str(tmp_path / "one"), {"OMP_NUM_THREADS": "4"}, nsteps=nsteps)   # the reference against itself: one rank, four threads
     except HarnessTimeout as e:
@@ -173,7 +184,7 @@ def test_fish_with_amr_over_mpi_ranks_through_the_shim(tmp_path, name, nranks, l
         assert np.array_equal(c[0], h[0]) and np.array_equal(c[1], h[1]), f"rank {r}: block lists differ"   # incl. who owns what
         assert np.abs(c[4] - h[4]).max() <= 1e-6, f"rank {r}: chi"
         dv, dp = max(dv, np.abs(c[2] - h[2]).max()), max(dp, np.abs(c[3] - h[3]).max())
-    print(f"{name}: {nblocks} blocks on levels {sorted(levels)}, {nranks} ranks: block lists identical; max|dv| = {dv:.2e} (reference vs itself "
+    print(f"{name} [{transport}]: {nblocks} blocks on levels {sorted(levels)}, {nranks} ranks: block lists identical; max|dv| = {dv:.2e} (reference vs itself "
           f"{noise_v:.2e}, |v| = {vmax:.2e}), max|dp| = {dp:.2e} (reference vs itself {noise_p:.2e}, |p| = {pmax:.2e})")
     assert dv <= tol_v, (dv, tol_v)
     assert dp <= tol_p, (dp, tol_p)

@@ -31,8 +31,12 @@ def same_bits_at_every_n(ck1, ckn):
     assert ckn["fused_iteration"]["vectors"] == ck1["fused_iteration"]["vectors"]
 
 
-def run_bench(*args, timeout=900):
+FAKE_RCCL = os.path.join(ROOT, "tests", "fake_rccl", "librccl_fake.so")
+
+
+def run_bench(*args, timeout=900, extra_env=None):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
 
 
@@ -169,3 +173,35 @@ def test_bench_on_a_multilevel_mesh_over_rank_views():
     ratio = cb["MB_sent_per_iteration (rank 0)"] / ca["MB_sent_per_iteration (rank 0)"]
     print(f"bench --amr on 2 rank views: {a['blocks']} blocks, {ca['MB_sent_per_iteration (rank 0)']} MB per iteration in sub-boxes, x{ratio:.2f} as whole blocks")
     assert ratio > 2.5
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_rccl_code_path_with_the_stand_in_library(n):
+    """`bench.py --gpus N` in its PRODUCTION configuration -- `--transport rccl`, the RELEASE library, comm.hip's RCCL branch: dlopen,
+    ncclGetUniqueId on rank 0, the id over gloo, ncclCommInitRank, grouped ncclSend / ncclRecv of the packed face slabs on the
+    communication stream, ncclAllReduce + the recurrence step behind it, the status agreement's flag, cup3d_comm_finalize -- on ONE GPU:
+    librccl is replaced AT ITS OWN API by tests/fake_rccl (CUP3D_RCCL_LIBRARY; stream-ordered copies through shared-memory mailboxes),
+    because RCCL refuses two ranks on one device.  Everything but RCCL's internals executes.  All five bitwise signals equal the
+    one-process run's and the recorded constants; max|u| along the run agrees to the projections' stopping tolerance."""
+    if not os.path.exists(FAKE_RCCL):
+        pytest.skip("tests/fake_rccl/librccl_fake.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    args = ("--size", "128", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-alt", "--no-pcie")
+    one = run_bench(*args)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    many = run_bench("--gpus", str(n), *args, timeout=800, extra_env={"CUP3D_RCCL_LIBRARY": FAKE_RCCL, "CUP3D_BENCH_SHARE_DEVICE": "1"})
+    assert many.returncode == 0, (many.stdout.decode()[-1500:], many.stderr.decode()[-3000:])
+    lines = [l for l in many.stdout.decode().strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, many.stdout.decode()[-2000:]
+    r1, rn = json.loads(one.stdout.decode().strip()), json.loads(lines[0])
+    assert rn["n_gpus"] == n and rn["config"]["transport"] == "rccl" and rn["config"]["library"] == "libcup3d_hip.so"   # the release build
+    assert rn["config"]["checksum"]["ok"] is True
+    same_bits_at_every_n(r1["config"]["checksum"], rn["config"]["checksum"])
+    u1, un = r1["config"]["umax_by_step"], rn["config"]["umax_by_step"]
+    assert len(u1) == len(un) == 3 and max(abs(a - b) / a for a, b in zip(u1, un)) <= 2e-3, (u1, un)
+    com = rn["config"]["communication"]
+    assert com["rccl_ranks"] == n and com["halo_exchanges_per_iteration"] >= 2 and com["allreduces_per_iteration"] >= 2
+    assert com["halo_ms_per_iteration"] > 0 and com["allreduce_ms_per_iteration"] > 0 and com["exposed_ms_per_iteration"] >= 0
+    print(f"{n} ranks through comm.hip's RCCL branch (stand-in library): iterations {rn['config']['bicgstab_iters_by_step']} "
+          f"(one process: {r1['config']['bicgstab_iters_by_step']}); per iteration: halo {com['halo_ms_per_iteration']} ms, all-reduce "
+          f"{com['allreduce_ms_per_iteration']} ms, exposed {com['exposed_ms_per_iteration']} ms")
