@@ -11,7 +11,9 @@
 //   * a send matches the receive the peer posts for it in the same order (one mailbox per ordered pair of ranks, sequence-numbered);
 //   * ncclAllReduce of doubles with ncclSum / ncclMax: every rank reduces all contributions in rank order -- identical bits everywhere.
 // How the bytes travel: device -> a POSIX shared-memory mailbox -> device, with stream-ordered copies and host functions
-// (hipLaunchHostFunc) that raise / wait for the mailbox's sequence numbers.  Slow by design.  One node only.
+// (hipLaunchHostFunc) that raise / wait for the mailbox's sequence numbers.  The mailboxes are PINNED in both processes
+// (hipHostRegister): an asynchronous copy from pageable memory would be staged when it is ENQUEUED -- before the host function in front of
+// it has seen the message arrive.  Slow by design.  One node only.
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -30,7 +32,7 @@
 namespace {
 
 constexpr int kMaxRanks = 8;
-constexpr size_t kMailboxBytes = 48u << 20;  // per ordered pair of ranks
+constexpr size_t kMailboxBytes = 16u << 20;  // per ordered pair of ranks: one shared-memory segment each, created when the pair's ranks attach
 constexpr int kReduceSlots = 4, kReduceMax = 64;
 
 struct Mailbox {
@@ -44,14 +46,13 @@ struct Shared {
   std::atomic<unsigned long long> contributed[kReduceSlots];      // ranks that have written their operand of all-reduce number seq (slot seq % 4)
   std::atomic<unsigned long long> finished[kMaxRanks];            // all-reduces rank r has completed
   double operand[kReduceSlots][kMaxRanks][kReduceMax];
-  Mailbox box[kMaxRanks][kMaxRanks];                              // [src][dst]
-  // followed by the mailboxes' payload: [src][dst][kMailboxBytes]
+  Mailbox box[kMaxRanks][kMaxRanks];                              // [src][dst]: the sequence numbers; the payload lives in a segment of its own
 };
-inline char *payload(Shared *S, int src, int dst) { return reinterpret_cast<char *>(S + 1) + ((size_t)src * kMaxRanks + dst) * kMailboxBytes; }
-inline size_t shared_bytes() { return sizeof(Shared) + (size_t)kMaxRanks * kMaxRanks * kMailboxBytes; }
+inline size_t shared_bytes() { return sizeof(Shared); }
 
 struct Comm {
   Shared *S = nullptr;
+  char *out_box[kMaxRanks] = {nullptr}, *in_box[kMaxRanks] = {nullptr};  // payload of the mailboxes me -> p and p -> me, mapped and pinned here
   int rank = 0, nranks = 1;
   char name[64] = {0};
   unsigned long long reduce_seq = 0;
@@ -142,12 +143,12 @@ ncclResult_t issue(const Pending &q) {
   if (q.send) {
     const unsigned long long seq = ++q.c->sent_to[q.peer];
     if (hipLaunchHostFunc(q.st, wait_slot_free, new SlotFree{S, me, q.peer, seq}) != hipSuccess) return ncclUnhandledCudaError;
-    if (hipMemcpyAsync(payload(S, me, q.peer), q.buf, q.bytes, hipMemcpyDeviceToHost, q.st) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipMemcpyAsync(q.c->out_box[q.peer], q.buf, q.bytes, hipMemcpyDeviceToHost, q.st) != hipSuccess) return ncclUnhandledCudaError;
     if (hipLaunchHostFunc(q.st, mark_sent, new SendDone{S, me, q.peer, q.bytes}) != hipSuccess) return ncclUnhandledCudaError;
   } else {
     const unsigned long long seq = ++q.c->recv_from[q.peer];
     if (hipLaunchHostFunc(q.st, wait_arrival, new RecvWait{S, q.peer, me, seq, q.bytes}) != hipSuccess) return ncclUnhandledCudaError;
-    if (hipMemcpyAsync(q.buf, payload(S, q.peer, me), q.bytes, hipMemcpyHostToDevice, q.st) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipMemcpyAsync(q.buf, q.c->in_box[q.peer], q.bytes, hipMemcpyHostToDevice, q.st) != hipSuccess) return ncclUnhandledCudaError;
     if (hipLaunchHostFunc(q.st, mark_consumed, new RecvWait{S, q.peer, me, seq, q.bytes}) != hipSuccess) return ncclUnhandledCudaError;
   }
   return ncclSuccess;
@@ -185,6 +186,21 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
   c->nranks = nranks;
   snprintf(c->name, sizeof c->name, "%s", id.internal);
   if (hipHostMalloc((void **)&c->h_red, kReduceMax * sizeof(double), hipHostMallocDefault) != hipSuccess) return ncclUnhandledCudaError;
+  if (hipHostRegister(c->S, shared_bytes(), hipHostRegisterDefault) != hipSuccess) return ncclUnhandledCudaError;  // the all-reduce operands land in it
+  for (int p2 = 0; p2 < nranks; ++p2) {  // the two mailboxes of every pair I am part of: whoever comes first creates the segment
+    if (p2 == rank) continue;
+    for (int dir = 0; dir < 2; ++dir) {
+      char seg[96];
+      snprintf(seg, sizeof seg, "%s_%d_%d", id.internal, dir ? p2 : rank, dir ? rank : p2);
+      const int sfd = shm_open(seg, O_CREAT | O_RDWR, 0600);
+      if (sfd < 0 || ftruncate(sfd, (off_t)kMailboxBytes) != 0) return ncclSystemError;
+      void *m = mmap(nullptr, kMailboxBytes, PROT_READ | PROT_WRITE, MAP_SHARED, sfd, 0);
+      close(sfd);
+      if (m == MAP_FAILED) return ncclSystemError;
+      if (hipHostRegister(m, kMailboxBytes, hipHostRegisterDefault) != hipSuccess) return ncclUnhandledCudaError;
+      (dir ? c->in_box : c->out_box)[p2] = static_cast<char *>(m);
+    }
+  }
   if (rank == 0) c->S->nranks = nranks;
   c->S->attached.fetch_add(1);
   wait_until([&] { return c->S->attached.load() >= nranks; }, "ncclCommInitRank: not every rank arrived within 120 s");
@@ -195,7 +211,18 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
 static ncclResult_t leave(ncclComm_t h) {
   Comm *c = reinterpret_cast<Comm *>(h);
   if (!c) return ncclInvalidArgument;
+  for (int p2 = 0; p2 < c->nranks; ++p2)
+    for (int dir = 0; dir < 2; ++dir) {
+      char *m = (dir ? c->in_box : c->out_box)[p2];
+      if (!m) continue;
+      (void)hipHostUnregister(m);
+      munmap(m, kMailboxBytes);
+      char seg[96];
+      snprintf(seg, sizeof seg, "%s_%d_%d", c->name, dir ? p2 : c->rank, dir ? c->rank : p2);
+      shm_unlink(seg);  // (the second of the pair finds it gone already)
+    }
   const bool last = c->S->detached.fetch_add(1) + 1 >= c->nranks;
+  (void)hipHostUnregister(c->S);
   munmap(c->S, shared_bytes());
   if (last) shm_unlink(c->name);
   if (c->h_red) (void)hipHostFree(c->h_red);
