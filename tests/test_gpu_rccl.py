@@ -189,7 +189,8 @@ def test_bench_rccl_code_path_with_the_stand_in_library(n):
     args = ("--size", "128", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-alt", "--no-pcie")
     one = run_bench(*args)
     assert one.returncode == 0, one.stderr.decode()[-2000:]
-    many = run_bench("--gpus", str(n), *args, timeout=800, extra_env={"CUP3D_RCCL_LIBRARY": FAKE_RCCL, "CUP3D_BENCH_SHARE_DEVICE": "1"})
+    many = run_bench("--gpus", str(n), *args, timeout=800, extra_env={"CUP3D_RCCL_LIBRARY": FAKE_RCCL, "CUP3D_BENCH_SHARE_DEVICE": "1",
+                                                                             "CUP3D_HIP_FLAVOUR": "release"})   # (the suite's own processes load the testing build)
     assert many.returncode == 0, (many.stdout.decode()[-1500:], many.stderr.decode()[-3000:])
     lines = [l for l in many.stdout.decode().strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, many.stdout.decode()[-2000:]
