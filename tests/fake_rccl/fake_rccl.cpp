@@ -68,12 +68,19 @@ thread_local std::vector<Pending> g_pending;
   fprintf(stderr, "fake_rccl: %s\n", what);
   abort();
 }
+int wait_limit() {  // seconds a host function waits for the other rank before it ends the process (CUP3D_FAKE_RCCL_WAIT, default 120)
+  static const int s = [] { const char *e = getenv("CUP3D_FAKE_RCCL_WAIT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 120; }();
+  return s;
+}
 template <class F>
-void wait_until(F ok, const char *what) {
+void wait_until(F ok, const char *what, int a = -1, int b = -1, unsigned long long seq = 0) {
   const auto t0 = std::chrono::steady_clock::now();
   while (!ok()) {
     std::this_thread::sleep_for(std::chrono::microseconds(20));
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) die(what);
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(wait_limit())) {
+      fprintf(stderr, "fake_rccl: pid %d, ranks %d -> %d, operation number %llu:\n", (int)getpid(), a, b, seq);
+      die(what);
+    }
   }
 }
 
@@ -88,13 +95,13 @@ void mark_sent(void *p) {
 struct SlotFree { Shared *S; int src, dst; unsigned long long seq; };
 void wait_slot_free(void *p) {  // the receiver has taken message seq - 1 out of the mailbox
   SlotFree *d = static_cast<SlotFree *>(p);
-  wait_until([&] { return d->S->box[d->src][d->dst].consumed.load(std::memory_order_acquire) + 1 >= d->seq; }, "a send waited 120 s for the receiver to empty the mailbox");
+  wait_until([&] { return d->S->box[d->src][d->dst].consumed.load(std::memory_order_acquire) + 1 >= d->seq; }, "a send waited for the receiver to empty the mailbox", d->src, d->dst, d->seq);
   delete d;
 }
 struct RecvWait { Shared *S; int src, dst; unsigned long long seq; size_t bytes; };
 void wait_arrival(void *p) {
   RecvWait *d = static_cast<RecvWait *>(p);
-  wait_until([&] { return d->S->box[d->src][d->dst].sent.load(std::memory_order_acquire) >= d->seq; }, "a receive waited 120 s for its message");
+  wait_until([&] { return d->S->box[d->src][d->dst].sent.load(std::memory_order_acquire) >= d->seq; }, "a receive waited for its message", d->src, d->dst, d->seq);
   if (d->S->box[d->src][d->dst].bytes != d->bytes) die("a receive's size differs from the matching send's (plan mismatch between two ranks)");
   delete d;
 }
@@ -114,7 +121,7 @@ void reduce_wait_slot(void *p) {  // slot seq % 4 was last used by all-reduce se
   Shared *S = d->c->S;
   if (d->seq > kReduceSlots)
     wait_until([&] { for (int r = 0; r < S->nranks; ++r) if (S->finished[r].load(std::memory_order_acquire) + kReduceSlots < d->seq) return false; return true; },
-               "an all-reduce waited 120 s for the other ranks to finish an earlier one");
+               "an all-reduce waited for the other ranks to finish an earlier one", d->c->rank, -1, d->seq);
   delete d;
 }
 void reduce_collect(void *p) {
@@ -122,7 +129,7 @@ void reduce_collect(void *p) {
   Shared *S = d->c->S;
   const int slot = (int)(d->seq % kReduceSlots);
   wait_until([&] { return S->contributed[slot].load(std::memory_order_acquire) >= (unsigned long long)S->nranks * ((d->seq - 1) / kReduceSlots + 1); },
-             "an all-reduce waited 120 s for the other ranks' operands");
+             "an all-reduce waited for the other ranks' operands", d->c->rank, -1, d->seq);
   for (int i = 0; i < d->n; ++i) {
     double a = S->operand[slot][0][i];
     for (int r = 1; r < S->nranks; ++r) a = d->is_max ? (a > S->operand[slot][r][i] ? a : S->operand[slot][r][i]) : a + S->operand[slot][r][i];  // rank order
@@ -203,7 +210,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
   }
   if (rank == 0) c->S->nranks = nranks;
   c->S->attached.fetch_add(1);
-  wait_until([&] { return c->S->attached.load() >= nranks; }, "ncclCommInitRank: not every rank arrived within 120 s");
+  wait_until([&] { return c->S->attached.load() >= nranks; }, "ncclCommInitRank: not every rank arrived", rank);
   *out = reinterpret_cast<ncclComm_t>(c);
   return ncclSuccess;
 }
