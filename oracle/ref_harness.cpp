@@ -82,6 +82,7 @@
 #include <string>
 #include <sys/stat.h>
 #include <sys/time.h>
+#include <thread>
 #include <type_traits>
 #include <unistd.h>
 #include <unordered_map>
@@ -183,6 +184,23 @@ int main(int argc, char **argv) {
   MPI_Init_thread(&argc, &argv, MPI_THREAD_FUNNELED, &provided);
   MPI_Comm_rank(MPI_COMM_WORLD, &::sim.rank);
   MPI_Comm_size(MPI_COMM_WORLD, &::sim.size);
+#ifdef CUP3D_WITH_HIP
+  /* sign of life between two of the reference's per-step lines (a step is hundreds of BiCGSTAB iterations; with eight ranks and a test
+     process time-slicing ONE device it can take minutes): every 5 s, if the library's exchange / all-reduce counters have moved, one
+     line.  A launch whose counters stand still prints nothing and is hung; one that prints is slow (tests/test_gpu_00_dropin_mpi.py) */
+  if (::sim.rank == 0)
+    std::thread([] {
+      long seen = -1;
+      for (;;) {
+        std::this_thread::sleep_for(std::chrono::seconds(5));
+        cup3d_run_stats st;
+        if (cup3d_stats_read(&st) != 0) continue;
+        const long now = st.halo_exchanges + st.allreduces + st.host_waits;
+        if (now != seen && seen != -1) printf("REF alive exchanges=%ld allreduces=%ld iterations=%ld\n", st.halo_exchanges, st.allreduces, st.solver_iterations);
+        seen = now;
+      }
+    }).detach();
+#endif
   int rargc = argc - split;
   char **rargv = argv + split; /* rargv[0] = "--" plays the role of argv[0] */
   Simulation *S = new Simulation(rargc, rargv, MPI_COMM_WORLD);

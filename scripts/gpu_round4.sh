@@ -194,9 +194,10 @@ if has fakerccl; then echo "== pytest: the RCCL code path with the stand-in libr
   CUP3D_TEST_RCCL_STAND_IN=1 timeout 1500 python -m pytest tests/test_gpu_rccl.py tests/test_gpu_00_dropin_mpi.py -m gpu -q -s -k "stand_in" --durations=5 > $OUT/pytest_rccl_stand_in.log 2>&1 ; echo "pytest rc=$?"
   grep -E "passed|failed|FAILED|Error|assert|ranks through|configs|fake_rccl" $OUT/pytest_rccl_stand_in.log | tail -30 | cut -c1-500; fi
 if has fakeorder; then echo "== pytest: configs[3] over 2 MPI ranks, host transport THEN the stand-in (the order of the whole suite)"
-  CUP3D_TEST_RCCL_STAND_IN=1 CUP3D_STALL_LIMIT=70 CUP3D_FAKE_RCCL_WAIT=40 timeout 280 python -m pytest tests/test_gpu_00_dropin_mpi.py -m gpu -q -s -x -k "configs3" > $OUT/pytest_stand_in_after_host.log 2>&1 ; echo "pytest rc=$?"
+  CUP3D_TEST_RCCL_STAND_IN=1 CUP3D_STALL_LIMIT=70 CUP3D_FAKE_RCCL_WAIT=40 timeout ${FAKEORDER_LIMIT:-280} python -m pytest tests/test_gpu_00_dropin_mpi.py -m gpu -q -s -x ${FAKEORDER_K:+-k "$FAKEORDER_K"} > $OUT/pytest_stand_in_after_host.log 2>&1 ; echo "pytest rc=$?"
   ls /dev/shm | head; df -h /dev/shm | tail -1
-  grep -E "passed|failed|FAILED|Error|assert|fake_rccl|HUNG|configs3" $OUT/pytest_stand_in_after_host.log | tail -30 | cut -c1-1200; fi
+  grep -c "REF alive" $OUT/pytest_stand_in_after_host.log
+  grep -E "passed|failed|FAILED|Error|assert|fake_rccl|HUNG|configs" $OUT/pytest_stand_in_after_host.log | tail -30 | cut -c1-1200; fi
 if has trace; then echo "== rocprofv3 kernel trace of the driver's bench"
   cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/trace -o fullstep -- python $OLDPWD/bench.py --steps ${TRACE_STEPS:-20} --warmup 5 --no-cpu --no-alt --no-pcie > $OLDPWD/$OUT/trace_bench.json 2> $OLDPWD/$OUT/trace.err ; echo "trace rc=$?"; cd $OLDPWD
   find $OUT/trace -name "*kernel_stats.csv" | head -2 | while read f; do head -12 "$f" | cut -c1-220; done

@@ -211,6 +211,17 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
   if (rank == 0) c->S->nranks = nranks;
   c->S->attached.fetch_add(1);
   wait_until([&] { return c->S->attached.load() >= nranks; }, "ncclCommInitRank: not every rank arrived", rank);
+  // every rank has opened everything it will ever open: the names can go now (the memory lives as long as it is mapped), so that a
+  // rank that ends without ncclCommDestroy -- or is killed -- leaves nothing behind in /dev/shm
+  for (int p2 = 0; p2 < nranks; ++p2) {
+    if (p2 == rank) continue;
+    for (int dir = 0; dir < 2; ++dir) {
+      char seg[96];
+      snprintf(seg, sizeof seg, "%s_%d_%d", id.internal, dir ? p2 : rank, dir ? rank : p2);
+      shm_unlink(seg);
+    }
+  }
+  shm_unlink(id.internal);
   *out = reinterpret_cast<ncclComm_t>(c);
   return ncclSuccess;
 }
