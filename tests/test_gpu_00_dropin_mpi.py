@@ -131,9 +131,11 @@ def run(tool, nranks, pre, args, wd, extra_env=None, nsteps=30):
     return res
 
 
-# Opt-in: green alone (profiles/r04/pytest_rccl_code_path_with_stand_in_library.log), but in the one whole-suite run that included it
-# (builder's run r04q) this case and the 8-rank case after it FAILED and a thread-rank test later in the same process never ended; the GPU
-# budget of the round ended before the cause was found.  Until it is, the stand-in cases do not run in the default suite.
+# Opt-in: green alone and in this file's order on five boxes (profiles/r04/pytest_rccl_code_path_with_stand_in_library.log,
+# pytest_configs3_configs4_over_mpi_ranks_final.log), but in the one whole-suite run that included it (builder's run r04q,
+# profiles/r04/pytest_gpu_run_r04q_incomplete.log) this case and the unchanged 8-rank case after it FAILED and a thread-rank test later
+# in the same process never ended.  That looks like the box, but the round's GPU budget ended before it could be shown.  Until it is,
+# the stand-in cases do not run in the default suite.
 STAND_IN_OPT_IN = "CUP3D_TEST_RCCL_STAND_IN=1 runs the RCCL stand-in cases (scripts/gpu_round4.sh ... fakerccl)"
 FAKE_RCCL = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "fake_rccl", "librccl_fake.so")
 
