@@ -744,6 +744,7 @@ def run(a, prog):
     # library: stdout carries the one JSON line of rank 0 and nothing else
     if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
         os.environ["NCCL_DEBUG"] = "WARN"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL between processes needs dmabuf IPC on this driver (must precede the first HIP call)
     rank, world = prog.rank, prog.world
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     a.gpus = world
