@@ -296,11 +296,14 @@ def progress_dir():
     return d
 
 
-def read_progress(d, world):
+def read_progress(d, world, since=None):
     out = []
     for r in range(world):
         try:
-            out.append(json.load(open(os.path.join(d, f"rank{r}.json"))))
+            rec = json.load(open(os.path.join(d, f"rank{r}.json")))
+            if since is not None and rec.get("started_unix", since) < since - 600:   # a directory reused by back-to-back runs (same port)
+                rec = {"rank": r, "stage": "never reported in THIS run (the file on record is an earlier run's)", "earlier_run": rec}
+            out.append(rec)
         except Exception:
             out.append({"rank": r, "stage": "never reported (the process did not get as far as bench.py's main)"})
     return out
@@ -340,7 +343,7 @@ class Progress:
         with self.lock:
             self.stage, self.detail, self.last = stage, detail, time.time()
             self.limit = limit if limit is not None else self.a.stall_timeout
-            rec = {"rank": self.rank, "pid": os.getpid(), "stage": stage, "detail": detail, "t": round(self.last - self.t0, 2)}
+            rec = {"rank": self.rank, "pid": os.getpid(), "stage": stage, "detail": detail, "t": round(self.last - self.t0, 2), "started_unix": int(self.t0)}
         tmp = self.path + ".tmp"
         with open(tmp, "w") as f:
             json.dump(rec, f)
@@ -359,7 +362,7 @@ class Progress:
         self.set(self.stage, f"FAILED: {error}", 1e9)
         if self.rank == 0:
             time.sleep(0.5)   # the other ranks' last words
-            sys.stdout.write(error_line(self.world, self.stage, error, read_progress(self.dir, self.world), self.a.steps, self.a.warmup) + "\n")
+            sys.stdout.write(error_line(self.world, self.stage, error, read_progress(self.dir, self.world, self.t0), self.a.steps, self.a.warmup) + "\n")
             sys.stdout.flush()
         else:
             time.sleep(3.0)   # rank 0 prints before the launcher tears the group down because this rank left
