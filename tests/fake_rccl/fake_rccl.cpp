@@ -14,6 +14,10 @@
 // (hipLaunchHostFunc) that raise / wait for the mailbox's sequence numbers.  The mailboxes are PINNED in both processes
 // (hipHostRegister): an asynchronous copy from pageable memory would be staged when it is ENQUEUED -- before the host function in front of
 // it has seen the message arrive.  Slow by design.  One node only.
+// (The waits are BLOCKING host functions, and the HIP runtime may run every stream's host functions of a process on one thread.  All
+//  RCCL calls of the library come from one stream per rank, so no wait can sit in front of the host function that would release it; a
+//  host that spread them over streams could deadlock HERE where RCCL would not.  A form without host functions -- hipStreamWriteValue64 /
+//  hipStreamWaitValue64 on the sequence numbers in the pinned shared segment -- would remove that difference; not built.)
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
