@@ -302,6 +302,23 @@ int cup3d_debug_mg_plan_check(const cup3d_grid_t *gh, const int32_t *owner, int 
   }
   return CUP3D_OK;
 }
+// TEST SUPPORT (no GPU): a rank's TENSORIAL view of a mesh -- the one cup3d_adapt_migrate and cup3d_grad_chi_on_tmp_over_ranks build
+// internally (edge / corner neighbours and the finer leaves behind them are ghosts too; whole blocks travel) -- so that its ghost list
+// can be checked against an independent consumer (tests/test_host_indexing.py)
+int cup3d_debug_grid_rank_view_tensorial(const cup3d_grid_t *gh, const int32_t *owner, int rank, int nranks, cup3d_grid_t **out) {
+  if (!gh || !owner || !out) return CUP3D_EINVAL;
+  const Grid *g = reinterpret_cast<const Grid *>(gh);
+  try {
+    std::unique_ptr<Grid> tmp;
+    const Grid *m = g;
+    if (!g->multilevel) { tmp = g->as_mesh(); m = tmp.get(); }
+    *out = reinterpret_cast<cup3d_grid_t *>(m->rank_view(owner, rank, nranks, /*tensorial=*/true).release());
+  } catch (const std::exception &e) {
+    set_error("cup3d_debug_grid_rank_view_tensorial: %s", e.what());
+    return CUP3D_EINVAL;
+  }
+  return CUP3D_OK;
+}
 #endif
 
 double cup3d_calc_max_timestep(double hmin, double umax, double nu, double cfl, int step, int rampup, double dt_old, double coefU[3]) {

@@ -654,3 +654,131 @@ def test_sub_boxes_hold_every_cell_the_reference_pinned_oracle_reads(seed):
                     assert not bad.any(), (bpd, lmax, bc, nranks, kind, r, k, int(bad.sum()), int(np.isnan(got).sum()))
                     checked += got.size
     assert checked > 0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_tensorial_view_lists_every_block_the_reference_pinned_oracle_reads(seed):
+    """The same for the TENSORIAL view (whole ghost blocks; built inside cup3d_adapt_migrate and cup3d_grad_chi_on_tmp_over_ranks): with
+    every block the rank neither owns nor lists as a ghost set to NaN, the oracle's tensorial tiles of the rank's own blocks -- [-1,2)
+    (RefineBlocks' parent tile, main.cpp:5493-5565) and [-2,3) (GradChiOnTmp, 8540-8600), edges and corners included -- come out as from
+    the intact field.  Random balanced meshes, contiguous and scattered ownership."""
+    rng = np.random.default_rng(4000 + seed)
+    bpd = tuple(int(v) for v in rng.choice([1, 2, 3], 3))
+    if bpd == (1, 1, 1):
+        bpd = (2, 1, 2)
+    lmax = int(rng.choice([3, 4]))
+    bc = tuple(str(b) for b in rng.choice(["periodic", "wall", "freespace"], 3))
+    refine = []
+    for l in range(lmax - 1):
+        n = [b << l for b in bpd]
+        for _ in range(int(rng.integers(1, 4))):
+            refine.append((l, int(rng.integers(0, n[0])), int(rng.integers(0, n[1])), int(rng.integers(0, n[2]))))
+    try:
+        lv, zs = O.build_balanced_mesh(bpd, lmax, bc, refine)
+    except Exception:
+        pytest.skip("the random refinement list named a block that no longer exists")
+    g = cu.operators.Grid(bpd, lmax, 0, 2 * np.pi, bc, leaves=(lv, zs))
+    m = O.OracleMesh(bpd, lmax, 2 * np.pi, bc, lv, zs)
+    nb = g.nblocks
+    field = rng.uniform(-1, 1, (nb, 8, 8, 8))
+    intact = {se: m.labs(field, *se, tensorial=True) for se in ((-1, 2), (-2, 3))}
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    fewer = 0
+    for nranks in (2, 3):
+        if nranks > nb:
+            continue
+        for kind in ("ranges", "scattered"):
+            owner = (np.arange(nb) * nranks // nb).astype(np.int32) if kind == "ranges" else rng.integers(0, nranks, nb).astype(np.int32)
+            if kind == "scattered":
+                owner[:nranks] = np.arange(nranks)
+            for r in range(nranks):
+                h = C.c_void_p()
+                assert L.cup3d_debug_grid_rank_view_tensorial(g.handle, p(owner), r, nranks, C.byref(h)) == 0, L.cup3d_last_error().decode()
+                sz = (C.c_long * 6)()
+                assert L.cup3d_grid_view_sizes(h, sz) == 0
+                nlocal, nghost, nfl, nfg, nsb, nsf = (int(v) for v in sz)
+                slot, face = np.zeros(nlocal + nghost, dtype=np.int32), np.zeros(max(nfl + nfg, 1), dtype=np.int32)
+                sb, sf = np.zeros(max(nsb, 1), dtype=np.int32), np.zeros(max(nsf, 1), dtype=np.int32)
+                cnt = [np.zeros(nranks, dtype=np.int64) for _ in range(4)]
+                assert L.cup3d_grid_view_plan(h, p(slot), p(face), p(sb), p(cnt[0]), p(cnt[1]), p(sf), p(cnt[2]), p(cnt[3])) == 0
+                L.cup3d_grid_destroy(h)
+                own = np.flatnonzero(owner == r)
+                assert np.array_equal(np.sort(slot[:nlocal]), own) and (owner[slot[nlocal:]] != r).all()
+                f = np.full_like(field, np.nan)
+                f[slot] = field[slot]
+                fewer += nb - len(slot)
+                for se in intact:
+                    got, want = m.labs(f, *se, tensorial=True)[own], intact[se][own]
+                    bad = ~((got == want) | (np.isnan(got) & np.isnan(want)))
+                    assert not bad.any(), (bpd, lmax, bc, nranks, kind, r, se, int(bad.sum()))
+    assert fewer >= 0
+
+
+def test_sub_boxes_and_tensorial_ghost_lists_are_tight():
+    """... and not much more than that travels.  A box is the bounding box of the cells its consumers read, so each of its six outer
+    layers must hold a cell the oracle's tile assembly reads: poison one layer at a time and a NaN must appear in the star part of some
+    own tile.  Measured: 6 of 276 outer layers of the width-1 boxes and 0 of 276 of the width-3 ones on these meshes (24 / 3 of 720 over six
+    seeds) are NOT read by the oracle -- the boxes follow the device consumers' addressing, which is a little wider there; why was not
+    looked into -- asserted below 6 %.  The tensorial view's ghost list is exact: every listed block is read."""
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    tot, loose, ghosts, unread = [0, 0], [0, 0], 0, 0
+    for seed in range(3):
+        rng = np.random.default_rng(3000 + seed)
+        bpd = tuple(int(v) for v in rng.choice([1, 2, 3], 3))
+        if bpd == (1, 1, 1):
+            bpd = (2, 1, 2)
+        lmax = int(rng.choice([3, 4]))
+        bc = tuple(str(b) for b in rng.choice(["periodic", "wall", "freespace"], 3))
+        refine = []
+        for l in range(lmax - 1):
+            n = [b << l for b in bpd]
+            for _ in range(int(rng.integers(1, 4))):
+                refine.append((l, int(rng.integers(0, n[0])), int(rng.integers(0, n[1])), int(rng.integers(0, n[2]))))
+        try:
+            lv, zs = O.build_balanced_mesh(bpd, lmax, bc, refine)
+        except Exception:
+            continue
+        g = cu.operators.Grid(bpd, lmax, 0, 2 * np.pi, bc, leaves=(lv, zs))
+        m = O.OracleMesh(bpd, lmax, 2 * np.pi, bc, lv, zs)
+        nb, nranks = g.nblocks, 2
+        fields = {0: rng.uniform(-1, 1, (nb, 8, 8, 8)), 1: rng.uniform(-1, 1, (nb, 8, 8, 8, 3))}
+        stencil = {0: (-1, 2), 1: (-3, 4)}
+        owner = (np.arange(nb) * nranks // nb).astype(np.int32)
+        for r in range(nranks):
+            v = g.rank_view(owner, r, nranks)
+            own = np.flatnonzero(owner == r)
+            for k in (0, 1):
+                idx = np.arange(8 + stencil[k][1] - stencil[k][0] - 1) + stencil[k][0]
+                out = (idx < 0) | (idx >= 8)
+                mask = (out[:, None, None].astype(int) + out[None, :, None] + out[None, None, :]) <= 1
+                for slot, bx in zip(v.global_slot[v.nlocal:], v.ghost_box[k].astype(int)):
+                    x0, y0, z0, x1, y1, z1 = bx
+                    if x1 <= x0 or y1 <= y0 or z1 <= z0:
+                        continue
+                    X, Y, Z = slice(x0, x1), slice(y0, y1), slice(z0, z1)
+                    for layer in ((Z, Y, slice(x0, x0 + 1)), (Z, Y, slice(x1 - 1, x1)), (Z, slice(y0, y0 + 1), X), (Z, slice(y1 - 1, y1), X),
+                                  (slice(z0, z0 + 1), Y, X), (slice(z1 - 1, z1), Y, X)):
+                        f = fields[k].copy()
+                        f[(slot,) + layer] = np.nan
+                        tot[k] += 1
+                        loose[k] += not np.isnan(m.labs(f, *stencil[k])[own][:, mask]).any()
+            # the tensorial view: every ghost block is read by the [-2,3) tensorial tiles of the rank's own blocks
+            h = C.c_void_p()
+            assert L.cup3d_debug_grid_rank_view_tensorial(g.handle, p(owner), r, nranks, C.byref(h)) == 0
+            sz = (C.c_long * 6)()
+            assert L.cup3d_grid_view_sizes(h, sz) == 0
+            nlocal, nghost, nfl, nfg, nsb, nsf = (int(t) for t in sz)
+            slot, face = np.zeros(nlocal + nghost, dtype=np.int32), np.zeros(max(nfl + nfg, 1), dtype=np.int32)
+            sb, sf = np.zeros(max(nsb, 1), dtype=np.int32), np.zeros(max(nsf, 1), dtype=np.int32)
+            cnt = [np.zeros(nranks, dtype=np.int64) for _ in range(4)]
+            assert L.cup3d_grid_view_plan(h, p(slot), p(face), p(sb), p(cnt[0]), p(cnt[1]), p(sf), p(cnt[2]), p(cnt[3])) == 0
+            L.cup3d_grid_destroy(h)
+            for gi in range(nlocal, nlocal + nghost):
+                f = fields[0].copy()
+                f[slot[gi]] = np.nan
+                ghosts += 1
+                unread += not np.isnan(m.labs(f, -2, 3, tensorial=True)[own]).any()
+    print(f"box layers checked {tot}, not read by the oracle {loose}; tensorial ghost blocks {ghosts}, not read {unread}")
+    assert min(tot) > 100 and ghosts > 20
+    assert loose[0] <= 0.06 * tot[0] and loose[1] <= 0.06 * tot[1], (tot, loose)
+    assert unread == 0
