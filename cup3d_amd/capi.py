@@ -160,6 +160,7 @@ DEBUG_SIGNATURES = {
     "cup3d_debug_wave_sum": (C.c_int, [_dp, _dp]),
     "cup3d_debug_ctl_step": (C.c_int, [C.c_int, _dp, _dp]),
     "cup3d_debug_mg_plan_check": (C.c_int, [_vp, _vp, C.c_int]),
+    "cup3d_debug_grid_inner_blocks": (C.c_int, [_vp, _vp]),
     "cup3d_debug_grid_rank_view_tensorial": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
 }
 

@@ -302,6 +302,14 @@ int cup3d_debug_mg_plan_check(const cup3d_grid_t *gh, const int32_t *owner, int 
   }
   return CUP3D_OK;
 }
+// TEST SUPPORT (no GPU): the local slots of a rank's grid / view whose kernels are launched BEFORE the halo exchange has completed
+// (Grid::inner; cup3d_grid_ninner gives their number)
+int cup3d_debug_grid_inner_blocks(const cup3d_grid_t *gh, int32_t *slots) {
+  if (!gh || !slots) return CUP3D_EINVAL;
+  const Grid *g = reinterpret_cast<const Grid *>(gh);
+  for (size_t i = 0; i < g->inner.size(); ++i) slots[i] = g->inner[i];
+  return CUP3D_OK;
+}
 // TEST SUPPORT (no GPU): a rank's TENSORIAL view of a mesh -- the one cup3d_adapt_migrate and cup3d_grad_chi_on_tmp_over_ranks build
 // internally (edge / corner neighbours and the finer leaves behind them are ghosts too; whole blocks travel) -- so that its ghost list
 // can be checked against an independent consumer (tests/test_host_indexing.py)

@@ -27,6 +27,8 @@ int cup3d_debug_ctl_step(int step, double *io, const double *totals);
 /* the multigrid option's level hierarchies of all `nranks` ranks for the leaf ownership `owner[nblocks]` of a global multi-level mesh,
  * checked against each other (tables in range, exchange plans symmetric node for node, every ancestor's octants complete); no GPU */
 int cup3d_debug_mg_plan_check(const cup3d_grid_t *mesh, const int32_t *owner, int nranks);
+/* the local slots whose kernels run before the halo exchange has completed (cup3d_grid_ninner of them); no GPU */
+int cup3d_debug_grid_inner_blocks(const cup3d_grid_t *grid_or_view, int32_t *slots);
 /* a rank's TENSORIAL view of a mesh (cup3d_grid_rank_view gives the star-stencil one): what cup3d_adapt_migrate and
  * cup3d_grad_chi_on_tmp_over_ranks build internally -- edge / corner neighbours are ghosts too, whole blocks travel; no GPU */
 int cup3d_debug_grid_rank_view_tensorial(const cup3d_grid_t *mesh, const int32_t *owner, int rank, int nranks, cup3d_grid_t **view);

@@ -782,3 +782,70 @@ def test_sub_boxes_and_tensorial_ghost_lists_are_tight():
     assert min(tot) > 100 and ghosts > 20
     assert loose[0] <= 0.06 * tot[0] and loose[1] <= 0.06 * tot[1], (tot, loose)
     assert unread == 0
+
+
+@pytest.mark.parametrize("seed", list(range(12)) + ["533 blocks"])
+def test_inner_blocks_of_a_rank_view_read_nothing_remote(seed):
+    """The overlap of the ghost-block exchange with the interior (halo_begin / halo_finish on rank views; the reference's inner_blocks,
+    main.cpp:2196-2199, 5598-5618): the stencil kernels run on the INNER blocks while the ghost blocks are still travelling, so a block
+    wrongly classified inner would read stale ghost slots -- a race the device tests can only catch by luck.  Here every block the rank
+    does not own is NaN and the oracle's star tiles ([-1,2) and [-3,4)) of the inner blocks must come out as from the intact field.
+    The split is conservative (any ghost among the 27 neighbours makes a block a boundary block): the fraction of boundary blocks that
+    do read something remote is printed."""
+    big = not isinstance(seed, int)
+    rng = np.random.default_rng(5000 + (99 if big else seed))
+    bpd = tuple(int(v) for v in rng.choice([1, 2, 3], 3))
+    if bpd == (1, 1, 1):
+        bpd = (2, 1, 2)
+    lmax = int(rng.choice([3, 4]))
+    bc = tuple(str(b) for b in rng.choice(["periodic", "wall", "freespace"], 3))
+    refine = []
+    for l in range(lmax - 1):
+        n = [b << l for b in bpd]
+        for _ in range(int(rng.integers(1, 4))):
+            refine.append((l, int(rng.integers(0, n[0])), int(rng.integers(0, n[1])), int(rng.integers(0, n[2]))))
+    if big:   # a mesh with an interior: a uniform level-2 grid refined in three places (the mesh of the byte-count test above)
+        bpd, lmax, bc = (2, 2, 2), 4, ("wall", "freespace", "periodic")
+        refine = [(0, i, j, k) for k in range(2) for j in range(2) for i in range(2)] + [(1, i, j, k) for k in range(4) for j in range(4) for i in range(4)]
+        refine += [(2, 3, 3, 3), (2, 4, 4, 4), (2, 6, 1, 2)]
+    try:
+        lv, zs = O.build_balanced_mesh(bpd, lmax, bc, refine)
+    except Exception:
+        pytest.skip("the random refinement list named a block that no longer exists")
+    g = cu.operators.Grid(bpd, lmax, 0, 2 * np.pi, bc, leaves=(lv, zs))
+    m = O.OracleMesh(bpd, lmax, 2 * np.pi, bc, lv, zs)
+    nb = g.nblocks
+    fields = {(-1, 2): rng.uniform(-1, 1, (nb, 8, 8, 8)), (-3, 4): rng.uniform(-1, 1, (nb, 8, 8, 8, 3))}
+    intact = {se: m.labs(f, *se) for se, f in fields.items()}
+    ninner_total = nbound = nbound_reading = 0
+    for nranks in (2, 3):
+        if nranks > nb:
+            continue
+        for kind in ("ranges", "scattered"):
+            owner = (np.arange(nb) * nranks // nb).astype(np.int32) if kind == "ranges" else rng.integers(0, nranks, nb).astype(np.int32)
+            if kind == "scattered":
+                owner[:nranks] = np.arange(nranks)
+            for r in range(nranks):
+                v = g.rank_view(owner, r, nranks)
+                inner = np.zeros(max(v.ninner, 1), dtype=np.int32)
+                assert L.cup3d_debug_grid_inner_blocks(v.handle, inner.ctypes.data_as(C.c_void_p)) == 0
+                inner = inner[:v.ninner]
+                assert len(set(inner.tolist())) == v.ninner and (inner < v.nlocal).all()
+                reads_remote = np.zeros(v.nlocal, bool)
+                for se, fld in fields.items():
+                    f = fld.copy()
+                    f[owner != r] = np.nan
+                    idx = np.arange(8 + se[1] - se[0] - 1) + se[0]
+                    out = (idx < 0) | (idx >= 8)
+                    mask = (out[:, None, None].astype(int) + out[None, :, None] + out[None, None, :]) <= 1
+                    loc = v.global_slot[:v.nlocal]
+                    got, want = m.labs(f, *se)[loc][:, mask], intact[se][loc][:, mask]
+                    same = ((got == want) | (np.isnan(got) & np.isnan(want))).reshape(v.nlocal, -1).all(axis=1)
+                    reads_remote |= ~same
+                assert not reads_remote[inner].any(), (bpd, lmax, bc, nranks, kind, r, np.flatnonzero(reads_remote[inner]))
+                ninner_total += v.ninner
+                nbound += v.nlocal - v.ninner
+                nbound_reading += int(reads_remote.sum())
+    print(f"inner blocks {ninner_total}; boundary blocks {nbound}, of which {nbound_reading} read something remote")
+    if big:
+        assert ninner_total > 500   # the case that does test something: hundreds of inner blocks per ownership
