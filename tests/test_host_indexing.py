@@ -849,3 +849,41 @@ def test_inner_blocks_of_a_rank_view_read_nothing_remote(seed):
     print(f"inner blocks {ninner_total}; boundary blocks {nbound}, of which {nbound_reading} read something remote")
     if big:
         assert ninner_total > 500   # the case that does test something: hundreds of inner blocks per ownership
+
+
+@pytest.mark.parametrize("bpd,level,bc,nranks", [((2, 2, 2), 1, ("periodic", "periodic", "periodic"), 3), ((1, 1, 1), 3, ("wall", "wall", "wall"), 8),
+                                                 ((3, 2, 1), 2, ("periodic", "wall", "freespace"), 5), ((1, 1, 1), 2, ("freespace", "periodic", "wall"), 2)])
+def test_inner_blocks_of_a_uniform_grid_read_nothing_remote(bpd, level, bc, nranks):
+    """The same on uniform grids sharded by Hilbert ranges (face-slab exchange overlapped with the inner blocks' pass, comm.hip
+    halo_begin / halo_finish): with every block outside the rank's range NaN, the [-3,4) star tiles of the rank's inner blocks are intact;
+    and every boundary block does read something remote (the split is exact here: a face neighbour is read or it is not)."""
+    g0 = cu.operators.Grid(bpd, level + 1, level, 2 * np.pi, bc)
+    m = O.OracleMesh(bpd, level + 1, 2 * np.pi, bc, g0.tables[:, 0].astype(np.int32), g0.tables[:, 1].copy())
+    nb = g0.nblocks
+    assert np.array_equal(g0.tables[:, :2], m.tables[:, :2])
+    rng = np.random.default_rng(7)
+    fld = rng.uniform(-1, 1, (nb, 8, 8, 8, 3))
+    intact = m.labs(fld, -3, 4)
+    idx = np.arange(14) - 3
+    out = (idx < 0) | (idx >= 8)
+    mask = (out[:, None, None].astype(int) + out[None, :, None] + out[None, None, :]) <= 1
+    start, total_inner = 0, 0
+    for r in range(nranks):
+        g = cu.operators.Grid(bpd, level + 1, level, 2 * np.pi, bc, rank=r, nranks=nranks)
+        n = g.nblocks
+        assert np.array_equal(g.tables[:, :2], g0.tables[start:start + n, :2])     # the rank's contiguous range of the global order
+        ninner = int(L.cup3d_grid_ninner(g.handle))
+        inner = np.zeros(max(ninner, 1), dtype=np.int32)
+        assert L.cup3d_debug_grid_inner_blocks(g.handle, inner.ctypes.data_as(C.c_void_p)) == 0
+        inner = inner[:ninner]
+        f = np.full_like(fld, np.nan)
+        f[start:start + n] = fld[start:start + n]
+        got, want = m.labs(f, -3, 4)[start:start + n][:, mask], intact[start:start + n][:, mask]
+        reads_remote = ~((got == want) | (np.isnan(got) & np.isnan(want))).reshape(n, -1).all(axis=1)
+        assert not reads_remote[inner].any(), (r, np.flatnonzero(reads_remote[inner]))
+        boundary = np.setdiff1d(np.arange(n), inner)
+        assert reads_remote[boundary].all(), (r, boundary[~reads_remote[boundary]])
+        total_inner += ninner
+        start += n
+    assert start == nb
+    print(f"{nranks} ranks, {nb} blocks: {total_inner} inner blocks")
