@@ -252,10 +252,11 @@ static int vcomm_pull(Sim *s, double *dst, size_t per, const std::vector<int64_t
 }
 
 // ------------------------------------------------------------------ rank views of a multi-level mesh (Grid::rank_view)
-// Before a stencil kernel: the blocks of `field` other ranks' tables refer to travel whole into the ghost slot range
-// [n_local, n_local + nghost) (SynchronizerMPI_AMR::sync / fetch, main.cpp:2356-2544, which ships sub-boxes and coarse shadow cells;
-// whole 8^3 blocks make every consumer -- same-level copies, restriction, the coarse shadow tile of the interpolation -- read the
-// owner's bits through the renumbered tables with no second code path).  After a flux-corrected kernel: the face-flux arrays of fine
+// Before a stencil kernel: the blocks of `field` other ranks' tables refer to travel into the ghost slot range
+// [n_local, n_local + nghost) (SynchronizerMPI_AMR::sync / fetch, main.cpp:2356-2544, which ships sub-boxes and coarse shadow cells).
+// Every consumer -- same-level copies, restriction, the coarse shadow tile of the interpolation -- addresses whole ghost block slots
+// through the renumbered tables, so there is one code path downstream; what TRAVELS is, by default, only the sub-box of each block
+// those consumers read (k_pack_boxes / k_unpack_boxes, plan: Grid::ghost_box / send_box), whole blocks for tensorial views.  After a flux-corrected kernel: the face-flux arrays of fine
 // faces whose coarse neighbour lives elsewhere (FluxCorrectionMPI::FillBlockCases, 2848-2945).
 __global__ void __launch_bounds__(256) k_pack_blocks(const double *__restrict__ field, const int32_t *__restrict__ slots, int nc, double *__restrict__ out) {
   const double *src = field + (size_t)slots[blockIdx.x] * nc * 512;

@@ -99,7 +99,8 @@ int cup3d_grid_adapted_owners(const cup3d_grid_t *mesh, const int32_t *owner, co
  * the local blocks' first, then the fine faces of ghost blocks whose fluxes / cells the local coarse-side faces need.  The tables
  * (cup3d_grid_neighbours, cup3d_grid_interface) are the global ones renumbered, so a kernel reads through them what it would read on
  * one rank once the two exchanges of cup3d_grid_view_plan have run; cup3d_sim_create on a view allocates the ghost slots and the
- * operators run those exchanges over RCCL (whole ghost blocks before a stencil kernel, face fluxes after a flux-corrected one). */
+ * operators run those exchanges over RCCL (ghost blocks before a stencil kernel -- of each only the sub-box the stencil's consumers read,
+ * cup3d_grid_view_boxes; whole blocks for the tensorial tiles of mesh adaptation --, face fluxes after a flux-corrected one). */
 int cup3d_grid_rank_view(const cup3d_grid_t *mesh, const int32_t *owner, int rank, int nranks, cup3d_grid_t **view);
 /* out: local blocks, ghost blocks, local interface faces, ghost faces, blocks sent per exchange, face-flux arrays sent per exchange */
 int cup3d_grid_view_sizes(const cup3d_grid_t *view, long out[6]);
