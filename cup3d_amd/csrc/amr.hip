@@ -82,6 +82,44 @@ __device__ __forceinline__ double interp1d(const double *__restrict__ P0, int p,
   return (coef[3] * P0[-2 * st] + coef[4] * P0[-st]) + coef[5] * P0[0];
 }
 
+// CoarseFineInterpolation, finite-difference mode (main.cpp:4419-4600): the coarse-side value `av` of a fine ghost cell -- the two 1-D
+// quadratic interpolations along the face's tangential axes plus the mixed term -- from the coarse layer behind the face.  P0 = the coarse
+// cell that holds the ghost cell, (p1, p2) its tangential position (0..3), st1 / st2 the strides of the layer along the two axes, bit1 /
+// bit2 which child of the coarse cell the ghost cell is.  ONE definition for the three callers (the ghost slabs of the star stencils,
+// k_ghost_prolong; the tensorial tiles of the mesh adaptation, k_refine and k_grad_chi): a bit-exactness fix lands once.
+__device__ __forceinline__ double fd_mode_av(const double *__restrict__ P0, int p1, int p2, int st1, int st2, int bit1, int bit2) {
+  const double dd1 = 0.25 * (2 * bit1 - 1), dd2 = 0.25 * (2 * bit2 - 1);
+  const double *coef1 = dd1 > 0 ? kCoefPlus : kCoefMinus, *coef2 = dd2 > 0 ? kCoefPlus : kCoefMinus;
+  int pp1, pm1, pp2, pm2;
+  const double x1D = interp1d(P0, p1, st1, coef1, pp1, pm1);
+  const double x2D = interp1d(P0, p2, st2, coef2, pp2, pm2);
+  double mixed_coef = 1.0;
+  if (p1 != 0 && p1 != 3) mixed_coef *= 0.5;
+  if (p2 != 0 && p2 != 3) mixed_coef *= 0.5;
+#define PC(i, j) P0[((i) - p1) * st1 + ((j) - p2) * st2]
+  const double mixed = mixed_coef * dd1 * dd2 * ((PC(pm1, pm2) + PC(pp1, pp2)) - (PC(pp1, pm2) + PC(pm1, pp2)));
+#undef PC
+  return (x1D + x2D) + mixed;
+}
+// ... blended with the block's own two cells behind the face (bv: the face cell, cv: the one behind it), main.cpp:4601-4608
+__device__ __forceinline__ double fd_mode_blend(double av, double bv, double cv, int layer) {
+  return layer == 0 ? (1.0 / 15.0) * (8.0 * av + (10.0 * bv - 3.0 * cv)) : (1.0 / 15.0) * (24.0 * av + (-15.0 * bv + 6 * cv));
+}
+// TestInterp (main.cpp:3883-3906): second-order Taylor expansion around a coarse cell; Cc(i, j, k) = the 3x3x3 coarse cells around it
+// (1, 1, 1 = the cell itself), bit[d] = which child along d
+template <class F>
+__device__ __forceinline__ double test_interp(F Cc, const int (&bit)[3]) {
+  const double dudx = 0.125 * (Cc(2, 1, 1) - Cc(0, 1, 1));
+  const double dudy = 0.125 * (Cc(1, 2, 1) - Cc(1, 0, 1));
+  const double dudz = 0.125 * (Cc(1, 1, 2) - Cc(1, 1, 0));
+  const double dudxdy = 0.015625 * (Cc(0, 0, 1) + Cc(2, 2, 1) - Cc(2, 0, 1) - Cc(0, 2, 1));
+  const double dudxdz = 0.015625 * (Cc(0, 1, 0) + Cc(2, 1, 2) - Cc(2, 1, 0) - Cc(0, 1, 2));
+  const double dudydz = 0.015625 * (Cc(1, 0, 0) + Cc(1, 2, 2) - Cc(1, 2, 0) - Cc(1, 0, 2));
+  const double lap = Cc(1, 1, 1) + 0.03125 * (Cc(0, 1, 1) + Cc(2, 1, 1) + Cc(1, 0, 1) + Cc(1, 2, 1) + Cc(1, 1, 0) + Cc(1, 1, 2) + (-6.0) * Cc(1, 1, 1));
+  const double sx = bit[0] ? 1.0 : -1.0, sy = bit[1] ? 1.0 : -1.0, sz = bit[2] ? 1.0 : -1.0;
+  return lap + sx * dudx + sy * dudy + sz * dudz + (sx * sy) * dudxdy + (sx * sz) * dudxdz + (sy * sz) * dudydz;
+}
+
 template <int W>
 __global__ void __launch_bounds__(64) k_ghost_prolong(AmrDev a, const int32_t *__restrict__ list, const double *__restrict__ field, int nc,
                                                       double *__restrict__ slabs) {
@@ -141,42 +179,22 @@ __global__ void __launch_bounds__(64) k_ghost_prolong(AmrDev a, const int32_t *_
     cb[ax2] = cc[ax2] = a2i;
     const double bv = own[cb[2] * 64 + cb[1] * 8 + cb[0]], cv = own[cc[2] * 64 + cc[1] * 8 + cc[0]];
     const int p1 = a1i >> 1, p2 = a2i >> 1;
-    const double dd1 = 0.25 * (2 * (a1i & 1) - 1), dd2 = 0.25 * (2 * (a2i & 1) - 1);
-    const double *coef1 = dd1 > 0 ? kCoefPlus : kCoefMinus, *coef2 = dd2 > 0 ? kCoefPlus : kCoefMinus;
-    const double *P0 = &patch[0][(p2 + 1) * 6 + (p1 + 1)];
-    int pp1, pm1, pp2, pm2;
-    const double x1D = interp1d(P0, p1, 1, coef1, pp1, pm1);
-    const double x2D = interp1d(P0, p2, 6, coef2, pp2, pm2);
-    double mixed_coef = 1.0;
-    if (p1 != 0 && p1 != 3) mixed_coef *= 0.5;
-    if (p2 != 0 && p2 != 3) mixed_coef *= 0.5;
-#define PC(i, j) patch[0][((j) + 1) * 6 + ((i) + 1)]
-    const double mixed = mixed_coef * dd1 * dd2 * ((PC(pm1, pm2) + PC(pp1, pp2)) - (PC(pp1, pm2) + PC(pm1, pp2)));
-#undef PC
-    const double av = (x1D + x2D) + mixed;
+    const double av = fd_mode_av(&patch[0][(p2 + 1) * 6 + (p1 + 1)], p1, p2, 1, 6, a1i & 1, a2i & 1);
     double *__restrict__ out = slabs + ((size_t)e * nc + c) * W * 64 + lane;
-    out[0] = (1.0 / 15.0) * (8.0 * av + (10.0 * bv - 3.0 * cv));  // 4601-4608
+    out[0] = fd_mode_blend(av, bv, cv, 0);
     if (W == 3) {
-      out[64] = (1.0 / 15.0) * (24.0 * av + (-15.0 * bv + 6 * cv));
+      out[64] = fd_mode_blend(av, bv, cv, 1);
       // ---- layer 3: TestInterp around the coarse cell two layers behind the face
       auto Cc = [&](int i, int j, int k) -> double {
         const int off[3] = {i, j, k};
         const int L = side ? off[ax] : 2 - off[ax];
         return patch[L][(p2 + off[ax2]) * 6 + (p1 + off[ax1])];
       };
-      const double dudx = 0.125 * (Cc(2, 1, 1) - Cc(0, 1, 1));
-      const double dudy = 0.125 * (Cc(1, 2, 1) - Cc(1, 0, 1));
-      const double dudz = 0.125 * (Cc(1, 1, 2) - Cc(1, 1, 0));
-      const double dudxdy = 0.015625 * (Cc(0, 0, 1) + Cc(2, 2, 1) - Cc(2, 0, 1) - Cc(0, 2, 1));
-      const double dudxdz = 0.015625 * (Cc(0, 1, 0) + Cc(2, 1, 2) - Cc(2, 1, 0) - Cc(0, 1, 2));
-      const double dudydz = 0.015625 * (Cc(1, 0, 0) + Cc(1, 2, 2) - Cc(1, 2, 0) - Cc(1, 0, 2));
-      const double lap = Cc(1, 1, 1) + 0.03125 * (Cc(0, 1, 1) + Cc(2, 1, 1) + Cc(1, 0, 1) + Cc(1, 2, 1) + Cc(1, 1, 0) + Cc(1, 1, 2) + (-6.0) * Cc(1, 1, 1));
       int bit[3];
       bit[ax] = side ? 0 : 1;  // the fine layer is the upper child of the coarse cell below the block, the lower one above it
       bit[ax1] = a1i & 1;
       bit[ax2] = a2i & 1;
-      const double sx = bit[0] ? 1.0 : -1.0, sy = bit[1] ? 1.0 : -1.0, sz = bit[2] ? 1.0 : -1.0;
-      out[128] = lap + sx * dudx + sy * dudy + sz * dudz + (sx * sy) * dudxdy + (sx * sz) * dudxdz + (sy * sz) * dudydz;
+      out[128] = test_interp(Cc, bit);
     }
   }
 }
@@ -310,35 +328,14 @@ __global__ void __launch_bounds__(256) k_refine(AmrDev a, RefineTab tab, const d
           const int ax = code[0] ? 0 : (code[1] ? 1 : 2), ax1 = ax == 0 ? 1 : 0, ax2 = ax == 2 ? 1 : 2;
           const int st1 = ax1 == 0 ? 1 : 8, st2 = ax2 == 1 ? 8 : 64;
           const int p1 = X[ax1], p2 = X[ax2];
-          const double dd1 = 0.25 * (2 * bit[ax1] - 1), dd2 = 0.25 * (2 * bit[ax2] - 1);
-          const double *coef1 = dd1 > 0 ? kCoefPlus : kCoefMinus, *coef2 = dd2 > 0 ? kCoefPlus : kCoefMinus;
-          const double *P0 = C0 + cix8(X[0], X[1], X[2]);
-          int pp1, pm1, pp2, pm2;
-          const double x1D = interp1d(P0, p1, st1, coef1, pp1, pm1);
-          const double x2D = interp1d(P0, p2, st2, coef2, pp2, pm2);
-          double mixed_coef = 1.0;
-          if (p1 != 0 && p1 != 3) mixed_coef *= 0.5;
-          if (p2 != 0 && p2 != 3) mixed_coef *= 0.5;
-#define PC(i, j) P0[((i) - p1) * st1 + ((j) - p2) * st2]
-          const double mixed = mixed_coef * dd1 * dd2 * ((PC(pm1, pm2) + PC(pp1, pp2)) - (PC(pp1, pm2) + PC(pm1, pp2)));
-#undef PC
-          const double av = (x1D + x2D) + mixed;
+          const double av = fd_mode_av(C0 + cix8(X[0], X[1], X[2]), p1, p2, st1, st2, bit[ax1], bit[ax2]);
           int cb[3] = {l[0], l[1], l[2]}, cc[3] = {l[0], l[1], l[2]};
           cb[ax] = code[ax] > 0 ? 7 : 0;
           cc[ax] = code[ax] > 0 ? 6 : 1;
           const double bv = lab[c * 1000 + lix10(cb[0], cb[1], cb[2])], cv = lab[c * 1000 + lix10(cc[0], cc[1], cc[2])];
-          v = (1.0 / 15.0) * (8.0 * av + (10.0 * bv - 3.0 * cv));
+          v = fd_mode_blend(av, bv, cv, 0);
         } else {  // edge / corner: TestInterp
-          auto Cc = [&](int i, int j, int k) -> double { return C0[cix8(X[0] - 1 + i, X[1] - 1 + j, X[2] - 1 + k)]; };
-          const double dudx = 0.125 * (Cc(2, 1, 1) - Cc(0, 1, 1));
-          const double dudy = 0.125 * (Cc(1, 2, 1) - Cc(1, 0, 1));
-          const double dudz = 0.125 * (Cc(1, 1, 2) - Cc(1, 1, 0));
-          const double dudxdy = 0.015625 * (Cc(0, 0, 1) + Cc(2, 2, 1) - Cc(2, 0, 1) - Cc(0, 2, 1));
-          const double dudxdz = 0.015625 * (Cc(0, 1, 0) + Cc(2, 1, 2) - Cc(2, 1, 0) - Cc(0, 1, 2));
-          const double dudydz = 0.015625 * (Cc(1, 0, 0) + Cc(1, 2, 2) - Cc(1, 2, 0) - Cc(1, 0, 2));
-          const double lap = Cc(1, 1, 1) + 0.03125 * (Cc(0, 1, 1) + Cc(2, 1, 1) + Cc(1, 0, 1) + Cc(1, 2, 1) + Cc(1, 1, 0) + Cc(1, 1, 2) + (-6.0) * Cc(1, 1, 1));
-          const double sx = bit[0] ? 1.0 : -1.0, sy = bit[1] ? 1.0 : -1.0, sz = bit[2] ? 1.0 : -1.0;
-          v = lap + sx * dudx + sy * dudy + sz * dudz + (sx * sy) * dudxdy + (sx * sz) * dudxdz + (sy * sz) * dudydz;
+          v = test_interp([&](int i, int j, int k) -> double { return C0[cix8(X[0] - 1 + i, X[1] - 1 + j, X[2] - 1 + k)]; }, bit);
         }
         lab[c * 1000 + e] = v;
       }
@@ -493,37 +490,15 @@ __global__ void __launch_bounds__(256) k_grad_chi(AmrDev a, const int32_t *__res
         const int ax = code[0] ? 0 : (code[1] ? 1 : 2), ax1 = ax == 0 ? 1 : 0, ax2 = ax == 2 ? 1 : 2;
         const int st1 = ax1 == 0 ? 1 : 8, st2 = ax2 == 1 ? 8 : 64;
         const int p1 = X[ax1], p2 = X[ax2];
-        const double dd1 = 0.25 * (2 * bit[ax1] - 1), dd2 = 0.25 * (2 * bit[ax2] - 1);
-        const double *coef1 = dd1 > 0 ? kCoefPlus : kCoefMinus, *coef2 = dd2 > 0 ? kCoefPlus : kCoefMinus;
-        const double *P0 = Ct + cix8(X[0], X[1], X[2]);
-        int pp1, pm1, pp2, pm2;
-        const double x1D = interp1d(P0, p1, st1, coef1, pp1, pm1);
-        const double x2D = interp1d(P0, p2, st2, coef2, pp2, pm2);
-        double mixed_coef = 1.0;
-        if (p1 != 0 && p1 != 3) mixed_coef *= 0.5;
-        if (p2 != 0 && p2 != 3) mixed_coef *= 0.5;
-#define PC(i, j) P0[((i) - p1) * st1 + ((j) - p2) * st2]
-        const double mixed = mixed_coef * dd1 * dd2 * ((PC(pm1, pm2) + PC(pp1, pp2)) - (PC(pp1, pm2) + PC(pm1, pp2)));
-#undef PC
-        const double av = (x1D + x2D) + mixed;
+        const double av = fd_mode_av(Ct + cix8(X[0], X[1], X[2]), p1, p2, st1, st2, bit[ax1], bit[ax2]);
         int cb[3] = {l[0], l[1], l[2]}, cc[3] = {l[0], l[1], l[2]};
         cb[ax] = code[ax] > 0 ? 7 : 0;
         cc[ax] = code[ax] > 0 ? 6 : 1;
         const double bv = lab[lix12(cb[0], cb[1], cb[2])], cv = lab[lix12(cc[0], cc[1], cc[2])];
         const int layer = code[ax] < 0 ? -1 - l[ax] : l[ax] - 8;
-        v = layer == 0 ? (1.0 / 15.0) * (8.0 * av + (10.0 * bv - 3.0 * cv)) : (1.0 / 15.0) * (24.0 * av + (-15.0 * bv + 6 * cv));  // 4601-4608
+        v = fd_mode_blend(av, bv, cv, layer);
       } else {  // edge / corner: TestInterp
-        const double *C0 = Ct;
-        auto Cc = [&](int i, int j, int k) -> double { return C0[cix8(X[0] - 1 + i, X[1] - 1 + j, X[2] - 1 + k)]; };
-        const double dudx = 0.125 * (Cc(2, 1, 1) - Cc(0, 1, 1));
-        const double dudy = 0.125 * (Cc(1, 2, 1) - Cc(1, 0, 1));
-        const double dudz = 0.125 * (Cc(1, 1, 2) - Cc(1, 1, 0));
-        const double dudxdy = 0.015625 * (Cc(0, 0, 1) + Cc(2, 2, 1) - Cc(2, 0, 1) - Cc(0, 2, 1));
-        const double dudxdz = 0.015625 * (Cc(0, 1, 0) + Cc(2, 1, 2) - Cc(2, 1, 0) - Cc(0, 1, 2));
-        const double dudydz = 0.015625 * (Cc(1, 0, 0) + Cc(1, 2, 2) - Cc(1, 2, 0) - Cc(1, 0, 2));
-        const double lap = Cc(1, 1, 1) + 0.03125 * (Cc(0, 1, 1) + Cc(2, 1, 1) + Cc(1, 0, 1) + Cc(1, 2, 1) + Cc(1, 1, 0) + Cc(1, 1, 2) + (-6.0) * Cc(1, 1, 1));
-        const double sx = bit[0] ? 1.0 : -1.0, sy = bit[1] ? 1.0 : -1.0, sz = bit[2] ? 1.0 : -1.0;
-        v = lap + sx * dudx + sy * dudy + sz * dudz + (sx * sy) * dudxdy + (sx * sz) * dudxdz + (sy * sz) * dudydz;
+        v = test_interp([&](int i, int j, int k) -> double { return Ct[cix8(X[0] - 1 + i, X[1] - 1 + j, X[2] - 1 + k)]; }, bit);
       }
       lab[e] = v;
     }

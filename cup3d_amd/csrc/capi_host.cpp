@@ -9,6 +9,9 @@
 #include <vector>
 
 #include "../../include/cup3d_hip.h"
+#ifdef CUP3D_TESTING
+#include "../../include/cup3d_hip_testing.h"
+#endif
 #include "grid.hpp"
 
 namespace cup3d {

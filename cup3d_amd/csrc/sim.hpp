@@ -15,6 +15,9 @@
 #include <vector>
 
 #include "../../include/cup3d_hip.h"
+#ifdef CUP3D_TESTING
+#include "../../include/cup3d_hip_testing.h"  // the test-support entry points are exported (CUP3D_API) from the testing build only
+#endif
 #include "grid.hpp"
 
 namespace cup3d {

@@ -40,7 +40,10 @@ def test_both_builds_export_the_boundary_and_only_the_test_build_the_test_suppor
     exported = {}
     for so in ("libcup3d_hip.so", "libcup3d_hip_testing.so"):
         out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(here, so)], stdout=subprocess.PIPE, check=True, text=True).stdout
-        exported[so] = {ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("cup3d_")}
+        every = {ln.split()[-1] for ln in out.splitlines() if ln.split()}
+        # -fvisibility=hidden + the linker's version script (csrc/exports.map): no C++ internal, no kernel stub, no libstdc++ instantiation
+        assert not {n for n in every if not n.startswith("cup3d_")}, (so, sorted(n for n in every if not n.startswith("cup3d_"))[:10])
+        exported[so] = every
         assert names <= exported[so], (so, names - exported[so])
     assert dbg <= exported["libcup3d_hip_testing.so"], dbg - exported["libcup3d_hip_testing.so"]
     assert not {n for n in exported["libcup3d_hip.so"] if n.startswith("cup3d_debug_")}, "the release library exports test-support symbols"
