@@ -168,6 +168,49 @@ def gather_sum(mine, a, dist, world):
     return tot if isinstance(mine, (list, tuple)) else tot[0]
 
 
+def read_profile(cap=160):
+    """cup3d_profile_read -> {entry name: (launches, total ms)} (hipEvents on the stream each kernel is launched on)"""
+    from cup3d_amd.capi import ProfileEntry, lib
+    ents = (ProfileEntry * cap)()
+    n = C.c_int(0)
+    lib().cup3d_profile_read(ents, cap, C.byref(n))
+    return {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n.value)}
+
+
+# algorithmic HBM bytes per FINE cell of one launch of the multigrid option's kernels (multigrid.hip; DESIGN.md section 4):
+#   mg_smooth            two red-black sweeps with frozen ghosts: iterate in 8, right-hand side in 8, iterate out 8 (the six ghost faces,
+#                        0.75 cells per cell, are neighbours' cells this or a neighbouring wavefront reads anyway: L2 hits, not counted)
+#   mg_smooth_from_zero  the first launch of a level: the iterate is zero and is not read
+#   mg_residual_restrict iterate in 8, right-hand side in 8, the summed residual of 8 cells out 8/8
+#   mg_prolong_add       fine iterate in 8 and out 8, the parent's cell in 8/8
+MG_ALGO_BYTES = {"mg_smooth": 24.0, "mg_smooth_from_zero": 16.0, "mg_residual_restrict": 17.0, "mg_prolong_add": 17.0}
+
+
+def multigrid_kernels(prof, fine_blocks):
+    """alt_multigrid.kernels: every kernel of the V-cycle PER LEVEL (entries "mg_smooth@L6", L0 = the coarsest level, one block) with the
+    HBM roofline of its level's cell count.  Only the fine levels can be near a roof: from level L-2 down a launch is shorter than its
+    own launch latency (<= 4096 blocks), which `note` says instead of pretending a fraction means something there."""
+    levels = sorted({int(k.split("@L")[1]) for k in prof if "@L" in k})
+    if not levels:
+        return []
+    top = max(levels)
+    out = []
+    for name, (launches, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+        if "@L" not in name or not launches:
+            continue
+        base, lv = name.split("@L")
+        lv = int(lv)
+        blocks = max(1, fine_blocks >> (3 * (top - lv)))
+        avg = ms / launches
+        ach = MG_ALGO_BYTES[base] * blocks * 512.0 / (avg * 1e-3) / 1e9
+        e = {"kernel": base, "level": lv, "blocks": blocks, "launches": launches, "avg_ms": round(avg, 5), "total_ms": round(ms, 3), "bound": "hbm",
+             "algorithmic_bytes_per_cell": MG_ALGO_BYTES[base], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+        if blocks <= 4096:
+            e["note"] = "launch-latency bound: fewer blocks than the chip has wavefront slots"
+        out.append(e)
+    return out
+
+
 POISSON_VECTORS = ("phat", "rhat", "shat", "what", "zhat", "qhat", "s", "w", "z", "t", "v", "q", "r", "y", "x", "r0", "b", "xopt")  # poisson.hip's order
 
 
@@ -579,10 +622,7 @@ def run_amr(a, prog=None, dist=None, rank=0, world=1):
                 "transport": "rccl" if a.transport == "rccl" else "host-memory TEST transport over gloo (a correctness run: bytes and counts are meaningful, the rate is not)"}
     if rank != 0:
         return None
-    ents = (ProfileEntry * 64)()
-    n = C.c_int(0)
-    lib().cup3d_profile_read(ents, 64, C.byref(n))
-    prof = {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n.value)}
+    prof = read_profile()
     total_ms = sum(ms for k, (_, ms) in prof.items() if not k.startswith("comm_")) or 1.0   # shares of the compute stream's time
     cells = nblocks_global * 512.0
     cells_local = sim.nblocks * 512.0
@@ -645,9 +685,7 @@ def run_micro(a, sim, prog):
         for bs in (0, 1):
             check(lib().cup3d_poisson_path_checksum(sim.handle, bs, 1, sums))
     lib().cup3d_device_synchronize()
-    ents = (ProfileEntry * 64)()
-    n = C.c_int(0)
-    lib().cup3d_profile_read(ents, 64, C.byref(n))
+    mprof = read_profile()
     lib().cup3d_profile_enable(0)
     cells = sim.nblocks * 512.0
     names = {"poisson_lhs": "one LHS apply (ComputeLHS, bMeanConstraint 1)", "poisson_block_cg": "one preconditioner apply (block CG)",
@@ -655,8 +693,7 @@ def run_micro(a, sim, prog):
              "bicgstab_loop2_cg": "fused vector update 2 (+ LHS + block CG)", "bicgstab_loop1_fdm": "fused vector update 1 (+ LHS + direct block solve)",
              "bicgstab_loop2_fdm": "fused vector update 2 (+ LHS + direct block solve)"}
     out = []
-    for i in range(n.value):
-        nm, ln, ms = ents[i].name.decode(), ents[i].launches, ents[i].total_ms
+    for nm, (ln, ms) in mprof.items():
         if nm in names and ln:
             ach = ALGO_BYTES[nm] * cells / (ms / ln * 1e-3) / 1e9
             out.append({"kernel": nm, "what": names[nm], "launches": ln, "avg_ms": round(ms / ln, 5), "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
@@ -766,6 +803,9 @@ def run(a, prog):
     local_dev = local_rank % ndev   # host transport: ranks may share a device
     torch.cuda.set_device(local_dev)
     cu.device_init(local_dev)
+    if (a.no_fuse or a.debug_option or a.transport == "host") and not hasattr(lib(), "cup3d_debug_set_option"):
+        sys.exit("bench.py: --no-fuse / --debug-option / --transport host need the testing build of the library (CUP3D_HIP_FLAVOUR=testing, "
+                 "libcup3d_hip_testing.so); the loaded one is %s" % os.path.basename(cu.capi.LIB_PATH))
     if a.no_fuse:
         check(lib().cup3d_debug_set_option(b"no_fuse", 1))
     for opt in (a.debug_option or []):   # tuning scans: --debug-option name=value (cup3d_debug_set_option)
@@ -879,11 +919,8 @@ def run(a, prog):
         t = torch.tensor([sec], dtype=torch.float64, device=a.tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         sec = float(t.item())
-    ents = (ProfileEntry * 64)()
-    n = C.c_int(0)
-    lib().cup3d_profile_read(ents, 64, C.byref(n))
+    prof = read_profile()
     lib().cup3d_profile_enable(0)
-    prof = {ents[i].name.decode(): (ents[i].launches, ents[i].total_ms) for i in range(n.value)}
     # device timings of the communication stream (hipEvents on that stream, rank 0's): what one iteration spends in face-slab exchanges
     # (pack + grouped send/recv), in all-reduces (+ the recurrence step behind them), and how long the COMPUTE stream sat waiting for
     # either -- the exposed part; the rest of the first two was hidden behind the inner blocks' pass of the loop kernels
@@ -900,6 +937,39 @@ def run(a, prog):
     tot, nblk = C.c_long(0), C.c_long(0)
     lib().cup3d_profile_block_cg_iterations(sim.handle, C.byref(tot), C.byref(nblk))
     a.cg_iters_per_block = tot.value / nblk.value if nblk.value else None
+
+    # SURVEY 8(d) metric (A): the advect-diffuse RK3 operator ALONE on this grid (BASELINE configs[1] is the same thing at 256^3 periodic:
+    # --stencil-only --size 256) -- five operator calls after the timed region, so `value` never sees them.  The velocity it leaves
+    # behind is not used again (every `alt` region uploads the initial condition).
+    a.stencil_sub = None
+    if not a.stencil_only and not a.implicit_diffusion:
+        stage("alt", "SURVEY 8(d) metric (A): the RK3 operator alone")
+        nrk = 5
+        adv(sim.dt)   # (untimed: the first call after the projection)
+        lib().cup3d_profile_enable(1)
+        lib().cup3d_profile_reset()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(nrk):
+            adv(sim.dt)
+        fence()
+        sec_a = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([sec_a], dtype=torch.float64, device=a.tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sec_a = float(t.item())
+        pa = read_profile()
+        lib().cup3d_profile_enable(0)
+        ncell = float(a.size) ** 3
+        per_op = sec_a / nrk
+        stages = {k: {"launches": v[0], "avg_ms": round(v[1] / v[0], 5)} for k, v in pa.items() if k.startswith("advdiff") and v[0]}
+        a.stencil_sub = {"what": "AdvectionDiffusion::operator() alone (3 fused RK stages), main.cpp:9640-9728; wall clock over %d calls, all ranks" % nrk,
+                         "value": round(ncell / per_op / 1e6, 1), "unit": "Mcell-updates/s", "ms_per_operator": round(per_op * 1e3, 4), "n_gpus": world,
+                         "bound": "hbm", "peak": HBM_PEAK_GBS,
+                         "frac_at_288_B_per_cell (SURVEY 8d: 3 x 96)": round(288.0 * ncell / per_op / 1e9 / (HBM_PEAK_GBS * world), 4),
+                         "frac_at_264_B_per_cell (stage 1 reads no tmpV: 72 + 96 + 96)": round(264.0 * ncell / per_op / 1e9 / (HBM_PEAK_GBS * world), 4),
+                         "target": "north_star: >= 0.40 of the HBM roofline on the fused advect-diffuse stencil at 512^3",
+                         "stages (hipEvents, rank 0)": stages}
 
     # PCIe-inclusive rate of the C++ shim (never `value`): the boundary hands over one host pointer per block; measured here through
     # that very path (cup3d_sim_upload_blocks / _download_blocks on resident, reused host pages), then applied to the bytes the shim
@@ -949,7 +1019,7 @@ def run(a, prog):
             lib().cup3d_profile_enable(0)
             one_step()
             iters.clear()
-            if solver == 1 and not a.no_profile:   # the kernels of the direct-solve iteration: what the streams alone allow
+            if solver in (1, 5) and not a.no_profile:   # the kernels of the direct-solve iteration (what the streams alone allow); of the V-cycle, per level
                 lib().cup3d_profile_enable(1)
                 lib().cup3d_profile_reset()
             fence()
@@ -966,13 +1036,21 @@ def run(a, prog):
             alts[solver] = {"block_preconditioner": SOLVERS[solver], "value": round(float(a.size) ** 3 * nsteps / sec2 / 1e6, 2), "unit": "Mcell-updates/s",
                             "ms_per_step": round(sec2 / nsteps * 1e3, 3), "bicgstab_iters_per_step": round(float(np.mean(iters)), 2),
                             "ms_per_bicgstab_iteration": round(sec2 * 1e3 / max(1, sum(iters)), 4), "warmup": 1, "steps": nsteps}
+            if solver == 5 and not a.no_profile:
+                p5 = read_profile()
+                lib().cup3d_profile_enable(0)
+                ks = multigrid_kernels(p5, sim.nblocks)
+                fine = [k for k in ks if k["kernel"] == "mg_smooth" and k["level"] == max(x["level"] for x in ks)]
+                alts[solver]["kernels"] = ks
+                alts[solver]["roofline"] = ({k: fine[0][k] for k in ("bound", "achieved", "peak", "unit", "frac")} |
+                                            {"kernel": "mg_smooth on the finest level (two red-black sweeps per launch)", "traffic": (traffic_record().get(f"mg_smooth@{a.size}"))}) if fine else None
+                mg_ms = sum(k["total_ms"] for k in ks)
+                alts[solver]["v_cycle_share_of_device_time"] = round(mg_ms / (sum(ms for _, ms in p5.values()) or 1.0), 4)
             if solver == 1 and not a.no_profile:
-                n2 = C.c_int(0)
-                lib().cup3d_profile_read(ents, 64, C.byref(n2))
+                p1 = read_profile()
                 lib().cup3d_profile_enable(0)
                 ks = []
-                for i in range(n2.value):
-                    nm, ln, ms = ents[i].name.decode(), ents[i].launches, ents[i].total_ms
+                for nm, (ln, ms) in p1.items():
                     if nm in ALGO_BYTES and ln and nm.endswith("_fdm"):
                         ach = ALGO_BYTES[nm] * sim.nblocks * 512.0 / (ms / ln * 1e-3) / 1e9
                         ks.append({"kernel": nm, "launches": ln, "avg_ms": round(ms / ln, 5), "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
@@ -993,6 +1071,13 @@ def run(a, prog):
         dist.destroy_process_group()
     if invalid:
         sys.exit(3)
+
+
+def traffic_record():
+    """profiles/traffic.json: HBM bytes per cell of the hot kernels from the rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in separate
+    runs, FETCH_SIZE corrected as the guide prescribes for gfx950), keyed "<profile entry>@<size>"; recorded, not measured by this run"""
+    f = os.path.join(ROOT, "profiles", "traffic.json")
+    return json.load(open(f)) if os.path.exists(f) else {}
 
 
 def ref_iters(a, device_iters=None):
@@ -1033,8 +1118,7 @@ def report(a, sim, prof, sec, iters, world, alt=None):
     value = cells * a.steps / sec / 1e6
     kernels = []
     total_ms = sum(ms for _, ms in prof.values()) or 1.0
-    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    traffic = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
+    traffic = traffic_record()
     for name, (launches, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
         if launches == 0:
             continue
@@ -1098,6 +1182,8 @@ def report(a, sim, prof, sec, iters, world, alt=None):
     }
     if alt is not None:
         out["alt"] = alt
+    if getattr(a, "stencil_sub", None):
+        out["stencil_only"] = a.stencil_sub   # SURVEY 8(d) metric (A); `value` above is metric (B), the full step
     if getattr(a, "alt_multigrid", None):
         out["alt_multigrid"] = a.alt_multigrid
     if getattr(a, "alt_reference_association", None):
@@ -1120,6 +1206,14 @@ def report(a, sim, prof, sec, iters, world, alt=None):
         out["cpu_baseline"]["all_cores_recorded"] = {"value": round(256 ** 3 / 338.49 / 1e6, 4), "unit": "Mcell-updates/s", "cores": 256, "size": 256,
                                                      "also": {"64 threads": round(256 ** 3 / 30.31 / 1e6, 3), "32 threads": round(256 ** 3 / 18.17 / 1e6, 3)},
                                                      "source": "profiles/r02/probe_reference_threads_256cubed.txt (one 256^3 step each; the reference anti-scales beyond 32 threads)"}
+        f512 = os.path.join(ROOT, "profiles", "r04", "reference_step_512.json")
+        if os.path.exists(f512):   # the headline size itself on the GPU box's host, recorded (five minutes per step: not re-run inside a bench)
+            rec = json.load(open(f512))
+            out["cpu_baseline"]["recorded_512"] = {"value": round(512 ** 3 / rec["reference_seconds"] / 1e6, 4), "unit": "Mcell-updates/s", "size": 512, "cores": rec.get("threads"),
+                                                   "kind": "reference", "seconds_per_step": rec["reference_seconds"], "steps": len(rec["steps"]),
+                                                   "bicgstab_iters_per_step": rec["ref_iters_per_step"],
+                                                   "source": "profiles/r04/reference_step_512.json (the compiled reference, one 512^3 step from step 21 on the GPU box's host; recorded, "
+                                                             "not timed by this run)"}
         if a.cpu_size != 128:
             out["cpu_baseline_128"] = cpu_baseline(128, 10, min(32, os.cpu_count() or 1))
     ck = getattr(a, "checksum", None)

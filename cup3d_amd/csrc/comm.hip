@@ -89,7 +89,12 @@ static int load_rccl() {
 // An RCCL call that fails leaves the communicator unusable and the peers possibly inside the matching call: abort the communicator
 // (ncclCommAbort: pending operations of THIS rank end instead of spinning) and refuse every later exchange with CUP3D_ECOMM -- the
 // host then ends the run on all ranks (the C++ shim: MPI_Abort, as the reference does, main.cpp:15265, 15289; bench.py: its watchdog).
+static thread_local int g_group_depth = 0;  // ncclGroupStart calls of this thread not yet closed (RCCL keeps the group per thread)
 static int rccl_fail(ncclResult_t r, const char *what) {
+  // a Send / Recv that failed between GroupStart and GroupEnd would leave this thread's RCCL group open: a later ncclCommInitRank (the
+  // recovery cup3d_comm_init offers) would then be deferred into that stale group.  Close it first; its own result is of no interest.
+  while (g_group_depth > 0 && g_comm.GroupEnd) { --g_group_depth; (void)g_comm.GroupEnd(); }
+  g_group_depth = 0;
   set_error("RCCL error %d (%s) in %s; communicator aborted", (int)r, g_comm.GetErrorString ? g_comm.GetErrorString(r) : "?", what);
   if (g_comm_ready && g_comm.comm && g_comm.CommAbort) g_comm.CommAbort(g_comm.comm);
   g_comm.comm = nullptr;
@@ -322,7 +327,7 @@ static int view_transfer(Sim *s, double *dst, size_t per, const std::vector<int6
   if (g_ht_on) return ht_exchange(s->halo_send, send_count, dst, recv_count, per, -1, exchange_stream(s));
   Comm *c = comm();
   if (!c) return no_comm("multi-rank mesh");
-  CUP3D_NCCL(c->GroupStart());
+  CUP3D_NCCL(c->GroupStart()); ++g_group_depth;
   size_t so = 0, ro = 0;
   for (int p = 0; p < g->nranks; ++p) {
     const size_t ns = (size_t)send_count[p] * per, nr = (size_t)recv_count[p] * per;
@@ -331,7 +336,7 @@ static int view_transfer(Sim *s, double *dst, size_t per, const std::vector<int6
     so += ns;
     ro += nr;
   }
-  CUP3D_NCCL(c->GroupEnd());
+  --g_group_depth; CUP3D_NCCL(c->GroupEnd());
   return CUP3D_OK;
 }
 
@@ -345,6 +350,9 @@ static int view_exchange_blocks_begin(Sim *s, double *field, int nc, int w) {
   }
   ProfileScope ps("comm_ghost_blocks", st);  // pack + transfer as the communication stream sees them
   const unsigned nsend = (unsigned)g->send_blocks.size(), nghost = (unsigned)g->nghost();
+  // the sub-box plans exist for the two stencil widths of the path (1: scalar stencils, 3: advect-diffuse) and box_recv holds three
+  // components: anything else would leave ghost layers stale without a sign -- refused
+  if ((w != 1 && w != 3) || nc < 1 || nc > 3) { set_error("ghost-block exchange: width %d / %d components (supported: width 1 or 3, 1..3 components)", w, nc); return CUP3D_EINVAL; }
   const int k = w == 3 ? 1 : 0;
   int rc;
   if (!g->send_cells[k].empty() && s->d_send_box[k] && !debug_option("whole_ghost_blocks")) {
@@ -447,13 +455,13 @@ int exchange_items(Sim *s, const double *sendbuf, const std::vector<int64_t> &se
     int rc = ht_exchange(sendbuf, send_count, recvbuf, recv_count, per, me, st);
     if (rc) return rc;
   } else {
-    CUP3D_NCCL(c->GroupStart());
+    CUP3D_NCCL(c->GroupStart()); ++g_group_depth;
     for (int p = 0; p < n; ++p) {
       if (p == me) continue;
       if (send_count[p]) CUP3D_NCCL(c->Send(sendbuf + so[p], (size_t)send_count[p] * per, ncclDouble, p, c->comm, st));
       if (recv_count[p]) CUP3D_NCCL(c->Recv(recvbuf + ro[p], (size_t)recv_count[p] * per, ncclDouble, p, c->comm, st));
     }
-    CUP3D_NCCL(c->GroupEnd());
+    --g_group_depth; CUP3D_NCCL(c->GroupEnd());
   }
   if (st != stream()) {
     CUP3D_HIP(hipEventRecord(s->ev_h2, st));
@@ -470,7 +478,7 @@ static int slab_transfer(Sim *s, size_t per_face, hipStream_t st) {
   if (g_ht_on) return ht_exchange(s->halo_send, g->send_count, s->halo_recv, g->recv_count, per_face, -1, st);
   Comm *c = comm();
   if (!c) return no_comm("multi-rank grid");
-  CUP3D_NCCL(c->GroupStart());
+  CUP3D_NCCL(c->GroupStart()); ++g_group_depth;
   size_t so = 0, ro = 0;
   for (int p = 0; p < g->nranks; ++p) {
     const size_t ns = (size_t)g->send_count[p] * per_face, nr = (size_t)g->recv_count[p] * per_face;
@@ -479,7 +487,7 @@ static int slab_transfer(Sim *s, size_t per_face, hipStream_t st) {
     so += ns;
     ro += nr;
   }
-  CUP3D_NCCL(c->GroupEnd());
+  --g_group_depth; CUP3D_NCCL(c->GroupEnd());
   return CUP3D_OK;
 }
 

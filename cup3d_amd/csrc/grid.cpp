@@ -527,20 +527,50 @@ std::unique_ptr<Grid> Grid::rank_view(const int32_t *owner, int rank_, int nrank
       }
     }
   }
-  // the multigrid option's hierarchy of this rank (it needs the global mesh, which the view does not keep)
+  // the multigrid option's hierarchy of this rank needs the global mesh, which the view does not keep: leave what it takes to build one
+  // on first use (mg_plan_get)
   if (!tensorial) {
-    try {
-      V.mg_plan = mg_hierarchy(owner, rank_, nranks_, &to_view);
-    } catch (const std::exception &) {
-      V.mg_plan = nullptr;  // (a mesh the hierarchy cannot be built on: block_solver 5 says so when it is asked for; everything else does not care)
-    }
+    auto src = std::make_shared<MGSource>();
+    for (int d = 0; d < 3; ++d) { src->bpd[d] = bpd[d]; src->bc[d] = bc[d]; }
+    src->maxextent = maxextent;
+    src->blevel.assign(blevel.begin(), blevel.end());
+    src->index.assign(index.begin(), index.end());
+    src->owner.assign(owner, owner + nblocks());
+    src->leaf_slot = to_view;
+    src->rank = rank_;
+    src->nranks = nranks_;
+    V.mg_source = src;
   }
   return v;
 }
 
 std::shared_ptr<MGHierarchy> Grid::mg_hierarchy(const int32_t *owner, int rank_, int nranks_, const std::vector<int32_t> *leaf_slot) const {
   if (!multilevel || n_local >= 0) throw std::invalid_argument("mg_hierarchy needs a global multi-level mesh");
-  const int64_t nb = nblocks();
+  MGSource src;
+  for (int d = 0; d < 3; ++d) { src.bpd[d] = bpd[d]; src.bc[d] = bc[d]; }
+  src.maxextent = maxextent;
+  src.blevel.assign(blevel.begin(), blevel.end());
+  src.index.assign(index.begin(), index.end());
+  if (owner) src.owner.assign(owner, owner + nblocks());
+  if (leaf_slot) src.leaf_slot = *leaf_slot;
+  src.rank = rank_;
+  src.nranks = nranks_;
+  return build_mg_hierarchy(src);
+}
+
+std::shared_ptr<const MGHierarchy> Grid::mg_plan_get() const {
+  if (!mg_plan && mg_source) mg_plan = build_mg_hierarchy(*mg_source);
+  return mg_plan;
+}
+
+std::shared_ptr<MGHierarchy> build_mg_hierarchy(const MGSource &src) {
+  const int *bpd = src.bpd, *bc = src.bc;
+  const double maxextent = src.maxextent;
+  const std::vector<int32_t> &blevel = src.blevel, &index = src.index;
+  const int32_t *owner = src.owner.empty() ? nullptr : src.owner.data();
+  const std::vector<int32_t> *leaf_slot = src.leaf_slot.empty() ? nullptr : &src.leaf_slot;
+  const int rank_ = src.rank, nranks_ = src.nranks;
+  const int64_t nb = (int64_t)blevel.size();
   int lmax = 0;
   for (int64_t b = 0; b < nb; ++b) lmax = std::max(lmax, (int)blevel[(size_t)b]);
   const int nlev = lmax + 1;

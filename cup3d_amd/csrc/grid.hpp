@@ -46,6 +46,17 @@ struct MGLevelPlan {
   std::vector<int64_t> rsend_count, rrecv_count;  // [nranks]
   std::vector<int32_t> rsend, rrecv;              // pairs: slot on level l - 1 (a ghost slot when sending, an owned one when receiving), octant
 };
+// what Grid::mg_hierarchy reads of a global multi-level mesh (kept by rank views so that the hierarchy can be built on first use)
+struct MGSource {
+  int bpd[3], bc[3];
+  double maxextent;
+  std::vector<int32_t> blevel, index;  // [nb], [nb][3] of ALL leaves, global order
+  std::vector<int32_t> owner;          // [nb]; empty: one rank owns everything
+  std::vector<int32_t> leaf_slot;      // [nb] slot of a leaf in the rank's field arrays (-1: not visible); empty: the global slot
+  int rank, nranks;
+};
+struct MGHierarchy;
+std::shared_ptr<MGHierarchy> build_mg_hierarchy(const MGSource &src);
 struct MGHierarchy {
   int rank = 0, nranks = 1;
   std::vector<MGLevelPlan> lev;  // [0] coarsest ... finest level present
@@ -142,7 +153,13 @@ struct Grid {
   // the multigrid hierarchy of rank `rank` when the leaves of this (global, multi-level) mesh are owned as `owner` says (nullptr: one
   // rank owns everything); leaf_slot[global leaf] = slot of the leaf in that rank's field arrays (nullptr: the global slot itself)
   std::shared_ptr<MGHierarchy> mg_hierarchy(const int32_t *owner, int rank, int nranks, const std::vector<int32_t> *leaf_slot) const;
-  std::shared_ptr<const MGHierarchy> mg_plan;  // views: built by rank_view (it needs the global mesh); else built on first use
+  // rank views: the hierarchy needs the GLOBAL leaf table, which a view does not keep -- so rank_view() leaves the little it takes to
+  // build one (levels, indices and owners of all leaves: 20 bytes per leaf) in mg_source, and the hierarchy itself, with its dense maps
+  // per level and the want-lists of every rank, is built by mg_plan_get() when block_solver 5 first asks for it (never, in most runs).
+  // Throws std::invalid_argument for a mesh that is not 2:1 balanced; std::logic_error (a plan bug) and std::bad_alloc are not swallowed.
+  std::shared_ptr<const MGSource> mg_source;
+  std::shared_ptr<const MGHierarchy> mg_plan_get() const;
+  mutable std::shared_ptr<const MGHierarchy> mg_plan;  // filled by mg_plan_get (one thread drives a Grid)
   Grid(const Grid &proto, int basics_only);  // box, curve and spacing of `proto`, no blocks (used by rank_view)
   int owner_of(int64_t z) const;
   static void partition(int64_t total, int rank, int nranks, int64_t *begin, int64_t *count);

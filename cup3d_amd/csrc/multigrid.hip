@@ -31,6 +31,7 @@ namespace cup3d {
 
 struct MGLevel {
   std::unique_ptr<Grid> grid;  // nullptr on the finest level (the solver's own grid)
+  int index = 0;               // position in Multigrid::lev (0 = coarsest): the per-level entries of the profile
   int64_t nb = 0;
   double h = 0;
   int32_t *d_nbr = nullptr;     // [nb][6]
@@ -50,6 +51,16 @@ struct MGLevel {
   int32_t *d_send_slots = nullptr, *d_rsend = nullptr, *d_rrecv = nullptr;
   double *pack = nullptr, *rpack = nullptr, *runpack = nullptr;  // send buffer of the ghost exchange; octant buffers of the restriction (64 doubles per item)
 };
+// profile entry of one kernel on one level, "mg_smooth@L6": the levels differ by a factor 8 in work, and the roofline of the V-cycle is a
+// statement about the fine ones (bench.py: alt_multigrid.kernels); interned strings, ProfileScope keeps the pointer's text
+static const char *level_name(int kind, int level) {
+  static const char *const base[4] = {"mg_smooth", "mg_smooth_from_zero", "mg_residual_restrict", "mg_prolong_add"};
+  static std::string names[4][24];
+  if (level < 0 || level >= 24) return base[kind];
+  std::string &n = names[kind][level];
+  if (n.empty()) n = std::string(base[kind]) + "@L" + std::to_string(level);
+  return n.c_str();
+}
 struct Multigrid {
   std::vector<MGLevel> lev;  // [0] coarsest ... [L] finest
   double *zeros = nullptr;   // ghost values behind faces owned by other ranks (see mg_setup); the x pointer itself on one rank
@@ -309,15 +320,18 @@ static int mg_setup_amr(Sim *s) {
   // ranks (the view does not keep the global mesh), here for a mesh on one rank
   try {
     if (g->n_local >= 0) {
-      if (!g->mg_plan) { set_error("multigrid: this rank view carries no level hierarchy (a tensorial view, or a mesh that is not 2:1 balanced)"); return CUP3D_EINVAL; }
-      mg->plan = g->mg_plan;
+      mg->plan = g->mg_plan_get();  // built now, on first use (std::invalid_argument: the mesh is not 2:1 balanced)
+      if (!mg->plan) { set_error("multigrid: this rank view carries no level hierarchy (a tensorial view)"); return CUP3D_EINVAL; }
     } else {
       if (g->nranks > 1) { set_error("multigrid on a multi-level mesh over ranks needs rank views (cup3d_grid_rank_view)"); return CUP3D_EINVAL; }
       mg->plan = g->mg_hierarchy(nullptr, 0, 1, nullptr);
     }
-  } catch (const std::exception &e) {
+  } catch (const std::invalid_argument &e) {  // the caller's mesh; a std::logic_error would be a bug in the plan and is not turned into "bad argument"
     set_error("multigrid: %s", e.what());
     return CUP3D_EINVAL;
+  } catch (const std::exception &e) {
+    set_error("multigrid: building the level hierarchy failed: %s", e.what());
+    return CUP3D_ESTATE;
   }
   const MGHierarchy &H = *mg->plan;
   mg->local = H.nranks > 1;
@@ -332,6 +346,7 @@ static int mg_setup_amr(Sim *s) {
   for (int l = 0; l < nlev; ++l) {
     MGLevel &M = mg->lev[l];
     const MGLevelPlan &P = H.lev[l];
+    M.index = l;
     M.plan = &P;
     M.nb = P.n_owned;
     M.nghost = P.n_ghost;
@@ -393,6 +408,7 @@ static int mg_setup(Sim *s) {
     int64_t max_halo_faces = 0;
     for (int i = nlev - 1; i >= 0; --i) {
       MGLevel &M = mg->lev[i];
+      M.index = i;
       const Grid *gl = g;
       if (i < nlev - 1) {
         M.grid.reset(new Grid(g->bpd, g->level_max, lmin + i, g->maxextent, g->bc, g->rank, N));
@@ -459,7 +475,7 @@ static int mg_smooth(const MGLevel &M, const double *zeros, double **xa, double 
     if (amr_sim && !zero) { int rc = mg_ghosts(amr_sim, M, *xa); if (rc) return rc; }
     const double *halo = M.xch ? (const double *)M.xch->halo_recv : (zeros ? zeros : (const double *)*xa);
     if (!halo) halo = *xa;  // a rank without remote faces
-    ProfileScope ps("mg_smooth");
+    ProfileScope ps(level_name(zero ? 1 : 0, M.index));
     if (M.nb == 0) { /* a rank that owns no node of this level still took part in the exchange above */ }
     else if (wave && zero) hipLaunchKernelGGL(k_mg_smooth_wave<true>, G, dim3(64), 0, stream(), g, (const double *)nullptr, halo, rhs, *xb, sweeps);
     else if (wave) hipLaunchKernelGGL(k_mg_smooth_wave<false>, G, dim3(64), 0, stream(), g, (const double *)*xa, halo, rhs, *xb, sweeps);
@@ -545,7 +561,7 @@ static int mg_vcycle_amr(Sim *s, Multigrid &mg, const double *in, double *out, i
     if (xs && (rc = mg_ghosts(xs, M, xa[l]))) return rc;  // the residual reads the neighbours' final iterate
     const GridDev g = level_gdev(M);
     {
-      ProfileScope ps("mg_residual_restrict");
+      ProfileScope ps(level_name(2, M.index));
       if (M.nb) hipLaunchKernelGGL(k_mg_residual_restrict, dim3(launch_groups(g)), dim3(256), 0, stream(), g, (const double *)xa[l], (const double *)M.slabs, (const double *)M.b,
                                    (const int32_t *)M.d_parent, mg.lev[l - 1].b);
     }
@@ -570,7 +586,7 @@ static int mg_vcycle_amr(Sim *s, Multigrid &mg, const double *in, double *out, i
     MGLevel &M = mg.lev[l];
     if (xs && (rc = mg_ghosts(xs, mg.lev[l - 1], xa[l - 1]))) return rc;  // remote parents and coarse neighbours: their final iterate
     {
-      ProfileScope ps("mg_prolong_add");
+      ProfileScope ps(level_name(3, M.index));
       if (M.nb) hipLaunchKernelGGL(k_mg_prolong_add, dim3((unsigned)M.nb), dim3(256), 0, stream(), (int)M.nb, xa[l], (const int32_t *)M.d_parent, (const double *)xa[l - 1]);
       if (M.ncf) hipLaunchKernelGGL(k_mg_cf_ghosts, dim3((unsigned)M.ncf), dim3(64), 0, stream(), (const int32_t *)M.d_cf, (const double *)xa[l - 1], M.slabs);
     }
@@ -608,7 +624,7 @@ int mg_vcycle(Sim *s, const double *in, double *out) {
     Sim *xs = mg.lev[l].xch;
     if (xs && (rc = halo_exchange(xs, xa[l], 1, 1))) return rc;
     const double *halo = xs && xs->halo_recv ? (const double *)xs->halo_recv : (const double *)xa[l];
-    ProfileScope ps("mg_residual_restrict");
+    ProfileScope ps(level_name(2, l));
     hipLaunchKernelGGL(k_mg_residual_restrict, dim3(launch_groups(g)), dim3(256), 0, stream(), g, (const double *)xa[l], halo, rhs[l], (const int32_t *)mg.lev[l].d_parent,
                        mg.lev[l - 1].b);
   }
@@ -632,7 +648,7 @@ int mg_vcycle(Sim *s, const double *in, double *out) {
   if (rc) return rc;
   for (int l = 1; l <= L; ++l) {  // upward leg
     {
-      ProfileScope ps("mg_prolong_add");
+      ProfileScope ps(level_name(3, l));
       hipLaunchKernelGGL(k_mg_prolong_add, dim3((unsigned)mg.lev[l].nb), dim3(256), 0, stream(), (int)mg.lev[l].nb, xa[l], (const int32_t *)mg.lev[l].d_parent,
                          (const double *)xa[l - 1]);
     }

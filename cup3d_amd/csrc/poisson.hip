@@ -1698,15 +1698,12 @@ int cup3d_pressure_project(cup3d_sim_t *h, double dt, int step, const cup3d_pois
   const long N = s->nb * 512L;
   const unsigned G = vec_groups(N), Gs = vec_groups_simple(N);
   const bool second_order = step > 2;  // sim.step > sim.step_2nd_start (= 2), main.cpp:15087, 15355
-  if (s->grid->nranks > 1) {
-    // the operator is a collective: a rank that cannot run it says so to all of them before the first exchange (comm.hip, agree)
-    int local = CUP3D_OK;
-    if (s->chi_conflict()) {
-      set_error("cup3d_pressure_project: chi was written on this rank but cup3d_sim_set_obstacles(0) says no rank holds an obstacle");
-      local = CUP3D_ESTATE;
-    }
-    TRY(agree(s, local, "cup3d_pressure_project"));
-  }
+  // Several ranks: chi written on THIS rank although cup3d_sim_set_obstacles(0) told every rank that none holds an obstacle.  The flag does
+  // not steer the sequence of collectives (chi_path() depends on what the ranks were told, which is the same everywhere), so it needs no
+  // agreement BEFORE the operator -- that was one stream drain + one blocking all-reduce + one host wait per time step.  It rides along
+  // with the mean-pressure all-reduce the operator performs anyway (15123) and every rank returns the error together at the end.
+  const bool over_ranks = s->grid->nranks > 1;
+  const double conflict = over_ranks && s->chi_conflict() ? 1.0 : 0.0;
   if (second_order) { ProfileScope ps("project_pointwise"); LAUNCH_VEC_S(k_copy, s->pres, s->pold, N); }  // pOld, 15075
   // tmpV = 0 (15076-15078) matters only as the udef lab of KernelPressureRHS; without obstacles the RHS kernel does not read it
   // (adding -0*fac*0 is the identity).  With a resident chi it does: unless the caller has placed udef there since the last
@@ -1725,7 +1722,18 @@ int cup3d_pressure_project(cup3d_sim_t *h, double dt, int step, const cup3d_pois
   const double hh = s->grid->h, vv = hh * hh * hh;
   Reducer red{s};
   { ProfileScope ps("project_pointwise"); LAUNCH_VEC(k_mean_dots, s->pres, N, vv, s->d_hb, red.out()); }
-  TRY(red.begin(2)); TRY(red.wait());                        // MPI_Allreduce(2), 15123
+  if (over_ranks) {  // + the chi-conflict flag of the ranks (above)
+    hipLaunchKernelGGL(k_set_one, dim3(1), dim3(1), 0, stream(), s->d_red, (size_t)kRedDots + 2, conflict);
+    TRY(red.begin(3));
+  } else {
+    TRY(red.begin(2));                                       // MPI_Allreduce(2), 15123
+  }
+  TRY(red.wait());
+  if (over_ranks && s->h_red[2] != 0.0) {
+    set_error(conflict != 0.0 ? "cup3d_pressure_project: chi was written on this rank but cup3d_sim_set_obstacles(0) says no rank holds an obstacle"
+                              : "cup3d_pressure_project: another rank holds a chi although cup3d_sim_set_obstacles(0) told every rank that none does");
+    return CUP3D_ESTATE;
+  }
   const double avg = s->h_red[0] / s->h_red[1];              // 15126
   { ProfileScope ps("project_pointwise"); LAUNCH_VEC_S(k_shift_mean, s->pres, second_order ? s->pold : (const double *)nullptr, N, avg); }
   TRY(cup3d_grad_p_update(h, dt));                           // KernelGradP + vel += tmpV/h^3, 15146-15159

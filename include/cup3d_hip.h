@@ -366,7 +366,7 @@ CUP3D_API int cup3d_profile_read(cup3d_profile_entry *entries, int max, int *n);
  * v = A zhat (14489), loop 2 (14502-14515), what = M^-1 w (14548): the fused kernels, the width-1 scalar halo exchanges, the
  * inner / boundary split -- with no dot product feeding back.  The stencil and the block-local solve do not see the partition, so
  * sums[18] (wrapping 64-bit sums of each vector's bit patterns over the rank's blocks, vector order of poisson.hip), added over the
- * ranks mod 2^64, are the same at every N.  block_solver 0 or 2 (the solvers with fused kernels); clobbers the work vectors only. */
+ * ranks mod 2^64, are the same at every N.  block_solver 0, 1 or 2 (the solvers with fused kernels); clobbers the work vectors only. */
 CUP3D_API int cup3d_poisson_path_checksum(cup3d_sim_t *, int block_solver, int mean_constraint, unsigned long long *sums18);
 /* CG iterations of the last block-CG launch made while cup3d_profile_enable(1) was on, summed over the rank's blocks (the flop count
  * behind bench.py's FP64 roofline of the block preconditioner, getZImplParallel main.cpp:14704-14745) */
