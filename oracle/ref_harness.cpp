@@ -188,18 +188,33 @@ int main(int argc, char **argv) {
   /* sign of life between two of the reference's per-step lines (a step is hundreds of BiCGSTAB iterations; with eight ranks and a test
      process time-slicing ONE device it can take minutes): every 5 s, if the library's exchange / all-reduce counters have moved, one
      line.  A launch whose counters stand still prints nothing and is hung; one that prints is slow (tests/test_gpu_00_dropin_mpi.py) */
-  if (::sim.rank == 0)
-    std::thread([] {
+  {
+    const int my_rank = ::sim.rank;
+    std::thread([my_rank] {
       long seen = -1;
+      const auto t0 = std::chrono::steady_clock::now();
+      auto moved = t0;
+      char name[64];
+      snprintf(name, sizeof name, "alive.r%d", my_rank);
       for (;;) {
         std::this_thread::sleep_for(std::chrono::seconds(5));
         cup3d_run_stats st;
         if (cup3d_stats_read(&st) != 0) continue;
         const long now = st.halo_exchanges + st.allreduces + st.host_waits;
-        if (now != seen && seen != -1) printf("REF alive exchanges=%ld allreduces=%ld iterations=%ld\n", st.halo_exchanges, st.allreduces, st.solver_iterations);
+        const auto t = std::chrono::steady_clock::now();
+        if (now != seen) moved = t;
+        if (my_rank == 0 && now != seen && seen != -1) printf("REF alive exchanges=%ld allreduces=%ld iterations=%ld\n", st.halo_exchanges, st.allreduces, st.solver_iterations);
+        /* every rank's last word, for the test to quote when a launch fails or is cut off: where did each rank stand, and since when */
+        if (FILE *f = fopen(name, "w")) {
+          fprintf(f, "rank %d after %.0f s: exchanges=%ld allreduces=%ld iterations=%ld host_waits=%ld, counters last moved %.0f s ago\n", my_rank,
+                  std::chrono::duration<double>(t - t0).count(), st.halo_exchanges, st.allreduces, st.solver_iterations, st.host_waits,
+                  std::chrono::duration<double>(t - moved).count());
+          fclose(f);
+        }
         seen = now;
       }
     }).detach();
+  }
 #endif
   int rargc = argc - split;
   char **rargv = argv + split; /* rargv[0] = "--" plays the role of argv[0] */

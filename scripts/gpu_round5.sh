@@ -1,0 +1,103 @@
+#!/bin/bash
+# One gpurun call of round 5.  Usage: gpurun --timeout 1500 -- 'bash scripts/gpu_round5.sh <tag> [stages...]'
+# Every pytest stage is self-describing even when it is cut off: PYTHONFAULTHANDLER, -rA --tb=long, and tests/conftest.py's live log
+# (CUP3D_LIVE_LOG: start / outcome of every test and a failure's traceback at once, fsync'ed).
+TAG=${1:-r05a}; shift
+STAGES=${@:-smoke suite}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp PYTHONFAULTHANDLER=1 PYTHONUNBUFFERED=1
+cd "$(dirname "$0")/.."
+has() { [[ " $STAGES " == *" $1 "* ]]; }
+echo "== host: $(nproc) cpus, $(free -g | awk '/Mem:/{print $2}') GB, devices: $(python -c 'import cup3d_amd.capi as c; print(c.device_count())' 2>/dev/null), $(date)"
+pt() {  # pt <log name> <limit s> <pytest args...>
+  local name=$1 limit=$2; shift 2
+  CUP3D_LIVE_LOG=$OUT/$name.live.log timeout $limit stdbuf -oL -eL python -m pytest "$@" -m gpu -q -rA --tb=long -o log_cli=false --durations=12 > $OUT/$name.log 2>&1
+  local rc=$?
+  echo "pytest [$name] rc=$rc"; grep -E "^(FAILED|ERROR)|passed|failed| error" $OUT/$name.log | tail -25 | cut -c1-400
+  if [ $rc -ne 0 ]; then echo "--- last lines of the live log:"; tail -15 $OUT/$name.live.log | cut -c1-600; fi
+  return $rc
+}
+summ() { python - "$1" <<'PY'
+import json, sys
+try:
+    r = json.loads([l for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith("{")][-1])
+except Exception as e:
+    print("  (no JSON)", e); sys.exit(0)
+if r.get("valid") is False and r.get("value") is None:
+    print("  ERROR LINE:", json.dumps(r)[:1500]); sys.exit(0)
+c = r["config"]
+print("  value", r["value"], "ms/step", r["ms_per_step"], "its/step", c.get("bicgstab_iters_per_step"), "ms/iteration", r.get("ms_per_bicgstab_iteration"), "lib", c.get("library"))
+ck = c.get("checksum") or {}
+print("  checksum", ck.get("ok"), {k: ck[k].get("ok") for k in ck if isinstance(ck[k], dict)}, "unchecked", ck.get("unchecked"))
+cm = c.get("communication") or {}
+print("  comm", {k: cm.get(k) for k in ("rccl_ranks", "allreduce_ms_per_iteration", "exposed_scalar_wait_ms_per_iteration", "exposed_halo_wait_ms_per_iteration", "halo_ms_per_iteration", "host_wait_fraction")})
+if r.get("stencil_only"): print("  stencil_only", {k: v for k, v in r["stencil_only"].items() if k not in ("what", "target")})
+for k in ("alt", "alt_multigrid", "alt_reference_association"):
+    if r.get(k): print("  ", k, r[k].get("value"), r[k].get("bicgstab_iters_per_step"), r[k].get("ms_per_bicgstab_iteration"))
+for k in (r.get("alt_multigrid") or {}).get("kernels", [])[:12]:
+    print("    mg", k["kernel"], "L%d" % k["level"], k["blocks"], k["launches"], k["avg_ms"], k["frac"])
+for k in r.get("kernels", [])[:9]:
+    print("   ", k["kernel"], k["launches"], k["avg_ms"], k.get("frac"), k.get("share"))
+PY
+}
+if has smoke; then echo "== smoke (release build)"
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1 ; echo "smoke rc=$?" ; tail -3 $OUT/smoke.log; fi
+if has standin; then echo "== the RCCL stand-in cases alone (stream-memory-operation mode + the host-function variant)"
+  pt pytest_stand_in 1500 tests/test_gpu_rccl.py -k "stand_in" ; pt pytest_stand_in_mpi 1500 tests/test_gpu_00_dropin_mpi.py -k "rccl_stand_in" -s; fi
+if has quick; then echo "== pytest: ${QUICK}"
+  pt pytest_quick ${QUICK_LIMIT:-1200} ${QUICK} ; fi
+if has suite; then echo "== pytest -m gpu (the WHOLE suite, stand-in cases included)"
+  pt pytest_gpu ${SUITE_LIMIT:-2400} tests ; tail -5 $OUT/pytest_gpu.log | cut -c1-300; fi
+for S in 128 256 512; do
+  if has bench$S; then echo "== bench $S (release build, no cpu baseline, no alt)"
+    timeout 900 python bench.py --size $S --no-cpu --no-alt --no-pcie --steps ${BENCH_STEPS:-10} --warmup ${BENCH_WARMUP:-3} ${BENCH_ARGS} > $OUT/bench_$S.json 2> $OUT/bench_$S.err ; echo "bench rc=$?" ; summ $OUT/bench_$S.json ; tail -2 $OUT/bench_$S.err
+  fi
+done
+if has driver; then echo "== the driver's command: python bench.py --gpus 1 --steps 20 --warmup 5"
+  timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_512_fullstep.json 2> $OUT/bench_512_fullstep.err ; echo "bench rc=$?" ; summ $OUT/bench_512_fullstep.json ; tail -3 $OUT/bench_512_fullstep.err
+fi
+if has driverq; then echo "== the driver's workload, shorter: --steps 8 --warmup 3, no CPU baseline"
+  timeout 1200 python bench.py --gpus 1 --steps 8 --warmup 3 --no-cpu ${DRIVERQ_ARGS} > $OUT/bench_512_short.json 2> $OUT/bench_512_short.err ; echo "bench rc=$?" ; summ $OUT/bench_512_short.json ; tail -3 $OUT/bench_512_short.err
+fi
+if has amr; then echo "== bench --amr (3 levels)"
+  timeout 900 python bench.py --amr --steps ${AMR_STEPS:-10} --warmup 3 ${AMR_ARGS} > $OUT/bench_amr.json 2> $OUT/bench_amr.err ; echo "rc=$?" ; python - $OUT/bench_amr.json <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+its = r["config"]["bicgstab_iters_per_step"]
+print("  value", r["value"], "ms/step", r["ms_per_step"], r["config"]["blocks"], its, "ms/iteration", round(r["ms_per_step"] / its, 4))
+for k in r["kernels"][:10]: print("   ", k["kernel"], k["launches"], k["avg_ms"], k["share"])
+PY
+fi
+# injected latency: what an iteration costs when every all-reduce takes L microseconds (FAKE_RCCL_ALLREDUCE_US), ONE process whose scalars
+# are forced through the communicator (force_allreduce: testing build), so that nothing but the latency changes between the runs
+if has latency; then echo "== injected all-reduce latency, one process, ${LAT_SIZE:-256}^3: ms per BiCGSTAB iteration and the exposed scalar wait"
+  for MODE in ${LAT_MODES:-0 1}; do for L in ${LAT_US:-0 25 50 100}; do
+    F=$OUT/bench_${LAT_SIZE:-256}_latency_${L}us_early${MODE}.json
+    CUP3D_RCCL_LIBRARY=$PWD/tests/fake_rccl/librccl_fake.so FAKE_RCCL_ALLREDUCE_US=$L CUP3D_FORCE_COMM=1 timeout 600 python bench.py --size ${LAT_SIZE:-256} --no-cpu --no-alt --no-pcie --steps ${LAT_STEPS:-6} --warmup 2 \
+      --debug-option force_allreduce=1 --debug-option early_allreduce=$MODE > $F 2> ${F%.json}.err ; echo "rc=$? (latency $L us, early_allreduce=$MODE)"; summ $F | head -4; tail -2 ${F%.json}.err
+  done; done; fi
+if has latency2; then echo "== injected all-reduce latency, TWO processes on one GPU (bench.py --gpus 2, stand-in library), ${LAT_SIZE:-256}^3"
+  for MODE in ${LAT_MODES:-0 1}; do for L in ${LAT_US:-0 50}; do
+    F=$OUT/bench_${LAT_SIZE:-256}_2ranks_latency_${L}us_early${MODE}.json
+    CUP3D_RCCL_LIBRARY=$PWD/tests/fake_rccl/librccl_fake.so CUP3D_BENCH_SHARE_DEVICE=1 FAKE_RCCL_ALLREDUCE_US=$L CUP3D_EARLY_ALLREDUCE=$MODE timeout 900 python bench.py --gpus 2 --size ${LAT_SIZE:-256} --no-cpu --no-alt --no-pcie \
+      --steps ${LAT_STEPS:-4} --warmup 2 > $F 2> ${F%.json}.err ; echo "rc=$? (2 ranks, latency $L us, early=$MODE)"; summ $F | head -4; tail -2 ${F%.json}.err
+  done; done; fi
+if has trace; then echo "== rocprofv3 --kernel-trace --stats of the driver's workload (short)"
+  ROOT=$(pwd); ( cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace -o t -- python $ROOT/bench.py --steps ${TRACE_STEPS:-6} --warmup 2 --no-cpu --no-pcie ${TRACE_ARGS} > $ROOT/$OUT/trace.log 2>&1 )
+  f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/rocprofv3_kernel_stats.csv && head -25 $f | cut -c1-200; rm -rf $OUT/trace; fi
+if has pmcmg; then echo "== rocprofv3 PMC passes over the multigrid option at 512^3 (FETCH_SIZE, WRITE_SIZE in separate runs)"
+  ROOT=$(pwd); rm -f $OUT/pmc_multigrid_kernels_512cubed.txt
+  for CN in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && timeout 900 rocprofv3 --pmc $CN --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_$CN -o p -- python $ROOT/bench.py --block-solver 5 --steps 2 --warmup 1 --no-cpu --no-alt --no-pcie --no-checksum > $ROOT/$OUT/pmcmg_$CN.log 2>&1 )
+    for f in $(find $OUT/pmc_$CN -name "*counter_collection.csv" | head -1); do python scripts/pmc_by_kernel_and_grid.py "$f" $CN k_mg_ k_advdiff | tee -a $OUT/pmc_multigrid_kernels_512cubed.txt; done
+    rm -rf $OUT/pmc_$CN
+  done; fi
+if has pmcmain; then echo "== rocprofv3 PMC passes over the driver's workload at 512^3, 2 steps (FETCH_SIZE, WRITE_SIZE in separate runs)"
+  ROOT=$(pwd); rm -f $OUT/pmc_fullstep_kernels_512cubed.txt
+  for CN in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && timeout 900 rocprofv3 --pmc $CN --kernel-trace --output-format csv -d $ROOT/$OUT/pmcm_$CN -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-alt --no-pcie --no-checksum > $ROOT/$OUT/pmcmain_$CN.log 2>&1 )
+    for f in $(find $OUT/pmcm_$CN -name "*counter_collection.csv" | head -1); do python scripts/pmc_by_kernel_and_grid.py "$f" $CN k_loop k_advdiff k_lhs k_precond k_refresh | tee -a $OUT/pmc_fullstep_kernels_512cubed.txt; done
+    rm -rf $OUT/pmcm_$CN
+  done; fi
+echo "== done $(date)"

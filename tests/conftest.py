@@ -24,3 +24,30 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---- a GPU session that is cut off from outside must still say what happened (round 4's one failing whole-suite run left two lines of
+# dots): with CUP3D_LIVE_LOG=<file> every test's start and outcome is appended to <file> AS IT HAPPENS (line-buffered, fsync'ed), and a
+# failure's full traceback -- pytest's own report only prints them when the session ends -- goes there at once.
+_LIVE = os.environ.get("CUP3D_LIVE_LOG")
+
+
+def _live(text):
+    if not _LIVE:
+        return
+    import time
+    with open(_LIVE, "a") as f:
+        f.write(time.strftime("%H:%M:%S ") + text + "\n")
+        f.flush()
+        os.fsync(f.fileno())
+
+
+def pytest_runtest_logstart(nodeid, location):
+    _live(f"START {nodeid}")
+
+
+def pytest_runtest_logreport(report):
+    if report.when == "call" or report.outcome != "passed":
+        _live(f"{report.outcome.upper():7s} {report.nodeid} [{report.when}] {getattr(report, 'duration', 0.0):.1f} s")
+    if report.failed:
+        _live("TRACEBACK of " + report.nodeid + "\n" + report.longreprtext + "\n" + "\n".join(f"--- captured {k} ---\n{v}" for k, v in report.sections))

@@ -176,23 +176,24 @@ def test_bench_on_a_multilevel_mesh_over_rank_views():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("n", [2, 3])
-def test_bench_rccl_code_path_with_the_stand_in_library(n):
+@pytest.mark.parametrize("n,mode", [(2, "values"), (3, "values"), (2, "hostfunc")])
+def test_bench_rccl_code_path_with_the_stand_in_library(n, mode):
     """`bench.py --gpus N` in its PRODUCTION configuration -- `--transport rccl`, the RELEASE library, comm.hip's RCCL branch: dlopen,
     ncclGetUniqueId on rank 0, the id over gloo, ncclCommInitRank, grouped ncclSend / ncclRecv of the packed face slabs on the
     communication stream, ncclAllReduce + the recurrence step behind it, the status agreement's flag, cup3d_comm_finalize -- on ONE GPU:
     librccl is replaced AT ITS OWN API by tests/fake_rccl (CUP3D_RCCL_LIBRARY; stream-ordered copies through shared-memory mailboxes),
     because RCCL refuses two ranks on one device.  Everything but RCCL's internals executes.  All five bitwise signals equal the
-    one-process run's and the recorded constants; max|u| along the run agrees to the projections' stopping tolerance."""
-    if os.environ.get("CUP3D_TEST_RCCL_STAND_IN") != "1":   # opt-in, see tests/test_gpu_00_dropin_mpi.py (STAND_IN_OPT_IN) for why
-        pytest.skip("CUP3D_TEST_RCCL_STAND_IN=1 runs the RCCL stand-in cases (scripts/gpu_round4.sh ... fakerccl)")
+    one-process run's and the recorded constants; max|u| along the run agrees to the projections' stopping tolerance.
+    mode: how the stand-in orders the copies of two processes -- "values": hipStreamWriteValue64 / hipStreamWaitValue64 on sequence words in
+    the pinned shared segment (device-side waits, as RCCL's are); "hostfunc": round 4's blocking host functions, kept as a variant.
+    (Round 4 ran these cases opt-in; they are part of the default suite again, tests/test_gpu_00_dropin_mpi.py says why.)"""
     if not os.path.exists(FAKE_RCCL):
         pytest.skip("tests/fake_rccl/librccl_fake.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
     args = ("--size", "128", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-alt", "--no-pcie")
     one = run_bench(*args)
     assert one.returncode == 0, one.stderr.decode()[-2000:]
     many = run_bench("--gpus", str(n), *args, timeout=800, extra_env={"CUP3D_RCCL_LIBRARY": FAKE_RCCL, "CUP3D_BENCH_SHARE_DEVICE": "1",
-                                                                             "CUP3D_HIP_FLAVOUR": "release"})   # (the suite's own processes load the testing build)
+                                                                             "CUP3D_HIP_FLAVOUR": "release", "FAKE_RCCL_MODE": mode, "FAKE_RCCL_VERBOSE": "1"})   # (the suite's own processes load the testing build)
     assert many.returncode == 0, (many.stdout.decode()[-1500:], many.stderr.decode()[-3000:])
     lines = [l for l in many.stdout.decode().strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, many.stdout.decode()[-2000:]
@@ -205,6 +206,7 @@ def test_bench_rccl_code_path_with_the_stand_in_library(n):
     com = rn["config"]["communication"]
     assert com["rccl_ranks"] == n and com["halo_exchanges_per_iteration"] >= 2 and com["allreduces_per_iteration"] >= 2
     assert com["halo_ms_per_iteration"] > 0 and com["allreduce_ms_per_iteration"] > 0 and com["exposed_ms_per_iteration"] >= 0
-    print(f"{n} ranks through comm.hip's RCCL branch (stand-in library): iterations {rn['config']['bicgstab_iters_by_step']} "
+    assert f"mode {mode}".encode() in many.stderr, many.stderr.decode()[-1500:]   # the stand-in says which ordering it runs
+    print(f"{n} ranks through comm.hip's RCCL branch (stand-in library, {mode}): iterations {rn['config']['bicgstab_iters_by_step']} "
           f"(one process: {r1['config']['bicgstab_iters_by_step']}); per iteration: halo {com['halo_ms_per_iteration']} ms, all-reduce "
           f"{com['allreduce_ms_per_iteration']} ms, exposed {com['exposed_ms_per_iteration']} ms")
