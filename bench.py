@@ -205,6 +205,8 @@ def multigrid_kernels(prof, fine_blocks):
         ach = MG_ALGO_BYTES[base] * blocks * 512.0 / (avg * 1e-3) / 1e9
         e = {"kernel": base, "level": lv, "blocks": blocks, "launches": launches, "avg_ms": round(avg, 5), "total_ms": round(ms, 3), "bound": "hbm",
              "algorithmic_bytes_per_cell": MG_ALGO_BYTES[base], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+        if lv == top:
+            e["traffic"] = traffic_record().get(f"{base}@{round((fine_blocks * 512) ** (1 / 3))}")   # PMC bytes per launch on the finest level (recorded)
         if blocks <= 4096:
             e["note"] = "launch-latency bound: fewer blocks than the chip has wavefront slots"
         out.append(e)
@@ -833,6 +835,13 @@ def run(a, prog):
             dist.broadcast(idbuf, 0)
             raw = (C.c_ubyte * 128)(*idbuf.tolist())
             check(lib().cup3d_comm_init(rank, world, raw))
+    elif os.environ.get("CUP3D_FORCE_COMM"):
+        # MEASUREMENT SUPPORT (testing build, --debug-option force_allreduce=1): ONE process whose solver scalars travel through the
+        # library's communicator all the same -- a one-rank communicator of CUP3D_RCCL_LIBRARY (tests/fake_rccl with FAKE_RCCL_ALLREDUCE_US:
+        # what an iteration costs when an all-reduce takes as long as it does between devices, nothing else changed)
+        raw = (C.c_ubyte * 128)()
+        check(lib().cup3d_comm_unique_id(raw))
+        check(lib().cup3d_comm_init(0, 1, raw))
     a.tdev = "cpu"   # torch.distributed's own tensors (gloo)
     stage("grid", "topology, allocation")
     if a.amr:

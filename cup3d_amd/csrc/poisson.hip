@@ -497,9 +497,7 @@ static int *cg_iters_buffer(Sim *s) {  // per-block CG iteration counts of the l
 }
 
 constexpr int kLoopPrio = 0;    // LhsIn::prio of the production launch (measured: profiles/r03)
-// workgroups of k_sums_finish: 64 below 2^17 blocks, 256 from there on (0.027 instead of 0.051 ms per launch at 512^3, 0.016 instead of
-// 0.014 at 256^3; wave priority 1..3 while streaming changes nothing: profiles/r03/probe_tuning_prio_sums.jsonl)
-inline int sums_groups(int64_t nb) { return nb >= (1 << 17) ? 256 : 64; }
+constexpr int kLoop1LdsPad = 0; // dynamic LDS of the first fused kernel's production launch (see launch_loop; measured: profiles/r05)
 // evaluation of the production block CG (EV bits of k_precond); measured on MI355X: see profiles/r02/probe_block_cg_variants.jsonl
 constexpr int kCgProduction = 0;
 
@@ -608,6 +606,9 @@ struct SolverCtl {
   int restarts, max_restarts;
   int xcur, xopt;  // which of the two x buffers holds x / the best iterate so far (x_opt; -1: none yet)
   int iter;        // iterations completed
+  unsigned seq;    // sequence number of the fused iteration in flight (the host's Sim::ctl_seq numbering: k_ctl_set places it, ctl_step2 advances
+                   // it): the slot of the status ring and the values of the early all-reduce's flags derive from it, so that the kernels of an
+                   // iteration take NO per-iteration argument
 };
 struct CtlSlot { SolverCtl c; unsigned seq; unsigned pad; };  // pinned status ring, slot = seq & 3
 // x is updated in place unless the buffer that holds it is also the x_opt snapshot: then the update goes to the other buffer
@@ -633,6 +634,7 @@ __host__ __device__ inline void ctl_step2(SolverCtl &c, const double *t) {
   c.norm = norm;
   c.xcur = ctl_xwrite(c);  // x lives where the second loop wrote it
   c.iter++;
+  c.seq++;
   int state = kRun;
   if (r0r * r0r < 1e-16 * norm_1 * norm_2 && c.restarts < c.max_restarts) {  // serious breakdown, 14566-14567
     c.restarts++;
@@ -654,12 +656,13 @@ __device__ __forceinline__ void ctl_publish(const SolverCtl *c, CtlSlot *ring, u
 // several ranks: the totals are all-reduced first (communication stream); this one-thread kernel behind the all-reduce steps the
 // struct -- identically on every rank, the all-reduced bits are the same everywhere -- and the compute stream waits for its event
 template <int STEP>
-__global__ void k_ctl_step(SolverCtl *ctl, const double *__restrict__ tot, CtlSlot *ring, unsigned seq) {
+__global__ void k_ctl_step(SolverCtl *ctl, const double *__restrict__ tot, CtlSlot *ring) {
   if (ctl->state != kRun) return;  // an iteration enqueued ahead of a stop / restart: nothing happened, nothing to step
   SolverCtl c = *ctl;
+  const unsigned it = c.seq;
   if (STEP == 1) ctl_step1(c, tot); else ctl_step2(c, tot);
   *ctl = c;
-  if (STEP == 2) ctl_publish(ctl, ring, seq);
+  if (STEP == 2) ctl_publish(ctl, ring, it);
 }
 __global__ void k_ctl_set(SolverCtl *ctl, SolverCtl v) { *ctl = v; }
 
@@ -700,6 +703,99 @@ __device__ __forceinline__ double dot2(double2 a, double2 b, double acc) { acc +
 // The arithmetic per cell is that of k_loop1 / k_loop2 and of cg_block, unchanged; the dot products are summed per block first
 // (wave tree) and the per-block values by k_sums_finish, another order than the grid-stride partials of the unfused kernels.
 // block_dots layout: [K][nb].
+// ------------------------------------------------------------------ totals of per-block values INSIDE the kernel that produces them
+// Rounds 2-4 finished the dot products of a fused loop in a launch of their own (k_sums_finish: 64 / 256 workgroups over the [K][nb]
+// per-block values, last workgroup totals and steps the scalars).  That launch -- 16-27 us plus the gap around it, twice per iteration --
+// is what the per-rank share of the workload on 8 GPUs (256^3: 1.15 ms per iteration) feels most, and it pins the moment the totals exist
+// to the END of the loop kernel, one block-CG phase later than they are complete.  Here the kernel finishes them itself: a wavefront
+// that has written its block's values takes a ticket in the counter of its GROUP (64 consecutive slots); the last one of a group adds
+// the group's 64 values (one per lane, wave tree) and takes a ticket in the counter of the SUPER-GROUP (64 groups); the last one there
+// adds the 64 group sums; the last super-group adds the super-group sums, stores the K totals and runs `then` (the recurrence step on
+// one rank; the flag the communication stream waits for over ranks).  Who is last varies from run to run, WHAT is added in which
+// order does not: sums of fixed sets in a fixed tree -- deterministic.  Counters count over all launches of a loop (inner / boundary
+// pass, plain / interface list): membership is by slot.  Release / acquire at agent scope as in grid_sum_finish (tile.hpp); the values
+// of other wavefronts are read with agent-scope loads.
+struct Arrive {
+  const double *vals;      // [K][nb] per-block values
+  double *g1, *g2;         // [K][n1], [K][n2]: sums of 64 blocks / of 64 groups
+  unsigned *c1, *c2, *c3;  // arrivals per group [n1], per super-group [n2], super-groups done [1]; all zero between two loops
+  long nb, n1, n2;
+  double *out;             // [K] totals (device memory)
+};
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ticket_of_wave(unsigned *counter) {  // lane 0's values are stored: release, then take a ticket; every lane gets it
+  unsigned t = 0;
+  if (threadIdx.x == 0) { __threadfence(); t = atomicAdd(counter, 1u); }
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+}
+template <int K, class Then>
+__device__ __forceinline__ void arrive(const Arrive &A, int slot, Then then) {
+  const int l = threadIdx.x;
+  const long g = slot >> 6, first = g << 6;
+  const unsigned gsize = (unsigned)(A.nb - first < 64 ? A.nb - first : 64);
+  if (ticket_of_wave(A.c1 + g) != gsize - 1) return;
+  __threadfence();  // acquire the group's values
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double v = wave_sum((unsigned)l < gsize ? ld_agent(A.vals + (size_t)k * A.nb + first + l) : 0.0);
+    if (l == 0) A.g1[(size_t)k * A.n1 + g] = v;
+  }
+  const long sg = g >> 6, gfirst = sg << 6;
+  const unsigned sgsize = (unsigned)(A.n1 - gfirst < 64 ? A.n1 - gfirst : 64);
+  if (l == 0) A.c1[g] = 0;
+  if (ticket_of_wave(A.c2 + sg) != sgsize - 1) return;
+  __threadfence();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double v = wave_sum((unsigned)l < sgsize ? ld_agent(A.g1 + (size_t)k * A.n1 + gfirst + l) : 0.0);
+    if (l == 0) A.g2[(size_t)k * A.n2 + sg] = v;
+  }
+  if (l == 0) A.c2[sg] = 0;
+  if (ticket_of_wave(A.c3) != (unsigned)A.n2 - 1) return;
+  __threadfence();
+  double tot[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double v = 0;
+    for (long j = l; j < A.n2; j += 64) v += ld_agent(A.g2 + (size_t)k * A.n2 + j);
+    tot[k] = wave_sum(v);
+    if (l == 0) A.out[k] = tot[k];
+  }
+  if (l == 0) {
+    *A.c3 = 0;
+    then(tot);
+  }
+}
+// what the wavefront that completes the dot products does with them
+struct DotsThen {
+  SolverCtl *ctl; CtlSlot *ring;
+  int which;         // 1: first loop (q.y, y.y -> omega, 14493), 2: second loop (the seven of 14546 -> 14558-14601)
+  int step;          // != 0: one rank -- step the solver's scalars (ctl_step1 / ctl_step2) and, after the second loop, publish them to the host's ring; 0: totals only
+  unsigned *flag;    // several ranks, early all-reduce: raised to 2 seq + which - 1 once the totals are in device memory (k_wait_totals on the communication stream)
+  __device__ __forceinline__ void operator()(const double *tot) const;
+};
+struct LoopSums {  // what a fused loop kernel needs to total its per-block values; constant over a solve, in DEVICE memory (Sim::d_loop_sums): the
+                   // kernels take a pointer -- as a by-value argument its 25 words stayed live across the plane loop and cost the occupancy
+  Arrive dots;     // K = 2 (first loop) / 7 (second loop) dot products, complete when the last block leaves its vector phase
+  Arrive mean;     // K = 1: sum(zhat h^3) / sum(what h^3) of the block solves (mean-constraint row, 9283-9326), complete when the kernel ends; vals == nullptr: not wanted
+  DotsThen then;
+};
+__device__ __forceinline__ void DotsThen::operator()(const double *tot) const {
+  const unsigned it = ctl->seq;
+  if (step != 0 && ctl->state == kRun) {  // (every wavefront that came this far saw kRun; only this one changes it)
+    SolverCtl c = *ctl;
+    if (which == 1) ctl_step1(c, tot); else ctl_step2(c, tot);
+    *ctl = c;
+    if (which == 2) ctl_publish(ctl, ring, it);
+  }
+  if (flag) {  // the totals (this lane's own stores) before the flag
+    __threadfence();
+    __hip_atomic_store(flag, 2 * it + (unsigned)(which - 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+struct NoThen { __device__ __forceinline__ void operator()(const double *) const {} };
+__global__ void k_set_loop_sums(LoopSums *dst, LoopSums a, LoopSums b) { dst[0] = a; dst[1] = b; }
+
 struct Loop1Args { double alpha, beta, omega; };
 struct Loop2Args { double alpha, omega; };
 
@@ -726,6 +822,11 @@ struct LhsIn {
   int corner_slot;      // slot of the block with index (0,0,0) on this rank, or -1
   int prio;             // wave priority (s_setprio) while the wavefront streams its block; back to 0 when the block CG starts
   const double *invD;   // DIRECT form of the block solve (block_solver 1): 1 / (lam_kx + lam_ky + lam_kz), [ky][kz][kx]; else unused
+  // early all-reduce over ranks (solve(): early): *total is valid once *mean_flag has reached mean_seq -- the wavefronts that USE the total
+  // wait for that (mode 1: the corner block's only); nullptr: the total was complete before the launch
+  const unsigned *mean_flag;
+  int mean_wait;        // which value: 1 = 2 (seq - 1) + 1 (first loop: the total of the previous iteration's second loop), 2 = 2 seq (second loop); seq = SolverCtl::seq
+  unsigned *fail;       // pinned: raised when that wait gives up (10 s)
 };
 struct TileRegs { double c[8], gv[6]; };
 // the 14 loads of a tile in two groups: the block's own column (needs nothing but the slot) and the six face slabs (need the
@@ -772,9 +873,18 @@ struct LhsFix {
   bool row_total;     // this lane holds the corner cell (plane 0) and mode 1: t = total (9299-9304)
   bool row_self;      // ... and mode > 2: t = u (9316-9325)
 };
-__device__ __forceinline__ LhsFix lhs_fix(const LhsIn &L, int slot, int l, double h) {
+__device__ __forceinline__ LhsFix lhs_fix(const LhsIn &L, const SolverCtl *ctl, int slot, int l, double h) {
   LhsFix f;
-  f.total = (L.mode == 1 || L.mode == 2) ? L.total[0] : 0.0;
+  const bool uses_total = L.mode == 2 || (L.mode == 1 && slot == L.corner_slot);  // wave-uniform
+  if (uses_total && L.mean_flag) {
+    const unsigned want = L.mean_wait == 1 ? 2 * (ctl->seq - 1) + 1 : 2 * ctl->seq;
+    const long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(L.mean_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > 1000000000LL) { if (l == 0) __hip_atomic_store(L.fail, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+  }
+  f.total = uses_total ? ld_agent(L.total) : 0.0;
   f.add = f.total * (h * h * h);
   f.add_mean = L.mode == 2;
   const bool corner = slot == L.corner_slot && l == 0;
@@ -806,8 +916,8 @@ __device__ __forceinline__ double tile_lhs(const double *T, const TileIdx &ix, d
 // DIRECT: the block solve behind the loop is the fast diagonalisation (fdm_block: the same M^-1, exact instead of by CG -- block_solver 1,
 // bench.py's `alt`), not the reference's CG: no iteration, no reductions, so the kernel is what the streams alone allow
 template <bool FMA, int EV, bool FLHS, bool DIRECT = false>
-__device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb,
-                                              double *__restrict__ block_sums, int *__restrict__ iters_out, const LhsIn &L) {
+__device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb,
+                                              double *block_sums, int *__restrict__ iters_out, const LhsIn &L, const LoopSums *__restrict__ Z) {
   __shared__ double P[FLHS ? kTileLds : (DIRECT ? kFdmLds : kCgLds)];
   const int slot = block_slot(g);
   if (slot < 0) return;
@@ -834,7 +944,7 @@ __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, c
   LhsFix fx{};
   TileRegs tr;
   if constexpr (FLHS) {  // the tile's loads first, the first plane of the streams right behind them, then the tile goes to LDS
-    fx = lhs_fix(L, slot, l, hq);
+    fx = lhs_fix(L, ctl, slot, l, hq);
     tile_issue_own(slot, V.v[WHAT], l, tr);
     ix = tile_idx(l);
   }
@@ -872,28 +982,30 @@ __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, c
   d0 = wave_sum(d0);
   d1 = wave_sum(d1);
   if (l == 0) { block_dots[slot] = d0; block_dots[nb + slot] = d1; }
+  arrive<2>(Z->dots, slot, Z->then);  // q.y, y.y are complete when the last block passes here: totals + omega (14493), one block solve before the kernel ends
   if (L.prio) __builtin_amdgcn_s_setprio(0);
   if constexpr (FLHS) __syncthreads();  // the tile is read no more: the block solve takes over its LDS
   if constexpr (DIRECT) fdm_block(g, slot, r, V.v[ZHAT], L.invD, block_sums, P);
   else cg_block<FMA, false, EV>(g, slot, r, V.v[ZHAT], block_sums, 0.0, 0.0, iters_out, P);  // zhat = M^-1 z, 14488
+  if (Z->mean.vals) arrive<1>(Z->mean, slot, NoThen());  // sum(zhat h^3) for the mean-constraint row of v = A zhat
 }
 // (with the LHS inside the compiler takes 110 registers -> 4 wavefronts per SIMD; held to 5 wavefronts it fits 94 without a spill and is
 //  SLOWER: 0.54 instead of 0.51 ms at 256^3, 3.96 instead of 3.93 at 512^3 -- gpurun_out r03c / r03d, profiles/r03)
 template <bool FMA, int EV, bool FLHS>
-__global__ void __launch_bounds__(64) k_loop1_cg(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
-                                                 int *__restrict__ iters_out, LhsIn L) {
-  loop1_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L);
+__global__ void __launch_bounds__(64) k_loop1_cg(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums,
+                                                 int *__restrict__ iters_out, LhsIn L, const LoopSums *__restrict__ Z) {
+  loop1_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L, Z);
 }
 // block_solver 1: first loop + the direct block solve (`alt`)
 template <bool FLHS>
-__global__ void __launch_bounds__(64) k_loop1_fdm(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
-                                                  LhsIn L) {
-  loop1_cg_body<true, 0, FLHS, true>(g, V, ctl, block_dots, nb, block_sums, nullptr, L);
+__global__ void __launch_bounds__(64) k_loop1_fdm(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums,
+                                                  LhsIn L, const LoopSums *__restrict__ Z) {
+  loop1_cg_body<true, 0, FLHS, true>(g, V, ctl, block_dots, nb, block_sums, nullptr, L, Z);
 }
 
 template <bool FMA, int EV, bool FLHS, bool DIRECT = false>
-__device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb,
-                                              double *__restrict__ block_sums, int *__restrict__ iters_out, const LhsIn &L) {
+__device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb,
+                                              double *block_sums, int *__restrict__ iters_out, const LhsIn &L, const LoopSums *__restrict__ Z) {
   __shared__ double P[FLHS ? kTileLds : (DIRECT ? kFdmLds : kCgLds)];
   const int slot = block_slot(g);
   if (slot < 0) return;
@@ -919,7 +1031,7 @@ __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, c
   LhsFix fx{};
   TileRegs tr;
   if constexpr (FLHS) {  // the tile's loads first, the first plane of the streams right behind them, then the tile goes to LDS
-    fx = lhs_fix(L, slot, l, hq);
+    fx = lhs_fix(L, ctl, slot, l, hq);
     tile_issue_own(slot, V.v[ZHAT], l, tr);
     ix = tile_idx(l);
   }
@@ -960,10 +1072,12 @@ __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, c
     if (l == 0) block_dots[(size_t)i * nb + slot] = t;
     if (i == 4 && l == 0) block_dots[(size_t)6 * nb + slot] = t;  // norm = the same sum as norm_1 (14512-14514)
   }
+  arrive<7>(Z->dots, slot, Z->then);  // the seven of 14546: totals + the recurrences (14558-14601) while the block solves still run
   if (L.prio) __builtin_amdgcn_s_setprio(0);
   if constexpr (FLHS) __syncthreads();
   if constexpr (DIRECT) fdm_block(g, slot, r, V.v[WHAT], L.invD, block_sums, P);
   else cg_block<FMA, false, EV>(g, slot, r, V.v[WHAT], block_sums, 0.0, 0.0, iters_out, P);  // what = M^-1 w, 14548
+  if (Z->mean.vals) arrive<1>(Z->mean, slot, NoThen());  // sum(what h^3) for the mean-constraint row of t = A what
 }
 // WITHOUT the LHS inside (FLHS = false: multi-level meshes, the no_fuse_lhs A/B): held to 96 registers (2 of the 122 the body asks for
 // are spilled, outside the CG loop) -> 5 wavefronts per SIMD: 3.63-3.70 ms instead of 3.75 at 512^3, 0.457-0.461 instead of 0.497 at
@@ -972,57 +1086,39 @@ __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, c
 // (With FLHS held to 96 it spills 30 registers inside the plane loop: the production kernel of uniform grids is k_loop2_cg_w4 below.)
 template <bool FMA, int EV, bool FLHS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
-k_loop2_cg(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums, int *__restrict__ iters_out, LhsIn L) {
-  loop2_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L);
+k_loop2_cg(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums, int *__restrict__ iters_out, LhsIn L, const LoopSums *__restrict__ Z) {
+  loop2_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L, Z);
 }
 // PRODUCTION on uniform grids (FLHS = true; what bench.py's `value` runs): the register allocation the compiler picks on its own, 128
 // registers -> 4 wavefronts per SIMD, no spills.  (Also the "loop2_four_waves" A/B of the FLHS = false form.)
 template <bool FMA, int EV, bool FLHS>
-__global__ void __launch_bounds__(64) k_loop2_cg_w4(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
-                                                    int *__restrict__ iters_out, LhsIn L) {
-  loop2_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L);
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_loop2_cg_w4(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums,
+                                                    int *__restrict__ iters_out, LhsIn L, const LoopSums *__restrict__ Z) {
+  loop2_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L, Z);
 }
 
 // block_solver 1: second loop + the direct block solve (`alt`)
 template <bool FLHS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_loop2_fdm(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *__restrict__ block_dots, long nb, double *__restrict__ block_sums,
-                                                  LhsIn L) {
-  loop2_cg_body<true, 0, FLHS, true>(g, V, ctl, block_dots, nb, block_sums, nullptr, L);
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_loop2_fdm(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums,
+                                                  LhsIn L, const LoopSums *__restrict__ Z) {
+  loop2_cg_body<true, 0, FLHS, true>(g, V, ctl, block_dots, nb, block_sums, nullptr, L, Z);
 }
 
-// K sums of nb per-block values each ([K][nb]) finished in one launch: 64 workgroups, the last one to arrive totals the partials.
-// MEAN: one more sum rides along -- the per-block sums of zhat h^3 / what h^3 the fused kernel left in mean_src; the total lands in
-// ro.out[K], where the LHS application that follows takes its mean-constraint row from (no k_mean_finish launch, and over ranks no
-// second all-reduce: the total travels with the dot products)
-// STEP 1 / 2: one rank -- the last workgroup also steps the solver's scalar struct with the totals (ctl_step1 / ctl_step2) and, after
-// the second loop, publishes it to the host's status ring; STEP 0: totals only (several ranks: the all-reduce comes first, k_ctl_step)
-struct CtlThen {
-  SolverCtl *ctl; CtlSlot *ring; unsigned seq; int step;
-  __device__ __forceinline__ void operator()(const double *tot) const {
-    if (step == 0 || ctl->state != kRun) return;  // (an iteration enqueued ahead of a stop / restart summed stale partials: dropped)
-    SolverCtl c = *ctl;
-    if (step == 1) ctl_step1(c, tot); else ctl_step2(c, tot);
-    *ctl = c;
-    if (step == 2) ctl_publish(ctl, ring, seq);
+// several ranks, all-reduce started EARLY (solve(): early): the communication stream holds this one-thread kernel in front of the
+// all-reduce; it returns when the loop kernel's last block has left its vector phase and the totals are in device memory (DotsThen
+// raises *flag to seq) -- one block-solve phase before that kernel ends, so the all-reduce and the recurrence step behind it run while
+// the compute stream is still busy.  Bounded: if the flag never comes (a loop kernel that died), *fail is raised and the stream moves on.
+__global__ void k_wait_totals(const SolverCtl *ctl, const unsigned *flag, unsigned seq, unsigned *fail, long long limit_ticks) {
+  // an iteration enqueued ahead of a stop or a restart: its loop kernels return at once and nobody will raise the flag.  (The struct is
+  // stepped on THIS stream only, k_ctl_step: what this kernel reads is what those loop kernels read.)
+  if (ctl->state != kRun) return;
+  const long long t0 = wall_clock64();
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+    __builtin_amdgcn_s_sleep(32);
+    if (wall_clock64() - t0 > limit_ticks) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
   }
-};
-template <int K, bool MEAN>
-__global__ void __launch_bounds__(256) k_sums_finish(const double *__restrict__ v, long nb, RedOut ro, const double *__restrict__ mean_src, CtlThen then) {
-  static_assert(K + (MEAN ? 1 : 0) <= kRedDotsEnd - kRedDots, "the totals of a loop must fit the kRedDots range of Sim::d_red");
-  double acc[K + (MEAN ? 1 : 0)];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    double t = 0;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (long)gridDim.x * 256) t += v[(size_t)k * nb + i];
-    acc[k] = t;
-  }
-  if (MEAN) {
-    double t = 0;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (long)gridDim.x * 256) t += mean_src[i];
-    acc[K] = t;
-  }
-  grid_sum_finish<K + (MEAN ? 1 : 0)>(acc, ro, then);
 }
+__global__ void k_raise(unsigned *flag, unsigned seq) { __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 // b = r = rhs, x = pres   (main.cpp:14408-14415)
 __global__ void __launch_bounds__(256) k_solver_init(Vecs V, const double *__restrict__ rhs, const double *__restrict__ pres, long n) {
@@ -1230,6 +1326,17 @@ static int ensure_vectors(Sim *s) {
     int rc = sim_alloc(&s->d_block_dots, (size_t)7 * s->nb, s);
     if (rc) return rc;
   }
+  if (!s->d_arrive) {  // Arrive: [dots | mean] x (n1 + n2 + 1) counters + 2 flags; (7 + 1) x (n1 + n2) partial sums
+    const size_t n1 = ((size_t)s->nb + 63) / 64, n2 = (n1 + 63) / 64, ncnt = 2 * (n1 + n2 + 1) + 2;
+    int rc = sim_alloc(&s->d_arrive_sums, 8 * (n1 + n2) + 8, s);
+    if (rc) return rc;
+    CUP3D_HIP(hipMalloc((void **)&s->d_arrive, ncnt * sizeof(unsigned)));
+    CUP3D_HIP(hipMalloc((void **)&s->d_loop_sums, 2 * sizeof(LoopSums)));
+    CUP3D_HIP(hipMemsetAsync(s->d_arrive, 0, ncnt * sizeof(unsigned), stream()));
+    CUP3D_HIP(hipHostMalloc((void **)&s->h_early_fail, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
+    *s->h_early_fail = 0;
+    CUP3D_HIP(hipHostGetDevicePointer((void **)&s->h_early_fail_dev, s->h_early_fail, 0));
+  }
   if (!s->h_ctl_dev) {  // the solver's scalar struct (device) and the pinned ring its outcome reaches the host through: all three or none
     hipError_t e = s->d_ctl ? hipSuccess : hipMalloc(&s->d_ctl, sizeof(SolverCtl));
     if (e == hipSuccess && !s->h_ctl) {
@@ -1265,6 +1372,11 @@ static int wait_status(Sim *s, unsigned seq, SolverCtl *out) {
   for (unsigned spin = 1; *flag != seq; ++spin) {
     __builtin_ia32_pause();
     if ((spin & 0x3fff) == 0) {  // every ~16k polls: have the streams drained (or failed) without the slot being written?
+      if (s->h_early_fail && *(volatile unsigned *)s->h_early_fail) {
+        set_error("BiCGSTAB: a device-side wait of the early all-reduce gave up after 10 s (%s): the loop kernel it waits for never delivered",
+                  *(volatile unsigned *)s->h_early_fail == 1 ? "the communication stream waiting for the dot products" : "the corner block's wavefront waiting for the mean-constraint total");
+        return CUP3D_ESTATE;
+      }
       hipError_t e = hipStreamQuery(stream());
       if (e == hipSuccess && s->comm_stream) e = hipStreamQuery(s->comm_stream);
       if (e == hipSuccess) {
@@ -1343,6 +1455,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   // the mean-constraint total of `what` for the first fused loop (FLHS): d_red[7] after a fused iteration (k_sums_finish<7, true>),
   // d_red[8] after a host-driven LHS(WHAT, T_) (k_mean_finish inside launch_lhs); of `zhat` for the second loop it is d_red[2]
   const double *what_total = s->d_red + kRedMeanLhs;
+  bool first_after_host = true;  // the next fused iteration follows a host-driven LHS(WHAT, T_): its total is complete before the launch
   // the restart of 14567-14593 / 7096-7120 (the breakdown was detected, and counted, by ctl_step2)
   auto restart = [&]() -> int {
     { ProfileScope ps("bicgstab_vector"); LAUNCH_VEC_S(k_copy, V.v[R_], V.v[R0], N); }
@@ -1357,6 +1470,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     hs.omega = 0.0;
     hs.state = kRun;
     what_total = s->d_red + kRedMeanLhs;
+    first_after_host = true;
     return CUP3D_OK;
   };
 
@@ -1396,52 +1510,93 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     ctl_step2(hs, s->h_red);   // 14558-14566, 14594-14601 (moves xcur to the buffer just written)
     if (hs.state == kRestart) TRY(restart());
     what_total = s->d_red + kRedMeanLhs;  // LHS(WHAT, T_) left sum(what h^3) there (k_mean_finish)
+    first_after_host = true;
     return CUP3D_OK;
   };
 
   // one fused iteration, enqueued without waiting for anything: both loop kernels take their scalars from d_ctl
   const bool direct = red.direct();
-  auto finish = [&](int K, int step, unsigned seq) -> int {  // totals of the K (+1) block-wise sums -> d_red -> the struct
-    ProfileScope ps("bicgstab_dots_finish");
-    const RedOut ro{s->d_partials, s->d_counters, s->d_red, nullptr, nullptr, 0u};
-    const CtlThen then{d_ctl, ring, seq, direct ? step : 0};
-    const dim3 SG(debug_option("sums_groups") > 0 ? debug_option("sums_groups") : sums_groups(s->nb));
-    if (K == 2) {
-      if (want_sums) hipLaunchKernelGGL((k_sums_finish<2, true>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, sums, then);
-      else hipLaunchKernelGGL((k_sums_finish<2, false>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, (const double *)nullptr, then);
-    } else {
-      if (want_sums) hipLaunchKernelGGL((k_sums_finish<7, true>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, sums, then);
-      else hipLaunchKernelGGL((k_sums_finish<7, false>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, (const double *)nullptr, then);
-    }
-    CUP3D_HIP(hipGetLastError());
-    if (direct) return CUP3D_OK;
-    // MPI_Iallreduce (14486, 14546) + the mean-constraint sum (9295) in one call on the communication stream, the struct stepped
-    // behind it; the preconditioner-free LHS enqueued next on the compute stream overlaps both, the next loop kernel waits (ev_a)
+  // The loop kernels total their dot products themselves (Arrive): buffers of the two in-kernel sums of a loop
+  const long n1 = (s->nb + 63) / 64, n2 = (n1 + 63) / 64;
+  unsigned *const cnt = s->d_arrive;
+  unsigned *const dots_flag = cnt + 2 * (n1 + n2 + 1), *const mean_flag = dots_flag + 1;
+  // (a solve that ended in an error half way through a loop may have left tickets behind; the two flags behind the counters only ever grow)
+  CUP3D_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * (n1 + n2 + 1)) * sizeof(unsigned), stream()));
+  auto arrive_args = [&](int which, const double *vals, double *out) {  // which 0: the dot products, 1: the block sums of the mean constraint
+    double *gs = s->d_arrive_sums + (which ? 7 * (n1 + n2) : 0);
+    unsigned *c = cnt + which * (n1 + n2 + 1);
+    return Arrive{vals, gs, gs + (which ? 1 : 7) * n1, c, c + n1, c + n1 + n2, (long)s->nb, n1, n2, out};
+  };
+  // Several ranks.  DEFAULT: when the loop kernel has ended, one all-reduce of its K totals (+ the mean-constraint total: two RCCL calls
+  // per iteration where the reference makes four) on the communication stream, the recurrence step behind it, the next loop kernel
+  // waits -- both all-reduces of an iteration are exposed.  EARLY (process-per-rank transports, CUP3D_EARLY_ALLREDUCE / "early_allreduce"):
+  // the all-reduce of the dot products starts when the LAST BLOCK LEAVES ITS VECTOR PHASE (k_wait_totals holds the communication
+  // stream until DotsThen raises the flag), i.e. it runs under the block solves of the kernel's last round; the mean-constraint total,
+  // which exists only when the kernel has ended, follows in an all-reduce of its own that nobody waits for on the host or on the
+  // compute stream: the ONE wavefront that needs it -- the corner block's, mode 1 -- waits for its flag inside the next loop kernel.
+  // (mode 2 adds the total to every cell: there the next kernel as a whole waits, and early buys only the first half.)
+  // What MPI_Iallreduce hides behind the preconditioner in the reference (14486-14490, 14546-14550) is hidden behind it here again.
+  // FLHS: v = A zhat and t = A what are formed inside the loop kernels (uniform grids; on multi-level meshes the LHS needs the
+  // coarse/fine ghost slabs and the flux correction, so it stays a launch of its own)
+  const bool flhs = fuse && !s->grid->multilevel && !debug_option("no_fuse_lhs");
+  static const bool early_env = [] { const char *e = getenv("CUP3D_EARLY_ALLREDUCE"); return e && atoi(e) != 0; }();
+  // (uniform grids only: on multi-level meshes the LHS is a launch of its own between the loops and reads the mean-constraint total itself)
+  const bool early = !direct && flhs && comm() && !virtual_ranks() && !host_transport() && scalar_stream(s) != stream() && (early_env || debug_option("early_allreduce"));
+  static const long long tick_rate = [] {  // wall_clock64 ticks per millisecond (100 MHz on CDNA3 / CDNA4)
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) return (long long)khz;
+    return 100000LL;
+  }();
+  auto after_loop = [&](int K, int step, unsigned seq) -> int {  // the totals of the loop just enqueued -> all ranks -> the struct
+    if (direct) return CUP3D_OK;  // one rank: the kernel's last arriving wavefront has totalled AND stepped (DotsThen)
     hipStream_t cs = scalar_stream(s);
-    if (cs != stream()) {
+    const int nmean = want_sums ? 1 : 0;
+    if (s->nb == 0) {  // a rank without blocks launched nothing: its contribution is zero, and nobody but the host can raise the early flag
+      CUP3D_HIP(hipMemsetAsync(s->d_red + kRedDots, 0, (size_t)(K + 1) * sizeof(double), stream()));
+      CUP3D_HIP(hipMemsetAsync(s->d_red + kRedEarlyMean, 0, 2 * sizeof(double), stream()));
+      if (early) hipLaunchKernelGGL(k_raise, dim3(1), dim3(1), 0, stream(), dots_flag, seq * 2 + (unsigned)(step - 1));
+    }
+    if (!early) {
+      if (cs != stream()) {
+        CUP3D_HIP(hipEventRecord(s->ev_b, stream()));
+        CUP3D_HIP(hipStreamWaitEvent(cs, s->ev_b, 0));
+      }
+      ProfileScope pc("comm_allreduce", cs);  // the all-reduce and the recurrence step behind it, as the communication stream sees them
+      TRY(allreduce(s, s->d_red, K + nmean, false, cs));
+      if (step == 1) hipLaunchKernelGGL(k_ctl_step<1>, dim3(1), dim3(1), 0, cs, d_ctl, (const double *)s->d_red, ring);
+      else hipLaunchKernelGGL(k_ctl_step<2>, dim3(1), dim3(1), 0, cs, d_ctl, (const double *)s->d_red, ring);
+      CUP3D_HIP(hipGetLastError());
+      CUP3D_HIP(hipEventRecord(s->ev_a, cs));
+      return CUP3D_OK;
+    }
+    hipLaunchKernelGGL(k_wait_totals, dim3(1), dim3(1), 0, cs, (const SolverCtl *)d_ctl, (const unsigned *)dots_flag, seq * 2 + (unsigned)(step - 1), s->h_early_fail_dev, 10000 * tick_rate);
+    {
+      ProfileScope pc("comm_allreduce", cs);  // (behind the wait for the totals: the all-reduce and the step, not the time the loop kernel took to deliver)
+      TRY(allreduce(s, s->d_red, K, false, cs));
+      if (step == 1) hipLaunchKernelGGL(k_ctl_step<1>, dim3(1), dim3(1), 0, cs, d_ctl, (const double *)s->d_red, ring);
+      else hipLaunchKernelGGL(k_ctl_step<2>, dim3(1), dim3(1), 0, cs, d_ctl, (const double *)s->d_red, ring);
+      CUP3D_HIP(hipGetLastError());
+      CUP3D_HIP(hipEventRecord(s->ev_a, cs));
+    }
+    if (nmean) {  // the mean-constraint total: complete when the kernel ends
       CUP3D_HIP(hipEventRecord(s->ev_b, stream()));
       CUP3D_HIP(hipStreamWaitEvent(cs, s->ev_b, 0));
-    }
-    {
-      ProfileScope pc("comm_allreduce", cs);  // the all-reduce and the recurrence step behind it, as the communication stream sees them
-      TRY(allreduce(s, s->d_red, K + (want_sums ? 1 : 0), false, cs));
-      if (step == 1) hipLaunchKernelGGL(k_ctl_step<1>, dim3(1), dim3(1), 0, cs, d_ctl, (const double *)s->d_red, ring, seq);
-      else hipLaunchKernelGGL(k_ctl_step<2>, dim3(1), dim3(1), 0, cs, d_ctl, (const double *)s->d_red, ring, seq);
+      ProfileScope pc("comm_allreduce_mean", cs);
+      TRY(allreduce(s, s->d_red + kRedEarlyMean + (step - 1), 1, false, cs));
+      hipLaunchKernelGGL(k_raise, dim3(1), dim3(1), 0, cs, mean_flag, seq * 2 + (unsigned)(step - 1));
       CUP3D_HIP(hipGetLastError());
+      if (mc == 2) CUP3D_HIP(hipEventRecord(s->ev_m, cs));  // every cell takes the total: the next kernel as a whole waits (scalars_ready)
     }
-    CUP3D_HIP(hipEventRecord(s->ev_a, cs));
     return CUP3D_OK;
   };
   auto scalars_ready = [&]() -> int {  // the compute stream waits for the struct stepped on the communication stream
     if (!direct && scalar_stream(s) != stream()) {
-      ProfileScope pw("comm_exposed_scalar_wait");  // compute stream idle until the all-reduced scalars are stepped (exposed: nothing left to hide them behind)
+      ProfileScope pw("comm_exposed_scalar_wait");  // compute stream idle until the all-reduced scalars are stepped (the exposed part of the all-reduce)
       CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_a, 0));
+      if (early && want_sums && mc == 2) CUP3D_HIP(hipStreamWaitEvent(stream(), s->ev_m, 0));
     }
     return CUP3D_OK;
   };
-  // FLHS: v = A zhat and t = A what are formed inside the loop kernels (uniform grids; on multi-level meshes the LHS needs the
-  // coarse/fine ghost slabs and the flux correction, so it stays a launch of its own)
-  const bool flhs = fuse && !s->grid->multilevel && !debug_option("no_fuse_lhs");
   // A/B, test builds only ("fuse_lhs_ml"): on a multi-level mesh (one rank) the blocks none of whose six faces is a coarse/fine interface
   // take the FLHS kernels too, and only the interface blocks keep k_lhs + ghost slabs + flux correction (launch_lhs on the interface
   // list).  Bit-identical t and v -- and NOT faster: each loop kernel becomes two launches (plain list, interface list), which costs what
@@ -1449,7 +1604,23 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   // out of the production path.
   const bool flhs_ml = fuse && s->grid->multilevel && s->grid->nranks == 1 && s->n_plain > 0 && !debug_option("no_fuse_lhs") && debug_option("fuse_lhs_ml");
   const bool split = s->grid->nranks > 1;
+  // the two loops' LoopSums, constant over this solve, in device memory
+  {
+    LoopSums Z[2];
+    for (int which = 1; which <= 2; ++which) {
+      const int K = which == 1 ? 2 : 7;
+      double *const mean_out = early ? s->d_red + kRedEarlyMean + (which - 1) : s->d_red + kRedDots + K;
+      Z[which - 1].dots = arrive_args(0, s->d_block_dots, s->d_red + kRedDots);
+      Z[which - 1].mean = arrive_args(1, want_sums ? sums : nullptr, mean_out);
+      // sc (the path checksum): totals only, nothing stepped
+      Z[which - 1].then = DotsThen{d_ctl, ring, which, direct && !sc ? 1 : 0, early && !sc ? dots_flag : nullptr};
+    }
+    hipLaunchKernelGGL(k_set_loop_sums, dim3(1), dim3(1), 0, stream(), s->d_loop_sums, Z[0], Z[1]);
+    CUP3D_HIP(hipGetLastError());
+  }
+  const LoopSums *const dZ = s->d_loop_sums;
   auto launch_loop = [&](int which, const double *u, const LhsIn &L) -> int {  // one loop kernel; over ranks: inner blocks while u's face slabs travel, then the rest
+    const LoopSums *const Z = dZ + (which - 1);
     if (flhs && split) TRY(halo_begin(s, u, 1, 1));
     for (int pass = 0; pass < ((flhs && split) || flhs_ml ? 2 : 1); ++pass) {
       const GridDev gp = flhs_ml ? (pass == 0 ? s->gdev_list(s->d_plain_list, s->n_plain) : s->gdev_list(s->d_iface_list, s->n_iface))
@@ -1459,16 +1630,19 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       if (gp.nblocks == 0) continue;
       ProfileScope ps(direct_solve ? (which == 1 ? "bicgstab_loop1_fdm" : "bicgstab_loop2_fdm") : (which == 1 ? "bicgstab_loop1_cg" : "bicgstab_loop2_cg"));
       const dim3 GG(launch_groups(gp)), BB(64);
-#define LOOP_ARGS gp, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, cg_it, L
+#define LOOP_ARGS gp, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, cg_it, L, Z
       if (direct_solve) {
-#define FDM_ARGS gp, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, L
+#define FDM_ARGS gp, V, (const SolverCtl *)d_ctl, s->d_block_dots, (long)s->nb, sums, L, Z
         if (which == 1 && fl) hipLaunchKernelGGL(k_loop1_fdm<true>, GG, BB, 0, stream(), FDM_ARGS);
         else if (which == 1) hipLaunchKernelGGL(k_loop1_fdm<false>, GG, BB, 0, stream(), FDM_ARGS);
         else if (fl) hipLaunchKernelGGL(k_loop2_fdm<true>, GG, BB, 0, stream(), FDM_ARGS);
         else hipLaunchKernelGGL(k_loop2_fdm<false>, GG, BB, 0, stream(), FDM_ARGS);
 #undef FDM_ARGS
       } else if (which == 1) {
-        if (P.block_solver == 0 && fl) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        // (with the in-kernel totals behind the plane loop the compiler finds a 94-register allocation of this kernel: 5 wavefronts per SIMD
+        //  where rounds 3-4 ran 4 at 110 registers.  "loop1_lds_pad" = bytes of dynamic LDS per workgroup on top of the tile's 7680: 2560
+        //  makes it 16 workgroups per CU, i.e. 4 per SIMD again -- the A/B of the occupancy without recompiling)
+        if (P.block_solver == 0 && fl) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction, true>), GG, BB, (unsigned)(kLoop1LdsPad + debug_option("loop1_lds_pad")), stream(), LOOP_ARGS);
         else if (P.block_solver == 0) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (fl) hipLaunchKernelGGL((k_loop1_cg<false, 0, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else hipLaunchKernelGGL((k_loop1_cg<false, 0, false>), GG, BB, 0, stream(), LOOP_ARGS);
@@ -1519,9 +1693,9 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
         return flhs_ml ? launch_lhs(s, V.v[in], V.v[out], 0, s->d_iface_list, s->n_iface) : launch_lhs(s, V.v[in], V.v[out], 0);
       };
       if (!flhs) TRY(LHS0(WHAT, T_));
-      TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, total, lhs_mode, s->grid->corner_slot, kLoopPrio, g_invD}));
+      TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, total, lhs_mode, s->grid->corner_slot, kLoopPrio, g_invD, nullptr, 0, nullptr}));
       if (!flhs) TRY(LHS0(ZHAT, V_));
-      TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, total, lhs_mode, s->grid->corner_slot, kLoopPrio, g_invD}));
+      TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, total, lhs_mode, s->grid->corner_slot, kLoopPrio, g_invD, nullptr, 0, nullptr}));
       for (int i = 0; i < NVEC; ++i) TRY(checksum_array(s, s->sv[i], N, &sc[i]));
       return CUP3D_OK;
     };
@@ -1538,18 +1712,24 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     // the mean-constraint row inside the kernels belongs to the corner block only if that block forms its own LHS
     const int corner_in = (flhs || (flhs_ml && s->corner_is_plain)) ? s->grid->corner_slot : -1;
     auto LHS_IFACE = [&](int in, int out) { return launch_lhs(s, V.v[in], V.v[out], mc, s->d_iface_list, s->n_iface); };
-    TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, what_total, lhs_mode, corner_in, prio, g_invD}));  // (t = A what,) loop 1, zhat = M^-1 z
+    // early all-reduce: the mean-constraint totals arrive in slots of their own behind a flag (after_loop); `wait_seq` = what the flag
+    // must have reached before the corner block's wavefront may read the total
+    const bool em = early && want_sums;
+    const double *const total1 = em && !first_after_host ? s->d_red + kRedEarlyMean + 1 : what_total;
+    const double *const total2 = em ? s->d_red + kRedEarlyMean : s->d_red + kRedDots + 2;
+    TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, total1, lhs_mode, corner_in, prio, g_invD, em && !first_after_host ? mean_flag : nullptr, 1, s->h_early_fail_dev}));  // (t = A what,) loop 1, zhat = M^-1 z
     s->sums_of = want_sums ? V.v[ZHAT] : nullptr;
-    TRY(finish(2, 1, seq));
-    if (want_sums) { s->mean_total_of = V.v[ZHAT]; s->mean_total = s->d_red + kRedDots + 2; }
+    TRY(after_loop(2, 1, seq));
+    if (want_sums) { s->mean_total_of = V.v[ZHAT]; s->mean_total = total2; }
     if (flhs_ml) TRY(LHS_IFACE(ZHAT, V_));
     else if (!flhs) TRY(LHS(ZHAT, V_));
     TRY(scalars_ready());
-    TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, s->d_red + kRedDots + 2, lhs_mode, corner_in, prio, g_invD}));  // (v = A zhat,) loop 2, what = M^-1 w
+    TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, total2, lhs_mode, corner_in, prio, g_invD, em ? mean_flag : nullptr, 2, s->h_early_fail_dev}));  // (v = A zhat,) loop 2, what = M^-1 w
     s->sums_of = want_sums ? V.v[WHAT] : nullptr;
-    TRY(finish(7, 2, seq));
-    if (want_sums) { s->mean_total_of = V.v[WHAT]; s->mean_total = s->d_red + kRedDots + 7; }
-    what_total = s->d_red + kRedDots + 7;
+    TRY(after_loop(7, 2, seq));
+    what_total = em ? s->d_red + kRedEarlyMean + 1 : s->d_red + kRedDots + 7;
+    first_after_host = false;
+    if (want_sums) { s->mean_total_of = V.v[WHAT]; s->mean_total = what_total; }
     if (flhs_ml) TRY(LHS_IFACE(WHAT, T_));  // t of the interface blocks for the next first loop; the others form theirs in that kernel
     else if (!flhs) TRY(LHS(WHAT, T_));
     TRY(scalars_ready());
@@ -1565,6 +1745,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     }
     // a run of fused iterations, up to the next multiple of 50: the host stays one iteration ahead of the device
     hs.state = kRun;
+    hs.seq = s->ctl_seq + 1;  // the number the next enqueued iteration gets
     hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, stream(), d_ctl, hs);
     int enq = k;  // next iteration to enqueue; k = next iteration whose outcome the host has not seen
     unsigned seq_of[2] = {0, 0};
@@ -1582,6 +1763,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
         enq = k;
         x_ptrs();
         TRY(restart());
+        hs.seq = s->ctl_seq + 1;
         hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, stream(), d_ctl, hs);
       }
     }

@@ -356,8 +356,8 @@ static int sim_build(Sim *s, const Grid *g) {
   CUP3D_HIP(hipMalloc((void **)&s->d_counters, 4 * sizeof(unsigned)));
   CUP3D_HIP(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned), g_stream));
   if ((rc = up(&s->d_nbr, g->nbr))) return rc;
-  if (g->nranks > 1) {
-    if ((rc = up(&s->d_inner, g->inner)) || (rc = up(&s->d_boundary, g->boundary)) || (rc = up(&s->d_send_faces, g->send_faces))) return rc;
+  if (g->nranks > 1 && ((rc = up(&s->d_inner, g->inner)) || (rc = up(&s->d_boundary, g->boundary)) || (rc = up(&s->d_send_faces, g->send_faces)))) return rc;
+  if (g->nranks > 1 || debug_option("force_allreduce")) {  // ("force_allreduce", testing build: ONE rank whose scalars go through the communicator -- latency measurements)
     // the communication stream outranks the compute stream: its pack kernels, RCCL's send / receive kernels and the one-thread
     // recurrence steps are dispatched ahead of the tens of thousands of loop-kernel workgroups queued on the compute stream, so an
     // exchange started with the inner blocks' pass really runs beside it instead of behind it
@@ -448,6 +448,7 @@ static int sim_build(Sim *s, const Grid *g) {
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_b, hipEventDisableTiming));
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_h1, hipEventDisableTiming));
   CUP3D_HIP(hipEventCreateWithFlags(&s->ev_h2, hipEventDisableTiming));
+  CUP3D_HIP(hipEventCreateWithFlags(&s->ev_m, hipEventDisableTiming));
   if (g->nranks > 1) {
     CUP3D_HIP(hipEventCreateWithFlags(&s->ev_vc_pack, hipEventDisableTiming));
     CUP3D_HIP(hipEventCreateWithFlags(&s->ev_vc_done, hipEventDisableTiming));
@@ -527,6 +528,10 @@ void cup3d_sim_destroy(cup3d_sim_t *h) {
   if (s->h_ctl) hipHostFree(s->h_ctl);
   if (s->d_counters) hipFree(s->d_counters);
   if (s->d_cg_iters) hipFree(s->d_cg_iters);
+  if (s->d_arrive_sums) hipFree(s->d_arrive_sums);
+  if (s->d_arrive) hipFree(s->d_arrive);
+  if (s->d_loop_sums) hipFree(s->d_loop_sums);
+  if (s->h_early_fail) hipHostFree(s->h_early_fail);
   release_stage(s);
   int32_t *ip[] = {s->d_nbr, s->d_inner, s->d_boundary, s->d_send_faces, s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_index,
                    s->d_restrict_list, s->d_prolong_list, s->d_fix_list[0], s->d_fix_list[1], s->d_fix_list[2], s->d_send_blocks, s->d_send_flux, s->d_raw_list, s->d_iface_list, s->d_plain_list};
@@ -542,6 +547,7 @@ void cup3d_sim_destroy(cup3d_sim_t *h) {
   if (s->ev_b) hipEventDestroy(s->ev_b);
   if (s->ev_h1) hipEventDestroy(s->ev_h1);
   if (s->ev_h2) hipEventDestroy(s->ev_h2);
+  if (s->ev_m) hipEventDestroy(s->ev_m);
   if (s->ev_vc_pack) hipEventDestroy(s->ev_vc_pack);
   if (s->ev_vc_done) hipEventDestroy(s->ev_vc_done);
   delete s;

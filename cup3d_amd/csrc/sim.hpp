@@ -88,11 +88,12 @@ enum RedSlot : int {
                      //         ([2] after loop 1, [7] after loop 2); outside a solve: max|u| ([0]), the penalisation's 6 sums + status ([0, 7))
   kRedDotsEnd = 8,
   kRedMeanLhs = 8,   // [8]: sum(p h^3) of a stand-alone LHS application (k_mean_finish, stencil.hip)
+  kRedEarlyMean = 9, // [9], [10]: several ranks, early all-reduce: sum(zhat h^3) / sum(what h^3) of a fused loop, all-reduced on their own behind a flag
   kRedChecksum = 12, // [12]: cup3d_sim_checksum's 64-bit accumulator
   kRedMg = 14,       // [14]: coarsest-level sum of the multigrid cycle over ranks (multigrid.hip)
   kRedSize = 16
 };
-static_assert(kRedDotsEnd <= kRedMeanLhs && kRedMeanLhs < kRedChecksum && kRedChecksum < kRedMg && kRedMg < kRedSize, "Sim::d_red slots overlap");
+static_assert(kRedDotsEnd <= kRedMeanLhs && kRedMeanLhs < kRedEarlyMean && kRedEarlyMean + 2 <= kRedChecksum && kRedChecksum < kRedMg && kRedMg < kRedSize, "Sim::d_red slots overlap");
 
 struct Sim {
   const Grid *grid = nullptr;
@@ -127,6 +128,12 @@ struct Sim {
   unsigned *d_counters = nullptr;  // [4] tickets of grid_sum_finish (tile.hpp), zero between launches
   int *d_cg_iters = nullptr;       // [nb] CG iterations per block of the last block-CG launch (only while profiling)
   double *d_block_dots = nullptr;  // [7][nb] per-block dot products of the fused loop + block-CG kernels (poisson.hip)
+  // ... and what totals them inside those kernels (Arrive, poisson.hip): group / super-group sums, arrival counters, the two flags the
+  // communication stream (dots) and the corner block's wavefront (mean-constraint total) wait for when the all-reduce starts early
+  double *d_arrive_sums = nullptr;
+  unsigned *d_arrive = nullptr;
+  struct LoopSums *d_loop_sums = nullptr;  // [2] (poisson.hip)
+  unsigned *h_early_fail = nullptr, *h_early_fail_dev = nullptr;  // pinned: a bounded device-side wait of the early all-reduce gave up
   void *mg = nullptr;              // level hierarchy of the multigrid preconditioner (multigrid.hip), built on first use
   int max_groups = 0;
   // staging for host transfers
@@ -166,7 +173,7 @@ struct Sim {
   double *halo_recv = nullptr, *halo_send = nullptr;  // n faces x 3 comps x 3 layers x 64
   size_t bytes = 0;
   hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_h1 = nullptr, ev_h2 = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_h1 = nullptr, ev_h2 = nullptr, ev_m = nullptr;
   hipEvent_t ev_vc_pack = nullptr, ev_vc_done = nullptr;  // virtual communicator (tests): "my send buffer is packed" / "my copies are enqueued"
 
   GridDev gdev(bool boundary_only = false, bool inner_only = false) const;
