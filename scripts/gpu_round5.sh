@@ -54,6 +54,11 @@ for S in 128 256 512; do
     timeout 900 python bench.py --size $S --no-cpu --no-alt --no-pcie --steps ${BENCH_STEPS:-10} --warmup ${BENCH_WARMUP:-3} ${BENCH_ARGS} > $OUT/bench_$S.json 2> $OUT/bench_$S.err ; echo "bench rc=$?" ; summ $OUT/bench_$S.json ; tail -2 $OUT/bench_$S.err
   fi
 done
+if has ab256; then echo "== A/B at 256^3 (one GPU's share of the headline on 8): default | first fused kernel held to 4 wavefronts per SIMD by LDS | no per-kernel events"
+  for V in "default:" "lds_pad:--debug-option loop1_lds_pad=2560" "testing_build:--debug-option loop1_lds_pad=0" "no_profile:--no-profile"; do
+    N=${V%%:*}; A=${V#*:}
+    timeout 600 python bench.py --size ${AB_SIZE:-256} --no-cpu --no-alt --no-pcie --steps ${AB_STEPS:-10} --warmup 3 $A > $OUT/bench_${AB_SIZE:-256}_$N.json 2> $OUT/bench_${AB_SIZE:-256}_$N.err ; echo "rc=$? ($N)"; summ $OUT/bench_${AB_SIZE:-256}_$N.json | head -1; summ $OUT/bench_${AB_SIZE:-256}_$N.json | grep bicgstab_loop
+  done; fi
 if has driver; then echo "== the driver's command: python bench.py --gpus 1 --steps 20 --warmup 5"
   timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_512_fullstep.json 2> $OUT/bench_512_fullstep.err ; echo "bench rc=$?" ; summ $OUT/bench_512_fullstep.json ; tail -3 $OUT/bench_512_fullstep.err
 fi

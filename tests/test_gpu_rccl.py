@@ -210,3 +210,46 @@ def test_bench_rccl_code_path_with_the_stand_in_library(n, mode):
     print(f"{n} ranks through comm.hip's RCCL branch (stand-in library, {mode}): iterations {rn['config']['bicgstab_iters_by_step']} "
           f"(one process: {r1['config']['bicgstab_iters_by_step']}); per iteration: halo {com['halo_ms_per_iteration']} ms, all-reduce "
           f"{com['allreduce_ms_per_iteration']} ms, exposed {com['exposed_ms_per_iteration']} ms")
+
+
+
+@pytest.mark.timeout(900)
+def test_early_allreduce_changes_nothing_but_the_timing():
+    """The all-reduce of a fused loop's dot products can start when the LAST BLOCK LEAVES ITS VECTOR PHASE instead of when the kernel ends
+    (poisson.hip, `early`: k_wait_totals on the communication stream, the mean-constraint total in an all-reduce of its own behind a flag
+    that only the corner block's wavefront waits for).  The arithmetic is the same -- the same totals, the same recurrence functions -- so
+    iteration counts and max|u| must be IDENTICAL, bit for bit, between: one process stepping its scalars inside the kernels; one process
+    whose scalars are forced through a one-rank communicator of the stand-in library (with 30 us of injected latency per all-reduce),
+    early off and on; and two processes over the stand-in library, early off and on."""
+    if not os.path.exists(FAKE_RCCL):
+        pytest.skip("tests/fake_rccl/librccl_fake.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    args = ("--size", "128", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-alt", "--no-pcie")
+    fake = {"CUP3D_RCCL_LIBRARY": FAKE_RCCL, "FAKE_RCCL_ALLREDUCE_US": "30"}
+
+    def go(*extra, env=None, timeout=500):
+        out = run_bench(*args, *extra, timeout=timeout, extra_env=env)
+        assert out.returncode == 0, (out.stdout.decode()[-1500:], out.stderr.decode()[-3000:])
+        lines = [l for l in out.stdout.decode().strip().splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout.decode()[-2000:]
+        return json.loads(lines[0])
+
+    one = go("--debug-option", "force_allreduce=0")   # (any debug option selects the testing build: the same flavour in all runs)
+    runs = {"one process, scalars stepped inside the kernels": one}
+    for early in (0, 1):
+        runs[f"one process through a one-rank communicator, early {early}"] = go(
+            "--debug-option", "force_allreduce=1", "--debug-option", f"early_allreduce={early}", env=dict(fake, CUP3D_FORCE_COMM="1"))
+    for name, r in runs.items():
+        c, c1 = r["config"], one["config"]
+        assert c["bicgstab_iters_by_step"] == c1["bicgstab_iters_by_step"] and c["umax_by_step"] == c1["umax_by_step"], (name, c["bicgstab_iters_by_step"], c1["bicgstab_iters_by_step"])
+        assert c["checksum"]["ok"] is True
+    e0, e1 = (runs[f"one process through a one-rank communicator, early {e}"]["config"]["communication"] for e in (0, 1))
+    assert e0["allreduces_per_iteration"] >= 2 and e1["allreduces_per_iteration"] >= 4   # early: the mean-constraint total travels on its own
+    two = {}
+    for early in (0, 1):
+        two[early] = go("--gpus", "2", env=dict(fake, CUP3D_BENCH_SHARE_DEVICE="1", CUP3D_HIP_FLAVOUR="release", CUP3D_EARLY_ALLREDUCE=str(early)), timeout=800)
+    a, b = two[0]["config"], two[1]["config"]
+    assert a["bicgstab_iters_by_step"] == b["bicgstab_iters_by_step"] and a["umax_by_step"] == b["umax_by_step"], (a["bicgstab_iters_by_step"], b["bicgstab_iters_by_step"])
+    same_bits_at_every_n(one["config"]["checksum"], b["checksum"])
+    assert b["communication"]["allreduces_per_iteration"] > a["communication"]["allreduces_per_iteration"]
+    print("early all-reduce: iterations", b["bicgstab_iters_by_step"], "identical to the default order of the same two ranks; exposed scalar wait per iteration",
+          a["communication"]["exposed_scalar_wait_ms_per_iteration"], "->", b["communication"]["exposed_scalar_wait_ms_per_iteration"], "ms (30 us injected per all-reduce)")
