@@ -922,7 +922,11 @@ def run(a, prog):
     a.comm = {"rccl_ranks": world, "halo_exchanges_per_iteration": round(st.halo_exchanges / nit, 2), "halo_bytes_sent_per_iteration (rank 0)": round(st.halo_bytes_sent / nit, 1),
               "allreduces_per_iteration": round(st.allreduces / nit, 2), "host_waits_per_iteration": round(st.host_waits / nit, 3),
               "host_wait_ms_per_step (spinning on the device's status, overlapped with queued kernels)": round(st.host_wait_seconds / a.steps * 1e3, 3),
-              "host_wait_fraction": round(st.host_wait_seconds / sec, 4)}
+              "host_wait_fraction": round(st.host_wait_seconds / sec, 4),
+              # several ranks: do the all-reduces of a fused loop start when its last block leaves the vector phase (CUP3D_EARLY_ALLREDUCE=1 /
+              # --debug-option early_allreduce=1) or when the kernel has ended (default)?
+              "early_allreduce": bool(int(os.environ.get("CUP3D_EARLY_ALLREDUCE", "0") or 0)) or any(o == "early_allreduce=1" for o in (a.debug_option or [])),
+              "injected_allreduce_latency_us (stand-in library only)": float(os.environ.get("FAKE_RCCL_ALLREDUCE_US", "0") or 0) if os.environ.get("CUP3D_RCCL_LIBRARY") else None}
     a.diffusion_iters = round(float(np.mean(diff_iters[-a.steps:])), 2) if diff_iters else None
     if dist is not None:
         t = torch.tensor([sec], dtype=torch.float64, device=a.tdev)

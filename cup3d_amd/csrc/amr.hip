@@ -45,9 +45,9 @@ __device__ __forceinline__ double avg_block(const double *__restrict__ blk, int 
 
 // ---- neighbour finer: slab[(e*nc + c)*W + gl][a2*8 + a1]
 template <int W>
-__global__ void __launch_bounds__(64) k_ghost_restrict(AmrDev a, const int32_t *__restrict__ list, const double *__restrict__ field, int nc,
+__device__ __forceinline__ void ghost_restrict_face(const AmrDev &a, int e, const double *__restrict__ field, int nc,
                                                        double *__restrict__ slabs) {
-  const int e = list[blockIdx.x], lane = threadIdx.x;
+  const int lane = threadIdx.x;
   const int sf = a.faces[2 * e], f = sf % 6, d = f >> 1, side = f & 1;
   const int a1 = lane & 7, a2 = lane >> 3;
   const int fe = a.fine[4 * e + (a1 >> 2) + 2 * (a2 >> 2)];
@@ -121,10 +121,10 @@ __device__ __forceinline__ double test_interp(F Cc, const int (&bit)[3]) {
 }
 
 template <int W>
-__global__ void __launch_bounds__(64) k_ghost_prolong(AmrDev a, const int32_t *__restrict__ list, const double *__restrict__ field, int nc,
+__device__ __forceinline__ void ghost_prolong_face(const AmrDev &a, int e, const double *__restrict__ field, int nc,
                                                       double *__restrict__ slabs) {
   __shared__ double patch[W][36];  // coarse shadow tile behind the face: [layer][(Z+1)*6 + (Y+1)], Y/Z in [-1,4] along (a1,a2)
-  const int e = list[blockIdx.x], lane = threadIdx.x;
+  const int lane = threadIdx.x;
   const int sf = a.faces[2 * e], slot = sf / 6, f = sf % 6, ax = f >> 1, side = f & 1;
   const int ax1 = ax == 0 ? 1 : 0, ax2 = ax == 2 ? 1 : 2;  // tangential axes (fast, slow) = the reference's (y,z)/(x,z)/(x,y)
   const int par[3] = {a.index[3 * slot] & 1, a.index[3 * slot + 1] & 1, a.index[3 * slot + 2] & 1};
@@ -215,6 +215,42 @@ __global__ void __launch_bounds__(64) k_flux_fix(AmrDev a, const int32_t *__rest
     const double coarse = flux[((size_t)e * nfc + c) * 64 + lane] + avg;
     double *__restrict__ o = out + ((size_t)slot * out_nc + c) * 512 + cell;
     *o = (*o + coarse) + 0.0;  // + 0.0: the three further FillCase_2 calls on the cleared face
+  }
+}
+
+// ONE launch for the ghost slabs of a stencil: workgroups [0, nr) restrict (neighbour finer), [nr, nr + np) interpolate (neighbour
+// coarser).  These launches are a few microseconds of work each and sit between the loop kernels of every BiCGSTAB iteration on a
+// multi-level mesh: what they cost is their number (rounds 1-4: two launches here, three in the flux correction below).
+template <int W>
+__global__ void __launch_bounds__(64) k_ghosts(AmrDev a, const int32_t *__restrict__ rlist, unsigned nr, const int32_t *__restrict__ plist, const double *__restrict__ field, int nc,
+                                               double *__restrict__ slabs) {
+  if (blockIdx.x < nr) ghost_restrict_face<W>(a, rlist[blockIdx.x], field, nc, slabs);
+  else ghost_prolong_face<W>(a, plist[blockIdx.x - nr], field, nc, slabs);
+}
+
+// The flux correction in ONE launch: one wavefront per coarse-side BLOCK walks the block's corrected faces in the order x-, x+, y-, y+,
+// z-, z+.  A cell lies on at most one face per direction, so every cell still receives its corrections direction by direction, x first
+// (FillCase_2 order, 2918-2926) -- bit-identical to the three launches of k_flux_fix; the barrier between two faces orders the second
+// face's read of a cell behind the first face's write of it (edge and corner cells of the block).
+__global__ void __launch_bounds__(64) k_flux_fix_blocks(AmrDev a, const int32_t *__restrict__ tab /* [n][6]: interface face behind face f, -1 none */, const double *__restrict__ flux, int nfc,
+                                                        double *out, int out_nc) {
+  const int lane = threadIdx.x;
+  const int a1 = lane & 7, a2 = lane >> 3;
+  for (int f = 0; f < 6; ++f) {
+    const int e = tab[6 * blockIdx.x + f];
+    if (e < 0) continue;
+    const int slot = a.faces[2 * e] / 6, d = f >> 1, j = (f & 1) ? 7 : 0;
+    const int cell = d == 0 ? a2 * 64 + a1 * 8 + j : (d == 1 ? a2 * 64 + j * 8 + a1 : j * 64 + a2 * 8 + a1);
+    const int fe = a.fine[4 * e + (a1 >> 2) + 2 * (a2 >> 2)];
+    const int i2 = 2 * (a1 & 3), i1 = 2 * (a2 & 3);
+    for (int c = 0; c < nfc; ++c) {
+      const double *__restrict__ F = flux + ((size_t)fe * nfc + c) * 64;
+      const double avg = (F[i2 + i1 * 8] + F[i2 + 1 + i1 * 8]) + (F[i2 + (i1 + 1) * 8] + F[i2 + 1 + (i1 + 1) * 8]);
+      const double coarse = flux[((size_t)e * nfc + c) * 64 + lane] + avg;
+      double *o = out + ((size_t)slot * out_nc + c) * 512 + cell;
+      *o = (*o + coarse) + 0.0;  // + 0.0: the three further FillCase_2 calls on the cleared face
+    }
+    __syncthreads();
   }
 }
 
@@ -582,13 +618,10 @@ int amr_fill_ghosts(Sim *s, const double *field, int nc, int w, double *slabs, i
   // both lists hold the faces of inner blocks first (sim_build): a rank view produces those while its ghost blocks travel
   const unsigned r0 = part == 2 ? s->n_restrict_inner : 0, r1 = part == 1 ? s->n_restrict_inner : s->n_restrict;
   const unsigned p0 = part == 2 ? s->n_prolong_inner : 0, p1 = part == 1 ? s->n_prolong_inner : s->n_prolong;
-  if (r1 > r0) {
-    if (w == 3) hipLaunchKernelGGL(k_ghost_restrict<3>, dim3(r1 - r0), dim3(64), 0, stream(), a, s->d_restrict_list + r0, field, nc, slabs);
-    else hipLaunchKernelGGL(k_ghost_restrict<1>, dim3(r1 - r0), dim3(64), 0, stream(), a, s->d_restrict_list + r0, field, nc, slabs);
-  }
-  if (p1 > p0) {
-    if (w == 3) hipLaunchKernelGGL(k_ghost_prolong<3>, dim3(p1 - p0), dim3(64), 0, stream(), a, s->d_prolong_list + p0, field, nc, slabs);
-    else hipLaunchKernelGGL(k_ghost_prolong<1>, dim3(p1 - p0), dim3(64), 0, stream(), a, s->d_prolong_list + p0, field, nc, slabs);
+  if (r1 + p1 > r0 + p0) {  // one launch: the restricting faces first, then the interpolating ones
+    const unsigned nr = r1 - r0, np = p1 - p0;
+    if (w == 3) hipLaunchKernelGGL(k_ghosts<3>, dim3(nr + np), dim3(64), 0, stream(), a, (const int32_t *)s->d_restrict_list + r0, nr, (const int32_t *)s->d_prolong_list + p0, field, nc, slabs);
+    else hipLaunchKernelGGL(k_ghosts<1>, dim3(nr + np), dim3(64), 0, stream(), a, (const int32_t *)s->d_restrict_list + r0, nr, (const int32_t *)s->d_prolong_list + p0, field, nc, slabs);
   }
   CUP3D_HIP(hipGetLastError());
   return CUP3D_OK;
@@ -601,10 +634,17 @@ int amr_flux_fix(Sim *s, int nfc, double *out, int out_nc) {
     if (rc) return rc;
   }
   ProfileScope ps("amr_flux_fix");
-  for (int d = 0; d < 3; ++d) {
-    const unsigned n = (unsigned)s->grid->fix_faces[d].size();
-    if (n) hipLaunchKernelGGL(k_flux_fix, dim3(n), dim3(64), 0, stream(), a, s->d_fix_list[d], s->d_flux, nfc, out, out_nc);
+#ifdef CUP3D_TESTING
+  if (debug_option("flux_fix_by_direction")) {  // A/B and the bit-for-bit cross-check: rounds 1-4's three launches, x faces, then y, then z
+    for (int d = 0; d < 3; ++d) {
+      const unsigned n = (unsigned)s->grid->fix_faces[d].size();
+      if (n) hipLaunchKernelGGL(k_flux_fix, dim3(n), dim3(64), 0, stream(), a, s->d_fix_list[d], s->d_flux, nfc, out, out_nc);
+    }
+    CUP3D_HIP(hipGetLastError());
+    return CUP3D_OK;
   }
+#endif
+  if (s->n_fix_blocks) hipLaunchKernelGGL(k_flux_fix_blocks, dim3(s->n_fix_blocks), dim3(64), 0, stream(), a, (const int32_t *)s->d_fix_blocks, (const double *)s->d_flux, nfc, out, out_nc);
   CUP3D_HIP(hipGetLastError());
   return CUP3D_OK;
 }

@@ -28,6 +28,17 @@ namespace cup3d {
 
 enum { PHAT, RHAT, SHAT, WHAT, ZHAT, QHAT, S_, W_, Z_, T_, V_, Q_, R_, Y_, X_, R0, B_, XOPT, NVEC };
 
+// Everything one wavefront hands to another inside a launch -- per-block values, group sums, counters, totals, flags -- travels by
+// AGENT-scope atomic stores / loads / read-modify-writes (sc1 on gfx950: written through and read past the per-XCD L2s, which are not
+// coherent with one another), ordered by s_waitcnt alone (a workgroup-scope fence).  NOT by __threadfence(): an agent-scope release fence is
+// a write-back of the XCD's whole L2 (buffer_wbl2), there to publish ORDINARY stores that may sit dirty in it -- one per wavefront, 262 144
+// per launch, made the loop kernels seven times slower (3.4 instead of 0.5 ms at 256^3, gpurun_out/r05b).  No ordinary store is published here.
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// this lane's agent-scope stores have completed (they are write-through: complete = visible to the agent) before anything that follows
+__device__ __forceinline__ void stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+
 // ------------------------------------------------------------------ block-local CG
 // One wavefront per 8^3 block: lane = (x,y) column, the 8 z-values of r, p, x, Ap in
 // registers; z-neighbours come from registers, x/y-neighbours from an LDS copy of p with
@@ -215,7 +226,7 @@ __device__ __forceinline__ void cg_block(const GridDev &g, int slot, double (&r)
   if (block_sums) {  // sum(z*h^3) of this block for the mean constraint of the LHS that follows (9283-9294)
     const double hq = block_h(g, slot), h3 = hq * hq * hq;
     sx = cg_sum<V2, ROWS>(sx * h3, P);
-    if (l == 0) block_sums[slot] = sx;
+    if (l == 0) st_agent(block_sums + slot, sx);  // (agent scope: the fused loop kernels total these inside the launch, Arrive)
   }
 }
 
@@ -449,7 +460,7 @@ __device__ __forceinline__ void fdm_block(const GridDev &g, int slot, double (&v
   if (block_sums) {
     const double hq = block_h(g, slot), h3 = hq * hq * hq;
     sx = wave_sum(sx * h3);
-    if (l == 0) block_sums[slot] = sx;
+    if (l == 0) st_agent(block_sums + slot, sx);  // (agent scope: the fused loop kernels total these inside the launch, Arrive)
   }
 }
 __global__ void __launch_bounds__(64) k_precond_fdm(GridDev g, const double *in, double *out, const double *__restrict__ invD,
@@ -722,10 +733,12 @@ struct Arrive {
   long nb, n1, n2;
   double *out;             // [K] totals (device memory)
 };
-__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned ticket_of_wave(unsigned *counter) {  // lane 0's values are stored: release, then take a ticket; every lane gets it
+__device__ __forceinline__ unsigned ticket_of_wave(unsigned *counter) {  // lane 0's values are stored: take a ticket; every lane gets it
   unsigned t = 0;
-  if (threadIdx.x == 0) { __threadfence(); t = atomicAdd(counter, 1u); }
+  if (threadIdx.x == 0) {
+    stores_done();
+    t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   return (unsigned)__builtin_amdgcn_readfirstlane((int)t);
 }
 template <int K, class Then>
@@ -733,36 +746,33 @@ __device__ __forceinline__ void arrive(const Arrive &A, int slot, Then then) {
   const int l = threadIdx.x;
   const long g = slot >> 6, first = g << 6;
   const unsigned gsize = (unsigned)(A.nb - first < 64 ? A.nb - first : 64);
-  if (ticket_of_wave(A.c1 + g) != gsize - 1) return;
-  __threadfence();  // acquire the group's values
+  if (ticket_of_wave(A.c1 + g) != gsize - 1) return;  // (the loads below are issued after the ticket has come back: control dependence)
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const double v = wave_sum((unsigned)l < gsize ? ld_agent(A.vals + (size_t)k * A.nb + first + l) : 0.0);
-    if (l == 0) A.g1[(size_t)k * A.n1 + g] = v;
+    if (l == 0) st_agent(A.g1 + (size_t)k * A.n1 + g, v);
   }
   const long sg = g >> 6, gfirst = sg << 6;
   const unsigned sgsize = (unsigned)(A.n1 - gfirst < 64 ? A.n1 - gfirst : 64);
-  if (l == 0) A.c1[g] = 0;
+  if (l == 0) st_agent(A.c1 + g, 0u);
   if (ticket_of_wave(A.c2 + sg) != sgsize - 1) return;
-  __threadfence();
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const double v = wave_sum((unsigned)l < sgsize ? ld_agent(A.g1 + (size_t)k * A.n1 + gfirst + l) : 0.0);
-    if (l == 0) A.g2[(size_t)k * A.n2 + sg] = v;
+    if (l == 0) st_agent(A.g2 + (size_t)k * A.n2 + sg, v);
   }
-  if (l == 0) A.c2[sg] = 0;
+  if (l == 0) st_agent(A.c2 + sg, 0u);
   if (ticket_of_wave(A.c3) != (unsigned)A.n2 - 1) return;
-  __threadfence();
   double tot[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     double v = 0;
     for (long j = l; j < A.n2; j += 64) v += ld_agent(A.g2 + (size_t)k * A.n2 + j);
     tot[k] = wave_sum(v);
-    if (l == 0) A.out[k] = tot[k];
+    if (l == 0) st_agent(A.out + k, tot[k]);
   }
   if (l == 0) {
-    *A.c3 = 0;
+    st_agent(A.c3, 0u);
     then(tot);
   }
 }
@@ -788,9 +798,9 @@ __device__ __forceinline__ void DotsThen::operator()(const double *tot) const {
     *ctl = c;
     if (which == 2) ctl_publish(ctl, ring, it);
   }
-  if (flag) {  // the totals (this lane's own stores) before the flag
-    __threadfence();
-    __hip_atomic_store(flag, 2 * it + (unsigned)(which - 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (flag) {  // the totals (this lane's own agent-scope stores) before the flag
+    stores_done();
+    st_agent(flag, 2 * it + (unsigned)(which - 1));
   }
 }
 struct NoThen { __device__ __forceinline__ void operator()(const double *) const {} };
@@ -981,7 +991,7 @@ __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, c
 #undef LOAD_PLANE
   d0 = wave_sum(d0);
   d1 = wave_sum(d1);
-  if (l == 0) { block_dots[slot] = d0; block_dots[nb + slot] = d1; }
+  if (l == 0) { st_agent(block_dots + slot, d0); st_agent(block_dots + nb + slot, d1); }
   arrive<2>(Z->dots, slot, Z->then);  // q.y, y.y are complete when the last block passes here: totals + omega (14493), one block solve before the kernel ends
   if (L.prio) __builtin_amdgcn_s_setprio(0);
   if constexpr (FLHS) __syncthreads();  // the tile is read no more: the block solve takes over its LDS
@@ -1069,8 +1079,8 @@ __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, c
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const double t = wave_sum(acc[i]);
-    if (l == 0) block_dots[(size_t)i * nb + slot] = t;
-    if (i == 4 && l == 0) block_dots[(size_t)6 * nb + slot] = t;  // norm = the same sum as norm_1 (14512-14514)
+    if (l == 0) st_agent(block_dots + (size_t)i * nb + slot, t);
+    if (i == 4 && l == 0) st_agent(block_dots + (size_t)6 * nb + slot, t);  // norm = the same sum as norm_1 (14512-14514)
   }
   arrive<7>(Z->dots, slot, Z->then);  // the seven of 14546: totals + the recurrences (14558-14601) while the block solves still run
   if (L.prio) __builtin_amdgcn_s_setprio(0);
@@ -1589,6 +1599,15 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     }
     return CUP3D_OK;
   };
+  // early: nothing orders the communication stream behind the loop kernel any more (that is the point), so it must be ordered behind the
+  // k_ctl_set that starts a run of fused iterations explicitly: k_wait_totals and k_ctl_step read the struct (an unordered k_wait_totals saw
+  // the state of the PREVIOUS run -- kDone -- returned at once, and the all-reduce took stale totals: 1000 iterations without converging)
+  auto ctl_set_seen_by_comm = [&]() -> int {
+    if (!early) return CUP3D_OK;
+    CUP3D_HIP(hipEventRecord(s->ev_b, stream()));
+    CUP3D_HIP(hipStreamWaitEvent(scalar_stream(s), s->ev_b, 0));
+    return CUP3D_OK;
+  };
   auto scalars_ready = [&]() -> int {  // the compute stream waits for the struct stepped on the communication stream
     if (!direct && scalar_stream(s) != stream()) {
       ProfileScope pw("comm_exposed_scalar_wait");  // compute stream idle until the all-reduced scalars are stepped (the exposed part of the all-reduce)
@@ -1747,6 +1766,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     hs.state = kRun;
     hs.seq = s->ctl_seq + 1;  // the number the next enqueued iteration gets
     hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, stream(), d_ctl, hs);
+    TRY(ctl_set_seen_by_comm());
     int enq = k;  // next iteration to enqueue; k = next iteration whose outcome the host has not seen
     unsigned seq_of[2] = {0, 0};
     for (;;) {
@@ -1765,6 +1785,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
         TRY(restart());
         hs.seq = s->ctl_seq + 1;
         hipLaunchKernelGGL(k_ctl_set, dim3(1), dim3(1), 0, stream(), d_ctl, hs);
+        TRY(ctl_set_seen_by_comm());
       }
     }
   }

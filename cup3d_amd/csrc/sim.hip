@@ -389,6 +389,17 @@ static int sim_build(Sim *s, const Grid *g) {
         (rc = up(&s->d_index, g->index)) || (rc = up(&s->d_restrict_list, lr)) || (rc = up(&s->d_prolong_list, lp)) ||
         (rc = up(&s->d_fix_list[0], g->fix_faces[0])) || (rc = up(&s->d_fix_list[1], g->fix_faces[1])) || (rc = up(&s->d_fix_list[2], g->fix_faces[2])))
       return rc;
+    {  // the corrected faces grouped by block (k_flux_fix_blocks): blocks in slot order, faces x-, x+, y-, y+, z-, z+
+      std::vector<int32_t> of_slot((size_t)std::max<int64_t>(nv, 1), -1), tab;
+      for (int d = 0; d < 3; ++d)
+        for (int32_t e : g->fix_faces[d]) {
+          const int32_t sf = g->amr_faces[2 * (size_t)e], slot = sf / 6, f = sf % 6;
+          if (of_slot[(size_t)slot] < 0) { of_slot[(size_t)slot] = (int32_t)(tab.size() / 6); tab.insert(tab.end(), 6, -1); }
+          tab[(size_t)of_slot[(size_t)slot] * 6 + f] = e;
+        }
+      s->n_fix_blocks = (unsigned)(tab.size() / 6);
+      if ((rc = up(&s->d_fix_blocks, tab))) return rc;
+    }
     A(s->d_hb, nv)
     CUP3D_HIP(hipMemcpy(s->d_hb, g->hb.data(), nv * sizeof(double), hipMemcpyHostToDevice));
     {
@@ -534,7 +545,7 @@ void cup3d_sim_destroy(cup3d_sim_t *h) {
   if (s->h_early_fail) hipHostFree(s->h_early_fail);
   release_stage(s);
   int32_t *ip[] = {s->d_nbr, s->d_inner, s->d_boundary, s->d_send_faces, s->d_amr_faces, s->d_amr_fine, s->d_nbr27, s->d_index,
-                   s->d_restrict_list, s->d_prolong_list, s->d_fix_list[0], s->d_fix_list[1], s->d_fix_list[2], s->d_send_blocks, s->d_send_flux, s->d_raw_list, s->d_iface_list, s->d_plain_list};
+                   s->d_restrict_list, s->d_prolong_list, s->d_fix_list[0], s->d_fix_list[1], s->d_fix_list[2], s->d_fix_blocks, s->d_send_blocks, s->d_send_flux, s->d_raw_list, s->d_iface_list, s->d_plain_list};
   if (s->d_raw_mask) hipFree(s->d_raw_mask);
   for (int k = 0; k < 2; ++k) {
     void *bp[] = {s->d_send_box[k], s->d_ghost_box[k], s->d_send_off[k], s->d_ghost_off[k]};

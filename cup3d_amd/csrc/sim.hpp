@@ -152,6 +152,8 @@ struct Sim {
   void *d_ctl = nullptr, *h_ctl = nullptr, *h_ctl_dev = nullptr;
   unsigned ctl_seq = 0;
   unsigned n_restrict = 0, n_prolong = 0;
+  int32_t *d_fix_blocks = nullptr;  // [n_fix_blocks][6]: per block with a corrected (coarse-side) face, the interface face behind each of its six faces or -1
+  unsigned n_fix_blocks = 0;
   unsigned n_restrict_inner = 0, n_prolong_inner = 0;  // leading entries of the two lists that belong to inner blocks (rank views)
   struct { const double *field = nullptr; int nc = 0, w = 0, bc_dir = -1; double *slabs = nullptr; bool open = false; } pending_fill;  // halo_begin -> halo_finish
   int32_t *d_send_blocks = nullptr, *d_send_flux = nullptr;  // rank views: exchange plans (comm.hip)
