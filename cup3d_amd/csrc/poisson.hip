@@ -137,7 +137,8 @@ __device__ __forceinline__ double cg_div(double n, double d) {
 // block CG 3.18 instead of 2.88 ms, fused kernels 4.1 instead of 3.8 ms at 512^3; kept for A/B only)
 // cg_block: the iteration itself, entered with r = the block's right-hand side / h already in registers (lane = (x, y), 8 z per lane) --
 // shared by the stand-alone preconditioner kernel and the kernels that produce that right-hand side on the fly (k_loop1_cg / k_loop2_cg)
-template <bool FMA, bool HELM, int EV>
+// AG: the block sum is handed to another wavefront of the SAME launch (Arrive, below): agent-scope store instead of an ordinary one
+template <bool FMA, bool HELM, int EV, bool AG = false>
 __device__ __forceinline__ void cg_block(const GridDev &g, int slot, double (&r)[8], double *out, double *__restrict__ block_sums, double nu, double dt,
                                          int *__restrict__ iters_out, double *P) {
   // (r01 kernel: 86 VGPRs -> 5 waves/SIMD.  Forcing 6 with amdgpu_waves_per_eu spills five values that are reloaded every iteration:
@@ -226,7 +227,7 @@ __device__ __forceinline__ void cg_block(const GridDev &g, int slot, double (&r)
   if (block_sums) {  // sum(z*h^3) of this block for the mean constraint of the LHS that follows (9283-9294)
     const double hq = block_h(g, slot), h3 = hq * hq * hq;
     sx = cg_sum<V2, ROWS>(sx * h3, P);
-    if (l == 0) st_agent(block_sums + slot, sx);  // (agent scope: the fused loop kernels total these inside the launch, Arrive)
+    if (l == 0) { if constexpr (AG) st_agent(block_sums + slot, sx); else block_sums[slot] = sx; }
   }
 }
 
@@ -405,6 +406,7 @@ __device__ __forceinline__ void sine_transform8(const double (&v)[8], double (&o
 constexpr int kFdmLds = 64 * 9;  // transposes; pitch 9 doubles keeps every ds_read/write_b64 conflict-free
 // the direct solve of one block by its wavefront: v[z] = (right-hand side / h) of cell (x = lane & 7, y = lane >> 3, z) on entry;
 // out receives M^-1, block_sums[slot] (if any) sum(z h^3).  T: kFdmLds doubles of LDS nobody else is using.
+template <bool AG = false>
 __device__ __forceinline__ void fdm_block(const GridDev &g, int slot, double (&v)[8], double *__restrict__ out, const double *__restrict__ invD,
                                           double *__restrict__ block_sums, double *T) {
   const int l = threadIdx.x, lo = l & 7, hi = l >> 3;
@@ -460,7 +462,7 @@ __device__ __forceinline__ void fdm_block(const GridDev &g, int slot, double (&v
   if (block_sums) {
     const double hq = block_h(g, slot), h3 = hq * hq * hq;
     sx = wave_sum(sx * h3);
-    if (l == 0) st_agent(block_sums + slot, sx);  // (agent scope: the fused loop kernels total these inside the launch, Arrive)
+    if (l == 0) { if constexpr (AG) st_agent(block_sums + slot, sx); else block_sums[slot] = sx; }
   }
 }
 __global__ void __launch_bounds__(64) k_precond_fdm(GridDev g, const double *in, double *out, const double *__restrict__ invD,
@@ -508,7 +510,6 @@ static int *cg_iters_buffer(Sim *s) {  // per-block CG iteration counts of the l
 }
 
 constexpr int kLoopPrio = 0;    // LhsIn::prio of the production launch (measured: profiles/r03)
-constexpr int kLoop1LdsPad = 0; // dynamic LDS of the first fused kernel's production launch (see launch_loop; measured: profiles/r05)
 // evaluation of the production block CG (EV bits of k_precond); measured on MI355X: see profiles/r02/probe_block_cg_variants.jsonl
 constexpr int kCgProduction = 0;
 
@@ -925,7 +926,8 @@ __device__ __forceinline__ double tile_lhs(const double *T, const TileIdx &ix, d
 
 // DIRECT: the block solve behind the loop is the fast diagonalisation (fdm_block: the same M^-1, exact instead of by CG -- block_solver 1,
 // bench.py's `alt`), not the reference's CG: no iteration, no reductions, so the kernel is what the streams alone allow
-template <bool FMA, int EV, bool FLHS, bool DIRECT = false>
+// TOT: the kernel totals its per-block values itself (Arrive; the early all-reduce over ranks) -- else a launch of k_sums_finish does
+template <bool FMA, int EV, bool FLHS, bool DIRECT = false, bool TOT = false>
 __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb,
                                               double *block_sums, int *__restrict__ iters_out, const LhsIn &L, const LoopSums *__restrict__ Z) {
   __shared__ double P[FLHS ? kTileLds : (DIRECT ? kFdmLds : kCgLds)];
@@ -991,13 +993,15 @@ __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, c
 #undef LOAD_PLANE
   d0 = wave_sum(d0);
   d1 = wave_sum(d1);
-  if (l == 0) { st_agent(block_dots + slot, d0); st_agent(block_dots + nb + slot, d1); }
-  arrive<2>(Z->dots, slot, Z->then);  // q.y, y.y are complete when the last block passes here: totals + omega (14493), one block solve before the kernel ends
+  if constexpr (TOT) {
+    if (l == 0) { st_agent(block_dots + slot, d0); st_agent(block_dots + nb + slot, d1); }
+    arrive<2>(Z->dots, slot, Z->then);  // q.y, y.y are complete when the last block passes here: the totals exist one block solve before the kernel ends
+  } else if (l == 0) { block_dots[slot] = d0; block_dots[nb + slot] = d1; }
   if (L.prio) __builtin_amdgcn_s_setprio(0);
   if constexpr (FLHS) __syncthreads();  // the tile is read no more: the block solve takes over its LDS
-  if constexpr (DIRECT) fdm_block(g, slot, r, V.v[ZHAT], L.invD, block_sums, P);
-  else cg_block<FMA, false, EV>(g, slot, r, V.v[ZHAT], block_sums, 0.0, 0.0, iters_out, P);  // zhat = M^-1 z, 14488
-  if (Z->mean.vals) arrive<1>(Z->mean, slot, NoThen());  // sum(zhat h^3) for the mean-constraint row of v = A zhat
+  if constexpr (DIRECT) fdm_block<TOT>(g, slot, r, V.v[ZHAT], L.invD, block_sums, P);
+  else cg_block<FMA, false, EV, TOT>(g, slot, r, V.v[ZHAT], block_sums, 0.0, 0.0, iters_out, P);  // zhat = M^-1 z, 14488
+  if constexpr (TOT) if (Z->mean.vals) arrive<1>(Z->mean, slot, NoThen());  // sum(zhat h^3) for the mean-constraint row of v = A zhat
 }
 // (with the LHS inside the compiler takes 110 registers -> 4 wavefronts per SIMD; held to 5 wavefronts it fits 94 without a spill and is
 //  SLOWER: 0.54 instead of 0.51 ms at 256^3, 3.96 instead of 3.93 at 512^3 -- gpurun_out r03c / r03d, profiles/r03)
@@ -1013,7 +1017,7 @@ __global__ void __launch_bounds__(64) k_loop1_fdm(GridDev g, Vecs V, const Solve
   loop1_cg_body<true, 0, FLHS, true>(g, V, ctl, block_dots, nb, block_sums, nullptr, L, Z);
 }
 
-template <bool FMA, int EV, bool FLHS, bool DIRECT = false>
+template <bool FMA, int EV, bool FLHS, bool DIRECT = false, bool TOT = false>
 __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb,
                                               double *block_sums, int *__restrict__ iters_out, const LhsIn &L, const LoopSums *__restrict__ Z) {
   __shared__ double P[FLHS ? kTileLds : (DIRECT ? kFdmLds : kCgLds)];
@@ -1079,15 +1083,20 @@ __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, c
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const double t = wave_sum(acc[i]);
-    if (l == 0) st_agent(block_dots + (size_t)i * nb + slot, t);
-    if (i == 4 && l == 0) st_agent(block_dots + (size_t)6 * nb + slot, t);  // norm = the same sum as norm_1 (14512-14514)
+    if constexpr (TOT) {
+      if (l == 0) st_agent(block_dots + (size_t)i * nb + slot, t);
+      if (i == 4 && l == 0) st_agent(block_dots + (size_t)6 * nb + slot, t);  // norm = the same sum as norm_1 (14512-14514)
+    } else {
+      if (l == 0) block_dots[(size_t)i * nb + slot] = t;
+      if (i == 4 && l == 0) block_dots[(size_t)6 * nb + slot] = t;  // norm = the same sum as norm_1 (14512-14514)
+    }
   }
-  arrive<7>(Z->dots, slot, Z->then);  // the seven of 14546: totals + the recurrences (14558-14601) while the block solves still run
+  if constexpr (TOT) arrive<7>(Z->dots, slot, Z->then);  // the seven of 14546: complete while the block solves still run
   if (L.prio) __builtin_amdgcn_s_setprio(0);
   if constexpr (FLHS) __syncthreads();
-  if constexpr (DIRECT) fdm_block(g, slot, r, V.v[WHAT], L.invD, block_sums, P);
-  else cg_block<FMA, false, EV>(g, slot, r, V.v[WHAT], block_sums, 0.0, 0.0, iters_out, P);  // what = M^-1 w, 14548
-  if (Z->mean.vals) arrive<1>(Z->mean, slot, NoThen());  // sum(what h^3) for the mean-constraint row of t = A what
+  if constexpr (DIRECT) fdm_block<TOT>(g, slot, r, V.v[WHAT], L.invD, block_sums, P);
+  else cg_block<FMA, false, EV, TOT>(g, slot, r, V.v[WHAT], block_sums, 0.0, 0.0, iters_out, P);  // what = M^-1 w, 14548
+  if constexpr (TOT) if (Z->mean.vals) arrive<1>(Z->mean, slot, NoThen());  // sum(what h^3) for the mean-constraint row of t = A what
 }
 // WITHOUT the LHS inside (FLHS = false: multi-level meshes, the no_fuse_lhs A/B): held to 96 registers (2 of the 122 the body asks for
 // are spilled, outside the CG loop) -> 5 wavefronts per SIMD: 3.63-3.70 ms instead of 3.75 at 512^3, 0.457-0.461 instead of 0.497 at
@@ -1102,9 +1111,23 @@ k_loop2_cg(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_d
 // PRODUCTION on uniform grids (FLHS = true; what bench.py's `value` runs): the register allocation the compiler picks on its own, 128
 // registers -> 4 wavefronts per SIMD, no spills.  (Also the "loop2_four_waves" A/B of the FLHS = false form.)
 template <bool FMA, int EV, bool FLHS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_loop2_cg_w4(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums,
+__global__ void __launch_bounds__(64) k_loop2_cg_w4(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums,
                                                     int *__restrict__ iters_out, LhsIn L, const LoopSums *__restrict__ Z) {
   loop2_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L, Z);
+}
+
+// The two kernels of an iteration with the totals INSIDE (TOT; uniform grids, block CG): the early all-reduce over ranks (solve(): `early`).
+// The second one is held to 128 registers (the compiler would take 136 -> 3 wavefronts per SIMD): one 8-byte value is parked in scratch
+// before the plane loop and fetched back when the block CG starts, never inside a loop.
+template <bool FMA, int EV>
+__global__ void __launch_bounds__(64) k_loop1_cg_tot(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums, int *__restrict__ iters_out, LhsIn L,
+                                                     const LoopSums *__restrict__ Z) {
+  loop1_cg_body<FMA, EV, true, false, true>(g, V, ctl, block_dots, nb, block_sums, iters_out, L, Z);
+}
+template <bool FMA, int EV>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_loop2_cg_tot(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums, int *__restrict__ iters_out, LhsIn L, const LoopSums *__restrict__ Z) {
+  loop2_cg_body<FMA, EV, true, false, true>(g, V, ctl, block_dots, nb, block_sums, iters_out, L, Z);
 }
 
 // block_solver 1: second loop + the direct block solve (`alt`)
@@ -1112,6 +1135,46 @@ template <bool FLHS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_loop2_fdm(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums,
                                                   LhsIn L, const LoopSums *__restrict__ Z) {
   loop2_cg_body<true, 0, FLHS, true>(g, V, ctl, block_dots, nb, block_sums, nullptr, L, Z);
+}
+
+// DEFAULT totalling of a fused loop's per-block values: K sums of nb values each ([K][nb]) finished in one launch of 64 / 256 workgroups,
+// the last one to arrive totals the partials (grid_sum_finish, tile.hpp).  MEAN: one more sum rides along -- the per-block sums of
+// zhat h^3 / what h^3 the fused kernel left in mean_src; the total lands in ro.out[K], where the LHS application that follows takes its
+// mean-constraint row from (no k_mean_finish launch, and over ranks no second all-reduce: the total travels with the dot products).
+// step 1 / 2: one rank -- the last workgroup also steps the solver's scalar struct with the totals (ctl_step1 / ctl_step2) and, after
+// the second loop, publishes it to the host's status ring; step 0: totals only (several ranks: the all-reduce comes first, k_ctl_step).
+// (Round 5 measured the alternative -- the loop kernels totalling these values themselves, Arrive above -- on one GPU: the launches it saves
+//  (16-27 us each) are paid back by the loop kernels (agent-scope stores whose completion a wavefront must wait for before it takes its
+//  ticket, +2 % on the second kernel at 512^3, +7-9 % on the smaller kernels of a multi-level mesh): neutral at 256^3, a loss elsewhere.  So
+//  this launch stays the default and the in-kernel totals serve what only they can do: the early all-reduce.)
+struct CtlThen {
+  SolverCtl *ctl; CtlSlot *ring; int step;
+  __device__ __forceinline__ void operator()(const double *tot) const {
+    if (step == 0 || ctl->state != kRun) return;  // (an iteration enqueued ahead of a stop / restart summed stale partials: dropped)
+    SolverCtl c = *ctl;
+    const unsigned it = c.seq;
+    if (step == 1) ctl_step1(c, tot); else ctl_step2(c, tot);
+    *ctl = c;
+    if (step == 2) ctl_publish(ctl, ring, it);
+  }
+};
+inline int sums_groups(int64_t nb) { return nb >= (1 << 17) ? 256 : 64; }  // (0.027 instead of 0.051 ms per launch at 512^3, 0.016 instead of 0.014 at 256^3: profiles/r03)
+template <int K, bool MEAN>
+__global__ void __launch_bounds__(256) k_sums_finish(const double *__restrict__ v, long nb, RedOut ro, const double *__restrict__ mean_src, CtlThen then) {
+  static_assert(K + (MEAN ? 1 : 0) <= kRedDotsEnd - kRedDots, "the totals of a loop must fit the kRedDots range of Sim::d_red");
+  double acc[K + (MEAN ? 1 : 0)];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double t = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (long)gridDim.x * 256) t += v[(size_t)k * nb + i];
+    acc[k] = t;
+  }
+  if (MEAN) {
+    double t = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (long)gridDim.x * 256) t += mean_src[i];
+    acc[K] = t;
+  }
+  grid_sum_finish<K + (MEAN ? 1 : 0)>(acc, ro, then);
 }
 
 // several ranks, all-reduce started EARLY (solve(): early): the communication stream holds this one-thread kernel in front of the
@@ -1551,20 +1614,34 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   const bool flhs = fuse && !s->grid->multilevel && !debug_option("no_fuse_lhs");
   static const bool early_env = [] { const char *e = getenv("CUP3D_EARLY_ALLREDUCE"); return e && atoi(e) != 0; }();
   // (uniform grids only: on multi-level meshes the LHS is a launch of its own between the loops and reads the mean-constraint total itself)
-  const bool early = !direct && flhs && comm() && !virtual_ranks() && !host_transport() && scalar_stream(s) != stream() && (early_env || debug_option("early_allreduce"));
+  const bool early = !direct && flhs && (P.block_solver == 0 || P.block_solver == 2) && comm() && !virtual_ranks() && !host_transport() && scalar_stream(s) != stream() && (early_env || debug_option("early_allreduce"));
   static const long long tick_rate = [] {  // wall_clock64 ticks per millisecond (100 MHz on CDNA3 / CDNA4)
     int dev = 0, khz = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) return (long long)khz;
     return 100000LL;
   }();
-  auto after_loop = [&](int K, int step, unsigned seq) -> int {  // the totals of the loop just enqueued -> all ranks -> the struct
-    if (direct) return CUP3D_OK;  // one rank: the kernel's last arriving wavefront has totalled AND stepped (DotsThen)
+  auto after_loop = [&](int K, int step, unsigned seq) -> int {  // the totals of the loop just enqueued (-> all ranks) -> the struct
+    if (!early) {  // DEFAULT: one launch totals the K (+1) block-wise sums; on one rank its last workgroup steps the struct as well
+      ProfileScope ps("bicgstab_dots_finish");
+      const RedOut ro{s->d_partials, s->d_counters, s->d_red, nullptr, nullptr, 0u};
+      const CtlThen then{d_ctl, ring, direct ? step : 0};
+      const dim3 SG(debug_option("sums_groups") > 0 ? debug_option("sums_groups") : sums_groups(s->nb));
+      if (K == 2) {
+        if (want_sums) hipLaunchKernelGGL((k_sums_finish<2, true>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, sums, then);
+        else hipLaunchKernelGGL((k_sums_finish<2, false>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, (const double *)nullptr, then);
+      } else {
+        if (want_sums) hipLaunchKernelGGL((k_sums_finish<7, true>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, sums, then);
+        else hipLaunchKernelGGL((k_sums_finish<7, false>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, (const double *)nullptr, then);
+      }
+      CUP3D_HIP(hipGetLastError());
+    }
+    if (direct) return CUP3D_OK;
     hipStream_t cs = scalar_stream(s);
     const int nmean = want_sums ? 1 : 0;
-    if (s->nb == 0) {  // a rank without blocks launched nothing: its contribution is zero, and nobody but the host can raise the early flag
+    if (early && s->nb == 0) {  // a rank without blocks launched nothing: its contribution is zero, and nobody but the host can raise the flag
       CUP3D_HIP(hipMemsetAsync(s->d_red + kRedDots, 0, (size_t)(K + 1) * sizeof(double), stream()));
       CUP3D_HIP(hipMemsetAsync(s->d_red + kRedEarlyMean, 0, 2 * sizeof(double), stream()));
-      if (early) hipLaunchKernelGGL(k_raise, dim3(1), dim3(1), 0, stream(), dots_flag, seq * 2 + (unsigned)(step - 1));
+      hipLaunchKernelGGL(k_raise, dim3(1), dim3(1), 0, stream(), dots_flag, seq * 2 + (unsigned)(step - 1));
     }
     if (!early) {
       if (cs != stream()) {
@@ -1623,8 +1700,8 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   // out of the production path.
   const bool flhs_ml = fuse && s->grid->multilevel && s->grid->nranks == 1 && s->n_plain > 0 && !debug_option("no_fuse_lhs") && debug_option("fuse_lhs_ml");
   const bool split = s->grid->nranks > 1;
-  // the two loops' LoopSums, constant over this solve, in device memory
-  {
+  // early: the two loops' LoopSums, constant over this solve, in device memory
+  if (early) {
     LoopSums Z[2];
     for (int which = 1; which <= 2; ++which) {
       const int K = which == 1 ? 2 : 7;
@@ -1632,7 +1709,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       Z[which - 1].dots = arrive_args(0, s->d_block_dots, s->d_red + kRedDots);
       Z[which - 1].mean = arrive_args(1, want_sums ? sums : nullptr, mean_out);
       // sc (the path checksum): totals only, nothing stepped
-      Z[which - 1].then = DotsThen{d_ctl, ring, which, direct && !sc ? 1 : 0, early && !sc ? dots_flag : nullptr};
+      Z[which - 1].then = DotsThen{d_ctl, ring, which, 0, sc ? nullptr : dots_flag};  // (over ranks the struct is stepped behind the all-reduce, k_ctl_step)
     }
     hipLaunchKernelGGL(k_set_loop_sums, dim3(1), dim3(1), 0, stream(), s->d_loop_sums, Z[0], Z[1]);
     CUP3D_HIP(hipGetLastError());
@@ -1658,10 +1735,9 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
         else hipLaunchKernelGGL(k_loop2_fdm<false>, GG, BB, 0, stream(), FDM_ARGS);
 #undef FDM_ARGS
       } else if (which == 1) {
-        // (with the in-kernel totals behind the plane loop the compiler finds a 94-register allocation of this kernel: 5 wavefronts per SIMD
-        //  where rounds 3-4 ran 4 at 110 registers.  "loop1_lds_pad" = bytes of dynamic LDS per workgroup on top of the tile's 7680: 2560
-        //  makes it 16 workgroups per CU, i.e. 4 per SIMD again -- the A/B of the occupancy without recompiling)
-        if (P.block_solver == 0 && fl) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction, true>), GG, BB, (unsigned)(kLoop1LdsPad + debug_option("loop1_lds_pad")), stream(), LOOP_ARGS);
+        if (early && P.block_solver == 0) hipLaunchKernelGGL((k_loop1_cg_tot<true, kCgProduction>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (early) hipLaunchKernelGGL((k_loop1_cg_tot<false, 0>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (P.block_solver == 0 && fl) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (fl) hipLaunchKernelGGL((k_loop1_cg<false, 0, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else hipLaunchKernelGGL((k_loop1_cg<false, 0, false>), GG, BB, 0, stream(), LOOP_ARGS);
@@ -1673,7 +1749,9 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
         else if (P.block_solver == 0 && !fl && four_waves) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
         else
 #endif
-        if (P.block_solver == 0 && fl) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        if (early && P.block_solver == 0) hipLaunchKernelGGL((k_loop2_cg_tot<true, kCgProduction>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (early) hipLaunchKernelGGL((k_loop2_cg_tot<false, 0>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (P.block_solver == 0 && fl) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (fl) hipLaunchKernelGGL((k_loop2_cg_w4<false, 0, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else hipLaunchKernelGGL((k_loop2_cg<false, 0, false>), GG, BB, 0, stream(), LOOP_ARGS);
@@ -1843,7 +1921,7 @@ int cup3d_debug_ctl_step(int step, double *io, const double *totals) {
   SolverCtl c;
   c.alpha = io[0]; c.beta = io[1]; c.omega = io[2]; c.r0r_prev = io[3]; c.norm = io[4]; c.init_norm = io[5]; c.min_norm = io[6];
   c.tol = io[7]; c.tol_rel = io[8]; c.state = (int)io[9]; c.restarts = (int)io[10]; c.max_restarts = (int)io[11];
-  c.xcur = (int)io[12]; c.xopt = (int)io[13]; c.iter = (int)io[14];
+  c.xcur = (int)io[12]; c.xopt = (int)io[13]; c.iter = (int)io[14]; c.seq = 0;
   if (step == 1) ctl_step1(c, totals); else ctl_step2(c, totals);
   io[0] = c.alpha; io[1] = c.beta; io[2] = c.omega; io[3] = c.r0r_prev; io[4] = c.norm; io[5] = c.init_norm; io[6] = c.min_norm;
   io[9] = c.state; io[10] = c.restarts; io[12] = c.xcur; io[13] = c.xopt; io[14] = c.iter;

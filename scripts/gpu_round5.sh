@@ -54,8 +54,8 @@ for S in 128 256 512; do
     timeout 900 python bench.py --size $S --no-cpu --no-alt --no-pcie --steps ${BENCH_STEPS:-10} --warmup ${BENCH_WARMUP:-3} ${BENCH_ARGS} > $OUT/bench_$S.json 2> $OUT/bench_$S.err ; echo "bench rc=$?" ; summ $OUT/bench_$S.json ; tail -2 $OUT/bench_$S.err
   fi
 done
-if has ab256; then echo "== A/B at 256^3 (one GPU's share of the headline on 8): default | first fused kernel held to 4 wavefronts per SIMD by LDS | no per-kernel events"
-  for V in "default:" "lds_pad:--debug-option loop1_lds_pad=2560" "testing_build:--debug-option loop1_lds_pad=0" "no_profile:--no-profile"; do
+if has ab256; then echo "== A/B at 256^3 (one GPU's share of the headline on 8): default | no per-kernel events"
+  for V in "default:" "no_profile:--no-profile"; do
     N=${V%%:*}; A=${V#*:}
     timeout 600 python bench.py --size ${AB_SIZE:-256} --no-cpu --no-alt --no-pcie --steps ${AB_STEPS:-10} --warmup 3 $A > $OUT/bench_${AB_SIZE:-256}_$N.json 2> $OUT/bench_${AB_SIZE:-256}_$N.err ; echo "rc=$? ($N)"; summ $OUT/bench_${AB_SIZE:-256}_$N.json | head -1; summ $OUT/bench_${AB_SIZE:-256}_$N.json | grep bicgstab_loop
   done; fi
@@ -74,6 +74,16 @@ print("  value", r["value"], "ms/step", r["ms_per_step"], r["config"]["blocks"],
 for k in r["kernels"][:10]: print("   ", k["kernel"], k["launches"], k["avg_ms"], k["share"])
 PY
 fi
+if has amrab; then echo "== bench --amr A/B (testing build, same box): the flux correction as ONE launch (production) vs one launch per direction (rounds 1-4)"
+  for V in 0 1; do
+    timeout 600 python bench.py --amr --steps ${AMR_STEPS:-10} --warmup 3 --debug-option flux_fix_by_direction=$V > $OUT/bench_amr_flux_fix_by_direction_$V.json 2> $OUT/bench_amr_ab_$V.err ; echo "rc=$? (flux_fix_by_direction=$V)"; python - $OUT/bench_amr_flux_fix_by_direction_$V.json <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+its = r["config"]["bicgstab_iters_per_step"]
+print("  value", r["value"], "ms/step", r["ms_per_step"], r["config"]["blocks"], its, "ms/iteration", round(r["ms_per_step"] / its, 4))
+for k in r["kernels"][:9]: print("   ", k["kernel"], k["launches"], k["avg_ms"], k["share"])
+PY
+  done; fi
 # injected latency: what an iteration costs when every all-reduce takes L microseconds (FAKE_RCCL_ALLREDUCE_US), ONE process whose scalars
 # are forced through the communicator (force_allreduce: testing build), so that nothing but the latency changes between the runs
 if has latency; then echo "== injected all-reduce latency, one process, ${LAT_SIZE:-256}^3: ms per BiCGSTAB iteration and the exposed scalar wait"

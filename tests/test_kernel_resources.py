@@ -31,20 +31,28 @@ def test_every_translation_unit_carries_gfx950_code(release):
 
 
 def test_fused_solver_kernels(release):
-    """k_loop1_cg / k_loop2_cg_w4 <FMA, EV = 0, FLHS = true>: the two launches of a BiCGSTAB iteration on uniform grids (round 5: the dot
-    products are totalled inside them, Arrive in poisson.hip -- code behind the plane loop that must not cost the loop its registers)"""
+    """k_loop1_cg / k_loop2_cg_w4 <FMA, EV = 0, FLHS = true>: the two launches of a BiCGSTAB iteration on uniform grids"""
     l1, l2 = release["k_loop1_cg<b1,i0,b1>"], release["k_loop2_cg_w4<b1,i0,b1>"]
     for k in (l1, l2):
-        assert k["agpr"] == 0, k
+        assert k["scratch_bytes"] == 0 and k["vgpr_spills"] == 0 and k["agpr"] == 0, k
         assert k["lds_bytes"] == 10 * 96 * 8, k              # the ghosted tile: 10 planes of pitch 96 doubles, one wavefront per workgroup
-        assert k["max_workgroup"] == 64, k
-    # the first kernel: no spill at all; 94 registers by the compiler's own choice
-    assert l1["scratch_bytes"] == 0 and l1["vgpr_spills"] == 0 and l1["vgpr"] <= 96 and l1["waves_per_simd"] == 5, l1
-    # the second one is HELD to 128 registers (4 wavefronts per SIMD; the compiler would take 136 -> 3): one 8-byte value is parked in scratch
-    # before the plane loop and fetched back when the block CG starts -- never inside a loop (checked in the ISA, DESIGN.md section 4)
-    assert l2["waves_per_simd"] == 4 and l2["vgpr"] <= 128 and l2["vgpr_spills"] <= 2 and l2["scratch_bytes"] <= 16, l2
-    # LDS would allow 21 wavefronts per CU: registers (second kernel) / LDS (first kernel: 20) bound the occupancy
+        assert k["waves_per_simd"] == 4 and k["max_workgroup"] == 64, k
+    assert l1["vgpr"] <= 112 and l2["vgpr"] <= 128, (l1["vgpr"], l2["vgpr"])
+    # LDS would allow 21 wavefronts per CU, the registers 16: registers bound the occupancy, as DESIGN.md says
     assert LDS_PER_CU // l1["lds_bytes"] >= 4 * 4
+
+
+def test_fused_solver_kernels_with_the_totals_inside(release):
+    """k_loop1_cg_tot / k_loop2_cg_tot <FMA, EV = 0>: the same two kernels totalling their per-block values themselves (Arrive, poisson.hip) --
+    the early all-reduce over ranks (CUP3D_EARLY_ALLREDUCE=1).  The arrival code sits behind the plane loop; the second kernel is HELD to 128
+    registers (the compiler would take 136 -> 3 wavefronts per SIMD): one 8-byte value is parked in scratch before the plane loop and fetched
+    back when the block CG starts -- never inside a loop (the ISA's only scratch accesses: one store pair up front, one load pair behind
+    the vector phase)."""
+    l1, l2 = release["k_loop1_cg_tot<b1,i0>"], release["k_loop2_cg_tot<b1,i0>"]
+    for k in (l1, l2):
+        assert k["agpr"] == 0 and k["lds_bytes"] == 10 * 96 * 8 and k["max_workgroup"] == 64, k
+    assert l1["scratch_bytes"] == 0 and l1["vgpr_spills"] == 0 and l1["vgpr"] <= 96, l1
+    assert l2["waves_per_simd"] == 4 and l2["vgpr"] <= 128 and l2["vgpr_spills"] <= 2 and l2["scratch_bytes"] <= 16, l2
 
 
 def test_fused_solver_kernels_with_the_direct_block_solve(release):
@@ -53,6 +61,7 @@ def test_fused_solver_kernels_with_the_direct_block_solve(release):
     is held to 128 registers (amdgpu_waves_per_eu(4, 8); the compiler would take 136 -> 3 wavefronts per SIMD)."""
     for name in ("k_loop1_fdm<b1>", "k_loop2_fdm<b1>"):
         k = release[name]
+        # (round 5: the first one comes out at 94 registers, 5 wavefronts per SIMD, by the compiler's own choice; it was 110 / 4)
         assert k["scratch_bytes"] == 0 and k["vgpr_spills"] == 0 and k["waves_per_simd"] in (4, 5) and k["lds_bytes"] == 10 * 96 * 8 and k["vgpr"] <= 128, k
     for name in ("k_loop1_fdm<b0>", "k_loop2_fdm<b0>"):   # multi-level meshes: no tile, the transposes' 4.5 KB only
         k = release[name]
@@ -80,8 +89,8 @@ def test_block_preconditioner_and_stencils(release):
 
 
 def test_no_other_kernel_uses_scratch(release):
-    # the register-held forms of the tests above (FMA-contracted / reference association; without / with the LHS inside)
-    held = {"k_loop2_cg<b1,i0,b0>", "k_loop2_cg<b0,i0,b0>", "k_loop2_cg_w4<b1,i0,b1>", "k_loop2_cg_w4<b0,i0,b1>"}
+    # the register-held forms of the tests above (FMA-contracted / reference association)
+    held = {"k_loop2_cg<b1,i0,b0>", "k_loop2_cg<b0,i0,b0>", "k_loop2_cg_tot<b1,i0>", "k_loop2_cg_tot<b0,i0>"}
     bad = {n: (k["scratch_bytes"], k["vgpr_spills"]) for n, k in release.items() if (k["scratch_bytes"] or k["vgpr_spills"]) and n not in held}
     assert not bad, bad
 
