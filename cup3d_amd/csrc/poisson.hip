@@ -1284,6 +1284,111 @@ __global__ void __launch_bounds__(256) k_dots7(Vecs V, long n, RedOut ro) {
   }
   grid_sum_finish<7>(acc, ro);
 }
+// ------------------------------------------------------------------ the every-50th iteration, fused (uniform grids, one rank)
+// Every 50th iteration the reference recomputes s, z and the true residual through _lhs instead of the recurrences (14465-14481,
+// 14516-14538): four block-CG applications, six LHS applications and six pointwise passes -- rounds 1-4 ran them as sixteen launches
+// (24 ms at 512^3, 3.4 times per step).  Here the chain is cut where it MUST be cut -- a block's LHS needs its neighbours' values of the
+// vector the previous block solve produced -- and nowhere else: four launches of ONE kernel form (k_refresh), each a tile LHS of its input
+// (tile_lhs: bit-identical to k_lhs), the pointwise work that consumes the result, and the block CG on it, by the wavefront that owns the
+// block; plus the two pointwise updates that precede an LHS of their own output (k_refresh_pointwise), which also leave the block sums
+// the mean-constraint row of that LHS needs -- in k_lhs's cell-to-thread mapping and order, so that the totals, and with them every
+// vector of the refresh, are BIT-IDENTICAL to the unfused launches ("no_fuse_refresh", tests); only the dot products are added in another
+// order (per block, then k_sums_finish -- as in every other iteration).
+//   kRefS:  s = A phat ; shat = M^-1 s                                   (14468-14469)
+//   kRefZ:  z = A shat ; q = r - alpha s, qhat = rhat - alpha shat, y = w - alpha z ; q.y, y.y ; zhat = M^-1 z   (14470-14480, 14488)
+//   kRefR:  r = b - A x ; rhat = M^-1 r                                   (14519-14523)
+//   kRefW:  w = A rhat ; the seven dot products ; what = M^-1 w           (14524-14537, 14548)
+enum { kRefS = 0, kRefZ = 1, kRefR = 2, kRefW = 3 };
+template <bool FMA, int EV, int KIND>
+__global__ void __launch_bounds__(64) k_refresh(GridDev g, Vecs V, double alpha, const double *__restrict__ xnew, double *__restrict__ block_dots, long nb,
+                                                double *__restrict__ block_sums, int *__restrict__ iters_out, LhsIn L) {
+  __shared__ double P[kTileLds];
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  const int l = threadIdx.x;
+  const double hq = block_h(g, slot), invh = 1 / hq;
+  const size_t bo = (size_t)slot * 512;
+  const double *const tin = KIND == kRefS ? V.v[PHAT] : (KIND == kRefZ ? V.v[SHAT] : (KIND == kRefR ? xnew : V.v[RHAT]));
+  double *const out = KIND == kRefS ? V.v[SHAT] : (KIND == kRefZ ? V.v[ZHAT] : (KIND == kRefR ? V.v[RHAT] : V.v[WHAT]));
+  const LhsFix fx = lhs_fix(L, nullptr, slot, l, hq);  // (no flag to wait for: the total of the input was complete before the launch)
+  const TileIdx ix = tile_idx(l);
+  TileRegs tr;
+  tile_issue_own(slot, tin, l, tr);
+  tile_issue_faces(g, slot, tin, L.halo, l, tr);
+  tile_commit(tr, P, l);
+  double r[8], acc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int zz = 0; zz < 8; ++zz) {
+    const size_t j = bo + zz * 64 + l;
+    double cc;
+    const double lhs = zz == 0 ? tile_lhs<0>(P, ix, cc, hq, fx) : tile_lhs<1>(P + (zz - 1) * kTilePitch, ix, cc, hq, fx);
+    if constexpr (KIND == kRefS) {
+      NTS(V.v[S_], j, lhs);
+      r[zz] = invh * lhs;
+    } else if constexpr (KIND == kRefZ) {
+      const double sv = NTL(V.v[S_], j), w = NTL(V.v[W_], j);
+      const double q = NTL(V.v[R_], j) - alpha * sv;
+      const double qhat = NTL(V.v[RHAT], j) - alpha * cc;   // cc = shat of this cell (the tile's centre)
+      const double y = w - alpha * lhs;
+      NTS(V.v[Z_], j, lhs); NTS(V.v[Q_], j, q); NTS(V.v[QHAT], j, qhat); NTS(V.v[Y_], j, y);
+      acc[0] += q * y;
+      acc[1] += y * y;
+      r[zz] = invh * lhs;
+    } else if constexpr (KIND == kRefR) {
+      const double rv = NTL(V.v[B_], j) - lhs;
+      NTS(V.v[R_], j, rv);
+      r[zz] = invh * rv;
+    } else {
+      const double r0 = NTL(V.v[R0], j), rv = NTL(V.v[R_], j);
+      NTS(V.v[W_], j, lhs);
+      acc[0] += r0 * rv;
+      acc[1] += r0 * lhs;
+      acc[2] += r0 * NTL(V.v[S_], j);
+      acc[3] += r0 * NTL(V.v[Z_], j);
+      acc[4] += rv * rv;   // norm_1
+      acc[5] += r0 * r0;   // norm_2
+      r[zz] = invh * lhs;
+    }
+  }
+  if constexpr (KIND == kRefZ) {
+    const double d0 = wave_sum(acc[0]), d1 = wave_sum(acc[1]);
+    if (l == 0) { block_dots[slot] = d0; block_dots[nb + slot] = d1; }
+  } else if constexpr (KIND == kRefW) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double t = wave_sum(acc[i]);
+      if (l == 0) block_dots[(size_t)i * nb + slot] = t;
+      if (i == 4 && l == 0) block_dots[(size_t)6 * nb + slot] = t;  // norm = the same sum as norm_1
+    }
+  }
+  __syncthreads();  // the tile is read no more: the block solve takes over its LDS
+  cg_block<FMA, false, EV>(g, slot, r, out, block_sums, 0.0, 0.0, iters_out, P);
+}
+// the two pointwise updates whose OUTPUT the next kernel applies the LHS to -- WHICH 0: phat = rhat + beta (phat - omega shat) (14467),
+// WHICH 1: x = x + alpha phat + omega qhat (14518) -- with the block sums of that output for the mean-constraint row: one workgroup per
+// block, k_lhs's cell-to-thread mapping and its sum (stencil.hip), so that the total is the one launch_lhs would have formed
+template <int WHICH>
+__global__ void __launch_bounds__(256) k_refresh_pointwise(GridDev g, Vecs V, double a, double b, double *__restrict__ block_sums) {
+  __shared__ double red[4];
+  const int slot = block_slot(g);
+  if (slot < 0) return;
+  int x, y, z0, cell0;
+  thread_cells(threadIdx.x, x, y, z0, cell0);
+  double c[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const size_t j = (size_t)slot * 512 + k * 256 + cell0;
+    if constexpr (WHICH == 0) c[k] = V.v[RHAT][j] + a * (V.v[PHAT][j] - b * V.v[SHAT][j]);
+    else c[k] = V.xin[j] + a * V.v[PHAT][j] + b * V.v[QHAT][j];
+    (WHICH == 0 ? V.v[PHAT] : V.v[X_])[j] = c[k];
+  }
+  if (block_sums) {
+    const double h = block_h(g, slot), h3 = h * h * h;
+    const double sum = group_sum<4>(c[0] * h3 + c[1] * h3, red);
+    if (threadIdx.x == 0) block_sums[slot] = sum;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_copy(const double *__restrict__ src, double *__restrict__ dst, long n) {
   GRID_STRIDE(j, n) dst[j] = src[j];
 }
@@ -1587,6 +1692,76 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     return CUP3D_OK;
   };
 
+  // the every-50th iteration as four launches of k_refresh + two of k_refresh_pointwise (see there): uniform grids, one rank, block CG
+  const bool fuse_refresh = fuse && !sc && !s->grid->multilevel && s->grid->nranks == 1 && red.direct() && (P.block_solver == 0 || P.block_solver == 2) &&
+                            !debug_option("no_fuse_lhs") && !debug_option("no_fuse_refresh");
+  auto refresh_iteration = [&]() -> int {
+    x_ptrs();
+    const GridDev g = s->gdev();
+    const dim3 GG(launch_groups(g));
+    double *const bsum = want_sums ? sums : nullptr;
+    const int lhs_mode = mc > 2 ? 3 : mc;
+    const double *const tot = s->d_red + kRedMeanLhs;
+    const LhsIn Lin{s->halo_recv, tot, lhs_mode, s->grid->corner_slot, 0, g_invD, nullptr, 0, nullptr};
+    auto REF = [&](int kind) -> int {  // one launch of k_refresh; the total of its input's h^3-weighted sum is in *tot
+      ProfileScope ps("bicgstab_refresh");
+#define REF_ARGS g, V, hs.alpha, (const double *)V.v[X_], s->d_block_dots, (long)s->nb, bsum, cg_it, Lin
+#define REF_LAUNCH(FMA_, EV_)                                                                                             \
+      switch (kind) {                                                                                                     \
+        case kRefS: hipLaunchKernelGGL((k_refresh<FMA_, EV_, kRefS>), GG, dim3(64), 0, stream(), REF_ARGS); break;          \
+        case kRefZ: hipLaunchKernelGGL((k_refresh<FMA_, EV_, kRefZ>), GG, dim3(64), 0, stream(), REF_ARGS); break;          \
+        case kRefR: hipLaunchKernelGGL((k_refresh<FMA_, EV_, kRefR>), GG, dim3(64), 0, stream(), REF_ARGS); break;          \
+        default: hipLaunchKernelGGL((k_refresh<FMA_, EV_, kRefW>), GG, dim3(64), 0, stream(), REF_ARGS); break;             \
+      }
+      if (P.block_solver == 0) { REF_LAUNCH(true, kCgProduction) } else { REF_LAUNCH(false, 0) }
+#undef REF_LAUNCH
+#undef REF_ARGS
+      CUP3D_HIP(hipGetLastError());
+      s->sums_of = nullptr;
+      s->mean_total_of = nullptr;
+      return CUP3D_OK;
+    };
+    // the K block-wise dot products -> d_red and the host.  (The block sums of the block solve's output do NOT ride along here as they do in the
+    //  fused loops: k_mean_finish totals them, as launch_lhs did in the unfused refresh -- the same total bit for bit.)
+    auto totals = [&](int K) -> int {
+      {
+        ProfileScope ps("bicgstab_dots_finish");
+        const CtlThen then{d_ctl, ring, 0};
+        const dim3 SG(sums_groups(s->nb));
+        const RedOut ro = red.out();
+        if (K == 2) hipLaunchKernelGGL((k_sums_finish<2, false>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, (const double *)nullptr, then);
+        else hipLaunchKernelGGL((k_sums_finish<7, false>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, (const double *)nullptr, then);
+        CUP3D_HIP(hipGetLastError());
+      }
+      TRY(red.begin(K));
+      if (want_sums) TRY(launch_mean_total(s));
+      return CUP3D_OK;
+    };
+    { ProfileScope ps("bicgstab_vector"); hipLaunchKernelGGL(k_refresh_pointwise<0>, GG, dim3(256), 0, stream(), g, V, hs.beta, hs.omega, bsum); }  // phat, 14467
+    if (want_sums) TRY(launch_mean_total(s));
+    TRY(REF(kRefS));                       // s = A phat, shat = M^-1 s
+    if (want_sums) TRY(launch_mean_total(s));
+    TRY(REF(kRefZ));                       // z = A shat; q, qhat, y; q.y, y.y; zhat = M^-1 z
+    TRY(totals(2));                        // MPI_Iallreduce(2), 14486
+    if (want_sums) { s->mean_total_of = V.v[ZHAT]; s->mean_total = tot; }
+    TRY(LHS(ZHAT, V_));                    // v = A zhat, 14489
+    TRY(red.wait());
+    ctl_step1(hs, s->h_red);               // 14493
+    { ProfileScope ps("bicgstab_vector"); hipLaunchKernelGGL(k_refresh_pointwise<1>, GG, dim3(256), 0, stream(), g, V, hs.alpha, hs.omega, bsum); }  // x, 14518
+    if (want_sums) TRY(launch_mean_total(s));
+    TRY(REF(kRefR));                       // r = b - A x, rhat = M^-1 r
+    if (want_sums) TRY(launch_mean_total(s));
+    TRY(REF(kRefW));                       // w = A rhat; the seven dot products; what = M^-1 w
+    TRY(totals(7));                        // MPI_Iallreduce(7), 14546
+    TRY(red.wait());                       // (t = A what, 14549: the next iteration is a fused one and forms it from the tile of what)
+    ctl_step2(hs, s->h_red);               // 14558-14566, 14594-14601 (moves xcur to the buffer just written)
+    if (want_sums) { s->mean_total_of = V.v[WHAT]; s->mean_total = tot; }
+    what_total = tot;                      // sum(what h^3): k_mean_finish left it in d_red[kRedMeanLhs], where the unfused LHS(WHAT, T_) leaves it
+    first_after_host = true;
+    if (hs.state == kRestart) TRY(restart());
+    return CUP3D_OK;
+  };
+
   // one fused iteration, enqueued without waiting for anything: both loop kernels take their scalars from d_ctl
   const bool direct = red.direct();
   // The loop kernels total their dot products themselves (Arrive): buffers of the two in-kernel sums of a loop
@@ -1836,6 +2011,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   int k = 0;
   while (k < P.max_iter && hs.state != kDone) {
     if (!fuse || k % 50 == 0) {
+      if (fuse_refresh) TRY(refresh_iteration()); else
       TRY(host_iteration(k));
       ++k;
       continue;

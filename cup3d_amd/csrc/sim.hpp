@@ -220,6 +220,7 @@ int amr_flux_fix(Sim *s, int nfc, double *out, int out_nc);
 // already, Sim::mean_total_of == p) -- the interface blocks of a multi-level mesh, while the loop kernels form the LHS of all others
 int launch_lhs(Sim *s, const double *p, double *out, int mean_constraint, const int32_t *list = nullptr, unsigned nlist = 0);
 int launch_precond(Sim *s, const double *in, double *out, bool want_sums);
+int launch_mean_total(Sim *s);  // total of the block sums in d_partials' tail -> d_red[kRedMeanLhs] (stencil.hip)
 // block_solver 5: one multigrid V-cycle from a zero guess as M^-1 (multigrid.hip; an alternative, not the reference's algorithm)
 int mg_vcycle(Sim *s, const double *in, double *out);
 void mg_destroy(Sim *s);

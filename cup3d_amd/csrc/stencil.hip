@@ -460,6 +460,16 @@ int launch_lhs(Sim *s, const double *p, double *out, int mc, const int32_t *list
   return CUP3D_OK;
 }
 
+// the total of the per-block sums currently in the tail of d_partials (a block solve with want_sums, k_lhs, k_refresh_pointwise left them
+// there) -> d_red[kRedMeanLhs]; one rank (the fused refresh of the solver, poisson.hip)
+int launch_mean_total(Sim *s) {
+  ProfileScope ps("poisson_mean_sum");
+  double *block_sums = s->d_partials + (size_t)s->max_groups * 8;
+  hipLaunchKernelGGL(k_mean_finish, dim3(64), dim3(256), 0, stream(), (const double *)block_sums, (int)s->nb, s->d_partials, s->d_counters + 1, s->d_red + kRedMeanLhs, (double *)nullptr);
+  CUP3D_HIP(hipGetLastError());
+  return CUP3D_OK;
+}
+
 }  // namespace cup3d
 
 using namespace cup3d;

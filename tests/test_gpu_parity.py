@@ -920,6 +920,7 @@ def test_lhs_inside_the_loop_kernels_is_bit_identical(bpd, lmax, level, bc, mc, 
     res = {}
     for opt in (0, 1):
         cu.capi.check(cu.lib().cup3d_debug_set_option(b"no_fuse_lhs", opt))
+        cu.capi.check(cu.lib().cup3d_debug_set_option(b"no_fuse_refresh", 1))   # the every-50th iterations in the same (unfused) form on both sides: their own test is below
         try:
             sim = cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=level, extent=2 * np.pi,
                                     BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], bMeanConstraint=mc, poissonTol=1e-9, poissonTolRel=1e-7, blockSolver=block_solver)
@@ -932,9 +933,54 @@ def test_lhs_inside_the_loop_kernels_is_bit_identical(bpd, lmax, level, bc, mc, 
             res[opt] = (r.iterations, r.restarts, r.norm, sim.download("pres"))
         finally:
             cu.capi.check(cu.lib().cup3d_debug_set_option(b"no_fuse_lhs", 0))
+            cu.capi.check(cu.lib().cup3d_debug_set_option(b"no_fuse_refresh", 0))
     assert res[0][0] > 3
     assert res[0][:3] == res[1][:3], (res[0][:3], res[1][:3])
     assert np.array_equal(res[0][3], res[1][3])
+
+
+@pytest.mark.parametrize("block_solver", [0, 2])
+@pytest.mark.parametrize("mc", [0, 1, 2, 3])
+@pytest.mark.parametrize("bpd,lmax,level,bc", [
+    ((1, 1, 1), 4, 3, ("wall", "wall", "wall")),
+    ((2, 1, 3), 2, 1, ("periodic", "freespace", "wall")),
+])
+def test_fused_refresh_iteration_matches_the_unfused_one(bpd, lmax, level, bc, mc, block_solver):
+    """Every 50th BiCGSTAB iteration recomputes s, z and the true residual through the LHS (main.cpp:14465-14481, 14516-14538).  Round 5
+    runs it as four launches of k_refresh (tile LHS + the pointwise work + the block CG by the wavefront that owns the block) and two of
+    k_refresh_pointwise, instead of sixteen launches (`no_fuse_refresh`).  Every VECTOR of the refresh is the same bits -- tile_lhs is
+    k_lhs's association, the block CG one function, the mean-constraint totals the same kernel over the same block sums in the same
+    order -- only the dot products are added per block first.  So: after ONE iteration (the k = 0 refresh) the pressures agree to
+    rounding (1e-12 of the pressure; omega, a quotient of two such sums, enters x); over a tight-tolerance solve that crosses two more
+    refreshes the counts stay inside the erratic-case band and the pressures agree to the solver's tolerance.  All bMeanConstraint modes;
+    FMA-contracted block CG and the reference's association."""
+    rng = np.random.default_rng(131 + mc)
+    res = {}
+    for opt in (0, 1):
+        cu.capi.check(cu.lib().cup3d_debug_set_option(b"no_fuse_refresh", opt))
+        try:
+            for max_iter in (1, 1000):
+                sim = cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=level, extent=2 * np.pi,
+                                        BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], bMeanConstraint=mc, poissonTol=1e-11, poissonTolRel=1e-10, blockSolver=block_solver)
+                if opt == 0 and max_iter == 1:
+                    rhs = rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8))
+                    rhs -= rhs.mean()
+                sim.upload("lhs", rhs)
+                sim.fill("pres", 0.0)
+                p, r = sim.poisson_params(), cu.capi.PoissonResult()
+                p.max_iter = max_iter
+                cu.capi.check(cu.lib().cup3d_poisson_solve(sim.handle, C.byref(p), C.byref(r)))
+                res[opt, max_iter] = (r.iterations, sim.download("pres"))
+        finally:
+            cu.capi.check(cu.lib().cup3d_debug_set_option(b"no_fuse_refresh", 0))
+    (i0, p0), (i1, p1) = res[0, 1], res[1, 1]
+    assert i0 == i1 == 1
+    scale = np.abs(p1).max()
+    assert scale > 0 and np.abs(p0 - p1).max() <= 1e-12 * scale, np.abs(p0 - p1).max() / scale
+    (i0, p0), (i1, p1) = res[0, 1000], res[1, 1000]
+    print(f"fused / unfused refresh: {i0} / {i1} iterations, max|dp| = {np.abs(p0 - p1).max():.2e} of {np.abs(p1).max():.2e}")
+    assert iters_band(i0, i1), (i0, i1)
+    assert np.abs(p0 - p1).max() <= 1e-6 * np.abs(p1).max()
 
 
 @pytest.mark.parametrize("bpd,lmax,level,bc", [((1, 1, 1), 4, 3, ("wall", "wall", "wall")), ((2, 1, 3), 3, 2, ("periodic", "freespace", "wall"))])
