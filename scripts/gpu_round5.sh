@@ -47,6 +47,13 @@ if has standin; then echo "== the RCCL stand-in cases alone (stream-memory-opera
   pt pytest_stand_in 1500 tests/test_gpu_rccl.py -k "stand_in" ; pt pytest_stand_in_mpi 1500 tests/test_gpu_00_dropin_mpi.py -k "rccl_stand_in" -s; fi
 if has quick; then echo "== pytest: ${QUICK}"
   pt pytest_quick ${QUICK_LIMIT:-1200} ${QUICK} ; fi
+if has exitdiag; then echo "== does the test process leave cleanly?  (glibc checks every free: MALLOC_CHECK_=3)"
+  for SEL in "fused_refresh" "not fused_refresh"; do
+    MALLOC_CHECK_=3 timeout 900 python -X faulthandler -m pytest tests/test_gpu_parity.py tests/test_gpu_resources.py -m gpu -q -k "$SEL" > "$OUT/exitdiag_${SEL// /_}.log" 2>&1 ; echo "exit code [$SEL] = $?"
+    tail -4 "$OUT/exitdiag_${SEL// /_}.log" | cut -c1-300
+  done
+  timeout 600 python -X faulthandler -m pytest tests/test_gpu_resources.py -m gpu -q > $OUT/exitdiag_resources_alone.log 2>&1 ; echo "exit code [resources alone, no malloc check] = $?"; tail -3 $OUT/exitdiag_resources_alone.log | cut -c1-300
+fi
 if has suite; then echo "== pytest -m gpu (the WHOLE suite, stand-in cases included)"
   pt pytest_gpu ${SUITE_LIMIT:-2400} tests ; tail -5 $OUT/pytest_gpu.log | cut -c1-300; fi
 for S in 128 256 512; do

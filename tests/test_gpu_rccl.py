@@ -240,7 +240,7 @@ def test_early_allreduce_is_deterministic_and_solves_the_same_problem():
     that only the corner block's wavefront waits for).  What must hold:
       * forcing the scalars of ONE process through a one-rank communicator (the stand-in library, 30 us injected per all-reduce) in the
         DEFAULT order changes nothing at all: the same totalling launch, the same recurrence functions -- iteration counts and max|u|
-        identical to the plain one-process run, bit for bit;
+        identical to the plain one-process run (with its every-50th iterations in the same launch-by-launch form), bit for bit;
       * the early order adds the dot products in another tree (the in-kernel one), so its iteration counts differ like those of any two
         summation orders of this erratic solver (66 / 84 / 82 against 131 / 105 / 113 seen) -- but it is DETERMINISTIC (two runs: identical
         counts and max|u|), every solve converges, the five bitwise signals hold, and max|u| along the run agrees with the default order to
@@ -262,7 +262,9 @@ def test_early_allreduce_is_deterministic_and_solves_the_same_problem():
         assert all(3 < i < 1000 for i in c["bicgstab_iters_by_step"]), c["bicgstab_iters_by_step"]
         assert max(abs(a - b) / a for a, b in zip(c["umax_by_step"], c1["umax_by_step"])) <= 2e-3, (c["umax_by_step"], c1["umax_by_step"])
 
-    one = go("--debug-option", "force_allreduce=0")["config"]   # (any debug option selects the testing build: the same flavour in all runs)
+    # (any debug option selects the testing build: the same flavour in all runs.  no_fuse_refresh: the every-50th iterations in the launch-by-
+    #  launch form the runs through a communicator use -- their fused form, one rank only, adds its dot products per block first)
+    one = go("--debug-option", "no_fuse_refresh=1")["config"]
     forced = lambda early: go("--debug-option", "force_allreduce=1", "--debug-option", f"early_allreduce={early}", env=dict(fake, CUP3D_FORCE_COMM="1"))["config"]
     d = forced(0)
     assert d["bicgstab_iters_by_step"] == one["bicgstab_iters_by_step"] and d["umax_by_step"] == one["umax_by_step"], (d["bicgstab_iters_by_step"], one["bicgstab_iters_by_step"])
