@@ -742,12 +742,23 @@ __device__ __forceinline__ unsigned ticket_of_wave(unsigned *counter) {  // lane
   }
   return (unsigned)__builtin_amdgcn_readfirstlane((int)t);
 }
+// a ticket taken by a wavefront that speaks for a whole GROUP: its sums were written by agent-scope stores as well, but they are read by a
+// wavefront on ANOTHER XCD a moment later, so this rare path (1 wavefront in 64) pays for the full agent-scope release (L2 write-back)
+__device__ __forceinline__ unsigned ticket_of_group(unsigned *counter) {
+  unsigned t = 0;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+}
 template <int K, class Then>
 __device__ __forceinline__ void arrive(const Arrive &A, int slot, Then then) {
   const int l = threadIdx.x;
   const long g = slot >> 6, first = g << 6;
   const unsigned gsize = (unsigned)(A.nb - first < 64 ? A.nb - first : 64);
   if (ticket_of_wave(A.c1 + g) != gsize - 1) return;  // (the loads below are issued after the ticket has come back: control dependence)
+  __threadfence();                                    // ... and behind an agent-scope acquire (the last arrivers only: 1 wavefront in 64)
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const double v = wave_sum((unsigned)l < gsize ? ld_agent(A.vals + (size_t)k * A.nb + first + l) : 0.0);
@@ -756,14 +767,16 @@ __device__ __forceinline__ void arrive(const Arrive &A, int slot, Then then) {
   const long sg = g >> 6, gfirst = sg << 6;
   const unsigned sgsize = (unsigned)(A.n1 - gfirst < 64 ? A.n1 - gfirst : 64);
   if (l == 0) st_agent(A.c1 + g, 0u);
-  if (ticket_of_wave(A.c2 + sg) != sgsize - 1) return;
+  if (ticket_of_group(A.c2 + sg) != sgsize - 1) return;
+  __threadfence();
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const double v = wave_sum((unsigned)l < sgsize ? ld_agent(A.g1 + (size_t)k * A.n1 + gfirst + l) : 0.0);
     if (l == 0) st_agent(A.g2 + (size_t)k * A.n2 + sg, v);
   }
   if (l == 0) st_agent(A.c2 + sg, 0u);
-  if (ticket_of_wave(A.c3) != (unsigned)A.n2 - 1) return;
+  if (ticket_of_group(A.c3) != (unsigned)A.n2 - 1) return;
+  __threadfence();
   double tot[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -799,8 +812,8 @@ __device__ __forceinline__ void DotsThen::operator()(const double *tot) const {
     *ctl = c;
     if (which == 2) ctl_publish(ctl, ring, it);
   }
-  if (flag) {  // the totals (this lane's own agent-scope stores) before the flag
-    stores_done();
+  if (flag) {  // the totals (this lane's own agent-scope stores) before the flag: a full agent-scope release, once per launch
+    __threadfence();
     st_agent(flag, 2 * it + (unsigned)(which - 1));
   }
 }
