@@ -733,6 +733,7 @@ struct Arrive {
   unsigned *c1, *c2, *c3;  // arrivals per group [n1], per super-group [n2], super-groups done [1]; all zero between two loops
   long nb, n1, n2;
   double *out;             // [K] totals (device memory)
+  int light;               // A/B (testing build, "arrive_light_release"): group leaders release like every wavefront (no L2 write-back); production: 0
 };
 __device__ __forceinline__ unsigned ticket_of_wave(unsigned *counter) {  // lane 0's values are stored: take a ticket; every lane gets it
   unsigned t = 0;
@@ -744,10 +745,10 @@ __device__ __forceinline__ unsigned ticket_of_wave(unsigned *counter) {  // lane
 }
 // a ticket taken by a wavefront that speaks for a whole GROUP: its sums were written by agent-scope stores as well, but they are read by a
 // wavefront on ANOTHER XCD a moment later, so this rare path (1 wavefront in 64) pays for the full agent-scope release (L2 write-back)
-__device__ __forceinline__ unsigned ticket_of_group(unsigned *counter) {
+__device__ __forceinline__ unsigned ticket_of_group(unsigned *counter, int light) {
   unsigned t = 0;
   if (threadIdx.x == 0) {
-    __threadfence();
+    if (light) stores_done(); else __threadfence();
     t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   return (unsigned)__builtin_amdgcn_readfirstlane((int)t);
@@ -767,7 +768,7 @@ __device__ __forceinline__ void arrive(const Arrive &A, int slot, Then then) {
   const long sg = g >> 6, gfirst = sg << 6;
   const unsigned sgsize = (unsigned)(A.n1 - gfirst < 64 ? A.n1 - gfirst : 64);
   if (l == 0) st_agent(A.c1 + g, 0u);
-  if (ticket_of_group(A.c2 + sg) != sgsize - 1) return;
+  if (ticket_of_group(A.c2 + sg, A.light) != sgsize - 1) return;
   __threadfence();
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -775,7 +776,7 @@ __device__ __forceinline__ void arrive(const Arrive &A, int slot, Then then) {
     if (l == 0) st_agent(A.g2 + (size_t)k * A.n2 + sg, v);
   }
   if (l == 0) st_agent(A.c2 + sg, 0u);
-  if (ticket_of_group(A.c3) != (unsigned)A.n2 - 1) return;
+  if (ticket_of_group(A.c3, A.light) != (unsigned)A.n2 - 1) return;
   __threadfence();
   double tot[K];
 #pragma unroll
@@ -1786,7 +1787,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   auto arrive_args = [&](int which, const double *vals, double *out) {  // which 0: the dot products, 1: the block sums of the mean constraint
     double *gs = s->d_arrive_sums + (which ? 7 * (n1 + n2) : 0);
     unsigned *c = cnt + which * (n1 + n2 + 1);
-    return Arrive{vals, gs, gs + (which ? 1 : 7) * n1, c, c + n1, c + n1 + n2, (long)s->nb, n1, n2, out};
+    return Arrive{vals, gs, gs + (which ? 1 : 7) * n1, c, c + n1, c + n1 + n2, (long)s->nb, n1, n2, out, debug_option("arrive_light_release")};
   };
   // Several ranks.  DEFAULT: when the loop kernel has ended, one all-reduce of its K totals (+ the mean-constraint total: two RCCL calls
   // per iteration where the reference makes four) on the communication stream, the recurrence step behind it, the next loop kernel
