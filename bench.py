@@ -1144,6 +1144,9 @@ def report(a, sim, prof, sec, iters, world, alt=None):
                       "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr})
             if tr is not None:  # a recorded PMC measurement of this kernel at this size, not a quantity of this run
                 e["traffic_source"] = traffic.get("_source", "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)")
+        if name == "bicgstab_refresh":
+            e["note"] = ("k_refresh, four forms per every-50th iteration (tile LHS of the input + the pointwise work on the result + the block CG by the wavefront "
+                         "that owns the block; 24 / 80 / 32 / 56 algorithmic B/cell): bound by the block CG (FP64 issue, 2.8 ms stand-alone), not by HBM")
         if name == "poisson_block_cg" and getattr(a, "cg_iters_per_block", None):
             # The block CG moves exactly its 16 B/cell (PMC) and sits at < 0.15 of the HBM roof: HBM is the wrong roof.  It is
             # bound by FP64 instruction issue: algorithmic flops = 17 per cell per CG iteration x the iterations the blocks of the
