@@ -199,8 +199,10 @@ __device__ __forceinline__ void ghost_prolong_face(const AmrDev &a, int e, const
   }
 }
 
-// ---- flux correction of the coarse side, one launch per normal direction (x, then y, then z: FillCase_2 order).
+// ---- flux correction of the coarse side, one launch per normal direction (x, then y, then z: FillCase_2 order): rounds 1-4's form, kept in the
+// TESTING build as the A/B and bit-for-bit cross-check of k_flux_fix_blocks below ("flux_fix_by_direction").
 // out[cell] += own face flux + ((f00 + f10) + (f01 + f11)) of the fine faces; flux arrays [(e*nfc + c)][a2*8+a1]
+#ifdef CUP3D_TESTING
 __global__ void __launch_bounds__(64) k_flux_fix(AmrDev a, const int32_t *__restrict__ list, const double *__restrict__ flux, int nfc,
                                                  double *__restrict__ out, int out_nc) {
   const int e = list[blockIdx.x], lane = threadIdx.x;
@@ -217,6 +219,7 @@ __global__ void __launch_bounds__(64) k_flux_fix(AmrDev a, const int32_t *__rest
     *o = (*o + coarse) + 0.0;  // + 0.0: the three further FillCase_2 calls on the cleared face
   }
 }
+#endif
 
 // ONE launch for the ghost slabs of a stencil: workgroups [0, nr) restrict (neighbour finer), [nr, nr + np) interpolate (neighbour
 // coarser).  These launches are a few microseconds of work each and sit between the loop kernels of every BiCGSTAB iteration on a
