@@ -8,10 +8,10 @@
 // step (same recurrences, same 50-iteration true-residual refresh, same breakdown
 // restart, same x_opt bookkeeping, same stopping rule) with the vectors resident in
 // HBM as flat [block][512] slabs -- which IS the block layout, so the reference's six
-// scatter/gather copies per iteration (9372-9392, 9342-9363) do not exist here.  The
-// scalar recurrences run on the host from 2 + 7 device-reduced dot products per
-// iteration, read back while the preconditioner + LHS of the same iteration execute
-// (the overlap the reference obtains from MPI_Iallreduce, 14486-14490 / 14546-14550).
+// scatter/gather copies per iteration (9372-9392, 9342-9363) do not exist here.  An
+// iteration is two launches (LHS + vector loop + block CG each: k_loop1_cg, k_loop2_cg);
+// the scalar recurrences live on the device (SolverCtl) and the host only watches; every
+// 50th iteration is four launches of k_refresh; over ranks the all-reduces can start early.
 // Elementwise updates keep the reference's association (no FMA contraction); only the
 // summation ORDER of the dot products and of the block-CG inner products differs
 // from the CPU, so pressure agrees to solver tolerance, not bitwise.
