@@ -1183,11 +1183,6 @@ def report(a, sim, prof, sec, iters, world, alt=None):
                    # of ranks beyond the stopping tolerance of the projection (the checksum below covers the stencil path bit for bit)
                    "umax_by_step": getattr(a, "umax_by_step", None),
                    "ref_iters_per_step": ref_iters(a, iters),
-                   # why this count is not round 4's: the solver's iteration count moves with the ORDER of its dot-product sums (README)
-                   "bicgstab_iters_note": ("since round 5 the every-50th iterations (true-residual refresh) run fused and add their dot products per block first, like "
-                                           "every other iteration: in the driver's window (512^3, steps 26..45) 179.35 iterations per step where round 4's launch-by-launch "
-                                           "refresh took 170.85 and the compiled reference 183.1 -- every vector of the refresh is the same bits; compare "
-                                           "ms_per_bicgstab_iteration across rounds, not only `value`") if not a.stencil_only and not a.implicit_diffusion else None,
                    "checksum": getattr(a, "checksum", None),
                    "communication": getattr(a, "comm", None),
                    "nu": a.nu, "implicit_diffusion": bool(a.implicit_diffusion),

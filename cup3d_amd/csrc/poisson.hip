@@ -1284,6 +1284,16 @@ __global__ void __launch_bounds__(256) k_loop2_x(Vecs V, long n, double alpha, d
 __global__ void __launch_bounds__(256) k_true_resid(Vecs V, long n) {
   GRID_STRIDE(j, n) V.v[R_][j] = V.v[B_][j] - V.v[R_][j];
 }
+// q.y, y.y of the refresh (14478-14480) from the q and y that k_refresh<kRefZ> stored: k_loop1_tail's two sums, thread for thread and term for term
+__global__ void __launch_bounds__(256) k_dots2(Vecs V, long n, RedOut ro) {
+  double acc[2] = {0, 0};
+  GRID_STRIDE(j, n) {
+    const double q = V.v[Q_][j], y = V.v[Y_][j];
+    acc[0] += q * y;
+    acc[1] += y * y;
+  }
+  grid_sum_finish<2>(acc, ro);
+}
 __global__ void __launch_bounds__(256) k_dots7(Vecs V, long n, RedOut ro) {
   double acc[7] = {0, 0, 0, 0, 0, 0, 0};
   GRID_STRIDE(j, n) {
@@ -1735,16 +1745,16 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       s->mean_total_of = nullptr;
       return CUP3D_OK;
     };
-    // the K block-wise dot products -> d_red and the host.  (The block sums of the block solve's output do NOT ride along here as they do in the
-    //  fused loops: k_mean_finish totals them, as launch_lhs did in the unfused refresh -- the same total bit for bit.)
+    // The dot products of a refresh are summed by the kernels of the launch-by-launch form, in THEIR order (grid-stride partials: k_dots2 =
+    // k_loop1_tail's two sums, k_dots7 itself), from the vectors k_refresh stored -- 0.35 + 1.27 ms per refresh for a solver that is bit for
+    // bit the launch-by-launch one: the same omega, alpha, iterates, iteration and restart counts ("no_fuse_refresh", tests).  (k_refresh also
+    // leaves per-block dot products behind, which this flow does not use: measured with them -- another order -- the iteration is 0.06 ms
+    // cheaper and the driver's window takes 179 iterations per step instead of 171, profiles/r05.)
     auto totals = [&](int K) -> int {
       {
-        ProfileScope ps("bicgstab_dots_finish");
-        const CtlThen then{d_ctl, ring, 0};
-        const dim3 SG(sums_groups(s->nb));
-        const RedOut ro = red.out();
-        if (K == 2) hipLaunchKernelGGL((k_sums_finish<2, false>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, (const double *)nullptr, then);
-        else hipLaunchKernelGGL((k_sums_finish<7, false>), SG, dim3(256), 0, stream(), s->d_block_dots, (long)s->nb, ro, (const double *)nullptr, then);
+        ProfileScope ps("bicgstab_vector");
+        if (K == 2) LAUNCH_VEC(k_dots2, V, N, red.out());
+        else LAUNCH_VEC(k_dots7, V, N, red.out());
         CUP3D_HIP(hipGetLastError());
       }
       TRY(red.begin(K));

@@ -948,12 +948,12 @@ def test_lhs_inside_the_loop_kernels_is_bit_identical(bpd, lmax, level, bc, mc, 
 def test_fused_refresh_iteration_matches_the_unfused_one(bpd, lmax, level, bc, mc, block_solver):
     """Every 50th BiCGSTAB iteration recomputes s, z and the true residual through the LHS (main.cpp:14465-14481, 14516-14538).  Round 5
     runs it as four launches of k_refresh (tile LHS + the pointwise work + the block CG by the wavefront that owns the block) and two of
-    k_refresh_pointwise, instead of sixteen launches (`no_fuse_refresh`).  Every VECTOR of the refresh is the same bits -- tile_lhs is
+    k_refresh_pointwise, instead of sixteen launches (`no_fuse_refresh`).  Every vector of the refresh is the same bits -- tile_lhs is
     k_lhs's association, the block CG one function, the mean-constraint totals the same kernel over the same block sums in the same
-    order -- only the dot products are added per block first.  So: after ONE iteration (the k = 0 refresh) the pressures agree to
-    rounding (1e-12 of the pressure; omega, a quotient of two such sums, enters x); over a tight-tolerance solve that crosses two more
-    refreshes the counts stay inside the erratic-case band and the pressures agree to the solver's tolerance.  All bMeanConstraint modes;
-    FMA-contracted block CG and the reference's association."""
+    order -- and its dot products are summed by the launch-by-launch form's own reduction kernels from the stored vectors.  So the two
+    solvers are THE SAME, bit for bit: after one iteration (the k = 0 refresh alone) and over a tight-tolerance solve that crosses further
+    refreshes -- iteration count, restart count, final norm and every bit of the pressure.  All bMeanConstraint modes; FMA-contracted
+    block CG and the reference's association."""
     rng = np.random.default_rng(131 + mc)
     res = {}
     for opt in (0, 1):
@@ -970,17 +970,15 @@ def test_fused_refresh_iteration_matches_the_unfused_one(bpd, lmax, level, bc, m
                 p, r = sim.poisson_params(), cu.capi.PoissonResult()
                 p.max_iter = max_iter
                 cu.capi.check(cu.lib().cup3d_poisson_solve(sim.handle, C.byref(p), C.byref(r)))
-                res[opt, max_iter] = (r.iterations, sim.download("pres"))
+                res[opt, max_iter] = ((r.iterations, r.restarts, r.norm), sim.download("pres"))
         finally:
             cu.capi.check(cu.lib().cup3d_debug_set_option(b"no_fuse_refresh", 0))
-    (i0, p0), (i1, p1) = res[0, 1], res[1, 1]
-    assert i0 == i1 == 1
-    scale = np.abs(p1).max()
-    assert scale > 0 and np.abs(p0 - p1).max() <= 1e-12 * scale, np.abs(p0 - p1).max() / scale
-    (i0, p0), (i1, p1) = res[0, 1000], res[1, 1000]
-    print(f"fused / unfused refresh: {i0} / {i1} iterations, max|dp| = {np.abs(p0 - p1).max():.2e} of {np.abs(p1).max():.2e}")
-    assert iters_band(i0, i1), (i0, i1)
-    assert np.abs(p0 - p1).max() <= 1e-6 * np.abs(p1).max()
+    for max_iter in (1, 1000):
+        (k0, p0), (k1, p1) = res[0, max_iter], res[1, max_iter]
+        assert k0 == k1, (max_iter, k0, k1)
+        assert np.array_equal(p0, p1), (max_iter, np.abs(p0 - p1).max())
+    assert res[0, 1][0][0] == 1 and res[0, 1000][0][0] > 3
+    print(f"fused = unfused refresh, bit for bit: {res[0, 1000][0][0]} iterations")
 
 
 @pytest.mark.parametrize("bpd,lmax,level,bc", [((1, 1, 1), 4, 3, ("wall", "wall", "wall")), ((2, 1, 3), 3, 2, ("periodic", "freespace", "wall"))])
