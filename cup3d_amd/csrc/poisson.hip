@@ -1316,8 +1316,8 @@ __global__ void __launch_bounds__(256) k_dots7(Vecs V, long n, RedOut ro) {
 // (tile_lhs: bit-identical to k_lhs), the pointwise work that consumes the result, and the block CG on it, by the wavefront that owns the
 // block; plus the two pointwise updates that precede an LHS of their own output (k_refresh_pointwise), which also leave the block sums
 // the mean-constraint row of that LHS needs -- in k_lhs's cell-to-thread mapping and order, so that the totals, and with them every
-// vector of the refresh, are BIT-IDENTICAL to the unfused launches ("no_fuse_refresh", tests); only the dot products are added in another
-// order (per block, then k_sums_finish -- as in every other iteration).
+// vector of the refresh, are BIT-IDENTICAL to the unfused launches ("no_fuse_refresh", tests).  The per-block dot products it also leaves
+// behind are NOT what solve() uses: the refresh's sums come from k_dots2 / k_dots7 over the stored vectors (refresh_iteration says why).
 //   kRefS:  s = A phat ; shat = M^-1 s                                   (14468-14469)
 //   kRefZ:  z = A shat ; q = r - alpha s, qhat = rhat - alpha shat, y = w - alpha z ; q.y, y.y ; zhat = M^-1 z   (14470-14480, 14488)
 //   kRefR:  r = b - A x ; rhat = M^-1 r                                   (14519-14523)
