@@ -672,12 +672,6 @@ def test_medium_128_oracle_advect_diffuse_and_solver():
 def test_rccl_plumbing_on_one_rank():
     """dlopen(librccl), ncclGetUniqueId, ncclCommInitRank and ncclAllReduce on the compute stream with a
     1-rank communicator: the library's own RCCL path, exercised as far as one GPU allows."""
-    # torch first, as bench.py does: torch brings its OWN copy of librccl, and cup3d_comm_init uses the copy the process has loaded already
-    # (comm.hip, load_rccl).  Without this line the test dlopens /opt/rocm's librccl, a later test file imports torch (test_gpu_resources.py
-    # does), and the process ends with two RCCL copies, whose teardown is known to corrupt the heap -- the suspect for `pytest
-    # tests/test_gpu_parity.py tests/test_gpu_resources.py` ending with glibc's "double free or corruption" AFTER its last test had passed
-    # (round 5, DESIGN.md section 7; the whole suite never did).
-    import torch  # noqa: F401
     raw = (C.c_ubyte * 128)()
     cu.capi.check(cu.lib().cup3d_debug_set_option(b"force_allreduce", 1))
     try:
