@@ -162,6 +162,11 @@ CUP3D_API int cup3d_device_synchronize(void);
  * argument, a HIP error -- leaves the others inside the collective, exactly as a failing rank does under the reference's MPI: treat any
  * non-zero status as fatal for the job, as the reference does (MPI_Abort at 8444, 15265, 15289; the C++ shim's CUP3D_HIP_CALL and
  * torch.distributed.run's process group do that for their hosts).  There is no rank-local error recovery. */
+/* ENVIRONMENT (read once per process, the same on every rank).  CUP3D_RCCL_LIBRARY=<path>: the RCCL to dlopen instead of the one the
+ * process has loaded / the loader finds.  CUP3D_EARLY_ALLREDUCE=1: the two all-reduces of a BiCGSTAB iteration (main.cpp:14486, 14546) start
+ * when the loop kernel's last block has left its vector phase instead of when the kernel has ended -- they then run under its block solves,
+ * as MPI_Iallreduce runs under the preconditioner in the reference; uniform grids, block CG, one process per device; the dot products are
+ * added in another (deterministic) order than by default.  Off unless set. */
 CUP3D_API int cup3d_comm_unique_id(void *id128);
 CUP3D_API int cup3d_comm_init(int rank, int nranks, const void *id128);
 CUP3D_API int cup3d_comm_finalize(void);
