@@ -55,6 +55,44 @@ def test_report_emits_the_contract():
     assert roof["traffic"] is None or roof["traffic"] > 0.9 * 136 * 512 ** 3
 
 
+def test_multigrid_kernels_get_a_roofline_per_level():
+    """alt_multigrid.kernels (round 5; north_star names these kernels): profile entries "mg_smooth@L6" ... -> one record per (kernel, level) with
+    the level's block count, the algorithmic bytes per cell of DESIGN.md section 4 and achieved / frac from the measured launch time; levels of
+    <= 4096 blocks say that they are launch-latency bound; the finest level carries the recorded PMC traffic."""
+    fine = 512 ** 3 // 512
+    prof = {"mg_smooth@L6": (450, 450 * 0.70), "mg_smooth_from_zero@L6": (150, 150 * 0.40), "mg_residual_restrict@L6": (150, 150 * 0.50), "mg_prolong_add@L6": (150, 150 * 0.35),
+            "mg_smooth@L5": (450, 450 * 0.095), "mg_smooth@L3": (450, 450 * 0.008), "mg_smooth_from_zero@L0": (150, 150 * 0.044), "poisson_lhs": (100, 50.0), "mg_gather": (10, 1.0)}
+    ks = bench.multigrid_kernels(prof, fine)
+    assert len(ks) == 7 and all("@" not in k["kernel"] for k in ks)          # only the per-level entries, split into (kernel, level)
+    by = {(k["kernel"], k["level"]): k for k in ks}
+    top = by["mg_smooth", 6]
+    assert top["blocks"] == fine and top["algorithmic_bytes_per_cell"] == 24.0 and top["bound"] == "hbm" and top["peak"] == 8000.0
+    want = 24.0 * 512 ** 3 / 0.70e-3 / 1e9
+    assert abs(top["achieved"] - want) < 0.1 and abs(top["frac"] - want / 8000.0) < 1e-4 and "note" not in top
+    assert top["traffic"] is None or top["traffic"] > 0.9 * 24 * 512 ** 3        # profiles/traffic.json: PMC bytes per launch on the finest level
+    assert by["mg_smooth_from_zero", 6]["algorithmic_bytes_per_cell"] == 16.0 and by["mg_residual_restrict", 6]["algorithmic_bytes_per_cell"] == 17.0
+    assert by["mg_smooth", 5]["blocks"] == fine // 8 and "traffic" not in by["mg_smooth", 5]
+    assert by["mg_smooth", 3]["blocks"] == fine // 512 and "launch-latency" in by["mg_smooth", 3]["note"]
+    assert by["mg_smooth_from_zero", 0]["blocks"] == 1
+    assert [k["total_ms"] for k in ks] == sorted((k["total_ms"] for k in ks), reverse=True)   # largest share first
+
+
+def test_this_rounds_bench_records_carry_the_completed_line():
+    """metric (A) (`stencil_only`) beside metric (B) (`value`), per-level multigrid kernels, the recorded 512^3 CPU figure."""
+    f = os.path.join(ROOT, "profiles", "r05", "bench_512_fullstep_unfused_refresh.json")
+    r = json.loads(open(f).read().strip().splitlines()[-1])
+    for k in REQUIRED:
+        assert k in r, k
+    so = r["stencil_only"]
+    assert so["unit"] == "Mcell-updates/s" and so["value"] > 11100 and 0.40 < so["frac_at_264_B_per_cell (stage 1 reads no tmpV: 72 + 96 + 96)"] < 1   # north_star: >= 0.40 of the roof
+    mg = r["alt_multigrid"]
+    assert mg["roofline"]["bound"] == "hbm" and 0 < mg["roofline"]["frac"] < 1 and len(mg["kernels"]) >= 12
+    assert {k["kernel"] for k in mg["kernels"]} >= {"mg_smooth", "mg_smooth_from_zero", "mg_residual_restrict", "mg_prolong_add"}
+    assert r["cpu_baseline"]["recorded_512"]["size"] == 512 and r["cpu_baseline"]["kind"] == "reference"
+    assert r["roofline"]["traffic"] and r["config"]["checksum"]["ok"] is True
+    assert abs(r["ms_per_bicgstab_iteration"] - r["ms_per_step"] / r["config"]["bicgstab_iters_per_step"]) < 1e-2
+
+
 def test_committed_bench_records_obey_the_contract():
     d = os.path.join(ROOT, "profiles", "r02")
     seen = 0
