@@ -498,14 +498,21 @@ def cpu_baseline(size_cpu, steps, threads):
         args = O.ref_args((1, 1, 1), level + 1, level, 2 * np.pi, ("wall",) * 3, nu=0.01, cfl=0.3, extra=["-rampup", "0"])
         try:
             # `steps` separate steps of the reference's own time loop, each timed by the harness: the MEDIAN step is the sample
-            recs, _ = O.run_ref(["zero chi", "set step 21", f"rep {steps}", "op steps 1"], args, threads=threads, timeout=600)
+            # `timeops` wraps every pipeline entry in a wall-clock timer: each step also says what AdvectionDiffusion (metric A,
+            # main.cpp:9640-9728) and PressureProjection (15061-15160) took on their own
+            recs, _ = O.run_ref(["zero chi", "set step 21", "timeops", f"rep {steps}", "op steps 1"], args, threads=threads, timeout=600)
             rs = [r for r in recs if r["op"] == "steps"]
             secs, its = sorted(r["seconds"] for r in rs), [r["iters"] for r in rs]
             sec = secs[len(secs) // 2]
+            med = lambda name: (lambda v: v[len(v) // 2] if v else None)(sorted(r["seconds"] for r in recs if r["op"] == "optime" and r.get("name") == name))
+            adv_s, proj_s = med("AdvectionDiffusion"), med("PressureProjection")
             return {"value": size_cpu ** 3 / sec / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "reference",
                     "sample": f"reference main.cpp operators, {size_cpu}^3 all-wall TGV, median of {len(rs)} steps from step 21 "
                               f"({', '.join('%.2f' % x for x in secs)} s), {np.mean(its):.1f} BiCGSTAB its/step",
-                    "seconds_per_step": [round(x, 3) for x in secs], "bicgstab_iters_per_step": float(np.mean(its)), "size": size_cpu}
+                    "seconds_per_step": [round(x, 3) for x in secs], "bicgstab_iters_per_step": float(np.mean(its)), "size": size_cpu,
+                    # metric (A) and the projection on their own (medians over the same steps)
+                    "advect_diffuse_seconds": adv_s, "projection_seconds": proj_s,
+                    "advect_diffuse_value": round(size_cpu ** 3 / adv_s / 1e6, 3) if adv_s else None}
         except Exception as e:  # fall through to the port
             sys.stderr.write(f"bench: ref_tool failed ({e}); timing the oracle port instead\n")
     g = O.OracleGrid((1, 1, 1), level + 1, level, 2 * np.pi, ("wall",) * 3)
@@ -738,6 +745,8 @@ def main():
     ap.add_argument("--no-checksum", action="store_true", help="skip config.checksum (one extra AdvectionDiffusion on two fields before the timed region)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host<->device transfer measurement behind `pcie_inclusive`")
     ap.add_argument("--debug-option", action="append", help="name=value for cup3d_debug_set_option (tuning scans)")
+    ap.add_argument("--full-line", action="store_true", help="print the FULL record as the one stdout line (round 5's form, ~20 KB) instead of the compact summary")
+    ap.add_argument("--detail-out", default="bench_detail.json", help="file the full record is written to (relative to the repo root; '' = nowhere)")
     ap.add_argument("--no-profile", action="store_true", help="A/B: no per-kernel HIP events in the timed region (no roofline in the output)")
     ap.add_argument("--no-fuse", action="store_true", help="A/B: vector loops and block CG as separate launches (round-1 structure)")
     ap.add_argument("--implicit-diffusion", action="store_true",
@@ -1237,11 +1246,103 @@ def report(a, sim, prof, sec, iters, world, alt=None):
         out["valid"] = False  # a bitwise signal did not reproduce its constant on this partition: the rate above measures a wrong program
     elif ck is not None and ck["ok"] is None:
         sys.stderr.write(f"bench: no recorded checksum constant for {ck['unchecked']} at --size {a.size}: unchecked, not invalid\n")
-    print(json.dumps(out))
+    detail = write_detail(a, out)
+    print(json.dumps(out if getattr(a, "full_line", False) else compact_line(out, detail)))
     sys.stdout.flush()
     if out.get("valid") is False:
         sys.stderr.write("bench: config.checksum does not match the oracle's constant -- results INVALID\n")
     return out
+
+
+COMPACT_LIMIT = 6144   # bytes; the driver's parser dropped round 5's 20 KB line (BENCH_r05.parsed = null)
+
+
+def write_detail(a, out):
+    """The FULL record (every kernel, the per-level multigrid list, per-step arrays, the checksums' values, notes) goes to a file next to
+    the progress files -- `--detail-out`, default bench_detail.json at the repo root and a copy under gpurun_out/ when that exists --
+    never to stdout: stdout carries the compact line only."""
+    path = getattr(a, "detail_out", None)
+    if not path:
+        return None
+    paths = [path if os.path.isabs(path) else os.path.join(ROOT, path)]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", os.path.basename(path)))
+    wrote = None
+    for f in paths:
+        try:
+            with open(f, "w") as fh:
+                json.dump(out, fh)
+                fh.write("\n")
+            wrote = wrote or os.path.relpath(f, ROOT)
+        except OSError as e:
+            sys.stderr.write(f"bench: could not write {f}: {e}\n")
+    return wrote
+
+
+def compact_line(out, detail=None):
+    """The ONE stdout line: the contract's keys, `roofline`, `cpu_baseline` and one number per side record -- no per-step arrays, no
+    notes, no per-level list (those are in the detail file).  Stays under COMPACT_LIMIT bytes (tests/test_bench_contract.py)."""
+    pick = lambda d, keys: {k: d[k] for k in keys if d is not None and k in d and d[k] is not None}
+    r = pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data",
+                   "ms_per_bicgstab_iteration"))
+    r["vs_baseline"] = out.get("vs_baseline")
+    if "valid" in out:
+        r["valid"] = out["valid"]
+    c = out.get("config") or {}
+    cfg = pick(c, ("workload", "cells", "blocks", "partition", "bicgstab_iters_per_step", "block_preconditioner", "library", "transport"))
+    ri = c.get("ref_iters_per_step")
+    if ri:
+        cfg["ref_iters_per_step"] = pick(ri, ("value", "device_over_the_same_steps", "steps_covered"))
+    ck = c.get("checksum")
+    if ck:
+        cfg["checksum"] = {"ok": ck.get("ok"), "signals": {k: v.get("ok") for k, v in ck.items() if isinstance(v, dict) and "ok" in v}}
+    cm = c.get("communication")
+    if cm:
+        cfg["communication"] = pick(cm, ("rccl_ranks", "halo_exchanges_per_iteration", "allreduces_per_iteration", "halo_ms_per_iteration", "allreduce_ms_per_iteration",
+                                         "exposed_ms_per_iteration", "exposed_halo_wait_ms_per_iteration", "exposed_scalar_wait_ms_per_iteration", "host_wait_fraction",
+                                         "early_allreduce"))
+    r["config"] = cfg
+    r["roofline"] = out.get("roofline")
+    ks = out.get("kernels") or []
+    dom = next((k for k in ks if out.get("roofline") and k["kernel"] == out["roofline"].get("kernel")), None)
+    if dom and r["roofline"]:
+        r["roofline"] = dict(r["roofline"], avg_ms=dom["avg_ms"], launches=dom["launches"], share=dom["share"])
+    r["kernels"] = [pick(k, ("kernel", "launches", "avg_ms", "share", "bound", "frac")) for k in ks[:8]]
+    cb = out.get("cpu_baseline")
+    if cb:
+        r["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind", "size", "bicgstab_iters_per_step", "advect_diffuse_seconds", "projection_seconds",
+                                      "advect_diffuse_value", "host_cores_available"))
+        r["cpu_baseline"]["sample"] = (cb.get("sample") or "")[:200]
+        if cb.get("recorded_512"):
+            r["cpu_baseline"]["recorded_512"] = pick(cb["recorded_512"], ("value", "cores", "seconds_per_step", "bicgstab_iters_per_step"))
+    so = out.get("stencil_only")
+    if so:
+        r["stencil_only"] = pick(so, ("value", "unit", "ms_per_operator", "n_gpus"))
+        for k, v in so.items():
+            if k.startswith("frac_at_264"):
+                r["stencil_only"]["frac_264"] = v
+            elif k.startswith("frac_at_288"):
+                r["stencil_only"]["frac_288"] = v
+        if cb and cb.get("advect_diffuse_value"):
+            r["stencil_only"]["cpu_reference_value"] = cb["advect_diffuse_value"]
+    for key in ("alt", "alt_multigrid", "alt_reference_association"):
+        if out.get(key):
+            r[key] = pick(out[key], ("value", "ms_per_step", "bicgstab_iters_per_step", "ms_per_bicgstab_iteration", "steps"))
+            if out[key].get("roofline"):
+                r[key]["roofline"] = pick(out[key]["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic"))
+    pc = out.get("pcie_inclusive")
+    if pc:
+        r["pcie_inclusive"] = pick(pc, ("upload_GBps", "download_GBps"))
+        r["pcie_inclusive"]["Mcell_updates_per_s"] = {m: v["Mcell_updates_per_s"] for m, v in pc.get("shim_modes", {}).items()}
+    if detail:
+        r["detail"] = detail
+    line = json.dumps(r)
+    if len(line) > COMPACT_LIMIT:   # cannot happen with the keys above; if a future key makes it so, the contract's keys win
+        for k in ("kernels", "pcie_inclusive", "alt_reference_association", "alt_multigrid", "alt"):
+            r.pop(k, None)
+            if len(json.dumps(r)) <= COMPACT_LIMIT:
+                break
+    return r
 
 
 if __name__ == "__main__":

@@ -458,7 +458,10 @@ def run_ref(script_lines, args, threads=1, workdir=None, timeout=3600):
             d = {"op": p[1]}
             for kv in p[2:]:
                 k, v = kv.split("=")
-                d[k] = float(v)
+                try:
+                    d[k] = float(v)
+                except ValueError:   # `REF optime name=<class> ...`
+                    d[k] = v
             recs.append(d)
     return recs, wd
 

@@ -23,7 +23,7 @@ class _Sim:
 
 def _args(**kw):
     a = argparse.Namespace(size=512, steps=5, warmup=2, stencil_only=False, implicit_diffusion=False, nu=0.01, block_solver=0, no_cpu=True, cpu_threads=32,
-                           cpu_size=256, cpu_steps=1)
+                           cpu_size=256, cpu_steps=1, full_line=True, detail_out=None)
     for k, v in kw.items():
         setattr(a, k, v)
     return a
@@ -75,6 +75,39 @@ def test_multigrid_kernels_get_a_roofline_per_level():
     assert by["mg_smooth", 3]["blocks"] == fine // 512 and "launch-latency" in by["mg_smooth", 3]["note"]
     assert by["mg_smooth_from_zero", 0]["blocks"] == 1
     assert [k["total_ms"] for k in ks] == sorted((k["total_ms"] for k in ks), reverse=True)   # largest share first
+
+
+def test_default_stdout_line_is_compact_and_carries_roofline_and_cpu_baseline(tmp_path):
+    """round 5's ~20 KB line was dropped by the driver's parser (BENCH_r05.parsed = null).  The stdout line is now a
+    summary of at most bench.COMPACT_LIMIT (6 KB) bytes with the contract's keys, `roofline` and `cpu_baseline`; the full record goes
+    to --detail-out.  Fed with round 5's full record (the largest line this bench ever printed) and with a synthetic report()."""
+    f = os.path.join(ROOT, "profiles", "r05", "bench_512_fullstep_unfused_refresh.json")
+    full = json.loads(open(f).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 15000
+    line = json.dumps(bench.compact_line(full, "bench_detail.json"))
+    assert len(line) < bench.COMPACT_LIMIT < 8192, len(line)
+    r = json.loads(line)
+    for k in REQUIRED + ["cpu_baseline", "ms_per_bicgstab_iteration"]:
+        assert k in r, k
+    assert r["value"] == full["value"] and r["ms_per_step"] == full["ms_per_step"] and r["config"]["workload"] == full["config"]["workload"]
+    assert r["roofline"]["kernel"] == full["roofline"]["kernel"] and r["roofline"]["frac"] == full["roofline"]["frac"] and r["roofline"]["traffic"]
+    assert r["roofline"]["avg_ms"] > 0 and r["cpu_baseline"]["kind"] == "reference" and r["cpu_baseline"]["cores"] and r["cpu_baseline"]["value"] > 0
+    assert r["cpu_baseline"]["recorded_512"]["value"] > 0 and len(r["cpu_baseline"]["sample"]) <= 200
+    assert r["config"]["checksum"]["ok"] is True and r["config"]["bicgstab_iters_per_step"] == full["config"]["bicgstab_iters_per_step"]
+    assert 0.4 < r["stencil_only"]["frac_264"] < 1 and r["stencil_only"]["frac_288"] > r["stencil_only"]["frac_264"]
+    assert r["alt"]["value"] > r["value"] and 0 < r["alt_multigrid"]["roofline"]["frac"] < 1
+    assert "bicgstab_iters_by_step" not in r["config"] and "umax_by_step" not in r["config"] and all("note" not in k for k in r["kernels"])
+    # report() itself: default = compact on stdout, full record in the detail file
+    prof = {"bicgstab_loop2_cg": (762, 762 * 3.9), "bicgstab_loop1_cg": (762, 762 * 3.8), "poisson_lhs": (1667, 1667 * 0.53)}
+    detail = str(tmp_path / "detail.json")
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.report(_args(full_line=False, detail_out=detail, umax_by_step=[1.0] * 6), _Sim(), prof, 7.4, [156] * 5, 1)
+    lines = buf.getvalue().strip().splitlines()
+    assert len(lines) == 1 and len(lines[0]) < bench.COMPACT_LIMIT
+    r, d = json.loads(lines[0]), json.load(open(detail))
+    assert r["roofline"]["kernel"] == "bicgstab_loop2_cg" and r["value"] == d["value"] and d["config"]["bicgstab_iters_by_step"] == [156] * 5
+    assert "bicgstab_iters_by_step" not in r["config"] and r["detail"]
 
 
 def test_this_rounds_bench_records_carry_the_completed_line():

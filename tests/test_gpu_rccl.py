@@ -37,7 +37,9 @@ FAKE_RCCL = os.path.join(ROOT, "tests", "fake_rccl", "librccl_fake.so")
 def run_bench(*args, timeout=900, extra_env=None):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(extra_env or {})
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    # --full-line: these tests read the full record (checksum values, per-step arrays); the default stdout line is the compact summary
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line", "--detail-out", "", *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=timeout)
 
 
 def test_one_process_bench_carries_a_matching_checksum():
