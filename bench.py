@@ -489,11 +489,21 @@ def relaunch_under_torchrun(n, need_devices=True, a=None):
     sys.exit(rc)
 
 
-def cpu_baseline(size_cpu, steps, threads):
+def cpu_baseline(size_cpu, steps, threads, stencil_only=False):
     """Time the compiled reference (oracle/_ref/ref_tool = unmodified main.cpp) on the host."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     level = int(np.log2(size_cpu // 8))
+    if stencil_only and O.have_ref_tool():
+        # BASELINE configs[1]: AdvectionDiffusion::operator() alone (main.cpp:9640-9728) on the periodic Taylor-Green box, dt = CFL h / umax
+        args = O.ref_args((1, 1, 1), level + 1, level, 2 * np.pi, ("periodic",) * 3, nu=0.01, cfl=0.3, extra=["-rampup", "0"])
+        dt = 0.3 * (2 * np.pi / size_cpu)
+        recs, _ = O.run_ref(["zero chi", "set step 21", f"op advdiff {dt!r}", f"rep {max(3, steps)}", f"op advdiff {dt!r}"], args, threads=threads, timeout=600)
+        secs = sorted(r["seconds"] for r in recs if r["op"] == "advdiff")[:-1] or [r["seconds"] for r in recs if r["op"] == "advdiff"]   # (the first call warms up: dropped as the slowest)
+        sec = secs[len(secs) // 2]
+        return {"value": size_cpu ** 3 / sec / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "reference", "size": size_cpu,
+                "sample": f"reference AdvectionDiffusion::operator() alone, {size_cpu}^3 periodic TGV, median of {len(secs)} calls ({', '.join('%.3f' % x for x in secs)} s)",
+                "advect_diffuse_seconds": sec, "advect_diffuse_value": round(size_cpu ** 3 / sec / 1e6, 3)}
     if O.have_ref_tool():
         args = O.ref_args((1, 1, 1), level + 1, level, 2 * np.pi, ("wall",) * 3, nu=0.01, cfl=0.3, extra=["-rampup", "0"])
         try:
@@ -1209,6 +1219,12 @@ def report(a, sim, prof, sec, iters, world, alt=None):
         out["alt"] = alt
     if getattr(a, "stencil_sub", None):
         out["stencil_only"] = a.stencil_sub   # SURVEY 8(d) metric (A); `value` above is metric (B), the full step
+    elif a.stencil_only:   # --stencil-only (BASELINE configs[1]): `value` IS metric (A); the operator's own roofline fractions beside it
+        per_op = sec / a.steps
+        out["stencil_only"] = {"what": "AdvectionDiffusion::operator() alone (3 fused RK stages + findMaxU per step), main.cpp:9640-9728: the timed region itself",
+                               "value": round(value, 1), "unit": "Mcell-updates/s", "ms_per_operator": round(per_op * 1e3, 4), "n_gpus": world, "bound": "hbm", "peak": HBM_PEAK_GBS,
+                               "frac_at_288_B_per_cell (SURVEY 8d: 3 x 96)": round(288.0 * cells / per_op / 1e9 / (HBM_PEAK_GBS * world), 4),
+                               "frac_at_264_B_per_cell (stage 1 reads no tmpV: 72 + 96 + 96)": round(264.0 * cells / per_op / 1e9 / (HBM_PEAK_GBS * world), 4)}
     if getattr(a, "alt_multigrid", None):
         out["alt_multigrid"] = a.alt_multigrid
     if getattr(a, "alt_reference_association", None):
@@ -1225,8 +1241,9 @@ def report(a, sim, prof, sec, iters, world, alt=None):
         # (profiles/r02/probe_reference_threads_256cubed.txt) -- so the baseline runs at the reference's best setting, 32 threads,
         # and `cores` says so.  Round 1's sample (128^3, 10 steps) stays beside it as cpu_baseline_128.
         threads = min(a.cpu_threads or (os.cpu_count() or 1), os.cpu_count() or 1)
-        out["cpu_baseline"] = cpu_baseline(a.cpu_size, a.cpu_steps, threads)
+        out["cpu_baseline"] = cpu_baseline(a.cpu_size, a.cpu_steps, threads, stencil_only=a.stencil_only)
         out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+    if not a.no_cpu and world == 1 and not a.stencil_only:
         # the all-core figure SURVEY 8d asks for, quoted from the recorded scan (one step takes 5.6 minutes there: not re-run here)
         out["cpu_baseline"]["all_cores_recorded"] = {"value": round(256 ** 3 / 338.49 / 1e6, 4), "unit": "Mcell-updates/s", "cores": 256, "size": 256,
                                                      "also": {"64 threads": round(256 ** 3 / 30.31 / 1e6, 3), "32 threads": round(256 ** 3 / 18.17 / 1e6, 3)},

@@ -66,15 +66,19 @@ static int load_rccl() {
   if (const char *path = getenv("CUP3D_RCCL_LIBRARY")) {
     if (!(g_comm.dl = dlopen(path, RTLD_NOW | RTLD_LOCAL))) { set_error("CUP3D_RCCL_LIBRARY: cannot dlopen %s: %s", path, dlerror()); return CUP3D_ECOMM; }
   }
-  // an RCCL the process has loaded already (torch.distributed brings its own copy) is the one to use: two copies of the library in
-  // one process corrupt each other's teardown.  Hosts that load RCCL themselves do so before cup3d_comm_init (bench.py imports torch first).
+  // An RCCL the process has loaded already (torch.distributed brings its own copy, soname "librccl.so") is the one to use.  Otherwise the
+  // system's is loaded -- RTLD_LOCAL, never RTLD_GLOBAL: every entry point is taken from the handle by dlsym, nothing needs its symbols
+  // in the global scope, and putting them there is what made a python host abort at exit with glibc's "double free or corruption"
+  // when it imported torch AFTER cup3d_comm_init (round 5's open defect, bisected in round 6: scripts/exit_repro.py "rccl,torch" = 134,
+  // "torch,rccl" = 0, "rccl" alone = 0): torch's own librccl.so, loaded second, bound its references to the first copy's global
+  // symbols, and two copies of one library then shared -- and twice destroyed -- one set of objects.
   for (const char *n : names) {
     if (g_comm.dl) break;
-    g_comm.dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    g_comm.dl = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
   }
   for (const char *n : names) {
     if (g_comm.dl) break;
-    g_comm.dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    g_comm.dl = dlopen(n, RTLD_NOW | RTLD_LOCAL);
   }
   if (!g_comm.dl) { set_error("cannot dlopen librccl: %s", dlerror()); return CUP3D_ECOMM; }
 #define SYM(field, name)                                                      \

@@ -528,8 +528,8 @@ std::unique_ptr<Grid> Grid::rank_view(const int32_t *owner, int rank_, int nrank
     }
   }
   // the multigrid option's hierarchy of this rank needs the global mesh, which the view does not keep: leave what it takes to build one
-  // on first use (mg_plan_get)
-  if (!tensorial) {
+  // on first use (mg_plan_get).  Multi-level meshes only: the multigrid path of a uniform mesh never reads it.
+  if (!tensorial && multilevel) {
     auto src = std::make_shared<MGSource>();
     for (int d = 0; d < 3; ++d) { src->bpd[d] = bpd[d]; src->bc[d] = bc[d]; }
     src->maxextent = maxextent;
@@ -559,6 +559,7 @@ std::shared_ptr<MGHierarchy> Grid::mg_hierarchy(const int32_t *owner, int rank_,
 }
 
 std::shared_ptr<const MGHierarchy> Grid::mg_plan_get() const {
+  if (!multilevel) throw std::invalid_argument("mg_plan_get needs a multi-level mesh");  // the precondition Grid::mg_hierarchy enforces
   if (!mg_plan && mg_source) mg_plan = build_mg_hierarchy(*mg_source);
   return mg_plan;
 }

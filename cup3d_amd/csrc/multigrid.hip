@@ -53,13 +53,21 @@ struct MGLevel {
 };
 // profile entry of one kernel on one level, "mg_smooth@L6": the levels differ by a factor 8 in work, and the roofline of the V-cycle is a
 // statement about the fine ones (bench.py: alt_multigrid.kernels); interned strings, ProfileScope keeps the pointer's text
+// The table is built ONCE, inside the initialisation of a function-local static (thread-safe since C++11: the ranks of the in-process
+// test communicator are host threads that make their first call for the same (kind, level) together -- ADVICE r5), and is never
+// destroyed (a leaked heap object: no destructor runs at exit while another thread may still hold a pointer into it).
 static const char *level_name(int kind, int level) {
   static const char *const base[4] = {"mg_smooth", "mg_smooth_from_zero", "mg_residual_restrict", "mg_prolong_add"};
-  static std::string names[4][24];
+  struct Names {
+    std::string n[4][24];
+    Names() {
+      for (int k = 0; k < 4; ++k)
+        for (int l = 0; l < 24; ++l) n[k][l] = std::string(base[k]) + "@L" + std::to_string(l);
+    }
+  };
+  static const Names *const names = new Names;
   if (level < 0 || level >= 24) return base[kind];
-  std::string &n = names[kind][level];
-  if (n.empty()) n = std::string(base[kind]) + "@L" + std::to_string(level);
-  return n.c_str();
+  return names->n[kind][level].c_str();
 }
 struct Multigrid {
   std::vector<MGLevel> lev;  // [0] coarsest ... [L] finest

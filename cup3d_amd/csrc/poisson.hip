@@ -167,6 +167,56 @@ __device__ __forceinline__ void cg_block(const GridDev &g, int slot, double (&r)
   const double kRel = 1e-7 * 1e-7, kAbs = 1e-16 * 1e-16;  // kSqrNorm{Rel,Abs}Criterion, 14619-14624
   const double sqrNorm0 = (double)1 / (512 * 512) * rr;    // 14734
   int kdone = 0;
+  if constexpr ((EV & 32) != 0) {
+    // EXPERIMENT (testing build, cg_variant 8 + 32): the same CG in the single-reduction form of Chronopoulos & Gear -- the
+    // stencil is applied to r instead of p, s = A p follows by recurrence (s <- A r + beta s), and p.Ap by  den <- r.Ar - beta^2 den,
+    // so the two inner products of an iteration (r.r and r.Ar) leave ONE dependent reduction point instead of two.  Same Krylov iterates
+    // in exact arithmetic, same stopping rule on the same quantity; one stencil application more per block (the last one is wasted),
+    // one vector more in registers, 8 more FMAs per iteration.
+    if (sqrNorm0 >= 1e-32) {
+      double s[8], w[8];
+      auto apply = [&](const double (&v)[8], double (&o)[8]) {
+        __syncthreads();
+#pragma unroll
+        for (int z = 0; z < 8; ++z) P[z * 80 + base] = v[z];
+        __syncthreads();
+#pragma unroll
+        for (int z = 0; z < 8; ++z) {
+          double t = mad<FMA>(centre, v[z], Pam[z * 80] + Pap[z * 80]);
+          t += Pym[z * 80];
+          t += Pyp[z * 80];
+          if (z > 0) t += v[z - 1];
+          if (z < 7) t += v[z + 1];
+          o[z] = t;
+        }
+      };
+      apply(r, w);
+      double den = 0;
+#pragma unroll
+      for (int z = 0; z < 8; ++z) { s[z] = w[z]; den = mad<FMA>(r[z], w[z], den); }
+      den = cg_sum<false>(den);
+      for (int k = 0; k < 100; ++k) {
+        kdone = k + 1;
+        const double a = cg_div<FDIV>(rr, den + 1e-55);
+#pragma unroll
+        for (int z = 0; z < 8; ++z) { x[z] = mad<FMA>(a, p[z], x[z]); r[z] = mad<FMA>(-a, s[z], r[z]); }
+        apply(r, w);
+        double ss = 0, dl = 0;
+#pragma unroll
+        for (int z = 0; z < 8; ++z) { ss = mad<FMA>(r[z], r[z], ss); dl = mad<FMA>(r[z], w[z], dl); }
+        ss = cg_sum<false>(ss);
+        dl = cg_sum<false>(dl);
+        const double beta = cg_div<FDIV>(ss, rr + 1e-55);
+        const double sqrNorm = (double)1 / (512 * 512) * ss;
+        if (sqrNorm < kRel * sqrNorm0 || sqrNorm < kAbs) break;
+#pragma unroll
+        for (int z = 0; z < 8; ++z) { p[z] = __builtin_fma(beta, p[z], r[z]); s[z] = __builtin_fma(beta, s[z], w[z]); }
+        den = __builtin_fma(-beta * beta, den, dl);
+        rr = ss;
+        if (rr <= 0) break;
+      }
+    }
+  } else
   if (sqrNorm0 >= 1e-32) {                                  // else: block stays 0 (14735-14736)
     __syncthreads();
     auto iteration = [&](int k) -> bool {                     // one trip of the loop at 14739; false = leave it
@@ -562,6 +612,7 @@ int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
         case 18: CG(true, 18); break;
         case 22: CG(true, 22); break;
         case 30: CG(true, 30); break;
+        case 32: CG(true, 32); break;   // Chronopoulos-Gear single-reduction form (EXPERIMENT)
         default: set_error("unknown cg_variant"); return CUP3D_EINVAL;
       }
       break;
@@ -1130,6 +1181,14 @@ __global__ void __launch_bounds__(64) k_loop2_cg_w4(GridDev g, Vecs V, const Sol
   loop2_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L, Z);
 }
 
+#ifdef CUP3D_TESTING
+// EXPERIMENT (single-reduction block CG, EV 32): the body asks for 130 registers; held to 128 for 4 wavefronts per SIMD
+template <bool FMA, int EV, bool FLHS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_loop2_cg_w4f(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums, int *__restrict__ iters_out, LhsIn L, const LoopSums *__restrict__ Z) {
+  loop2_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L, Z);
+}
+#endif
 // The two kernels of an iteration with the totals INSIDE (TOT; uniform grids, block CG): the early all-reduce over ranks (solve(): `early`).
 // The second one is held to 128 registers (the compiler would take 136 -> 3 wavefronts per SIMD): one 8-byte value is parked in scratch
 // before the plane loop and fetched back when the block CG starts, never inside a loop.
@@ -1528,16 +1587,25 @@ static int ensure_vectors(Sim *s) {
     int rc = sim_alloc(&s->d_block_dots, (size_t)7 * s->nb, s);
     if (rc) return rc;
   }
-  if (!s->d_arrive) {  // Arrive: [dots | mean] x (n1 + n2 + 1) counters + 2 flags; (7 + 1) x (n1 + n2) partial sums
+  // Arrive: [dots | mean] x (n1 + n2 + 1) counters + 2 flags; (7 + 1) x (n1 + n2) partial sums.  Each allocation is guarded by its OWN
+  // pointer (one guard over four allocations left the later ones null for ever when one of them failed once)
+  {
     const size_t n1 = ((size_t)s->nb + 63) / 64, n2 = (n1 + 63) / 64, ncnt = 2 * (n1 + n2 + 1) + 2;
-    int rc = sim_alloc(&s->d_arrive_sums, 8 * (n1 + n2) + 8, s);
-    if (rc) return rc;
-    CUP3D_HIP(hipMalloc((void **)&s->d_arrive, ncnt * sizeof(unsigned)));
-    CUP3D_HIP(hipMalloc((void **)&s->d_loop_sums, 2 * sizeof(LoopSums)));
-    CUP3D_HIP(hipMemsetAsync(s->d_arrive, 0, ncnt * sizeof(unsigned), stream()));
-    CUP3D_HIP(hipHostMalloc((void **)&s->h_early_fail, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
-    *s->h_early_fail = 0;
-    CUP3D_HIP(hipHostGetDevicePointer((void **)&s->h_early_fail_dev, s->h_early_fail, 0));
+    if (!s->d_arrive_sums) {
+      int rc = sim_alloc(&s->d_arrive_sums, 8 * (n1 + n2) + 8, s);
+      if (rc) return rc;
+    }
+    if (!s->d_arrive) {
+      CUP3D_HIP(hipMalloc((void **)&s->d_arrive, ncnt * sizeof(unsigned)));
+      const hipError_t e = hipMemsetAsync(s->d_arrive, 0, ncnt * sizeof(unsigned), stream());
+      if (e != hipSuccess) { (void)hipFree(s->d_arrive); s->d_arrive = nullptr; return hip_fail(e, "hipMemsetAsync(d_arrive)", __FILE__, __LINE__); }
+    }
+    if (!s->d_loop_sums) CUP3D_HIP(hipMalloc((void **)&s->d_loop_sums, 2 * sizeof(LoopSums)));
+    if (!s->h_early_fail_dev) {
+      if (!s->h_early_fail) CUP3D_HIP(hipHostMalloc((void **)&s->h_early_fail, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
+      *s->h_early_fail = 0;
+      CUP3D_HIP(hipHostGetDevicePointer((void **)&s->h_early_fail_dev, s->h_early_fail, 0));
+    }
   }
   if (!s->h_ctl_dev) {  // the solver's scalar struct (device) and the pinned ring its outcome reaches the host through: all three or none
     hipError_t e = s->d_ctl ? hipSuccess : hipMalloc(&s->d_ctl, sizeof(SolverCtl));
@@ -1792,8 +1860,6 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   const long n1 = (s->nb + 63) / 64, n2 = (n1 + 63) / 64;
   unsigned *const cnt = s->d_arrive;
   unsigned *const dots_flag = cnt + 2 * (n1 + n2 + 1), *const mean_flag = dots_flag + 1;
-  // (a solve that ended in an error half way through a loop may have left tickets behind; the two flags behind the counters only ever grow)
-  CUP3D_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * (n1 + n2 + 1)) * sizeof(unsigned), stream()));
   auto arrive_args = [&](int which, const double *vals, double *out) {  // which 0: the dot products, 1: the block sums of the mean constraint
     double *gs = s->d_arrive_sums + (which ? 7 * (n1 + n2) : 0);
     unsigned *c = cnt + which * (n1 + n2 + 1);
@@ -1814,6 +1880,9 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   static const bool early_env = [] { const char *e = getenv("CUP3D_EARLY_ALLREDUCE"); return e && atoi(e) != 0; }();
   // (uniform grids only: on multi-level meshes the LHS is a launch of its own between the loops and reads the mean-constraint total itself)
   const bool early = !direct && flhs && (P.block_solver == 0 || P.block_solver == 2) && comm() && !virtual_ranks() && !host_transport() && scalar_stream(s) != stream() && (early_env || debug_option("early_allreduce"));
+  // (a solve that ended in an error half way through a loop may have left tickets behind; the two flags behind the counters only ever grow;
+  //  only the early kernels take tickets)
+  if (early) CUP3D_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * (n1 + n2 + 1)) * sizeof(unsigned), stream()));
   static const long long tick_rate = [] {  // wall_clock64 ticks per millisecond (100 MHz on CDNA3 / CDNA4)
     int dev = 0, khz = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) return (long long)khz;
@@ -1934,6 +2003,10 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
         else hipLaunchKernelGGL(k_loop2_fdm<false>, GG, BB, 0, stream(), FDM_ARGS);
 #undef FDM_ARGS
       } else if (which == 1) {
+#ifdef CUP3D_TESTING  // EXPERIMENT: the single-reduction block CG behind the loops (cg_variant 8 + 32; uniform grids, one rank)
+        if (P.block_solver == 0 && fl && !early && debug_option("cg_variant") == 40) hipLaunchKernelGGL((k_loop1_cg<true, 32, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        else
+#endif
         if (early && P.block_solver == 0) hipLaunchKernelGGL((k_loop1_cg_tot<true, kCgProduction>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (early) hipLaunchKernelGGL((k_loop1_cg_tot<false, 0>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0 && fl) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
@@ -1944,7 +2017,8 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
         // with the LHS inside, the second loop asks for 128 registers: 4 wavefronts per SIMD without spills (k_loop2_cg_w4; held to 96 it
         // spills 30 registers inside the plane loop), and the 7.5 KB tile needs 16 wavefronts per CU or fewer anyway
 #ifdef CUP3D_TESTING  // A/B of the occupancy, test builds only: with the LHS inside at 96 registers (30 spilled); without it at 4 wavefronts
-        if (P.block_solver == 0 && fl && debug_option("loop2_flhs_five_waves")) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        if (P.block_solver == 0 && fl && !early && debug_option("cg_variant") == 40) hipLaunchKernelGGL((k_loop2_cg_w4f<true, 32, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (P.block_solver == 0 && fl && debug_option("loop2_flhs_five_waves")) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0 && !fl && four_waves) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
         else
 #endif

@@ -201,7 +201,10 @@ CUP3D_API int cup3d_sim_mark_written(cup3d_sim_t *, int field);
  * exchange of the pressure right-hand side runs).  1: chi / udef path (KernelPressureRHS 14858-14871); 0: obstacle-free path, no udef
  * exchange, tmpV not cleared; -1 (default): not told -- one rank decides by "chi was written", several ranks always take the chi path.
  * A chi written (upload / fill / mark_written) is never dropped silently: on one rank it takes the chi path even after 0; on several
- * ranks cup3d_pressure_project refuses the combination on EVERY rank (CUP3D_ESTATE, agreed before the first exchange). */
+ * ranks cup3d_pressure_project refuses the combination on EVERY rank: CUP3D_ESTATE on all of them together, agreed inside the
+ * mean-pressure all-reduce the operator performs anyway (15123) -- i.e. AFTER the Poisson solve.  The simulation state is then
+ * UNDEFINED (pres, the previous-pressure copy, lhs and tmpV have been overwritten; vel has not been projected): the host must end the
+ * run or re-upload its fields, exactly as after the MPI_Abort the reference answers an inconsistent run with (15265, 15289). */
 CUP3D_API int cup3d_sim_set_obstacles(cup3d_sim_t *, int any_rank_has_obstacles);
 /* Wrapping 64-bit sum of the bit patterns of every FP64 value of the rank's own blocks of `field` (ghost blocks of a rank view
  * excluded).  Integer addition commutes, so the sum of the ranks' values is independent of the partition: bench.py all-gathers it

@@ -13,6 +13,8 @@ os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
 os.environ.setdefault("CUP3D_HIP_FLAVOUR", "testing")
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+if os.environ.get("CUP3D_TEST_TORCH_FIRST"):   # bisect of round 5's exit-time abort (scripts/gpu_round6.sh exitsubset): torch's ROCm libraries before ours
+    import torch  # noqa: F401
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
