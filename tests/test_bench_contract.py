@@ -110,6 +110,29 @@ def test_default_stdout_line_is_compact_and_carries_roofline_and_cpu_baseline(tm
     assert "bicgstab_iters_by_step" not in r["config"] and r["detail"]
 
 
+def test_iteration_count_at_512_over_the_drivers_window_against_the_recorded_reference():
+    """SURVEY 8c (+-10 % on the iteration count) at the HEADLINE size, as a window mean: the device's counts over the driver's window
+    (steps 26..45 of --warmup 5 --steps 20; committed with the round's own run of the driver's command) against the compiled reference's
+    recorded counts for the same steps (profiles/r03/reference_window_512.json: 10-27 minutes per step, recorded once).  The same
+    assertion at 256^3 runs live on the GPU (tests/test_gpu_rccl.py)."""
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r03", "reference_window_512.json")))
+    by_step = {st["step"]: st["iters"] for st in rec["steps"]}
+    seen = 0
+    for f in ("r06/bench_512_driver_command_detail.json", "r06/bench_512_driver_command_detail_intermediate.json", "r05/bench_512_fullstep_unfused_refresh.json"):
+        path = os.path.join(ROOT, "profiles", f)
+        if not os.path.exists(path):
+            continue
+        r = json.loads(open(path).read().strip().splitlines()[-1])
+        assert r["steps"] == 20 and r["warmup"] == 5 and r["config"]["cells"] == 512 ** 3
+        dev = r["config"]["bicgstab_iters_by_step"]
+        ref = [by_step[n] for n in range(26, 46)]
+        assert len(dev) == 20 and r["config"]["ref_iters_per_step"]["by_step"] == ref
+        mean_dev, mean_ref = sum(dev) / 20, sum(ref) / 20
+        assert abs(mean_dev - mean_ref) <= 0.10 * mean_ref, (f, mean_dev, mean_ref)
+        seen += 1
+    assert seen >= 2
+
+
 def test_this_rounds_bench_records_carry_the_completed_line():
     """metric (A) (`stencil_only`) beside metric (B) (`value`), per-level multigrid kernels, the recorded 512^3 CPU figure."""
     f = os.path.join(ROOT, "profiles", "r05", "bench_512_fullstep_unfused_refresh.json")

@@ -16,14 +16,27 @@ pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not (O.have_ref_tool() and os.path.exists(REF_HIP)), reason="oracle/_ref binaries not built")]
 
 
-def run(tool, script, args, wd):
+def run(tool, script, args, wd, extra_env=None):
     with open(os.path.join(wd, "script.txt"), "w") as f:
         f.write("\n".join(script) + "\n")
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", **(extra_env or {}))
     out = subprocess.run([tool, "script.txt", "--"] + list(args), cwd=wd, env=env, check=True, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, timeout=600).stdout.decode()
     return [dict([("op", l.split()[1])] + [(kv.split("=")[0], float(kv.split("=")[1])) for kv in l.split()[2:]])
             for l in out.splitlines() if l.startswith("REF ")]
+
+
+@pytest.mark.parametrize("mode", ["hip on", "hip resident3"])
+def test_cpp_host_leaves_cleanly_under_a_checked_heap(tmp_path, mode):
+    """SURVEY 8b "Errors": a drop-in for a C++ main() must not abort its host at exit.  The unmodified reference TU + the shim, three
+    steps, under glibc's checked heap (MALLOC_CHECK_=3: every free verified, abort on corruption): exit code 0 (`run` raises otherwise).
+    (Round 5's exit-time "double free or corruption" was a PYTHON host's: two copies of librccl, comm.hip load_rccl; scripts/exit_repro.py
+    is its reproducer and tests/test_gpu_release_flavour.py its regression test.)"""
+    args = O.ref_args((1, 1, 1), 3, 2, 2 * np.pi, ("wall", "periodic", "freespace"), nu=0.01, cfl=0.3, extra=["-rampup", "3"])
+    d = tmp_path / "hip"
+    d.mkdir()
+    r = run(REF_HIP, [mode, "zero chi", "op steps 3", "dump vel v.bin"], args, str(d), extra_env={"MALLOC_CHECK_": "3"})
+    assert r and r[-1]["op"] == "steps" and np.isfinite(O.read_blocks(os.path.join(str(d), "v.bin"), 64, 3)).all()
 
 
 @pytest.mark.parametrize("mode", ["hip on", "hip resident", "hip resident2"])

@@ -65,14 +65,6 @@ def iters_close(got, ref, block_solver=0):
     return abs(got - ref) <= 0.1 * ref + 2
 
 
-def iters_band(got, ref):
-    """The same, for inputs on which BiCGSTAB's count is erratic (all-wall boxes, many steps into a run: the count swings by 20-30 %
-    between two summation orders of the SAME algorithm -- e.g. device 62 / oracle 81 and device 59 / oracle 47 in one test, and the
-    multi-threaded reference itself gives 166 and 196 on one 512^3 step; the widest seen here: device 129 / oracle 94): two-sided, a
-    factor of 1.5 either way (+ 5)."""
-    return got <= 1.5 * ref + 5 and ref <= 1.5 * got + 5
-
-
 def assert_fields_close(got, ref, scale, what, tol):
     err = np.abs(got - ref).max()
     assert err <= tol * scale, f"{what}: max|d| = {err:.3e} > {tol} * {scale:.3e}"
@@ -256,6 +248,8 @@ def test_reference_association_block_cg_is_the_closer_one(golden_dir, name):
 @pytest.mark.parametrize("block_solver", [0, 1, 2, 4])
 @pytest.mark.parametrize("name", FIELD_CASES)
 def test_golden_poisson_solve(golden_dir, name, block_solver):
+    if block_solver in (3, 4) and not hasattr(cu.lib(), "cup3d_debug_set_option"):
+        pytest.skip("A/B variant of the block CG: testing build only (this process runs the release library)")
     z = load(golden_dir, name)
     sim = make_sim(z, blockSolver=block_solver)
     g = sim.grid
@@ -796,7 +790,7 @@ def test_solver_runs_ahead_of_the_host_across_restarts_and_refreshes(level, bc):
     """All-wall Taylor-Green, three projections from step 21: 70-120 BiCGSTAB iterations each, i.e. runs of fused iterations whose
     scalars never leave the device (SolverCtl, poisson.hip) interrupted by the host-driven every-50th iterations, and serious
     breakdowns (the oracle restarts in several of these solves) that the device reports one iteration after the host enqueued the
-    next one.  Iteration counts within the erratic-case band of the oracle's (iters_band), every returned iterate within the stopping rule's bound; the same
+    next one.  Iteration counts: the WINDOW of the three solves within 15 % of the oracle's, every returned iterate within the stopping rule's bound; the same
     solves with the host-driven loops (`no_fuse`) agree with the fused ones in count (same arithmetic, other summation order)."""
     ext = 2 * np.pi
     o = O.OracleGrid((1, 1, 1), level + 1, level, ext, bc)
@@ -808,6 +802,7 @@ def test_solver_runs_ahead_of_the_host_across_restarts_and_refreshes(level, bc):
     ref, pref = vel.copy(), np.zeros((o.nb, 8, 8, 8))
     sim.upload("vel", vel)
     seen_restart = False
+    window = {"device": 0, "host_driven": 0, "oracle": 0}
     for step in (21, 22, 23):
         before, pbefore = sim.download("vel"), sim.download("pres")
         sim.step = step
@@ -815,7 +810,11 @@ def test_solver_runs_ahead_of_the_host_across_restarts_and_refreshes(level, bc):
         rv, rp = before.copy(), pbefore.copy()
         info, _, _ = o.project(rv, rp, dt, step)                 # the oracle from the DEVICE's state: one step, no drift between the two
         print(f"level {level} {bc[0]}: step {step}: device {r.iterations} its / {r.restarts} restarts, oracle {info.iters} / {info.restarts}")
-        assert iters_band(r.iterations, info.iters), (step, r.iterations, info.iters)
+        # per step the count of this solver swings by 20-40 % between two summation orders of the SAME algorithm (recorded here: device 129 /
+        # oracle 94, 62 / 81, 85 / 66): only a gross bound per step (a broken solver), the assertion of record is the WINDOW below
+        assert r.iterations <= 2 * info.iters + 5 and info.iters <= 2 * r.iterations + 5, (step, r.iterations, info.iters)
+        window["device"] += r.iterations
+        window["oracle"] += info.iters
         assert abs(r.restarts - info.restarts) <= 2
         seen_restart |= r.restarts > 0 or info.restarts > 0
         assert_two_valid_iterates(o, o.index, sim.download("pres"), rp, tau_of(r), sim.download("vel"), rv, dt, o.h)
@@ -829,10 +828,17 @@ def test_solver_runs_ahead_of_the_host_across_restarts_and_refreshes(level, bc):
             r2 = cu.PressureProjection(s2)(dt)
         finally:
             cu.capi.check(cu.lib().cup3d_debug_set_option(b"no_fuse", 0))
-        assert iters_band(r2.iterations, info.iters), (step, r2.iterations, info.iters)
+        assert r2.iterations <= 2 * info.iters + 5 and info.iters <= 2 * r2.iterations + 5, (step, r2.iterations, info.iters)
+        window["host_driven"] += r2.iterations
         print(f"    host-driven unfused loops: {r2.iterations} its / {r2.restarts} restarts")
         assert_two_valid_iterates(o, o.index, s2.download("pres"), rp, tau_of(r2))
         del s2
+    # the window: the three solves together, device (fused and host-driven) against the oracle restarted from the device's state each step.
+    # Recorded spreads of the sums over round 5's runs: -11 % ... +5 %; SURVEY 8c's +-10 % is what ONE summation order of the reference
+    # itself does not keep from run to run (166 / 196 on one 512^3 step), so the band here is 15 %.
+    print(f"level {level} {bc[0]}: window of three solves: device {window['device']}, host-driven {window['host_driven']}, oracle {window['oracle']}")
+    for k in ("device", "host_driven"):
+        assert abs(window[k] - window["oracle"]) <= 0.15 * window["oracle"] + 3, window
     assert seen_restart or level == 3
 
 
@@ -1006,9 +1012,10 @@ def test_direct_block_solve_inside_the_loop_kernels(bpd, lmax, level, bc):
             cu.capi.check(cu.lib().cup3d_debug_set_option(b"no_fuse_fdm", 0))
     (i0, p0), (i1, p1) = res[0], res[1]
     print(f"direct block solve fused / unfused: {i0} / {i1} iterations")
-    # (two orders of the same dot products -- the in-kernel arrival tree and the grid-stride partials: on this tight-tolerance solve of a random
-    #  right-hand side the count swings like every erratic case of this suite; 116 / 141 seen)
-    assert i0 > 3 and iters_band(i0, i1), (i0, i1)
+    # (two orders of the same dot products -- per block then k_sums_finish over blocks, against the grid-stride partials of the unfused loops;
+    #  measured with the final default path, round 6: 131 / 133 and 127 / 141.  ADVICE r5: round 5's factor-1.5 band belonged to the in-kernel
+    #  arrival tree, which is not this path's totalling any more -- back to 15 % (+ 3))
+    assert i0 > 3 and abs(i0 - i1) <= 0.15 * max(i0, i1) + 3, (i0, i1)
     p0, p1 = p0 - p0.mean(), p1 - p1.mean()
     assert np.abs(p0 - p1).max() <= 1e-7 * np.abs(p1).max()
 

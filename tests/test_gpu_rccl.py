@@ -62,8 +62,8 @@ def test_one_process_bench_carries_a_matching_checksum():
 
 def test_iteration_count_over_the_bench_window_against_the_references_recorded_one():
     """The solver's iteration count per step is erratic (it swings by 20-30 % between two summation orders of the SAME algorithm, the
-    multi-threaded reference's own included), so a per-step comparison needs a wide band (tests/test_gpu_parity.py: iters_band, a factor
-    1.5).  Over a WINDOW of steps the swings average out: the compiled reference's own time loop was recorded for 25 steps from step 21
+    multi-threaded reference's own included), so a per-step comparison says little (tests/test_gpu_parity.py keeps a gross factor-2 bound per step
+    and asserts windows).  Over a WINDOW of steps the swings average out: the compiled reference's own time loop was recorded for 25 steps from step 21
     at 256^3 (profiles/r03/reference_window_256.json: 71 ... 195 per step, mean 120.6) -- the device, running the same 25 steps of the
     bench's workload, must land within 15 % of that mean (round 4: 111; at 512^3, the driver's window: 170.9 against 183.1, in every
     bench line as config.ref_iters_per_step)."""
