@@ -393,8 +393,16 @@ class Progress:
         with open(tmp, "w") as f:
             json.dump(rec, f)
         os.replace(tmp, self.path)
+        self.last_write = time.time()
 
     def beat(self, detail):
+        """heartbeat inside a stage.  The progress FILE is rewritten at most four times a second: a write per step cost 0.6 ms -- nothing
+        against a 1.4 s step of the headline, a third of a 1.1 ms step of --stencil-only --size 256 (round 6: 1.75 instead of 1.13 ms)"""
+        now = time.time()
+        if now - getattr(self, "last_write", 0.0) < 0.25:
+            with self.lock:
+                self.detail, self.last = detail, now     # the watchdog still sees progress
+            return
         self.set(self.stage, detail, self.limit)
 
     def fail(self, error, code=4):

@@ -499,6 +499,15 @@ static int slab_transfer(Sim *s, size_t per_face, hipStream_t st) {
 // exchange runs on the communication stream while the caller launches the blocks that have
 // no remote neighbour on the compute stream; halo_finish() then makes the compute stream wait
 // for the slabs before the boundary blocks are launched.
+#ifdef CUP3D_TESTING
+// MEASUREMENT SUPPORT ("halo_delay_us", scripts/halo_overlap_probe.py): a one-thread kernel that holds the exchange stream for the given
+// time behind the transfer -- what a slab exchange costs when the bytes take that long to arrive.  The compute stream sees it only in
+// halo_finish's wait: the part of it that the inner blocks' pass did not cover is the EXPOSED halo time.
+__global__ void k_hold_stream(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+#endif
 int halo_begin(Sim *s, const double *field, int nc, int w) {
   const Grid *g = s->grid;
   if (g->multilevel) {  // coarse/fine ghost slabs take the halo slabs' place
@@ -523,6 +532,9 @@ int halo_begin(Sim *s, const double *field, int nc, int w) {
     int rc = launch_pack(s, field, nc, w, st);
     if (rc) return rc;
     if ((rc = slab_transfer(s, per_face, st))) return rc;
+#ifdef CUP3D_TESTING
+    if (const int us = debug_option("halo_delay_us")) hipLaunchKernelGGL(k_hold_stream, dim3(1), dim3(1), 0, st, (long long)us * 100);  // wall_clock64: 100 MHz
+#endif
   }
   if (st != stream()) CUP3D_HIP(hipEventRecord(s->ev_h2, st));
   return CUP3D_OK;
