@@ -61,7 +61,7 @@ def main():
         for s in sims:
             rng = np.random.default_rng(11 + s.grid.rank)
             rhs.append(rng.uniform(-1, 1, (s.nblocks, 8, 8, 8)))
-        info = {"blocks_per_rank": [int(s.nblocks) for s in sims], "inner_blocks_per_rank": [int(s.grid.ninner) for s in sims]}
+        info = {"blocks_per_rank": [int(s.nblocks) for s in sims], "inner_blocks_per_rank": [int(lib().cup3d_grid_ninner(s.grid.handle)) for s in sims]}
         for delay in [int(x) for x in a.delays.split(",")]:
             check(lib().cup3d_debug_set_option(b"halo_delay_us", delay))
             res = {}
