@@ -903,6 +903,7 @@ struct LhsIn {
   const unsigned *mean_flag;
   int mean_wait;        // which value: 1 = 2 (seq - 1) + 1 (first loop: the total of the previous iteration's second loop), 2 = 2 seq (second loop); seq = SolverCtl::seq
   unsigned *fail;       // pinned: raised when that wait gives up (10 s)
+  double *extra;        // EXPERIMENT (testing build, "extra_streams"): scratch of 2 x nb x 512 doubles the XTRA kernels write their dummy streams to; else nullptr
 };
 struct TileRegs { double c[8], gv[6]; };
 // the 14 loads of a tile in two groups: the block's own column (needs nothing but the slot) and the six face slabs (need the
@@ -992,7 +993,10 @@ __device__ __forceinline__ double tile_lhs(const double *T, const TileIdx &ix, d
 // DIRECT: the block solve behind the loop is the fast diagonalisation (fdm_block: the same M^-1, exact instead of by CG -- block_solver 1,
 // bench.py's `alt`), not the reference's CG: no iteration, no reductions, so the kernel is what the streams alone allow
 // TOT: the kernel totals its per-block values itself (Arrive; the early all-reduce over ranks) -- else a launch of k_sums_finish does
-template <bool FMA, int EV, bool FLHS, bool DIRECT = false, bool TOT = false>
+// XTRA (EXPERIMENT, testing build): what does the iteration pay per byte?  XTRA = 1: the first loop reads one more stream (b, folded into a
+// dot product with weight 0: same bits) and the second writes one more (w again, to scratch): +16 B/cell per iteration, the mirror image of
+// forming v inside the first loop instead of streaming it.  XTRA = 2: one more read AND one more write in both loops: +32 B/cell.
+template <bool FMA, int EV, bool FLHS, bool DIRECT = false, bool TOT = false, int XTRA = 0>
 __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb,
                                               double *block_sums, int *__restrict__ iters_out, const LhsIn &L, const LoopSums *__restrict__ Z) {
   __shared__ double P[FLHS ? kTileLds : (DIRECT ? kFdmLds : kCgLds)];
@@ -1013,10 +1017,13 @@ __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, c
                                  V.v[T_] + bo, V.v[V_] + bo, V.v[R_] + bo};
   double *const oP = V.v[PHAT] + bo, *const oS = V.v[S_] + bo, *const oSH = V.v[SHAT] + bo, *const oZ = V.v[Z_] + bo, *const oQ = V.v[Q_] + bo,
                *const oQH = V.v[QHAT] + bo, *const oY = V.v[Y_] + bo, *const oT = V.v[T_] + bo;
-  double in[2][NS];
+  double in[2][NS + 1];
+  const double *const xsrc = V.v[B_] + bo;
+  double *const xdst = XTRA ? L.extra + bo : nullptr;
 #define LOAD_PLANE(buf, off)                                                            \
   _Pragma("unroll") for (int i = 0; i < NS; ++i)                                        \
-    if (!(FLHS && (i == iWHAT || i == iT))) in[buf][i] = NTL(src[i], off);
+    if (!(FLHS && (i == iWHAT || i == iT))) in[buf][i] = NTL(src[i], off);              \
+  if constexpr (XTRA != 0) in[buf][NS] = NTL(xsrc, off);
   TileIdx ix{0, 0, 0};
   LhsFix fx{};
   TileRegs tr;
@@ -1053,6 +1060,8 @@ __device__ __forceinline__ void loop1_cg_body(const GridDev &g, const Vecs &V, c
     NTS(oP, j, phat); NTS(oS, j, sv); NTS(oSH, j, shat); NTS(oZ, j, z); NTS(oQ, j, q); NTS(oQH, j, qhat); NTS(oY, j, y);
     d0 += q * y;
     d1 += y * y;
+    if constexpr (XTRA != 0) d0 += 0.0 * c[NS];
+    if constexpr (XTRA == 2) NTS(xdst, j, y);
     r[zz] = invh * z;  // the right-hand side of the block solve, main.cpp:14723
   }
 #undef LOAD_PLANE
@@ -1082,7 +1091,7 @@ __global__ void __launch_bounds__(64) k_loop1_fdm(GridDev g, Vecs V, const Solve
   loop1_cg_body<true, 0, FLHS, true>(g, V, ctl, block_dots, nb, block_sums, nullptr, L, Z);
 }
 
-template <bool FMA, int EV, bool FLHS, bool DIRECT = false, bool TOT = false>
+template <bool FMA, int EV, bool FLHS, bool DIRECT = false, bool TOT = false, int XTRA = 0>
 __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb,
                                               double *block_sums, int *__restrict__ iters_out, const LhsIn &L, const LoopSums *__restrict__ Z) {
   __shared__ double P[FLHS ? kTileLds : (DIRECT ? kFdmLds : kCgLds)];
@@ -1102,10 +1111,13 @@ __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, c
   const double *const src[NS] = {V.v[QHAT] + bo, V.v[Y_] + bo, V.v[R0] + bo, xin + bo, V.v[PHAT] + bo, V.v[Q_] + bo, V.v[WHAT] + bo, V.v[ZHAT] + bo,
                                  V.v[T_] + bo, V.v[V_] + bo, V.v[S_] + bo, V.v[Z_] + bo};
   double *const oX = (xw ? V.v[XOPT] : V.v[X_]) + bo, *const oR = V.v[R_] + bo, *const oRH = V.v[RHAT] + bo, *const oW = V.v[W_] + bo, *const oV = V.v[V_] + bo;
-  double in[2][NS];
+  double in[2][NS + 1];
+  const double *const xsrc = V.v[B_] + bo;
+  double *const xdst = XTRA ? L.extra + (size_t)nb * 512 + bo : nullptr;
 #define LOAD_PLANE(buf, off)                                                            \
   _Pragma("unroll") for (int i = 0; i < NS; ++i)                                        \
-    if (!(FLHS && (i == iZHAT || i == iV))) in[buf][i] = NTL(src[i], off);
+    if (!(FLHS && (i == iZHAT || i == iV))) in[buf][i] = NTL(src[i], off);              \
+  if constexpr (XTRA == 2) in[buf][NS] = NTL(xsrc, off);
   TileIdx ix{0, 0, 0};
   LhsFix fx{};
   TileRegs tr;
@@ -1136,6 +1148,8 @@ __device__ __forceinline__ void loop2_cg_body(const GridDev &g, const Vecs &V, c
     const double rhat = qhat - a.omega * (c[iWHAT] - a.alpha * zhat);
     const double w = y - a.omega * (c[iT] - a.alpha * v);
     NTS(oX, j, x); NTS(oR, j, rv); NTS(oRH, j, rhat); NTS(oW, j, w);
+    if constexpr (XTRA != 0) NTS(xdst, j, w);
+    if constexpr (XTRA == 2) acc[5] += 0.0 * c[NS];
     acc[0] += r0 * rv;
     acc[1] += r0 * w;
     acc[2] += r0 * c[iS];
@@ -1182,6 +1196,17 @@ __global__ void __launch_bounds__(64) k_loop2_cg_w4(GridDev g, Vecs V, const Sol
 }
 
 #ifdef CUP3D_TESTING
+// EXPERIMENT ("extra_streams" = XTRA): the production kernels of uniform grids with dummy streams added (see loop1_cg_body)
+template <int XTRA>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))  // (left alone the compiler holds XTRA = 1, 2 to 94 registers, 5 wavefronts: another kernel)
+k_loop1_cg_x(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums, int *__restrict__ iters_out, LhsIn L, const LoopSums *__restrict__ Z) {
+  loop1_cg_body<true, 0, true, false, false, XTRA>(g, V, ctl, block_dots, nb, block_sums, iters_out, L, Z);
+}
+template <int XTRA>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_loop2_cg_x(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums, int *__restrict__ iters_out, LhsIn L, const LoopSums *__restrict__ Z) {
+  loop2_cg_body<true, 0, true, false, false, XTRA>(g, V, ctl, block_dots, nb, block_sums, iters_out, L, Z);
+}
 // EXPERIMENT (single-reduction block CG, EV 32): the body asks for 130 registers; held to 128 for 4 wavefronts per SIMD
 template <bool FMA, int EV, bool FLHS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
@@ -2005,6 +2030,8 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       } else if (which == 1) {
 #ifdef CUP3D_TESTING  // EXPERIMENT: the single-reduction block CG behind the loops (cg_variant 8 + 32; uniform grids, one rank)
         if (P.block_solver == 0 && fl && !early && debug_option("cg_variant") == 40) hipLaunchKernelGGL((k_loop1_cg<true, 32, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (P.block_solver == 0 && fl && !early && L.extra && debug_option("extra_streams") == 1) hipLaunchKernelGGL(k_loop1_cg_x<1>, GG, BB, 0, stream(), LOOP_ARGS);
+        else if (P.block_solver == 0 && fl && !early && L.extra && debug_option("extra_streams") == 2) hipLaunchKernelGGL(k_loop1_cg_x<2>, GG, BB, 0, stream(), LOOP_ARGS);
         else
 #endif
         if (early && P.block_solver == 0) hipLaunchKernelGGL((k_loop1_cg_tot<true, kCgProduction>), GG, BB, 0, stream(), LOOP_ARGS);
@@ -2018,6 +2045,8 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
         // spills 30 registers inside the plane loop), and the 7.5 KB tile needs 16 wavefronts per CU or fewer anyway
 #ifdef CUP3D_TESTING  // A/B of the occupancy, test builds only: with the LHS inside at 96 registers (30 spilled); without it at 4 wavefronts
         if (P.block_solver == 0 && fl && !early && debug_option("cg_variant") == 40) hipLaunchKernelGGL((k_loop2_cg_w4f<true, 32, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (P.block_solver == 0 && fl && !early && L.extra && debug_option("extra_streams") == 1) hipLaunchKernelGGL(k_loop2_cg_x<1>, GG, BB, 0, stream(), LOOP_ARGS);
+        else if (P.block_solver == 0 && fl && !early && L.extra && debug_option("extra_streams") == 2) hipLaunchKernelGGL(k_loop2_cg_x<2>, GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0 && fl && debug_option("loop2_flhs_five_waves")) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0 && !fl && four_waves) hipLaunchKernelGGL((k_loop2_cg_w4<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
         else
@@ -2085,16 +2114,17 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
     // early all-reduce: the mean-constraint totals arrive in slots of their own behind a flag (after_loop); `wait_seq` = what the flag
     // must have reached before the corner block's wavefront may read the total
     const bool em = early && want_sums;
+    double *const xtra = debug_option("extra_streams") && !helm ? s->tmpV : nullptr;  // EXPERIMENT (testing build): tmpV is idle during the pressure solve
     const double *const total1 = em && !first_after_host ? s->d_red + kRedEarlyMean + 1 : what_total;
     const double *const total2 = em ? s->d_red + kRedEarlyMean : s->d_red + kRedDots + 2;
-    TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, total1, lhs_mode, corner_in, prio, g_invD, em && !first_after_host ? mean_flag : nullptr, 1, s->h_early_fail_dev}));  // (t = A what,) loop 1, zhat = M^-1 z
+    TRY(launch_loop(1, V.v[WHAT], LhsIn{s->halo_recv, total1, lhs_mode, corner_in, prio, g_invD, em && !first_after_host ? mean_flag : nullptr, 1, s->h_early_fail_dev, xtra}));  // (t = A what,) loop 1, zhat = M^-1 z
     s->sums_of = want_sums ? V.v[ZHAT] : nullptr;
     TRY(after_loop(2, 1, seq));
     if (want_sums) { s->mean_total_of = V.v[ZHAT]; s->mean_total = total2; }
     if (flhs_ml) TRY(LHS_IFACE(ZHAT, V_));
     else if (!flhs) TRY(LHS(ZHAT, V_));
     TRY(scalars_ready());
-    TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, total2, lhs_mode, corner_in, prio, g_invD, em ? mean_flag : nullptr, 2, s->h_early_fail_dev}));  // (v = A zhat,) loop 2, what = M^-1 w
+    TRY(launch_loop(2, V.v[ZHAT], LhsIn{s->halo_recv, total2, lhs_mode, corner_in, prio, g_invD, em ? mean_flag : nullptr, 2, s->h_early_fail_dev, xtra}));  // (v = A zhat,) loop 2, what = M^-1 w
     s->sums_of = want_sums ? V.v[WHAT] : nullptr;
     TRY(after_loop(7, 2, seq));
     what_total = em ? s->d_red + kRedEarlyMean + 1 : s->d_red + kRedDots + 7;

@@ -166,4 +166,22 @@ if has stencil256; then echo "== BASELINE configs[1] at its own size: 256^3 peri
     cp gpurun_out/bench_detail_stencil_$SZ.json $OUT/bench_${SZ}_stencil_only.json; cat $OUT/bench_${SZ}_stencil_only_stdout.json | cut -c1-3000; tail -2 $OUT/bench_${SZ}_stencil_only.err
   done
 fi
+if has slope; then echo "== EXPERIMENT: what does the BiCGSTAB iteration pay per byte?  dummy streams ADDED to the production loop kernels (+16 / +32 B per cell and iteration)"
+  for SZ in ${SLOPE_SIZES:-512 256}; do for V in 0 1 2; do
+    F=$OUT/bench_${SZ}_extra_streams_$V.json
+    timeout 900 python bench.py --full-line --detail-out '' --size $SZ --no-cpu --no-alt --no-pcie --steps ${SLOPE_STEPS:-8} --warmup 3 --debug-option extra_streams=$V > $F 2> ${F%.json}.err; echo "rc=$? (size $SZ extra_streams $V)"; summ $F | head -1; summ $F | grep bicgstab_loop; tail -1 ${F%.json}.err
+  done; done
+fi
+if has haloprobe; then echo "== halo overlap probe (two thread ranks, injected slab latency), ${HALO_RUNS:-3} runs"
+  for R in $(seq 1 ${HALO_RUNS:-3}); do timeout 600 python scripts/halo_overlap_probe.py --delays ${HALO_DELAYS:-0,50,100,200,400,800} --iters 40 2>> $OUT/halo_probe.err > $OUT/halo_overlap_probe_run$R.jsonl; python - $OUT/halo_overlap_probe_run$R.jsonl <<'PY'
+import json, sys
+rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
+base = None
+for r in rows:
+    e = [v for k, v in r.items() if k.startswith("exposed_halo_wait")][0]
+    base = e if base is None else base
+    inj = r["injected_ms_per_iteration"]
+    print("  delay", r["injected_delay_us_per_exchange"], "us: wall", r["wall_ms_per_iteration"], "exposed", e, "injected", inj, "incremental exposed/injected", round((e - base) / inj, 3) if inj else None)
+PY
+  done; fi
 echo "== done $(date)"
