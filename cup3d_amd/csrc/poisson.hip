@@ -1902,7 +1902,9 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
   // FLHS: v = A zhat and t = A what are formed inside the loop kernels (uniform grids; on multi-level meshes the LHS needs the
   // coarse/fine ghost slabs and the flux correction, so it stays a launch of its own)
   const bool flhs = fuse && !s->grid->multilevel && !debug_option("no_fuse_lhs");
-  static const bool early_env = [] { const char *e = getenv("CUP3D_EARLY_ALLREDUCE"); return e && atoi(e) != 0; }();
+  // read at every solve (a getenv against a solve of milliseconds): bench.py --gpus N times its alt_early_allreduce region in the same
+  // process, after the default order has produced `value`
+  const bool early_env = [] { const char *e = getenv("CUP3D_EARLY_ALLREDUCE"); return e && atoi(e) != 0; }();
   // (uniform grids only: on multi-level meshes the LHS is a launch of its own between the loops and reads the mean-constraint total itself)
   const bool early = !direct && flhs && (P.block_solver == 0 || P.block_solver == 2) && comm() && !virtual_ranks() && !host_transport() && scalar_stream(s) != stream() && (early_env || debug_option("early_allreduce"));
   // (a solve that ended in an error half way through a loop may have left tickets behind; the two flags behind the counters only ever grow;

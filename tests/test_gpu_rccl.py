@@ -34,12 +34,13 @@ def same_bits_at_every_n(ck1, ckn):
 FAKE_RCCL = os.path.join(ROOT, "tests", "fake_rccl", "librccl_fake.so")
 
 
-def run_bench(*args, timeout=900, extra_env=None):
+def run_bench(*args, timeout=900, extra_env=None, alt_early=False):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(extra_env or {})
     # --full-line: these tests read the full record (checksum values, per-step arrays); the default stdout line is the compact summary
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line", "--detail-out", "", *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                          timeout=timeout)
+    # --no-alt-early: the optional early-all-reduce region of N > 1 runs has its own test below
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-line", "--detail-out", "", *([] if alt_early else ["--no-alt-early"]), *args], env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
 
 
 def test_one_process_bench_carries_a_matching_checksum():
@@ -285,3 +286,32 @@ def test_early_allreduce_is_deterministic_and_solves_the_same_problem():
     print("early all-reduce: one process", e1["bicgstab_iters_by_step"], "(default order", one["bicgstab_iters_by_step"], "), two processes", two[1]["bicgstab_iters_by_step"],
           "(default order", two[0]["bicgstab_iters_by_step"], "); exposed scalar wait per iteration, one process:", d["communication"]["exposed_scalar_wait_ms_per_iteration"], "->",
           e1["communication"]["exposed_scalar_wait_ms_per_iteration"], "ms (30 us injected per all-reduce)")
+
+
+@pytest.mark.timeout(900)
+def test_bench_times_the_early_order_as_an_optional_region_that_cannot_lose_the_result():
+    """`bench.py --gpus N` over RCCL: `value` comes from the DEFAULT order of the all-reduces (the one every multi-rank test has run); the
+    early order (CUP3D_EARLY_ALLREDUCE, poisson.hip) is timed afterwards in the same process as `alt_early_allreduce` -- the reference
+    hides its two MPI_Iallreduce by default (main.cpp:14486-14490, 14546-14550).  The region is optional: (a) it runs and reports (two
+    ranks, the stand-in library); (b) a rank that hangs inside it does not cost the run its result -- the watchdog prints the MAIN line
+    with alt_early_allreduce = {"error": ...} and the exit code is 0."""
+    if not os.path.exists(FAKE_RCCL):
+        pytest.skip("tests/fake_rccl/librccl_fake.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    args = ("--gpus", "2", "--size", "128", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-alt", "--no-pcie")
+    env = {"CUP3D_RCCL_LIBRARY": FAKE_RCCL, "CUP3D_BENCH_SHARE_DEVICE": "1", "CUP3D_HIP_FLAVOUR": "release"}
+    ok = run_bench(*args, timeout=800, extra_env=env, alt_early=True)
+    assert ok.returncode == 0, (ok.stdout.decode()[-1500:], ok.stderr.decode()[-3000:])
+    lines = [l for l in ok.stdout.decode().strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    e = r["alt_early_allreduce"]
+    assert "error" not in e and e["value"] > 0 and e["bicgstab_iters_per_step"] > 3 and e["allreduce_ms_per_iteration"] > 0
+    assert r["config"]["communication"]["early_allreduce"] is False and r["config"]["checksum"]["ok"] is True      # `value` is the default order's
+    print(f"2 ranks (stand-in): default order {r['ms_per_bicgstab_iteration']} ms per iteration, early order {e['ms_per_bicgstab_iteration']}")
+    hang = run_bench(*args, "--fail-at", "alt_early:1:hang", "--stall-timeout", "25", timeout=800, extra_env=env, alt_early=True)
+    assert hang.returncode == 0, (hang.stdout.decode()[-1500:], hang.stderr.decode()[-3000:])
+    lines = [l for l in hang.stdout.decode().strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, hang.stdout.decode()[-2000:]
+    r2 = json.loads(lines[0])
+    assert r2["value"] > 0 and r2.get("valid", True) is True and r2["config"]["checksum"]["ok"] is True
+    assert "error" in r2["alt_early_allreduce"] and "alt_early" in r2["alt_early_allreduce"]["error"]
