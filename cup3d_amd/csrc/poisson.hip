@@ -560,8 +560,16 @@ static int *cg_iters_buffer(Sim *s) {  // per-block CG iteration counts of the l
 }
 
 constexpr int kLoopPrio = 0;    // LhsIn::prio of the production launch (measured: profiles/r03)
-// evaluation of the production block CG (EV bits of k_precond); measured on MI355X: see profiles/r02/probe_block_cg_variants.jsonl
-constexpr int kCgProduction = 0;
+// Evaluation of the production block CG (EV bits of cg_block).  Round 6: 6 = single-width LDS reads (bit 2: 32 ds_read_b64 with immediate
+// plane offsets instead of 16 half-rate ds_read2_b64 + 8 address adds per CG iteration) + reciprocal divisions (bit 4: v_rcp_f64, two
+// Newton steps and a residual correction, within 1 ulp of the IEEE quotient, 8 instead of 12 instructions, twice per iteration).
+// Rounds 2-5 ran EV 0: the variants had only been compared on the stand-alone kernel with an input that converges in three CG
+// iterations (profiles/r02/probe_block_cg_variants_*.jsonl: all within 2 %).  Behind the loops on the solver's own inputs (27 CG
+// iterations per block) the A/B on one box reads 9.17 -> 8.77 ms per BiCGSTAB iteration at 512^3 and 1.194 -> 1.142 at 256^3 (-4.3 %),
+// with identical BiCGSTAB counts (profiles/r06/block_cg_evaluation_behind_the_loops/): bit 2 alone -2.5 % (bit-identical results),
+// bit 4 alone -1.6 %, bit 8 (three-operand FMA for the p update) nothing.  Like the FMA contraction, the reciprocal division is a
+// rounding-level deviation inside a block solve that is truncated at 1e-7; block_solver 2 stays the reference's association and IEEE division.
+constexpr int kCgProduction = 6;
 
 int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
   GridDev g = s->gdev();
@@ -580,9 +588,9 @@ int launch_precond(Sim *s, const double *in, double *out, bool want_sums) {
     return CUP3D_OK;
   }
   ProfileScope ps("poisson_block_cg");
-  // Production (block_solver 0, kCgProduction = EV 0) contracts a*b+c into FMAs here (and only here); wave sums by DPP, IEEE divisions
-  // (the matrix-pipe sums and reciprocal divisions described above k_precond were measured slower and exist in the testing flavour
-  // only).  Its result sits behind two wave reductions per iteration whose summation order already differs from the CPU's, and the
+  // Production (block_solver 0, kCgProduction) contracts a*b+c into FMAs here (and only here) and divides by reciprocal + correction
+  // (within 1 ulp); wave sums by DPP (the matrix-pipe sums described above k_precond were measured slower and exist in the testing
+  // flavour only).  Its result sits behind two wave reductions per iteration whose summation order already differs from the CPU's, and the
   // CG's own truncation is 1e-7, so the contraction is a tolerance-level deviation (tests bound it against the reference's z).
   // block_solver 2 = the reference's association (no contraction).
   const dim3 G(launch_groups(g)), B(64);
@@ -1200,12 +1208,12 @@ __global__ void __launch_bounds__(64) k_loop2_cg_w4(GridDev g, Vecs V, const Sol
 template <int XTRA>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))  // (left alone the compiler holds XTRA = 1, 2 to 94 registers, 5 wavefronts: another kernel)
 k_loop1_cg_x(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums, int *__restrict__ iters_out, LhsIn L, const LoopSums *__restrict__ Z) {
-  loop1_cg_body<true, 0, true, false, false, XTRA>(g, V, ctl, block_dots, nb, block_sums, iters_out, L, Z);
+  loop1_cg_body<true, kCgProduction, true, false, false, XTRA>(g, V, ctl, block_dots, nb, block_sums, iters_out, L, Z);
 }
 template <int XTRA>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_loop2_cg_x(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums, int *__restrict__ iters_out, LhsIn L, const LoopSums *__restrict__ Z) {
-  loop2_cg_body<true, 0, true, false, false, XTRA>(g, V, ctl, block_dots, nb, block_sums, iters_out, L, Z);
+  loop2_cg_body<true, kCgProduction, true, false, false, XTRA>(g, V, ctl, block_dots, nb, block_sums, iters_out, L, Z);
 }
 // EXPERIMENT (single-reduction block CG, EV 32): the body asks for 130 registers; held to 128 for 4 wavefronts per SIMD
 template <bool FMA, int EV, bool FLHS>
@@ -2032,6 +2040,9 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
       } else if (which == 1) {
 #ifdef CUP3D_TESTING  // EXPERIMENT: the single-reduction block CG behind the loops (cg_variant 8 + 32; uniform grids, one rank)
         if (P.block_solver == 0 && fl && !early && debug_option("cg_variant") == 40) hipLaunchKernelGGL((k_loop1_cg<true, 32, true>), GG, BB, 0, stream(), LOOP_ARGS);
+#define FUSED_EV(E) else if (P.block_solver == 0 && fl && !early && debug_option("fused_cg_ev") == (E) + 1) hipLaunchKernelGGL((k_loop1_cg<true, E, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        FUSED_EV(0) FUSED_EV(2) FUSED_EV(4) FUSED_EV(8) FUSED_EV(10) FUSED_EV(12) FUSED_EV(14)   // A/B of the block CG's evaluation behind the loops: option value = EV + 1
+#undef FUSED_EV
         else if (P.block_solver == 0 && fl && !early && L.extra && debug_option("extra_streams") == 1) hipLaunchKernelGGL(k_loop1_cg_x<1>, GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0 && fl && !early && L.extra && debug_option("extra_streams") == 2) hipLaunchKernelGGL(k_loop1_cg_x<2>, GG, BB, 0, stream(), LOOP_ARGS);
         else
@@ -2047,6 +2058,9 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
         // spills 30 registers inside the plane loop), and the 7.5 KB tile needs 16 wavefronts per CU or fewer anyway
 #ifdef CUP3D_TESTING  // A/B of the occupancy, test builds only: with the LHS inside at 96 registers (30 spilled); without it at 4 wavefronts
         if (P.block_solver == 0 && fl && !early && debug_option("cg_variant") == 40) hipLaunchKernelGGL((k_loop2_cg_w4f<true, 32, true>), GG, BB, 0, stream(), LOOP_ARGS);
+#define FUSED_EV(E) else if (P.block_solver == 0 && fl && !early && debug_option("fused_cg_ev") == (E) + 1) hipLaunchKernelGGL((k_loop2_cg_w4f<true, E, true>), GG, BB, 0, stream(), LOOP_ARGS);
+        FUSED_EV(0) FUSED_EV(2) FUSED_EV(4) FUSED_EV(8) FUSED_EV(10) FUSED_EV(12) FUSED_EV(14)
+#undef FUSED_EV
         else if (P.block_solver == 0 && fl && !early && L.extra && debug_option("extra_streams") == 1) hipLaunchKernelGGL(k_loop2_cg_x<1>, GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0 && fl && !early && L.extra && debug_option("extra_streams") == 2) hipLaunchKernelGGL(k_loop2_cg_x<2>, GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0 && fl && debug_option("loop2_flhs_five_waves")) hipLaunchKernelGGL((k_loop2_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);

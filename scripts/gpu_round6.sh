@@ -140,14 +140,14 @@ if has pmcmg; then echo "== rocprofv3 PMC passes over the multigrid option at 51
   ROOT=$(pwd); rm -f $OUT/pmc_multigrid_kernels_512cubed.txt
   for CN in FETCH_SIZE WRITE_SIZE; do
     ( cd /tmp && timeout 900 rocprofv3 --pmc $CN --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_$CN -o p -- python $ROOT/bench.py --block-solver 5 --steps 2 --warmup 1 --no-cpu --no-alt --no-pcie --no-checksum > $ROOT/$OUT/pmcmg_$CN.log 2>&1 )
-    for f in $(find $OUT/pmc_$CN -name "*counter_collection.csv" | head -1); do python scripts/pmc_by_kernel_and_grid.py "$f" $CN k_mg_ k_advdiff | tee -a $OUT/pmc_multigrid_kernels_512cubed.txt; done
+    for f in $(find $OUT/pmc_$CN -name "*counter_collection.csv" | head -1); do python scripts/pmc_by_kernel_and_grid.py "$f" $CN k_mg_ k_advdiff k_solver_init k_copy k_lhs | tee -a $OUT/pmc_multigrid_kernels_512cubed.txt; done
     rm -rf $OUT/pmc_$CN
   done; fi
 if has pmcmain; then echo "== rocprofv3 PMC passes over the driver's workload at 512^3, 2 steps (FETCH_SIZE, WRITE_SIZE in separate runs)"
   ROOT=$(pwd); rm -f $OUT/pmc_fullstep_kernels_512cubed.txt
   for CN in FETCH_SIZE WRITE_SIZE; do
     ( cd /tmp && timeout 900 rocprofv3 --pmc $CN --kernel-trace --output-format csv -d $ROOT/$OUT/pmcm_$CN -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-alt --no-pcie --no-checksum > $ROOT/$OUT/pmcmain_$CN.log 2>&1 )
-    for f in $(find $OUT/pmcm_$CN -name "*counter_collection.csv" | head -1); do python scripts/pmc_by_kernel_and_grid.py "$f" $CN k_loop k_advdiff k_lhs k_precond k_refresh | tee -a $OUT/pmc_fullstep_kernels_512cubed.txt; done
+    for f in $(find $OUT/pmcm_$CN -name "*counter_collection.csv" | head -1); do python scripts/pmc_by_kernel_and_grid.py "$f" $CN k_loop k_advdiff k_lhs k_precond k_refresh k_solver_init k_copy | tee -a $OUT/pmc_fullstep_kernels_512cubed.txt; done
     rm -rf $OUT/pmcm_$CN
   done; fi
 if has cgcg; then echo "== EXPERIMENT: single-reduction (Chronopoulos-Gear) block CG, EV 32: stand-alone kernel, then behind the loops"
@@ -184,4 +184,10 @@ for r in rows:
     print("  delay", r["injected_delay_us_per_exchange"], "us: wall", r["wall_ms_per_iteration"], "exposed", e, "injected", inj, "incremental exposed/injected", round((e - base) / inj, 3) if inj else None)
 PY
   done; fi
+if has cgev; then echo "== the evaluation variants of the block CG BEHIND THE LOOPS on the real workload (fused_cg_ev: 2 = single-width LDS reads, 8 = three-operand FMA p update, 4 = reciprocal divisions)"
+  for SZ in ${CGEV_SIZES:-512 256}; do for V in ${CGEV_VARIANTS:-0 2 8 10 14 0}; do
+    F=$OUT/bench_${SZ}_fused_cg_ev_$V.json
+    timeout 900 python bench.py --full-line --detail-out '' --size $SZ --no-cpu --no-alt --no-pcie --steps ${CGEV_STEPS:-8} --warmup 3 --debug-option fused_cg_ev=$V > $F 2> ${F%.json}.err; echo "rc=$? (size $SZ fused_cg_ev $V)"; summ $F | head -1; summ $F | grep bicgstab_loop; tail -1 ${F%.json}.err | grep -v amdgpu.ids
+  done; done
+fi
 echo "== done $(date)"
