@@ -118,7 +118,7 @@ def test_iteration_count_at_512_over_the_drivers_window_against_the_recorded_ref
     rec = json.load(open(os.path.join(ROOT, "profiles", "r03", "reference_window_512.json")))
     by_step = {st["step"]: st["iters"] for st in rec["steps"]}
     seen = 0
-    for f in ("r06/bench_512_driver_command_detail.json", "r06/bench_512_driver_command_detail_intermediate.json", "r05/bench_512_fullstep_unfused_refresh.json"):
+    for f in ("r06/bench_512_driver_command_detail.json", "r06/bench_512_driver_command_detail_before_the_block_cg_change.json", "r05/bench_512_fullstep_unfused_refresh.json"):
         path = os.path.join(ROOT, "profiles", f)
         if not os.path.exists(path):
             continue
