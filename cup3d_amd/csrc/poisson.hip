@@ -119,10 +119,11 @@ __device__ __forceinline__ double wave_sum_rows(double v, double *P) {
   const int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
-template <bool MFMA, bool ROWS = false>
+template <bool MFMA, bool ROWS = false, bool ZERO_OLD = false>
 __device__ __forceinline__ double cg_sum(double v, double *P = nullptr) {
   if constexpr (MFMA) return wave_sum_mfma(v);
   else if constexpr (ROWS) return wave_sum_rows(v, P);
+  else if constexpr (ZERO_OLD) return wave_sum_zero_old(v);
   else return wave_sum(v);
 }
 template <bool FAST>
@@ -143,7 +144,7 @@ __device__ __forceinline__ void cg_block(const GridDev &g, int slot, double (&r)
                                          int *__restrict__ iters_out, double *P) {
   // (r01 kernel: 86 VGPRs -> 5 waves/SIMD.  Forcing 6 with amdgpu_waves_per_eu spills five values that are reloaded every iteration:
   //  0.476 vs 0.431 ms at 256^3, so the natural allocation stays.)
-  constexpr bool V2 = (EV & 1) != 0, LDSV = (EV & 2) != 0, FDIV = (EV & 4) != 0 && FMA, ROWS = (EV & 16) != 0;
+  constexpr bool V2 = (EV & 1) != 0, LDSV = (EV & 2) != 0, FDIV = (EV & 4) != 0 && FMA, ROWS = (EV & 16) != 0, ZOLD = (EV & 64) != 0;
   const int l = threadIdx.x;
   const int base = ((l >> 3) + 1) * 8 + (l & 7);
   for (int i = l; i < 640; i += 64) P[i] = 0.0;
@@ -163,7 +164,7 @@ __device__ __forceinline__ void cg_block(const GridDev &g, int slot, double (&r)
     p[z] = r[z];
     x[z] = 0;
   }
-  rr = cg_sum<V2, ROWS>(rr, P);
+  rr = cg_sum<V2, ROWS, ZOLD>(rr, P);
   const double kRel = 1e-7 * 1e-7, kAbs = 1e-16 * 1e-16;  // kSqrNorm{Rel,Abs}Criterion, 14619-14624
   const double sqrNorm0 = (double)1 / (512 * 512) * rr;    // 14734
   int kdone = 0;
@@ -243,7 +244,7 @@ __device__ __forceinline__ void cg_block(const GridDev &g, int slot, double (&r)
         a2 = mad<FMA>(p[z], t, a2);
       }
       __syncthreads();
-      a2 = cg_sum<V2, ROWS>(a2, P);
+      a2 = cg_sum<V2, ROWS, ZOLD>(a2, P);
       const double a = cg_div<FDIV>(rr, a2 + 1e-55);        // 14684
       double ss = 0;
 #pragma unroll
@@ -252,7 +253,7 @@ __device__ __forceinline__ void cg_block(const GridDev &g, int slot, double (&r)
         r[z] = mad<FMA>(-a, Ax[z], r[z]);                   // subAndSumSqr, 14636-14638
         ss = mad<FMA>(r[z], r[z], ss);
       }
-      ss = cg_sum<V2, ROWS>(ss, P);
+      ss = cg_sum<V2, ROWS, ZOLD>(ss, P);
       const double beta = cg_div<FDIV>(ss, rr + 1e-55);       // 14690
       const double sqrNorm = (double)1 / (512 * 512) * ss;  // 14691
       if (sqrNorm < kRel * sqrNorm0 || sqrNorm < kAbs) return false;  // 14692-14694 (returns -1)
@@ -276,7 +277,7 @@ __device__ __forceinline__ void cg_block(const GridDev &g, int slot, double (&r)
   if (iters_out && l == 0) iters_out[slot] = kdone;  // measurement only (cup3d_profile_enable): CG iterations this block took
   if (block_sums) {  // sum(z*h^3) of this block for the mean constraint of the LHS that follows (9283-9294)
     const double hq = block_h(g, slot), h3 = hq * hq * hq;
-    sx = cg_sum<V2, ROWS>(sx * h3, P);
+    sx = cg_sum<V2, ROWS, ZOLD>(sx * h3, P);
     if (l == 0) { if constexpr (AG) st_agent(block_sums + slot, sx); else block_sums[slot] = sx; }
   }
 }
@@ -2041,7 +2042,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
 #ifdef CUP3D_TESTING  // EXPERIMENT: the single-reduction block CG behind the loops (cg_variant 8 + 32; uniform grids, one rank)
         if (P.block_solver == 0 && fl && !early && debug_option("cg_variant") == 40) hipLaunchKernelGGL((k_loop1_cg<true, 32, true>), GG, BB, 0, stream(), LOOP_ARGS);
 #define FUSED_EV(E) else if (P.block_solver == 0 && fl && !early && debug_option("fused_cg_ev") == (E) + 1) hipLaunchKernelGGL((k_loop1_cg<true, E, true>), GG, BB, 0, stream(), LOOP_ARGS);
-        FUSED_EV(0) FUSED_EV(2) FUSED_EV(4) FUSED_EV(8) FUSED_EV(10) FUSED_EV(12) FUSED_EV(14)   // A/B of the block CG's evaluation behind the loops: option value = EV + 1
+        FUSED_EV(0) FUSED_EV(2) FUSED_EV(4) FUSED_EV(8) FUSED_EV(10) FUSED_EV(12) FUSED_EV(14) FUSED_EV(70)   // (70 = production + rounds 1-5's wave sum) A/B of the block CG's evaluation behind the loops: option value = EV + 1
 #undef FUSED_EV
         else if (P.block_solver == 0 && fl && !early && L.extra && debug_option("extra_streams") == 1) hipLaunchKernelGGL(k_loop1_cg_x<1>, GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0 && fl && !early && L.extra && debug_option("extra_streams") == 2) hipLaunchKernelGGL(k_loop1_cg_x<2>, GG, BB, 0, stream(), LOOP_ARGS);
@@ -2059,7 +2060,7 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
 #ifdef CUP3D_TESTING  // A/B of the occupancy, test builds only: with the LHS inside at 96 registers (30 spilled); without it at 4 wavefronts
         if (P.block_solver == 0 && fl && !early && debug_option("cg_variant") == 40) hipLaunchKernelGGL((k_loop2_cg_w4f<true, 32, true>), GG, BB, 0, stream(), LOOP_ARGS);
 #define FUSED_EV(E) else if (P.block_solver == 0 && fl && !early && debug_option("fused_cg_ev") == (E) + 1) hipLaunchKernelGGL((k_loop2_cg_w4f<true, E, true>), GG, BB, 0, stream(), LOOP_ARGS);
-        FUSED_EV(0) FUSED_EV(2) FUSED_EV(4) FUSED_EV(8) FUSED_EV(10) FUSED_EV(12) FUSED_EV(14)
+        FUSED_EV(0) FUSED_EV(2) FUSED_EV(4) FUSED_EV(8) FUSED_EV(10) FUSED_EV(12) FUSED_EV(14) FUSED_EV(70)
 #undef FUSED_EV
         else if (P.block_solver == 0 && fl && !early && L.extra && debug_option("extra_streams") == 1) hipLaunchKernelGGL(k_loop2_cg_x<1>, GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0 && fl && !early && L.extra && debug_option("extra_streams") == 2) hipLaunchKernelGGL(k_loop2_cg_x<2>, GG, BB, 0, stream(), LOOP_ARGS);

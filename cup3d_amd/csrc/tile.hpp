@@ -40,14 +40,38 @@ __device__ __forceinline__ double broadcast_lane63(double v) {
   const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+// The two cross-row steps of wave_sum write only the rows of their row mask; the other rows keep `old`.  Only lane 63 of the result is
+// used (and, for the second step, lane 31 of the first step's result: row 1), both in written rows -- so `old` may be anything.  With
+// old = 0 the compiler emits two v_mov_b32 0 (+ a hazard nop) per step, with old = the source two copies of it (the DPP move's
+// destination is tied to `old`); with old = the PREVIOUS step's moved value, which is dead by then, it emits nothing: 8 vector
+// instructions fewer per CG iteration of the block preconditioner, same bits.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_rows(double v, double dead) {
+  const long long b = __builtin_bit_cast(long long, v), o = __builtin_bit_cast(long long, dead);
+  const int lo = __builtin_amdgcn_update_dpp((int)o, (int)b, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 // all 64 lanes receive the same sum
 __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_move<0xB1>(v);              // quad_perm [1,0,3,2]
   v += dpp_move<0x4E>(v);              // quad_perm [2,3,0,1]
   v += dpp_move<0x141>(v);             // row_half_mirror
-  v += dpp_move<0x140>(v);             // row_mirror: every lane of a row holds the row total
-  v += dpp_move<0x142, 0xa>(v);        // row_bcast15 into rows 1 and 3
-  v += dpp_move<0x143, 0xc>(v);        // row_bcast31 into rows 2 and 3: lane 63 = total
+  const double t4 = dpp_move<0x140>(v);  // row_mirror: every lane of a row holds the row total
+  v += t4;
+  const double t5 = dpp_move_rows<0x142, 0xa>(v, t4);   // row_bcast15 into rows 1 and 3 (rows 0 and 2 hold leftovers, never read)
+  v += t5;
+  v += dpp_move_rows<0x143, 0xc>(v, t5);                // row_bcast31 into rows 2 and 3: lane 63 = (R3 + R2) + (R1 + R0)
+  return broadcast_lane63(v);
+}
+// rounds 1-5's form of the two cross-row steps (old = 0: two v_mov_b32 0 and a nop per step) -- kept for the A/B (EV bit 64 of cg_block)
+__device__ __forceinline__ double wave_sum_zero_old(double v) {
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x141>(v);
+  v += dpp_move<0x140>(v);
+  v += dpp_move<0x142, 0xa>(v);
+  v += dpp_move<0x143, 0xc>(v);
   return broadcast_lane63(v);
 }
 __device__ __forceinline__ double wave_max(double v) {

@@ -190,4 +190,12 @@ if has cgev; then echo "== the evaluation variants of the block CG BEHIND THE LO
     timeout 900 python bench.py --full-line --detail-out '' --size $SZ --no-cpu --no-alt --no-pcie --steps ${CGEV_STEPS:-8} --warmup 3 --debug-option fused_cg_ev=$V > $F 2> ${F%.json}.err; echo "rc=$? (size $SZ fused_cg_ev $V)"; summ $F | head -1; summ $F | grep bicgstab_loop; tail -1 ${F%.json}.err | grep -v amdgpu.ids
   done; done
 fi
+if has advvar; then echo "== advect-diffuse stage with single-width LDS reads (advdiff_variant 7) against the production kernel (16 = 0 through the testing build)"
+  timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "kernel_variants_bit_exact" 2>&1 | tail -2
+  for SZ in ${ADV_SIZES:-512 256}; do for V in ${ADV_VARIANTS:-16 7 16 7}; do
+    F=$OUT/bench_${SZ}_stencil_only_advdiff_variant_$V.json
+    timeout 600 python bench.py --full-line --detail-out '' --stencil-only --size $SZ --no-cpu --steps ${ADV_STEPS:-60} --warmup 10 --debug-option advdiff_variant=$V > $F 2> ${F%.json}.err; echo "rc=$? (size $SZ advdiff_variant $V)"
+    python -c "import json; r=json.loads(open('$F').read().strip().splitlines()[-1]); print('  value', r['value'], 'ms/step', r['ms_per_step'], [(k['kernel'], k['avg_ms'], k.get('frac')) for k in r['kernels'][:3]])"
+  done; done
+fi
 echo "== done $(date)"

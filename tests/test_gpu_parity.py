@@ -179,7 +179,7 @@ def test_golden_stencil_operators_bit_exact(golden_dir, name):
     assert np.array_equal(cu.MeshAdaptation(rt, ct).Tag(sim, "tmpV"), m.tag(w, rt, ct))
 
 
-@pytest.mark.parametrize("variant", [1, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 4, 5, 6, 7, 16])
 @pytest.mark.parametrize("name", FIELD_CASES)
 def test_advect_diffuse_kernel_variants_bit_exact(golden_dir, name, variant):
     """The A/B variants of the advect-diffuse stage that are supposed to give the SAME bits as the production kernel: IEEE division
