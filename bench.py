@@ -382,7 +382,9 @@ class Progress:
             except ValueError:
                 pass   # not the main thread (tests importing bench): no signal hook
             threading.Thread(target=self.watch, daemon=True).start()
-        self.set("start")
+        # 'start' = the imports (torch pages in from a cold image: minutes on a bad day, seen in round 6) -- not a collective, so not the
+        # business of a short --stall-timeout
+        self.set("start", limit=max(a.stall_timeout, 600.0))
 
     def set(self, stage, detail="", limit=None):
         with self.lock:
@@ -856,10 +858,11 @@ def run(a, prog):
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        stage("rendezvous", "torch.distributed on gloo")
+        # (the rendezvous waits for the slowest rank's imports: the same generous limit as 'start'; the collectives after it keep --stall-timeout)
+        stage("rendezvous", "torch.distributed on gloo", limit=max(a.stall_timeout, 600.0))
         # gloo with CPU tensors carries the bootstrap, the checksum gather, the barriers and the timing reduce: the process holds ONE
         # RCCL communicator, the library's own (no second one to keep apart from it)
-        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=a.stall_timeout))
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=max(a.stall_timeout, 600.0)))
         stage("comm_init", "host-memory test transport" if a.transport == "host" else "ncclCommInitRank of the library's communicator")
         if a.transport == "host":
             a.host_transport = install_host_transport(dist, rank, world)   # keeps the ctypes callbacks alive

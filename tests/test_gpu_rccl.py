@@ -169,7 +169,7 @@ def test_a_rank_that_hangs_or_dies_yields_one_diagnostic_line(how, stage):
     assert len(r["rank_progress"]) == 2
     stages = [p["stage"] for p in r["rank_progress"]]
     assert stage in stages, r      # the line says where the run was
-    assert took < 200, took        # (25 s stall limit + start-up; a silent hang would sit here for the launcher's half hour)
+    assert took < 390, took        # (25 s stall limit + start-up -- importing torch in two fresh processes took from 3 s to minutes on the pool's boxes; a silent hang would sit here for the launcher's half hour)
 
 
 @pytest.mark.timeout(600)
