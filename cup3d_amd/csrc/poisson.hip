@@ -1093,6 +1093,17 @@ __global__ void __launch_bounds__(64) k_loop1_cg(GridDev g, Vecs V, const Solver
                                                  int *__restrict__ iters_out, LhsIn L, const LoopSums *__restrict__ Z) {
   loop1_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L, Z);
 }
+// The same kernel held to 5 wavefronts per SIMD (94 registers, no spill; the 7.5 KB tile allows 21 per CU).  Round 3 measured this
+// SLOWER with the ds_read2_b64 form of the block CG; with the single-width reads of round 6, which leave the LDS headroom for a fifth
+// wavefront, it is 3 % FASTER at 512^3 (3.78 against 3.90 ms, 262 144 blocks = 51 rounds of wavefronts) and 1.5 % slower at 256^3
+// (0.512 against 0.505 ms: 6.4 rounds, the tail of the last round weighs more) -- profiles/r06/loop1_five_waves/.  Production takes it
+// from kFiveWavesFrom blocks per launch; same body, same bits.
+constexpr int kFiveWavesFrom = 131072;
+template <bool FMA, int EV, bool FLHS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
+k_loop1_cg_w5(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums, int *__restrict__ iters_out, LhsIn L, const LoopSums *__restrict__ Z) {
+  loop1_cg_body<FMA, EV, FLHS>(g, V, ctl, block_dots, nb, block_sums, iters_out, L, Z);
+}
 // block_solver 1: first loop + the direct block solve (`alt`)
 template <bool FLHS>
 __global__ void __launch_bounds__(64) k_loop1_fdm(GridDev g, Vecs V, const SolverCtl *__restrict__ ctl, double *block_dots, long nb, double *block_sums,
@@ -2050,6 +2061,8 @@ static int solve(Sim *s, const cup3d_poisson_params &P, cup3d_poisson_result *re
 #endif
         if (early && P.block_solver == 0) hipLaunchKernelGGL((k_loop1_cg_tot<true, kCgProduction>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (early) hipLaunchKernelGGL((k_loop1_cg_tot<false, 0>), GG, BB, 0, stream(), LOOP_ARGS);
+        else if (P.block_solver == 0 && fl && (debug_option("loop1_five_waves") ? debug_option("loop1_five_waves") == 1 : gp.nblocks >= kFiveWavesFrom))  // (A/B: 1 = always, 2 = never)
+          hipLaunchKernelGGL((k_loop1_cg_w5<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0 && fl) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction, true>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (P.block_solver == 0) hipLaunchKernelGGL((k_loop1_cg<true, kCgProduction, false>), GG, BB, 0, stream(), LOOP_ARGS);
         else if (fl) hipLaunchKernelGGL((k_loop1_cg<false, 0, true>), GG, BB, 0, stream(), LOOP_ARGS);

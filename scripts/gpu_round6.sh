@@ -198,4 +198,10 @@ if has advvar; then echo "== advect-diffuse stage with single-width LDS reads (a
     python -c "import json; r=json.loads(open('$F').read().strip().splitlines()[-1]); print('  value', r['value'], 'ms/step', r['ms_per_step'], [(k['kernel'], k['avg_ms'], k.get('frac')) for k in r['kernels'][:3]])"
   done; done
 fi
+if has opt; then echo "== A/B of one debug option on the real workload: OPT_NAME=${OPT_NAME} values ${OPT_VALUES:-0 1 0 1}"
+  for SZ in ${OPT_SIZES:-512 256}; do for V in ${OPT_VALUES:-0 1 0 1}; do
+    F=$OUT/bench_${SZ}_${OPT_NAME}_$V.json
+    timeout 900 python bench.py --full-line --detail-out '' --size $SZ --no-cpu --no-alt --no-pcie --steps ${OPT_STEPS:-8} --warmup 3 --debug-option ${OPT_NAME}=$V > $F 2> ${F%.json}.err; echo "rc=$? (size $SZ ${OPT_NAME} $V)"; summ $F | head -1; summ $F | grep bicgstab_loop; tail -1 ${F%.json}.err | grep -v amdgpu.ids
+  done; done
+fi
 echo "== done $(date)"

@@ -964,6 +964,32 @@ def test_lhs_inside_the_loop_kernels_is_bit_identical(bpd, lmax, level, bc, mc, 
     assert np.array_equal(res[0][3], res[1][3])
 
 
+@pytest.mark.parametrize("mc", [0, 1, 2])
+@pytest.mark.parametrize("bpd,lmax,level,bc", [((1, 1, 1), 4, 3, ("wall", "wall", "wall")), ((2, 1, 3), 2, 1, ("periodic", "freespace", "wall"))])
+def test_first_loop_kernel_at_five_wavefronts_per_simd_is_bit_identical(bpd, lmax, level, bc, mc):
+    """Launches of >= 131072 blocks (the headline's 262144) take the first fused loop kernel held to 5 wavefronts per SIMD (k_loop1_cg_w5,
+    poisson.hip; 3 % faster there, slower on small launches): the same body at another register allocation, so every iterate is the same
+    bits.  No test grid reaches that size, hence `loop1_five_waves`: 1 = always, 2 = never."""
+    rng = np.random.default_rng(57 + mc)
+    res = {}
+    for opt in (1, 2):
+        cu.capi.check(cu.lib().cup3d_debug_set_option(b"loop1_five_waves", opt))
+        try:
+            sim = cu.SimulationData(bpdx=bpd[0], bpdy=bpd[1], bpdz=bpd[2], levelMax=lmax, levelStart=level, extent=2 * np.pi,
+                                    BC_x=bc[0], BC_y=bc[1], BC_z=bc[2], bMeanConstraint=mc, poissonTol=1e-9, poissonTolRel=1e-7)
+            if opt == 1:
+                rhs = rng.uniform(-1, 1, (sim.nblocks, 8, 8, 8))
+                rhs -= rhs.mean()
+            sim.upload("lhs", rhs)
+            sim.fill("pres", 0.0)
+            r = cu.makePoissonSolver(sim).solve()
+            res[opt] = (r.iterations, r.restarts, r.norm, sim.download("pres"))
+        finally:
+            cu.capi.check(cu.lib().cup3d_debug_set_option(b"loop1_five_waves", 0))
+    assert res[1][0] > 3 and res[1][:3] == res[2][:3], (res[1][:3], res[2][:3])
+    assert np.array_equal(res[1][3], res[2][3])
+
+
 @pytest.mark.parametrize("block_solver", [0, 2])
 @pytest.mark.parametrize("mc", [0, 1, 2, 3])
 @pytest.mark.parametrize("bpd,lmax,level,bc", [

@@ -40,6 +40,10 @@ def test_fused_solver_kernels(release):
     assert l1["vgpr"] <= 112 and l2["vgpr"] <= 128, (l1["vgpr"], l2["vgpr"])
     # LDS would allow 21 wavefronts per CU, the registers 16: registers bound the occupancy, as DESIGN.md says
     assert LDS_PER_CU // l1["lds_bytes"] >= 4 * 4
+    # round 6: launches of >= 131072 blocks (the headline's 262144) take the first kernel held to 5 wavefronts per SIMD -- without a spill
+    w5 = release["k_loop1_cg_w5<b1,i6,b1>"]
+    assert w5["scratch_bytes"] == 0 and w5["vgpr_spills"] == 0 and w5["waves_per_simd"] == 5 and w5["vgpr"] <= 96, w5
+    assert w5["lds_bytes"] == l1["lds_bytes"] and LDS_PER_CU // w5["lds_bytes"] >= 5 * 4
 
 
 def test_fused_solver_kernels_with_the_totals_inside(release):
