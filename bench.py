@@ -1427,6 +1427,16 @@ def compact_line(out, detail=None):
         r["pcie_inclusive"]["Mcell_updates_per_s"] = {m: v["Mcell_updates_per_s"] for m, v in pc.get("shim_modes", {}).items()}
     if detail:
         r["detail"] = detail
+
+    def finite(x):   # strict JSON: a NaN or an infinity (a 0/0 of an empty region) would make the whole line unparsable
+        if isinstance(x, float) and (x != x or x in (float("inf"), float("-inf"))):
+            return None
+        if isinstance(x, dict):
+            return {k: finite(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [finite(v) for v in x]
+        return x
+    r = finite(r)
     line = json.dumps(r)
     if len(line) > COMPACT_LIMIT:   # cannot happen with the keys above; if a future key makes it so, the contract's keys win
         for k in ("kernels", "pcie_inclusive", "alt_reference_association", "alt_multigrid", "alt"):

@@ -108,6 +108,10 @@ def test_default_stdout_line_is_compact_and_carries_roofline_and_cpu_baseline(tm
     r, d = json.loads(lines[0]), json.load(open(detail))
     assert r["roofline"]["kernel"] == "bicgstab_loop2_cg" and r["value"] == d["value"] and d["config"]["bicgstab_iters_by_step"] == [156] * 5
     assert "bicgstab_iters_by_step" not in r["config"] and r["detail"]
+    # strict JSON whatever the numbers: a NaN in the record becomes null in the line
+    bad = dict(full, value=float("nan"), roofline=dict(full["roofline"], frac=float("inf")))
+    line = json.dumps(bench.compact_line(bad), allow_nan=False)
+    assert json.loads(line)["value"] is None and json.loads(line)["roofline"]["frac"] is None
 
 
 def test_iteration_count_at_512_over_the_drivers_window_against_the_recorded_reference():
