@@ -56,7 +56,7 @@ if has exitdiag; then echo "== does the test process leave cleanly?  (glibc chec
 fi
 if has earlydet; then echo "== is the early all-reduce deterministic?  the same forced-communicator run ${DET_RUNS:-5} times at 128^3 (and at 64^3): iteration counts"
   for SZ in 128 64; do for R in $(seq 1 ${DET_RUNS:-5}); do
-    CUP3D_RCCL_LIBRARY=$PWD/tests/fake_rccl/librccl_fake.so FAKE_RCCL_ALLREDUCE_US=30 CUP3D_FORCE_COMM=1 timeout 300 python bench.py --size $SZ --steps 3 --warmup 1 --no-cpu --no-alt --no-pcie \
+    CUP3D_RCCL_LIBRARY=$PWD/tests/fake_rccl/librccl_fake.so FAKE_RCCL_ALLREDUCE_US=30 CUP3D_FORCE_COMM=1 timeout 300 python bench.py --full-line --detail-out '' --size $SZ --steps 3 --warmup 1 --no-cpu --no-alt --no-pcie \
       --debug-option force_allreduce=1 --debug-option early_allreduce=1 ${DET_ARGS} 2> $OUT/earlydet_${SZ}_$R.err | python -c "import sys, json; r = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('  $SZ run $R', r['config']['bicgstab_iters_by_step'], r['config']['umax_by_step'][-1])"
   done; done; fi
 if has suite; then echo "== pytest -m gpu (the WHOLE suite, stand-in cases included)"
