@@ -420,6 +420,7 @@ class Progress:
             if self.rank == 0:
                 time.sleep(0.5)
                 fallback(f"stage '{self.stage}': {error}", read_progress(self.dir, self.world, self.t0))
+                sys.stdout.flush()   # (os._exit below does not)
             else:
                 time.sleep(3.0)
             sys.stderr.write(f"bench.py rank {self.rank}: optional region failed: {error} (stage {self.stage}); the main result stands\n")

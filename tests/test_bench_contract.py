@@ -314,3 +314,31 @@ def test_checksum_is_independent_of_the_partition_over_gloo():
         assert sum(g[2] for g in got) == G.nblocks
         assert all(g[1] == want for g in got), (world, got, want)
         assert all(g[3] == want_comp for g in got), (world, got, want_comp)
+
+
+def test_a_failure_inside_an_optional_region_prints_the_main_result_and_exits_zero(tmp_path):
+    """bench.py --gpus N times the early all-reduce order AFTER the main result exists (`alt_early_allreduce`); while that region runs,
+    Progress.fallback holds a function that prints the main line.  A failure there -- the watchdog's stall limit, an exception -- must
+    print THAT line (with the error noted in it) and leave with exit code 0, where a failure anywhere else prints the error line and
+    leaves non-zero.  No GPU: Progress.fail() itself, in a subprocess (it ends the process)."""
+    code = r"""
+import argparse, json, sys, os
+sys.path.insert(0, %r)
+import bench
+a = argparse.Namespace(stall_timeout=5.0, timeout=100.0, watchdog=False, steps=3, warmup=1)
+os.environ["CUP3D_BENCH_PROGRESS_DIR"] = %r
+p = bench.Progress(0, 1, a)
+p.set("alt_early", "optional region")
+if sys.argv[1] == "optional":
+    p.fallback = lambda error, rank_progress: print(json.dumps({"metric": "m", "value": 95.2, "alt_early_allreduce": {"error": error, "ranks": len(rank_progress)}}))  # (Progress.fail flushes stdout before it leaves)
+p.fail("no progress for 5 s in stage 'alt_early'")
+""" % (ROOT, str(tmp_path))
+    opt = subprocess.run([sys.executable, "-c", code, "optional"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert opt.returncode == 0, opt.stderr.decode()[-500:]
+    r = json.loads(opt.stdout.decode().strip().splitlines()[-1])
+    assert r["value"] == 95.2 and "alt_early" in r["alt_early_allreduce"]["error"] and r["alt_early_allreduce"]["ranks"] == 1
+    assert b"the main result stands" in opt.stderr
+    hard = subprocess.run([sys.executable, "-c", code, "mandatory"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert hard.returncode != 0
+    r = json.loads(hard.stdout.decode().strip().splitlines()[-1])
+    assert r["valid"] is False and r["value"] is None and r["stage"] == "alt_early"
